@@ -1,0 +1,269 @@
+// host_graph.cpp -- host-side crystal-graph builder behind include/chgnet_graph.h.
+//
+// Native replacement for the reference's structure -> CrystalGraph step
+// (chgnet/graph/converter.py:102-190): periodic neighbour list, directed/undirected
+// bond bookkeeping (create_graph.c:135-203 semantics) and the bond-graph ("line
+// graph") enumeration (graph.py:283-327), emitting flat arrays instead of Python
+// Node/Edge objects.  Pure C++17, no third-party containers.
+
+#include "chgnet_graph.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct NeighborRows {
+  std::vector<int64_t> center, neighbor, image;  // image is [E,3]
+  std::vector<double> dist;
+};
+
+inline void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Brute-force periodic neighbour search, exact for any cell shape: along each lattice
+// axis the number of images needed is ceil(r / h_axis), h_axis = V / |a_j x a_k|.
+int neighbor_list(int32_t n, const double* frac, const double* L, double r, double tol,
+                  NeighborRows& rows) {
+  const double *a = L, *b = L + 3, *c = L + 6;
+  double bc[3], ca[3], ab[3];
+  cross3(b, c, bc);
+  cross3(c, a, ca);
+  cross3(a, b, ab);
+  const double vol = a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2];
+  if (!(std::fabs(vol) > 1e-12)) return CHG_GRAPH_EINVAL;
+  const double h[3] = {
+      std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
+      std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
+      std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
+  int reach[3];
+  for (int k = 0; k < 3; ++k) reach[k] = static_cast<int>(std::ceil(r / h[k])) + 1;
+  const double r2 = r * r;
+
+  // cartesian coordinates (row-vector convention: x = frac @ L)
+  std::vector<double> cart(3 * static_cast<size_t>(n));
+  for (int32_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k)
+      cart[3 * i + k] = frac[3 * i] * a[k] + frac[3 * i + 1] * b[k] + frac[3 * i + 2] * c[k];
+
+  for (int32_t i = 0; i < n; ++i) {
+    for (int32_t j = 0; j < n; ++j) {
+      // image window centred on the fractional separation so unwrapped inputs work
+      int lo[3], hi[3];
+      for (int k = 0; k < 3; ++k) {
+        const double df = frac[3 * i + k] - frac[3 * j + k];
+        lo[k] = static_cast<int>(std::floor(df)) - reach[k];
+        hi[k] = static_cast<int>(std::ceil(df)) + reach[k];
+      }
+      for (int ia = lo[0]; ia <= hi[0]; ++ia)
+        for (int ib = lo[1]; ib <= hi[1]; ++ib)
+          for (int ic = lo[2]; ic <= hi[2]; ++ic) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+              const double dx = cart[3 * j + k] + ia * a[k] + ib * b[k] + ic * c[k] - cart[3 * i + k];
+              d2 += dx * dx;
+            }
+            if (d2 < r2) {
+              const double d = std::sqrt(d2);
+              if (d > tol) {
+                rows.center.push_back(i);
+                rows.neighbor.push_back(j);
+                rows.image.push_back(ia);
+                rows.image.push_back(ib);
+                rows.image.push_back(ic);
+                rows.dist.push_back(d);
+              }
+            }
+          }
+    }
+  }
+  return CHG_GRAPH_OK;
+}
+
+template <class T>
+T* dup_array(const std::vector<T>& v) {
+  T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+  if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+int build_from_rows(int32_t n_atoms, int64_t E, const int64_t* center, const int64_t* neighbor,
+                    const int64_t* image, const double* dist, double r_bond, chg_graph** out) {
+  if (n_atoms < 0 || E < 0 || !out) return CHG_GRAPH_EINVAL;
+  for (int64_t e = 0; e < E; ++e)
+    if (center[e] < 0 || center[e] >= n_atoms || neighbor[e] < 0 || neighbor[e] >= n_atoms)
+      return CHG_GRAPH_EINVAL;
+
+  std::vector<int32_t> atom_graph(2 * E), img32(3 * E), d2u(E);
+  std::vector<int32_t> u2d;          // first directed edge of each undirected bond
+  std::vector<int32_t> u_second;     // second directed edge (-1 until paired)
+  std::vector<int32_t> u_count;      // number of directed edges attached
+  u2d.reserve(E / 2 + 1);
+  u_second.reserve(E / 2 + 1);
+  u_count.reserve(E / 2 + 1);
+
+  // unordered atom pair -> undirected bonds created under it, in creation order
+  // (create_graph.c:152-189; legacy graph.py:166-214)
+  std::unordered_map<uint64_t, std::vector<int32_t>> by_pair;
+  by_pair.reserve(static_cast<size_t>(E));
+
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t ci = center[e], ni = neighbor[e];
+    atom_graph[2 * e] = static_cast<int32_t>(ci);
+    atom_graph[2 * e + 1] = static_cast<int32_t>(ni);
+    for (int k = 0; k < 3; ++k) img32[3 * e + k] = static_cast<int32_t>(image[3 * e + k]);
+    const uint64_t lo = static_cast<uint64_t>(std::min(ci, ni)), hi = static_cast<uint64_t>(std::max(ci, ni));
+    auto& group = by_pair[(hi << 32) | lo];
+    int32_t joined = -1;
+    for (int32_t u : group) {
+      const int32_t f = u2d[u];  // its first directed edge must be the exact reverse
+      if (center[f] == ni && neighbor[f] == ci && image[3 * f] == -image[3 * e] &&
+          image[3 * f + 1] == -image[3 * e + 1] && image[3 * f + 2] == -image[3 * e + 2]) {
+        joined = u;
+        break;
+      }
+    }
+    if (joined < 0) {
+      joined = static_cast<int32_t>(u2d.size());
+      u2d.push_back(static_cast<int32_t>(e));
+      u_second.push_back(-1);
+      u_count.push_back(1);
+      group.push_back(joined);
+    } else {
+      if (u_count[joined] == 1) u_second[joined] = static_cast<int32_t>(e);
+      u_count[joined] += 1;
+    }
+    d2u[e] = joined;
+  }
+  const int64_t Eu = static_cast<int64_t>(u2d.size());
+  if (E != 2 * Eu) return CHG_GRAPH_EUNPAIRED;  // graph.py:273-278
+
+  // per-centre neighbour groups in dict-insertion order (graph.py:23-33):
+  // group order = first appearance of the neighbour id, edges inside a group in row order
+  std::vector<std::vector<int32_t>> per_center(n_atoms);
+  for (int64_t e = 0; e < E; ++e) per_center[center[e]].push_back(static_cast<int32_t>(e));
+  std::vector<int32_t> first_seen(n_atoms, -1);
+  for (int32_t i = 0; i < n_atoms; ++i) {
+    auto& lst = per_center[i];
+    int32_t rank = 0;
+    std::vector<int32_t> touched;
+    for (int32_t e : lst)
+      if (first_seen[neighbor[e]] < 0) {
+        first_seen[neighbor[e]] = rank++;
+        touched.push_back(static_cast<int32_t>(neighbor[e]));
+      }
+    std::stable_sort(lst.begin(), lst.end(), [&](int32_t x, int32_t y) {
+      return first_seen[neighbor[x]] < first_seen[neighbor[y]];
+    });
+    for (int32_t t : touched) first_seen[t] = -1;
+  }
+
+  // line graph (graph.py:283-327)
+  std::vector<int32_t> bond_graph;
+  for (int32_t u = 0; u < Eu; ++u) {
+    const int32_t f = u2d[u];
+    if (dist[f] > r_bond) continue;            // note '>' (graph.py:289)
+    if (u_count[u] != 2) return CHG_GRAPH_EUNPAIRED;
+    const int32_t ends[2] = {atom_graph[2 * f], atom_graph[2 * f + 1]};
+    const int32_t des[2] = {f, u_second[u]};
+    for (int s = 0; s < 2; ++s) {
+      const int32_t ctr = ends[s], de = des[s];
+      for (int32_t other : per_center[ctr]) {
+        if (other == de) continue;
+        if (dist[other] < r_bond) {            // note '<' (graph.py:313)
+          bond_graph.push_back(ctr);
+          bond_graph.push_back(u);
+          bond_graph.push_back(de);
+          bond_graph.push_back(d2u[other]);
+          bond_graph.push_back(other);
+        }
+      }
+    }
+  }
+
+  std::vector<char> is_center(n_atoms, 0);
+  for (int64_t e = 0; e < E; ++e) is_center[center[e]] = 1;
+  int32_t n_iso = 0;
+  for (int32_t i = 0; i < n_atoms; ++i) n_iso += is_center[i] ? 0 : 1;
+
+  chg_graph* g = static_cast<chg_graph*>(std::calloc(1, sizeof(chg_graph)));
+  if (!g) return CHG_GRAPH_ENOMEM;
+  g->n_atoms = n_atoms;
+  g->n_directed = static_cast<int32_t>(E);
+  g->n_undirected = static_cast<int32_t>(Eu);
+  g->n_angles = static_cast<int32_t>(bond_graph.size() / 5);
+  g->n_isolated = n_iso;
+  g->atom_graph = dup_array(atom_graph);
+  g->image = dup_array(img32);
+  g->distance = dup_array(std::vector<double>(dist, dist + E));
+  g->directed2undirected = dup_array(d2u);
+  g->undirected2directed = dup_array(u2d);
+  g->bond_graph = dup_array(bond_graph);
+  if (!g->atom_graph || !g->image || !g->distance || !g->directed2undirected ||
+      !g->undirected2directed || !g->bond_graph) {
+    chg_graph_free(g);
+    return CHG_GRAPH_ENOMEM;
+  }
+  *out = g;
+  return CHG_GRAPH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int chg_graph_build(int32_t n_atoms, const double* frac, const double* lattice, double r_atom,
+                    double r_bond, double numerical_tol, chg_graph** out) {
+  if (n_atoms < 0 || !frac || !lattice || !out || !(r_atom > 0)) return CHG_GRAPH_EINVAL;
+  try {
+    NeighborRows rows;
+    const int st = neighbor_list(n_atoms, frac, lattice, r_atom, numerical_tol, rows);
+    if (st != CHG_GRAPH_OK) return st;
+    return build_from_rows(n_atoms, static_cast<int64_t>(rows.center.size()), rows.center.data(),
+                           rows.neighbor.data(), rows.image.data(), rows.dist.data(), r_bond, out);
+  } catch (const std::bad_alloc&) {
+    return CHG_GRAPH_ENOMEM;
+  }
+}
+
+int chg_graph_from_neighbors(int32_t n_atoms, int64_t n_edges, const int64_t* center,
+                             const int64_t* neighbor, const int64_t* image, const double* distance,
+                             double r_bond, chg_graph** out) {
+  if (n_edges > 0 && (!center || !neighbor || !image || !distance)) return CHG_GRAPH_EINVAL;
+  try {
+    return build_from_rows(n_atoms, n_edges, center, neighbor, image, distance, r_bond, out);
+  } catch (const std::bad_alloc&) {
+    return CHG_GRAPH_ENOMEM;
+  }
+}
+
+void chg_graph_free(chg_graph* g) {
+  if (!g) return;
+  std::free(g->atom_graph);
+  std::free(g->image);
+  std::free(g->distance);
+  std::free(g->directed2undirected);
+  std::free(g->undirected2directed);
+  std::free(g->bond_graph);
+  std::free(g);
+}
+
+const char* chg_graph_strerror(int status) {
+  switch (status) {
+    case CHG_GRAPH_OK: return "ok";
+    case CHG_GRAPH_EINVAL: return "invalid argument (null pointer, negative size, index out of range or singular lattice)";
+    case CHG_GRAPH_ENOMEM: return "out of host memory";
+    case CHG_GRAPH_EUNPAIRED: return "number of directed edges != 2 * number of undirected edges (directed edges are not complete)";
+    default: return "unknown status";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+/* chgnet_graph.h -- C-ABI of the host-side crystal-graph builder (libchgnet_graph.so).
+ *
+ * Replaces, for the path structure -> CrystalGraph record:
+ *   - pymatgen Structure.get_neighbor_list, sole call site
+ *     chgnet/graph/converter.py:132-134  (third-party, un-vendored; restated here)
+ *   - the reference's only native entry point
+ *     ReturnElems2* create_graph(int64_t*, int64_t, int64_t*, int64_t*, double*, int64_t)
+ *     chgnet/graph/fast_converter_libraries/create_graph.c:100-107, wrapped by
+ *     make_graph(...) chgnet/graph/cygraph.pyx:69-76
+ *   - Graph.adjacency_list / Graph.line_graph_adjacency_list
+ *     chgnet/graph/graph.py:226-247, 249-328
+ * It emits the CrystalGraph tensors (chgnet/graph/crystalgraph.py:18-100) directly as
+ * flat int32 / float64 arrays instead of Python Node/Edge objects.
+ *
+ * Plain C types only; all output arrays are owned by the library and released with
+ * chg_graph_free().  Functions return 0 on success, a negative chg_graph_status
+ * otherwise; chg_graph_strerror() maps a status to text.  Thread-safe (no globals).
+ */
+#ifndef CHGNET_GRAPH_H
+#define CHGNET_GRAPH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  CHG_GRAPH_OK = 0,
+  CHG_GRAPH_EINVAL = -1,        /* bad argument (null pointer, n<0, singular lattice) */
+  CHG_GRAPH_ENOMEM = -2,
+  CHG_GRAPH_EUNPAIRED = -3      /* Ed != 2*Eu: graph.py:273-278 raises ValueError */
+} chg_graph_status;
+
+typedef struct chg_graph {
+  int32_t n_atoms;
+  int32_t n_directed;      /* Ed */
+  int32_t n_undirected;    /* Eu, Ed == 2*Eu */
+  int32_t n_angles;        /* A  */
+  int32_t n_isolated;      /* atoms that never appear as a centre (converter.py:161) */
+  int32_t* atom_graph;     /* [Ed,2] (centre, neighbour)                graph.py:240 */
+  int32_t* image;          /* [Ed,3] periodic image of the neighbour    converter.py:180 */
+  double*  distance;       /* [Ed]   neighbour-list distance (float64)               */
+  int32_t* directed2undirected; /* [Ed]                                 graph.py:241-245 */
+  int32_t* undirected2directed; /* [Eu] first directed edge of each bond graph.py:285 */
+  int32_t* bond_graph;     /* [A,5] (atom, und_i, dir_i, und_j, dir_j)  graph.py:316-324 */
+} chg_graph;
+
+/* Periodic neighbour list + graph in one call.
+ * frac [n,3] fractional coordinates, lattice [3,3] rows = a,b,c (Angstrom), both float64.
+ * Pairs with numerical_tol < d < r_atom are listed centre-major (neighbour index, then
+ * image, ascending within a centre).  Angles use bonds with d <= r_bond as the owning
+ * bond and d < r_bond as the second bond, exactly as graph.py:289,313. */
+int chg_graph_build(int32_t n_atoms, const double* frac, const double* lattice,
+                    double r_atom, double r_bond, double numerical_tol, chg_graph** out);
+
+/* Same graph construction from a caller-supplied neighbour list (the arrays pymatgen's
+ * get_neighbor_list returns); rows are taken in the given order, which fixes the
+ * directed / undirected numbering exactly as create_graph.c:135-203 does. */
+int chg_graph_from_neighbors(int32_t n_atoms, int64_t n_edges, const int64_t* center,
+                             const int64_t* neighbor, const int64_t* image /*[E,3]*/,
+                             const double* distance, double r_bond, chg_graph** out);
+
+void chg_graph_free(chg_graph* g);
+const char* chg_graph_strerror(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHGNET_GRAPH_H */
