@@ -1,0 +1,103 @@
+"""ctypes binding of libchgnet_hip.so (include/chgnet_hip.h).  No fallback: a missing or
+unloadable library raises ``RuntimeError`` -- the product never computes on the CPU."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+c_int_p = ctypes.POINTER(ctypes.c_int32)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+TASK_BITS = {"e": 1, "f": 2, "s": 4, "m": 8}
+
+EXPORTED_SYMBOLS = (
+    "chg_device_count", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
+    "chg_batch_upload", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
+    "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
+    "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
+    "chg_debug_fetch", "chg_test_rows_gemm",
+)
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_conv", ctypes.c_int32), ("cutoff_coeff", ctypes.c_int32), ("is_intensive", ctypes.c_int32),
+        ("has_composition", ctypes.c_int32), ("atom_graph_cutoff", ctypes.c_float),
+        ("bond_graph_cutoff", ctypes.c_float), ("n_weights", ctypes.c_int64),
+    ]
+
+
+class BatchHost(ctypes.Structure):
+    _fields_ = [
+        ("n_struct", ctypes.c_int32), ("n_atoms", ctypes.c_int32), ("n_directed", ctypes.c_int32),
+        ("n_undirected", ctypes.c_int32), ("n_angles", ctypes.c_int32), ("n_bnodes", ctypes.c_int32),
+        ("z", c_int_p), ("frac", c_float_p), ("lattice", c_float_p), ("atom_owner", c_int_p), ("atom_off", c_int_p),
+        ("e_center", c_int_p), ("e_nbr", c_int_p), ("e_image", c_float_p), ("e_d2u", c_int_p), ("e_owner", c_int_p),
+        ("u_u2d", c_int_p), ("u_bnode", c_int_p), ("bn_und", c_int_p),
+        ("a_ctr", c_int_p), ("a_b1c", c_int_p), ("a_b2c", c_int_p), ("a_d1", c_int_p), ("a_d2", c_int_p),
+    ]
+
+
+class OutHost(ctypes.Structure):
+    _fields_ = [(n, c_float_p) for n in ("energy", "force", "stress", "magmom", "site_energy", "atom_fea", "crystal_fea")]
+
+
+_LIB = None
+
+
+def hip_lib_path() -> str:
+    from chgnet_amd.build import HIP_LIB
+
+    return HIP_LIB
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP engine library; raise loudly if it is not built or cannot be loaded."""
+    global _LIB  # noqa: PLW0603
+    if _LIB is not None:
+        return _LIB
+    path = hip_lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"chgnet_amd: HIP extension {path} is missing. Build it with `python -m chgnet_amd.build` "
+            "(needs hipcc). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:
+        raise RuntimeError(f"chgnet_amd: cannot load HIP extension {path}: {exc}") from exc
+    vp = ctypes.c_void_p
+    lib.chg_device_count.restype = ctypes.c_int
+    lib.chg_engine_create.argtypes = [ctypes.POINTER(ModelDesc), c_float_p, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.chg_engine_destroy.argtypes = [vp]
+    lib.chg_last_error.argtypes = [vp]
+    lib.chg_last_error.restype = ctypes.c_char_p
+    lib.chg_batch_upload.argtypes = [vp, ctypes.POINTER(BatchHost), ctypes.POINTER(vp)]
+    lib.chg_batch_update_geometry.argtypes = [vp, vp, c_float_p, c_float_p]
+    lib.chg_batch_free.argtypes = [vp, vp]
+    lib.chg_batch_device_bytes.argtypes = [vp]
+    lib.chg_batch_device_bytes.restype = ctypes.c_int64
+    lib.chg_predict.argtypes = [vp, vp, ctypes.c_uint32]
+    lib.chg_synchronize.argtypes = [vp]
+    lib.chg_batch_download.argtypes = [vp, vp, ctypes.POINTER(OutHost)]
+    lib.chg_timer_start.argtypes = [vp]
+    lib.chg_timer_stop_ms.argtypes = [vp, c_float_p]
+    lib.chg_profile_enable.argtypes = [vp, ctypes.c_int]
+    lib.chg_profile_reset.argtypes = [vp]
+    lib.chg_profile_count.argtypes = [vp]
+    lib.chg_profile_read.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
+    lib.chg_debug_fetch.argtypes = [vp, vp, ctypes.c_char_p, c_float_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    lib.chg_test_rows_gemm.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is ctypes.c_int and name not in ("chg_device_count", "chg_profile_count"):
+            fn.restype = ctypes.c_int
+    _LIB = lib
+    return lib
+
+
+def task_mask(task: str) -> int:
+    mask = 0
+    for ch in task:
+        mask |= TASK_BITS[ch]
+    return mask

@@ -28,7 +28,7 @@ HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-munsafe-fp-atomics",      # native global_atomic_add_f32, no CAS loops
     "-ffp-contract=fast",
-    "-Wall", "-Wno-unused-function",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
 ]
 
 

@@ -1,0 +1,818 @@
+// engine.hip -- C-ABI (include/chgnet_hip.h) and launch orchestration of the gfx950 CHGNet engine.
+//
+// One chg_engine per GPU owns the weight blob and a HIP stream; one chg_batch owns a packed
+// batch of structures plus every activation / gradient buffer the forward and reverse sweeps
+// need, carved from a single device arena.  chg_predict enqueues the whole E/F/S/M computation
+// on the engine's stream without any host synchronisation.
+//
+// Order of layers follows CHGNet._compute (reference chgnet/model/model.py:442-503); the reverse
+// sweep is the hand-derived adjoint of it, producing dE/dv_e once and both
+// forces and the virial from it, instead of the reference's two autograd.grad passes
+// (model.py:517-535).
+
+#include "chgnet_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels_conv.h"
+#include "kernels_geom.h"
+
+using namespace chg;
+
+namespace {
+
+constexpr int MAX_CONV = 8;
+
+struct GatedPtrs { GatedW g; };
+
+struct ACW { const float *w_cn, *w_bond, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
+struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
+struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };
+
+struct Weights {
+  const float *atomref, *emb, *freq_ag, *freq_bg, *freq_ang, *w_bond_emb, *w_wag, *w_wbg, *w_ang_emb;
+  ACW ac[MAX_CONV];
+  BCW bc[MAX_CONV];
+  AUW au[MAX_CONV];
+  const float *site_w, *site_b, *ro_ln_g, *ro_ln_b, *mlp_w0, *mlp_b0, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2, *mlp_w3, *mlp_b3;
+};
+
+struct ProfEntry { std::string label; int64_t launches = 0; double ms = 0.0; };
+struct PendingEvent { int entry; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct chg_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  chg_model_desc desc{};
+  float* d_weights = nullptr;
+  Weights w{};
+  std::string err;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  std::map<std::string, int> prof_index;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  int num_cus = 256;
+};
+
+struct chg_batch {
+  int B = 0, N = 0, Ed = 0, Eu = 0, A = 0, Eb = 0, L = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  // inputs
+  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
+  float *frac, *lattice, *e_image;
+  // geometry / features
+  float* cart;
+  f32x4 *ev, *eu;
+  float *hb0, *wag, *wbgc;
+  float* atom[MAX_CONV + 1];
+  float* hbc[MAX_CONV + 1];
+  float* ang[MAX_CONV];
+  float *P, *Q, *R, *S, *agg, *aggB;
+  // outputs
+  float *energy_sum, *comp_sum, *energy, *site_energy, *magmom, *crystal_fea, *force, *virial, *volume;
+  // reverse sweep
+  float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
+  uint32_t last_task = 0;
+  std::map<std::string, std::pair<const float*, size_t>> named;
+};
+
+namespace {
+
+#define HIP_TRY(eng, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      (eng)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                               \
+      return CHG_EHIP;                                                                              \
+    }                                                                                               \
+  } while (0)
+
+// ---- weight blob layout: MUST mirror chgnet_amd/pack.py:weight_layout -------------------------------
+struct Cursor {
+  const float* base;
+  size_t pos = 0;
+  const float* take(size_t n) {
+    pos += (4 - pos % 4) % 4;  // 16-byte alignment of every tensor
+    const float* p = base + pos;
+    pos += n;
+    return p;
+  }
+};
+
+void take_gated_tail(Cursor& c, GatedW& g, const float*& w2c_t, const float*& w2g_t) {
+  g.w2c = c.take(D * D); g.b2c = c.take(D); g.w2g = c.take(D * D); g.b2g = c.take(D);
+  w2c_t = c.take(D * D); w2g_t = c.take(D * D);
+}
+void take_ln(Cursor& c, GatedW& g) {
+  g.ln1_g = c.take(D); g.ln1_b = c.take(D); g.ln2_g = c.take(D); g.ln2_b = c.take(D);
+}
+
+size_t layout_weights(const float* base, int L, Weights& w) {
+  Cursor c{base};
+  const float *dummy1, *dummy2;
+  w.atomref = c.take(94); w.emb = c.take(94 * D);
+  w.freq_ag = c.take(NRAD); w.freq_bg = c.take(NRAD); w.freq_ang = c.take(NFREQ);
+  w.w_bond_emb = c.take(D * NRAD); w.w_wag = c.take(D * NRAD); w.w_wbg = c.take(D * NRAD); w.w_ang_emb = c.take(D * NANG);
+  for (int l = 0; l < L; ++l) {
+    ACW& a = w.ac[l];
+    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D);
+    take_gated_tail(c, a.g, dummy1, dummy2);
+    take_ln(c, a.g);
+    a.w_out = c.take(D * D); a.b_out = c.take(D); a.w_out_t = c.take(D * D);
+    a.w_cn_t = c.take(4 * D * D); a.w_bond_t = c.take(2 * D * D);
+  }
+  for (int l = 0; l < L - 1; ++l) {
+    BCW& b = w.bc[l];
+    b.w_bij = c.take(4 * D * D); b.w_ang = c.take(2 * D * D); b.w_ctr = c.take(2 * D * D); b.b1 = c.take(2 * D);
+    take_gated_tail(c, b.g, dummy1, dummy2);
+    take_ln(c, b.g);
+    b.w_out = c.take(D * D); b.b_out = c.take(D); b.w_out_t = c.take(D * D);
+    b.w_bij_t = c.take(4 * D * D); b.w_ang_t = c.take(2 * D * D); b.w_ctr_t = c.take(2 * D * D);
+  }
+  for (int l = 0; l < L - 1; ++l) {
+    AUW& u = w.au[l];
+    u.w_bij = c.take(4 * D * D); u.w_ang = c.take(2 * D * D); u.w_ctr = c.take(2 * D * D); u.b1 = c.take(2 * D);
+    u.g = GatedW{};
+    take_ln(c, u.g);
+    u.w_bij_t = c.take(4 * D * D); u.w_ang_t = c.take(2 * D * D); u.w_ctr_t = c.take(2 * D * D);
+  }
+  w.site_w = c.take(D); w.site_b = c.take(1); w.ro_ln_g = c.take(D); w.ro_ln_b = c.take(D);
+  w.mlp_w0 = c.take(D * D); w.mlp_b0 = c.take(D); w.mlp_w1 = c.take(D * D); w.mlp_b1 = c.take(D);
+  w.mlp_w2 = c.take(D * D); w.mlp_b2 = c.take(D); w.mlp_w3 = c.take(D); w.mlp_b3 = c.take(1);
+  c.take(D * D); c.take(D * D); c.take(D * D);  // mlp_w*_t (kept in the blob for the layout contract)
+  return c.pos;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------
+int prof_entry(chg_engine* eng, const char* label) {
+  auto it = eng->prof_index.find(label);
+  if (it != eng->prof_index.end()) return it->second;
+  eng->prof.push_back(ProfEntry{label});
+  const int idx = (int)eng->prof.size() - 1;
+  eng->prof_index[label] = idx;
+  return idx;
+}
+
+hipEvent_t get_event(chg_engine* eng) {
+  if (!eng->event_pool.empty()) {
+    hipEvent_t e = eng->event_pool.back();
+    eng->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct LaunchScope {
+  chg_engine* eng;
+  PendingEvent pe{};
+  bool on;
+  LaunchScope(chg_engine* e, const char* label) : eng(e), on(e->profiling) {
+    if (on) {
+      pe.entry = prof_entry(eng, label);
+      pe.start = get_event(eng);
+      pe.stop = get_event(eng);
+      hipEventRecord(pe.start, eng->stream);
+    }
+  }
+  ~LaunchScope() {
+    if (on) {
+      hipEventRecord(pe.stop, eng->stream);
+      eng->pending.push_back(pe);
+    }
+  }
+};
+
+int collect_profile(chg_engine* eng) {
+  for (auto& pe : eng->pending) {
+    float ms = 0.f;
+    HIP_TRY(eng, hipEventSynchronize(pe.stop));
+    HIP_TRY(eng, hipEventElapsedTime(&ms, pe.start, pe.stop));
+    eng->prof[pe.entry].launches += 1;
+    eng->prof[pe.entry].ms += ms;
+    eng->event_pool.push_back(pe.start);
+    eng->event_pool.push_back(pe.stop);
+  }
+  eng->pending.clear();
+  return CHG_OK;
+}
+
+int grid_for(int rows, int max_blocks) {
+  int ntiles = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int g = std::min(ntiles, max_blocks);
+  if (g >= 8) g &= ~7;  // multiple of 8: tile_range keeps neighbouring ranges on one XCD
+  return std::max(g, 1);
+}
+
+template <int K, int NOUT>
+int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
+  if (p.rows <= 0) return CHG_OK;
+  LaunchScope ls(eng, label);
+  const size_t lds = rows_gemm_lds<K, NOUT>();
+  hipLaunchKernelGGL((k_rows_gemm<K, NOUT>), dim3(grid_for(p.rows, 4 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+// Y[out] (+)= X[in] . Wt^T, dispatch on (K, NOUT); K = 256 / NOUT = 256 are split by the callers
+int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt,
+              const float* bias, const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int accumulate) {
+  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate};
+  if (K == 64 && NOUT == 64) return launch_rows_gemm<64, 64>(eng, label, p);
+  if (K == 64 && NOUT == 128) return launch_rows_gemm<64, 128>(eng, label, p);
+  if (K == 128 && NOUT == 64) return launch_rows_gemm<128, 64>(eng, label, p);
+  eng->err = "rows_gemm: unsupported shape";
+  return CHG_EINVAL;
+}
+
+int zero(chg_engine* eng, void* p, size_t bytes) {
+  if (bytes == 0) return CHG_OK;
+  LaunchScope ls(eng, "memset");
+  HIP_TRY(eng, hipMemsetAsync(p, 0, bytes, eng->stream));
+  return CHG_OK;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int rows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * (D / 4)) return;
+  const int r = t / (D / 4), q = t % (D / 4);
+  reinterpret_cast<f32x4*>(dst)[t] = reinterpret_cast<const f32x4*>(src + (size_t)idx[r] * D)[q];
+}
+
+#define TRY(x)                   \
+  do {                           \
+    int _s = (x);                \
+    if (_s != CHG_OK) return _s; \
+  } while (0)
+
+inline dim3 g1(int64_t n, int b = 256) { return dim3((unsigned)std::max<int64_t>(1, (n + b - 1) / b)); }
+inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4 waves per block, grid-stride
+  return (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 16 * (int64_t)eng->num_cus));
+}
+
+// ---- AtomConv ----------------------------------------------------------------------------------------
+// tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half),  Q = h_bond^l . Wb^T
+int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, b->P, 4 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn + 2 * D * D, nullptr, nullptr, 0, b->P + 2 * D, 4 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, nullptr, nullptr, 0, b->Q, 2 * D, nullptr, b->Eu, 0));
+  if (b->Eb > 0 && b->hbc[l] != b->hbc[0])   // bond-graph nodes carry layer-l features
+    TRY(rows_gemm(eng, "gemm_Qnode", 64, 128, b->hbc[l], D, nullptr, w.w_bond, nullptr, nullptr, 0, b->Q, 2 * D, b->bn_und, b->Eb, 0));
+  return CHG_OK;
+}
+
+AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
+  AtomConvArgs a{};
+  a.P = b->P; a.Q = b->Q; a.wag = b->wag;
+  a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_d2u = b->e_d2u; a.n_edges = b->Ed;
+  a.gw = eng->w.ac[l].g;
+  a.agg = b->agg; a.GA = b->GA; a.GP = b->GP; a.GQ = b->GQ; a.Gwag = b->Gwag;
+  return a;
+}
+
+int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  TRY(zero(eng, b->agg, sizeof(float) * (size_t)b->N * D));
+  if (b->Ed > 0) {
+    TRY(atomconv_tables(eng, b, l));
+    LaunchScope ls(eng, "atomconv_fwd");
+    hipLaunchKernelGGL((k_atomconv<false>), dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
+    HIP_TRY(eng, hipGetLastError());
+  }
+  // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
+  return rows_gemm(eng, "gemm_out", 64, 64, b->agg, D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
+}
+
+int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
+  TRY(atomconv_tables(eng, b, l));
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
+  TRY(zero(eng, b->GP, sizeof(float) * (size_t)b->N * 4 * D));
+  TRY(zero(eng, b->GQ, sizeof(float) * (size_t)b->Eu * 2 * D));
+  {
+    LaunchScope ls(eng, "atomconv_bwd");
+    hipLaunchKernelGGL((k_atomconv<true>), dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
+    HIP_TRY(eng, hipGetLastError());
+  }
+  if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
+    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP, 4 * D, nullptr, w.w_cn_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
+    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP + 2 * D, 4 * D, nullptr, w.w_cn_t + 2 * D * D, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
+  }
+  return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, 1);
+}
+
+// ---- BondConv / AngleUpdate ----------------------------------------------------------------------------
+// tables: S = atom . Wctr^T + b1 (per atom),  R = hbc . [Wi;Wj]^T (per bond-graph node)
+int angle_tables(chg_engine* eng, chg_batch* b, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
+  TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, b->S, 2 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij, nullptr, nullptr, 0, b->R, 4 * D, nullptr, b->Eb, 0));
+  return rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij + 2 * D * D, nullptr, nullptr, 0, b->R + 2 * D, 4 * D, nullptr, b->Eb, 0);
+}
+
+AngleArgs angle_args(chg_batch* b, const float* ang, const float* w_ang, const GatedW& g, float* out) {
+  AngleArgs a{};
+  a.R = b->R; a.S = b->S; a.ang = ang; a.wbgc = b->wbgc;
+  a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
+  a.w_ang = w_ang; a.gw = g; a.out = out;
+  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR; a.GS = b->GS; a.Gwbgc = b->Gwbgc;
+  return a;
+}
+
+template <bool HIDDEN, bool BWD>
+int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
+  LaunchScope ls(eng, label);
+  const size_t lds = angle_lds<HIDDEN>();
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, a);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
+  const BCW& w = eng->w.bc[l];
+  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
+  TRY(zero(eng, b->aggB, sizeof(float) * (size_t)b->Eb * D));
+  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, b->aggB))));
+  // hbc[l+1] = agg . Wout^T + b_out + hbc[l]          (layers.py:255-260)
+  return rows_gemm(eng, "gemm_out", 64, 64, b->aggB, D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
+}
+
+int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
+  const AUW& w = eng->w.au[l];
+  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
+  return launch_angle<false, false>(eng, "angleupd_fwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
+}
+
+// scatter of the table gradients back to atoms / bond nodes
+int angle_table_grads(chg_engine* eng, chg_batch* b, const float* w_bij_t, const float* w_ctr_t) {
+  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR, 4 * D, nullptr, w_bij_t, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
+  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR + 2 * D, 4 * D, nullptr, w_bij_t + 2 * D * D, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
+  return rows_gemm(eng, "gemm_GS", 128, 64, b->GS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
+}
+
+int bondconv_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const BCW& w = eng->w.bc[l];
+  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, w.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, b->Eb, 0));
+  TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
+  TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
+  TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, nullptr))));
+  return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
+}
+
+int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const AUW& w = eng->w.au[l];
+  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
+  TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
+  TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
+  TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, nullptr))));
+  return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
+}
+
+BondEmbedArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
+  const Weights& w = eng->w;
+  BondEmbedArgs a{};
+  a.ev = b->ev; a.u_u2d = b->u_u2d; a.u_bnode = b->u_bnode; a.n_und = b->Eu;
+  a.freq_ag = w.freq_ag; a.freq_bg = w.freq_bg; a.w_emb = w.w_bond_emb; a.w_ag = w.w_wag; a.w_bg = w.w_wbg;
+  a.rc_ag = eng->desc.atom_graph_cutoff; a.rc_bg = eng->desc.bond_graph_cutoff;
+  const double p = eng->desc.cutoff_coeff;   // basis.py:184-186
+  a.env = Envelope{(float)(-(p + 1) * (p + 2) / 2), (float)(p * (p + 2)), (float)(-p * (p + 1) / 2), eng->desc.cutoff_coeff};
+  a.hb0 = b->hb0; a.wag = b->wag; a.wbgc = b->wbgc;
+  a.Gb = b->Gb; a.Gwag = b->Gwag; a.Gwbgc = b->Gwbgc; a.Grk = b->Grk;
+  return a;
+}
+
+AngleEmbedArgs angle_embed_args(chg_engine* eng, chg_batch* b) {
+  AngleEmbedArgs a{};
+  a.eu = b->eu; a.a_d1 = b->a_d1; a.a_d2 = b->a_d2; a.n_angles = b->A;
+  a.freq = eng->w.freq_ang; a.w_emb = eng->w.w_ang_emb;
+  a.ang0 = b->ang[0]; a.Gang = b->Gang; a.Gu = b->Gu;
+  return a;
+}
+
+int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
+  const Weights& w = eng->w;
+  const int L = b->L;
+  const bool want_f = task & CHG_TASK_F, want_s = task & CHG_TASK_S, want_m = task & CHG_TASK_M;
+  const bool want_grad = want_f || want_s;
+  hipStream_t st = eng->stream;
+
+  // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
+  { LaunchScope ls(eng, "cart");
+    hipLaunchKernelGGL(k_cart, g1(b->N), dim3(256), 0, st, b->frac, b->lattice, b->atom_owner, b->cart, b->N); }
+  if (b->Ed > 0) {
+    { LaunchScope ls(eng, "edge_geom");
+      hipLaunchKernelGGL(k_edge_geom, g1(b->Ed), dim3(256), 0, st, b->cart, b->lattice, b->e_center, b->e_nbr, b->e_image, b->e_owner, b->ev, b->eu, b->Ed); }
+    { LaunchScope ls(eng, "bond_embed_fwd");
+      hipLaunchKernelGGL((k_bond_embed<false>), dim3(wave_grid(eng, b->Eu)), dim3(256), 0, st, bond_embed_args(eng, b)); }
+  }
+  if (b->A > 0) {
+    LaunchScope ls(eng, "angle_embed_fwd");
+    hipLaunchKernelGGL((k_angle_embed<false>), dim3(wave_grid(eng, b->A)), dim3(256), 0, st, angle_embed_args(eng, b));
+  }
+  { LaunchScope ls(eng, "atom_embed");
+    hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
+  if (b->Eb > 0) {
+    LaunchScope ls(eng, "gather_hbc0");
+    hipLaunchKernelGGL(k_gather_rows, g1((int64_t)b->Eb * (D / 4)), dim3(256), 0, st, b->hb0, b->bn_und, b->hbc[0], b->Eb);
+  }
+  HIP_TRY(eng, hipGetLastError());
+
+  // ---- message passing (model.py:442-496) ----
+  for (int l = 0; l < L - 1; ++l) {
+    TRY(atomconv_fwd(eng, b, l));
+    if (b->A > 0) {
+      TRY(bondconv_fwd(eng, b, l));
+      if (l < L - 2) TRY(angleupd_fwd(eng, b, l));   // the last AngleUpdate's output is never consumed
+    }
+  }
+  if (want_m) {
+    LaunchScope ls(eng, "magmom");
+    hipLaunchKernelGGL(k_magmom, dim3(wave_grid(eng, b->N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->magmom, b->N);
+  }
+  TRY(atomconv_fwd(eng, b, L - 1));
+
+  // ---- readout (model.py:497-509) and its adjoint ----
+  TRY(zero(eng, b->energy_sum, sizeof(float) * b->B));
+  TRY(zero(eng, b->comp_sum, sizeof(float) * b->B));
+  TRY(zero(eng, b->crystal_fea, sizeof(float) * (size_t)b->B * D));
+  {
+    ReadoutArgs r{};
+    r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = b->N;
+    r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
+    r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
+    r.has_composition = eng->desc.has_composition;
+    r.site_energy = b->site_energy; r.energy = b->energy_sum; r.comp_energy = b->comp_sum; r.crystal_fea = b->crystal_fea;
+    r.Ga = want_grad ? b->Ga : nullptr;
+    LaunchScope ls(eng, "readout");
+    hipLaunchKernelGGL(k_readout, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
+    HIP_TRY(eng, hipGetLastError());
+  }
+
+  // ---- reverse sweep: dE/dv_e ----
+  if (want_grad) {
+    TRY(zero(eng, b->Gb, sizeof(float) * (size_t)b->Eu * D));
+    TRY(zero(eng, b->Gwag, sizeof(float) * (size_t)b->Eu * D));
+    TRY(zero(eng, b->Gwbgc, sizeof(float) * (size_t)b->Eb * D));
+    TRY(zero(eng, b->Gang, sizeof(float) * (size_t)b->A * D));
+    TRY(atomconv_bwd(eng, b, L - 1));
+    for (int l = L - 2; l >= 0; --l) {
+      if (b->A > 0) {
+        if (l < L - 2) TRY(angleupd_bwd(eng, b, l));
+        TRY(bondconv_bwd(eng, b, l));
+      }
+      TRY(atomconv_bwd(eng, b, l));
+    }
+    TRY(zero(eng, b->Gu, sizeof(float) * (size_t)b->Ed * 4));
+    TRY(zero(eng, b->force, sizeof(float) * (size_t)b->N * 3));
+    TRY(zero(eng, b->virial, sizeof(float) * (size_t)b->B * 9));
+    if (b->Ed > 0) {
+      { LaunchScope ls(eng, "bond_embed_bwd");
+        hipLaunchKernelGGL((k_bond_embed<true>), dim3(wave_grid(eng, b->Eu)), dim3(256), 0, st, bond_embed_args(eng, b)); }
+      if (b->A > 0) {
+        LaunchScope ls(eng, "angle_embed_bwd");
+        hipLaunchKernelGGL((k_angle_embed<true>), dim3(wave_grid(eng, b->A)), dim3(256), 0, st, angle_embed_args(eng, b));
+      }
+      ForceArgs f{};
+      f.ev = b->ev; f.eu = b->eu; f.Gu = b->Gu; f.Grk = b->Grk;
+      f.e_center = b->e_center; f.e_nbr = b->e_nbr; f.e_d2u = b->e_d2u; f.e_owner = b->e_owner; f.u_u2d = b->u_u2d;
+      f.n_edges = b->Ed; f.force = b->force; f.virial = b->virial;
+      LaunchScope ls(eng, "edge_force");
+      hipLaunchKernelGGL(k_edge_force, g1(b->Ed), dim3(256), 0, st, f);
+    }
+    HIP_TRY(eng, hipGetLastError());
+  }
+  {
+    FinalizeArgs f{};
+    f.lattice = b->lattice; f.atom_off = b->atom_off; f.n_struct = b->B;
+    f.is_intensive = eng->desc.is_intensive; f.has_composition = eng->desc.has_composition; f.want_stress = want_s;
+    f.energy_sum = b->energy_sum; f.comp_sum = b->comp_sum; f.energy_out = b->energy; f.virial = b->virial; f.volume = b->volume;
+    LaunchScope ls(eng, "finalize");
+    hipLaunchKernelGGL(k_finalize, g1(b->B), dim3(256), 0, st, f);
+    HIP_TRY(eng, hipGetLastError());
+  }
+  b->last_task = task;
+  return CHG_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t pos = 0;
+  template <class T>
+  T* take(size_t n) {
+    pos = (pos + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + pos) : nullptr;
+    pos += std::max<size_t>(n, 1) * sizeof(T);
+    return p;
+  }
+};
+
+void carve(chg_batch* b, char* base, size_t& total) {
+  Carver c{base};
+  const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+  const int L = b->L;
+  b->z = c.take<int>(N); b->atom_owner = c.take<int>(N); b->atom_off = c.take<int>(B + 1);
+  b->e_center = c.take<int>(Ed); b->e_nbr = c.take<int>(Ed); b->e_d2u = c.take<int>(Ed); b->e_owner = c.take<int>(Ed);
+  b->u_u2d = c.take<int>(Eu); b->u_bnode = c.take<int>(Eu); b->bn_und = c.take<int>(Eb);
+  b->a_ctr = c.take<int>(A); b->a_b1c = c.take<int>(A); b->a_b2c = c.take<int>(A); b->a_d1 = c.take<int>(A); b->a_d2 = c.take<int>(A);
+  b->frac = c.take<float>(3 * N); b->lattice = c.take<float>(9 * B); b->e_image = c.take<float>(3 * Ed);
+  b->cart = c.take<float>(3 * N); b->ev = c.take<f32x4>(Ed); b->eu = c.take<f32x4>(Ed);
+  b->hb0 = c.take<float>(Eu * D); b->wag = c.take<float>(Eu * D); b->wbgc = c.take<float>(Eb * D);
+  for (int l = 0; l <= L; ++l) b->atom[l] = c.take<float>(N * D);
+  for (int l = 0; l < L; ++l) b->hbc[l] = (A > 0 || l == 0) ? c.take<float>(Eb * D) : nullptr;
+  for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
+  b->P = c.take<float>(N * 4 * D); b->Q = c.take<float>(Eu * 2 * D); b->R = c.take<float>(Eb * 4 * D); b->S = c.take<float>(N * 2 * D);
+  b->agg = c.take<float>(N * D); b->aggB = c.take<float>(Eb * D);
+  b->energy_sum = c.take<float>(B); b->comp_sum = c.take<float>(B); b->energy = c.take<float>(B);
+  b->site_energy = c.take<float>(N); b->magmom = c.take<float>(N); b->crystal_fea = c.take<float>(B * D);
+  b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B); b->volume = c.take<float>(B);
+  b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D); b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D);
+  b->Gwbgc = c.take<float>(Eb * D); b->Gang = c.take<float>(A * D); b->GP = c.take<float>(N * 4 * D); b->GQ = c.take<float>(Eu * 2 * D);
+  b->GR = c.take<float>(Eb * 4 * D); b->GS = c.take<float>(N * 2 * D); b->Gagg = c.take<float>(Eb * D);
+  b->Grk = c.take<float>(Eu); b->Gu = c.take<float>(4 * Ed);
+  if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
+  total = (c.pos + 255) & ~size_t(255);
+}
+
+void register_names(chg_batch* b) {
+  auto& m = b->named;
+  m.clear();
+  const size_t N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb, B = b->B;
+  m["cart"] = {b->cart, 3 * N};
+  m["ev"] = {reinterpret_cast<const float*>(b->ev), 4 * Ed};
+  m["eu"] = {reinterpret_cast<const float*>(b->eu), 4 * Ed};
+  m["hb0"] = {b->hb0, Eu * D}; m["wag"] = {b->wag, Eu * D}; m["wbgc"] = {b->wbgc, Eb * D};
+  for (int l = 0; l <= b->L; ++l) m["atom" + std::to_string(l)] = {b->atom[l], N * D};
+  for (int l = 0; l < b->L; ++l) m["hbc" + std::to_string(l)] = {b->hbc[l], Eb * D};
+  for (int l = 0; l < b->L - 1; ++l) m["ang" + std::to_string(l)] = {b->ang[l], A * D};
+  m["P"] = {b->P, N * 4 * D}; m["Q"] = {b->Q, Eu * 2 * D}; m["R"] = {b->R, Eb * 4 * D}; m["S"] = {b->S, N * 2 * D};
+  m["agg"] = {b->agg, N * D}; m["aggB"] = {b->aggB, Eb * D};
+  m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
+  m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
+  m["GR"] = {b->GR, Eb * 4 * D}; m["GS"] = {b->GS, N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
+  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["energy_sum"] = {b->energy_sum, B};
+}
+
+template <class T>
+int h2d(chg_engine* eng, T* dst, const T* src, size_t n) {
+  if (n == 0) return CHG_OK;
+  if (!src) { eng->err = "chg_batch_upload: null host array"; return CHG_EINVAL; }
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, eng->stream));
+  return CHG_OK;
+}
+template <class T>
+int d2h(chg_engine* eng, T* dst, const T* src, size_t n) {
+  if (n == 0 || !dst) return CHG_OK;
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, eng->stream));
+  return CHG_OK;
+}
+
+template <class K>
+int set_lds(chg_engine* eng, K kernel, size_t bytes) {
+  HIP_TRY(eng, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CHG_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+extern "C" {
+
+int chg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int device, chg_engine** out) {
+  if (!desc || !weights_blob || !out) return CHG_EINVAL;
+  if (desc->n_conv < 2 || desc->n_conv > MAX_CONV) return CHG_EUNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CHG_ENODEV;
+  chg_engine* eng = new (std::nothrow) chg_engine();
+  if (!eng) return CHG_ENOMEM;
+  *out = eng;  // returned even on failure so that chg_last_error is readable; destroy it either way
+  eng->device = device;
+  eng->desc = *desc;
+  HIP_TRY(eng, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(eng, hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    eng->err = std::string("device is ") + prop.gcnArchName + ", this library contains gfx950 code only";
+    return CHG_ENODEV;
+  }
+  eng->num_cus = prop.multiProcessorCount;
+  HIP_TRY(eng, hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+  HIP_TRY(eng, hipEventCreate(&eng->t0));
+  HIP_TRY(eng, hipEventCreate(&eng->t1));
+  Weights probe{};
+  const size_t need = layout_weights(nullptr, desc->n_conv, probe);
+  if ((int64_t)need != desc->n_weights) {
+    eng->err = "weight blob has " + std::to_string(desc->n_weights) + " floats, layout needs " + std::to_string(need);
+    return CHG_EINVAL;
+  }
+  HIP_TRY(eng, hipMalloc(&eng->d_weights, need * sizeof(float)));
+  HIP_TRY(eng, hipMemcpy(eng->d_weights, weights_blob, need * sizeof(float), hipMemcpyHostToDevice));
+  layout_weights(eng->d_weights, desc->n_conv, eng->w);
+  // kernels that need more than the default 64 KiB of dynamic LDS
+  int s;
+  if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
+  if ((s = set_lds(eng, k_atomconv<false>, atomconv_lds()))) return s;
+  if ((s = set_lds(eng, k_atomconv<true>, atomconv_lds()))) return s;
+  if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle<false, false>, angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_readout, readout_lds()))) return s;
+  return CHG_OK;
+}
+
+int chg_engine_destroy(chg_engine* eng) {
+  if (!eng) return CHG_OK;
+  hipSetDevice(eng->device);
+  if (eng->stream) hipStreamSynchronize(eng->stream);
+  for (auto& pe : eng->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
+  for (auto e : eng->event_pool) hipEventDestroy(e);
+  if (eng->t0) hipEventDestroy(eng->t0);
+  if (eng->t1) hipEventDestroy(eng->t1);
+  if (eng->d_weights) hipFree(eng->d_weights);
+  if (eng->stream) hipStreamDestroy(eng->stream);
+  delete eng;
+  return CHG_OK;
+}
+
+const char* chg_last_error(const chg_engine* eng) { return eng ? eng->err.c_str() : "null engine"; }
+
+int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) {
+  if (!eng || !h || !out) return CHG_EINVAL;
+  if (h->n_struct <= 0 || h->n_atoms <= 0 || h->n_directed < 0 || h->n_directed != 2 * h->n_undirected || h->n_angles < 0 ||
+      h->n_bnodes < 0 || (h->n_angles > 0 && h->n_bnodes == 0)) {
+    eng->err = "chg_batch_upload: inconsistent counts";
+    return CHG_EINVAL;
+  }
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  chg_batch* b = new (std::nothrow) chg_batch();
+  if (!b) return CHG_ENOMEM;
+  b->B = h->n_struct; b->N = h->n_atoms; b->Ed = h->n_directed; b->Eu = h->n_undirected; b->A = h->n_angles; b->Eb = h->n_bnodes;
+  b->L = eng->desc.n_conv;
+  size_t total = 0;
+  carve(b, nullptr, total);
+  if (hipMalloc(&b->arena, total) != hipSuccess) {
+    eng->err = "chg_batch_upload: hipMalloc of " + std::to_string(total) + " bytes failed";
+    delete b;
+    return CHG_ENOMEM;
+  }
+  b->arena_bytes = total;
+  carve(b, b->arena, total);
+  register_names(b);
+  int s = CHG_OK;
+  const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+#define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
+  UP(z, N); UP(atom_owner, N); UP(atom_off, B + 1); UP(frac, 3 * N); UP(lattice, 9 * B);
+  UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed);
+  UP(u_u2d, Eu); UP(u_bnode, Eu); UP(bn_und, Eb);
+  UP(a_ctr, A); UP(a_b1c, A); UP(a_b2c, A); UP(a_d1, A); UP(a_d2, A);
+#undef UP
+  if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "chg_batch_upload: sync failed"; s = CHG_EHIP; }
+  if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
+  *out = b;
+  return CHG_OK;
+}
+
+int chg_batch_update_geometry(chg_engine* eng, chg_batch* b, const float* frac, const float* lattice) {
+  if (!eng || !b) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  int s = CHG_OK;
+  if (frac) s = h2d(eng, b->frac, frac, (size_t)3 * b->N);
+  if (s == CHG_OK && lattice) s = h2d(eng, b->lattice, lattice, (size_t)9 * b->B);
+  if (s == CHG_OK) HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  return s;
+}
+
+int chg_batch_free(chg_engine* eng, chg_batch* b) {
+  if (!b) return CHG_OK;
+  if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
+  if (b->arena) hipFree(b->arena);
+  delete b;
+  return CHG_OK;
+}
+
+int64_t chg_batch_device_bytes(const chg_batch* b) { return b ? (int64_t)b->arena_bytes : 0; }
+
+int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
+  if (!eng || !b) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  return run_predict(eng, b, task_mask | CHG_TASK_E);
+}
+
+int chg_synchronize(chg_engine* eng) {
+  if (!eng) return CHG_EINVAL;
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  if (eng->profiling) return collect_profile(eng);
+  return CHG_OK;
+}
+
+int chg_batch_download(chg_engine* eng, chg_batch* b, const chg_out_host* o) {
+  if (!eng || !b || !o) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  const size_t B = b->B, N = b->N;
+  int s = d2h(eng, o->energy, b->energy, B);
+  if (s == CHG_OK && (b->last_task & CHG_TASK_F)) s = d2h(eng, o->force, b->force, 3 * N);
+  if (s == CHG_OK && (b->last_task & CHG_TASK_S)) s = d2h(eng, o->stress, b->virial, 9 * B);
+  if (s == CHG_OK && (b->last_task & CHG_TASK_M)) s = d2h(eng, o->magmom, b->magmom, N);
+  if (s == CHG_OK) s = d2h(eng, o->site_energy, b->site_energy, N);
+  if (s == CHG_OK) s = d2h(eng, o->atom_fea, b->atom[b->L - 1], N * D);
+  if (s == CHG_OK) s = d2h(eng, o->crystal_fea, b->crystal_fea, B * D);
+  if (s != CHG_OK) return s;
+  return chg_synchronize(eng);
+}
+
+int chg_timer_start(chg_engine* eng) {
+  if (!eng) return CHG_EINVAL;
+  HIP_TRY(eng, hipEventRecord(eng->t0, eng->stream));
+  return CHG_OK;
+}
+
+int chg_timer_stop_ms(chg_engine* eng, float* elapsed_ms) {
+  if (!eng || !elapsed_ms) return CHG_EINVAL;
+  HIP_TRY(eng, hipEventRecord(eng->t1, eng->stream));
+  HIP_TRY(eng, hipEventSynchronize(eng->t1));
+  HIP_TRY(eng, hipEventElapsedTime(elapsed_ms, eng->t0, eng->t1));
+  return CHG_OK;
+}
+
+int chg_profile_enable(chg_engine* eng, int on) {
+  if (!eng) return CHG_EINVAL;
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  if (eng->profiling) collect_profile(eng);
+  eng->profiling = on != 0;
+  return CHG_OK;
+}
+
+int chg_profile_reset(chg_engine* eng) {
+  if (!eng) return CHG_EINVAL;
+  for (auto& p : eng->prof) { p.launches = 0; p.ms = 0.0; }
+  return CHG_OK;
+}
+
+int chg_profile_count(chg_engine* eng) { return eng ? (int)eng->prof.size() : 0; }
+
+int chg_profile_read(chg_engine* eng, int i, char* label, int label_cap, int64_t* launches, double* total_ms) {
+  if (!eng || i < 0 || i >= (int)eng->prof.size()) return CHG_EINVAL;
+  const ProfEntry& p = eng->prof[i];
+  if (label && label_cap > 0) { std::strncpy(label, p.label.c_str(), label_cap - 1); label[label_cap - 1] = 0; }
+  if (launches) *launches = p.launches;
+  if (total_ms) *total_ms = p.ms;
+  return CHG_OK;
+}
+
+int chg_debug_fetch(chg_engine* eng, chg_batch* b, const char* name, float* dst, int64_t capacity, int64_t* n_written) {
+  if (!eng || !b || !name || !dst) return CHG_EINVAL;
+  auto it = b->named.find(name);
+  if (it == b->named.end()) { eng->err = std::string("chg_debug_fetch: unknown buffer ") + name; return CHG_EINVAL; }
+  const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  if (n) HIP_TRY(eng, hipMemcpy(dst, it->second.first, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (n_written) *n_written = (int64_t)n;
+  return CHG_OK;
+}
+
+int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const float* bias, float* y, int rows, int k, int nout) {
+  if (!eng || !x || !wt || !y || rows <= 0) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr;
+  HIP_TRY(eng, hipMalloc(&dx, sizeof(float) * (size_t)rows * k));
+  HIP_TRY(eng, hipMalloc(&dw, sizeof(float) * (size_t)nout * k));
+  HIP_TRY(eng, hipMalloc(&db, sizeof(float) * (size_t)nout));
+  HIP_TRY(eng, hipMalloc(&dy, sizeof(float) * (size_t)rows * nout));
+  HIP_TRY(eng, hipMemcpy(dx, x, sizeof(float) * (size_t)rows * k, hipMemcpyHostToDevice));
+  HIP_TRY(eng, hipMemcpy(dw, wt, sizeof(float) * (size_t)nout * k, hipMemcpyHostToDevice));
+  if (bias) HIP_TRY(eng, hipMemcpy(db, bias, sizeof(float) * (size_t)nout, hipMemcpyHostToDevice));
+  int s = rows_gemm(eng, "test_gemm", k, nout, dx, k, nullptr, dw, bias ? db : nullptr, nullptr, 0, dy, nout, nullptr, rows, 0);
+  if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "test gemm failed"; s = CHG_EHIP; }
+  if (s == CHG_OK) hipMemcpy(y, dy, sizeof(float) * (size_t)rows * nout, hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dw); hipFree(db); hipFree(dy);
+  return s;
+}
+
+}  // extern "C"

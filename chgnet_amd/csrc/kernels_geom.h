@@ -1,0 +1,332 @@
+// kernels_geom.h -- geometry, basis functions, embeddings and the final force / virial step.
+//
+// Reference ops replaced (file:line relative to /root/reference/chgnet):
+//   frac @ lattice, bond vectors under PBC      model/model.py:840, model/encoders.py:98-102
+//   RadialBessel x CutoffPolynomial (both cutoffs) model/basis.py:108-116, 197-206
+//   bond_embedding / bond_weights_ag / _bg      model/model.py:435-437
+//   AngleEncoder (acos, Fourier) + angle_embedding model/encoders.py:144-146, basis.py:33-40, model.py:439
+//   AtomEmbedding                               model/model.py:432-434
+//   site_wise magmom head                       model/model.py:484-487
+//   autograd of all of the above w.r.t. positions / strain  model/model.py:517-535
+// Bases are never materialised: each kernel evaluates them in registers and contracts them
+// with the 31x64 embedding weights immediately.
+#pragma once
+
+#include "mfma_tile.h"
+
+namespace chg {
+
+constexpr int NRAD = 31;
+constexpr int NANG = 31;
+constexpr int NFREQ = 15;
+constexpr float KAPPA = 0.999999f;          // fp32(1 - 1e-6), encoders.py:144
+constexpr float INV_SQRT_PI = 0.56418958354775628f;
+constexpr float INV_SQRT_2 = 0.70710678118654752f;
+constexpr float EV_A3_TO_GPA = 160.21766208f;  // model.py:532
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// ---- cartesian coordinates: x = frac @ lattice ------------------------------------------------
+__global__ void k_cart(const float* __restrict__ frac, const float* __restrict__ lattice, const int* __restrict__ owner,
+                       float* __restrict__ cart, int n_atoms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const float* L = lattice + 9 * owner[i];
+  const float f0 = frac[3 * i], f1 = frac[3 * i + 1], f2 = frac[3 * i + 2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cart[3 * i + k] = fmaf(f2, L[6 + k], fmaf(f1, L[3 + k], f0 * L[k]));
+}
+
+// ---- directed bond vectors, lengths and unit vectors ---------------------------------------------
+// ev[e] = (vx, vy, vz, r),  eu[e] = (ux, uy, uz, 0)
+__global__ void k_edge_geom(const float* __restrict__ cart, const float* __restrict__ lattice, const int* __restrict__ e_center,
+                            const int* __restrict__ e_nbr, const float* __restrict__ e_image, const int* __restrict__ e_owner,
+                            f32x4* __restrict__ ev, f32x4* __restrict__ eu, int n_edges) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const float* L = lattice + 9 * e_owner[e];
+  const int c = e_center[e], n = e_nbr[e];
+  const float i0 = e_image[3 * e], i1 = e_image[3 * e + 1], i2 = e_image[3 * e + 2];
+  float v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float off = fmaf(i2, L[6 + k], fmaf(i1, L[3 + k], i0 * L[k]));  // image @ lattice
+    const float nb = cart[3 * n + k] + off;                               // encoders.py:98
+    v[k] = cart[3 * c + k] - nb;                                          // encoders.py:99
+  }
+  const float r = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  f32x4 a = {v[0], v[1], v[2], r};
+  f32x4 b = {v[0] / r, v[1] / r, v[2] / r, 0.f};                           // zero-length bond -> NaN, as the reference
+  ev[e] = a;
+  eu[e] = b;
+}
+
+// ---- radial basis helpers ----------------------------------------------------------------------
+struct Envelope { float a, b, c; int p; };
+__device__ __forceinline__ float ipow(float x, int n) {
+  float r = 1.f, b = x;
+  while (n) {
+    if (n & 1) r *= b;
+    b *= b;
+    n >>= 1;
+  }
+  return r;
+}
+// basis value and d/dr for one frequency (basis.py:108-116, 197-206)
+__device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope env, float& val, float& dval) {
+  const float inv_rc = 1.0f / rc;
+  const float ds = r * inv_rc;
+  const float arg = freq * ds;
+  const float norm = sqrtf(2.0f * inv_rc);
+  float sn, cs;
+  sincosf(arg, &sn, &cs);
+  const float s = r / rc;
+  float e = 0.f, de = 0.f;
+  if (s < 1.0f) {
+    const float sp1 = ipow(s, env.p - 1), sp = sp1 * s;
+    e = 1.0f + env.a * sp + env.b * sp * s + env.c * sp * s * s;
+    de = (env.a * env.p * sp1 + env.b * (env.p + 1) * sp + env.c * (env.p + 2) * sp * s) * inv_rc;
+  }
+  const float base = norm * sn / r;
+  const float dbase = norm * (freq * inv_rc * cs / r - sn / (r * r));
+  val = e * base;
+  dval = de * base + e * dbase;
+}
+
+struct BondEmbedArgs {
+  const f32x4* ev;            // [Ed]
+  const int* u_u2d;           // [Eu]
+  const int* u_bnode;         // [Eu] compact bond-node index or -1
+  int n_und;
+  const float *freq_ag, *freq_bg;   // [31]
+  const float *w_emb, *w_ag, *w_bg; // [64][31]
+  float rc_ag, rc_bg;
+  Envelope env;
+  float *hb0, *wag, *wbgc;    // fwd out: [Eu,64], [Eu,64], [Eb,64]
+  // backward
+  const float *Gb, *Gwag, *Gwbgc;
+  float* Grk;                 // [Eu] dE/d r_k
+};
+
+// one wave per undirected bond (grid-stride), lane = output feature; lanes 0..30 also evaluate basis j
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bond_embed(BondEmbedArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float we[NRAD], wa[NRAD], wb[NRAD];
+#pragma unroll
+  for (int jj = 0; jj < NRAD; ++jj) {
+    we[jj] = p.w_emb[lane * NRAD + jj];
+    wa[jj] = p.w_ag[lane * NRAD + jj];
+    wb[jj] = p.w_bg[lane * NRAD + jj];
+  }
+  const int jb = lane < NRAD ? lane : 0;
+  const float f6 = p.freq_ag[jb], f3 = p.freq_bg[jb];
+  for (int k = wave; k < p.n_und; k += nwaves) {
+    const float r = p.ev[p.u_u2d[k]][3];
+    const int node = p.u_bnode[k];
+    float v6, d6, v3, d3;
+    rbf_eval(r, p.rc_ag, f6, p.env, v6, d6);
+    rbf_eval(r, p.rc_bg, f3, p.env, v3, d3);
+    if (!BWD) {
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NRAD; ++jj) {
+        const float b6 = bcast(v6, jj), b3 = bcast(v3, jj);
+        h0 = fmaf(b6, we[jj], h0);
+        h1 = fmaf(b6, wa[jj], h1);
+        h2 = fmaf(b3, wb[jj], h2);
+      }
+      p.hb0[(size_t)k * D + lane] = h0;
+      p.wag[(size_t)k * D + lane] = h1;
+      if (node >= 0) p.wbgc[(size_t)node * D + lane] = h2;
+    } else {
+      const float g0 = p.Gb[(size_t)k * D + lane], g1 = p.Gwag[(size_t)k * D + lane];
+      const float g2 = node >= 0 ? p.Gwbgc[(size_t)node * D + lane] : 0.f;
+      float t = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NRAD; ++jj) {
+        const float b6 = bcast(d6, jj), b3 = bcast(d3, jj);
+        t = fmaf(fmaf(g0, we[jj], g1 * wa[jj]), b6, t);
+        t = fmaf(g2 * wb[jj], b3, t);
+      }
+      t = wave_sum(t);
+      if (lane == 0) p.Grk[k] = t;
+    }
+  }
+}
+
+struct AngleEmbedArgs {
+  const f32x4* eu;            // [Ed] unit vectors
+  const int *a_d1, *a_d2;     // [A] directed edges of the two bonds
+  int n_angles;
+  const float* freq;          // [15]
+  const float* w_emb;         // [64][31]
+  float* ang0;                // fwd out [A,64]
+  const float* Gang;          // bwd in  [A,64]
+  float* Gu;                  // bwd out [Ed,4] zeroed, dE/d unit vectors
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_angle_embed(AngleEmbedArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float w[NANG];
+#pragma unroll
+  for (int jj = 0; jj < NANG; ++jj) w[jj] = p.w_emb[lane * NANG + jj];
+  // lane jj evaluates basis jj: 0 -> const, 1..15 -> sin(g t), 16..30 -> cos(g t)   (basis.py:35-40)
+  const int fi = lane == 0 ? 0 : (lane <= NFREQ ? lane - 1 : (lane < NANG ? lane - 1 - NFREQ : 0));
+  const float g = p.freq[fi];
+  for (int a = wave; a < p.n_angles; a += nwaves) {
+    const int d1 = p.a_d1[a], d2 = p.a_d2[a];
+    const f32x4 u1 = p.eu[d1], u2 = p.eu[d2];
+    const float cosv = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]) * KAPPA;
+    const float theta = acosf(cosv);
+    float sn, cs;
+    sincosf(g * theta, &sn, &cs);
+    float val, dval;
+    if (lane == 0) {
+      val = INV_SQRT_2 * INV_SQRT_PI;
+      dval = 0.f;
+    } else if (lane <= NFREQ) {
+      val = sn * INV_SQRT_PI;
+      dval = g * cs * INV_SQRT_PI;
+    } else {
+      val = cs * INV_SQRT_PI;
+      dval = -g * sn * INV_SQRT_PI;
+    }
+    if (!BWD) {
+      float hsum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NANG; ++jj) hsum = fmaf(bcast(val, jj), w[jj], hsum);
+      p.ang0[(size_t)a * D + lane] = hsum;
+    } else {
+      const float ga = p.Gang[(size_t)a * D + lane];
+      float t = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NANG; ++jj) t = fmaf(bcast(dval, jj), w[jj], t);
+      const float gtheta = wave_sum(t * ga);
+      const float gcos = -gtheta / sqrtf(1.0f - cosv * cosv) * KAPPA;
+      if (lane < 3) {
+        atomicAdd(reinterpret_cast<float*>(p.Gu + 0) + 4 * (size_t)d1 + lane, gcos * u2[lane]);
+        atomicAdd(reinterpret_cast<float*>(p.Gu + 0) + 4 * (size_t)d2 + lane, gcos * u1[lane]);
+      }
+    }
+  }
+}
+
+// ---- atom embedding ------------------------------------------------------------------------------
+__global__ void k_atom_embed(const int* __restrict__ z, const float* __restrict__ emb, float* __restrict__ out, int n_atoms) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_atoms * (D / 4)) return;
+  const int i = idx / (D / 4), q = idx % (D / 4);
+  reinterpret_cast<f32x4*>(out)[idx] = reinterpret_cast<const f32x4*>(emb + (size_t)(z[i] - 1) * D)[q];
+}
+
+// ---- magmom head: |h . w + b| ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_magmom(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
+                                                float* __restrict__ out, int n_atoms) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float wl = w[lane], bb = b[0];
+  for (int i = wave; i < n_atoms; i += nwaves) {
+    const float s = wave_sum(atom[(size_t)i * D + lane] * wl);
+    if (lane == 0) out[i] = fabsf(s + bb);
+  }
+}
+
+// ---- dE/dv_e -> forces and per-structure virial (SURVEY App. B "Geometry") -----------------------
+struct ForceArgs {
+  const f32x4 *ev, *eu;
+  const float* Gu;            // [Ed,4]
+  const float* Grk;           // [Eu]
+  const int *e_center, *e_nbr, *e_d2u, *e_owner, *u_u2d;
+  int n_edges;
+  float* force;               // [N,3] zeroed
+  float* virial;              // [B,9] zeroed
+};
+
+__global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = e < p.n_edges;
+  float gv[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  int owner = -1;
+  if (valid) {
+    const f32x4 vr = p.ev[e], u = p.eu[e];
+    const int k = p.e_d2u[e];
+    const float gr = (p.u_u2d[k] == e) ? p.Grk[k] : 0.f;   // lengths enter only via the representative edge
+    const float g0 = p.Gu[4 * (size_t)e], g1 = p.Gu[4 * (size_t)e + 1], g2 = p.Gu[4 * (size_t)e + 2];
+    const float dotp = g0 * u[0] + g1 * u[1] + g2 * u[2];
+    const float inv_r = 1.0f / vr[3];
+    gv[0] = gr * u[0] + (g0 - dotp * u[0]) * inv_r;
+    gv[1] = gr * u[1] + (g1 - dotp * u[1]) * inv_r;
+    gv[2] = gr * u[2] + (g2 - dotp * u[2]) * inv_r;
+    v[0] = vr[0];
+    v[1] = vr[1];
+    v[2] = vr[2];
+    owner = p.e_owner[e];
+    const int c = p.e_center[e], n = p.e_nbr[e];
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      atomicAdd(p.force + 3 * (size_t)c + k3, -gv[k3]);
+      atomicAdd(p.force + 3 * (size_t)n + k3, gv[k3]);
+    }
+  }
+  // virial: dE/d eps[a][b] = sum_e v_e[a] * gv_e[b]; reduce across the wave when it sits in one structure
+  const int first = __builtin_amdgcn_readfirstlane(owner);
+  const bool uniform = __all(owner == first || owner < 0) != 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float t = v[a] * gv[b];
+      if (uniform) {
+        const float s = wave_sum(t);
+        if ((threadIdx.x & 63) == 0 && first >= 0) atomicAdd(p.virial + 9 * (size_t)first + 3 * a + b, s);
+      } else if (valid) {
+        atomicAdd(p.virial + 9 * (size_t)owner + 3 * a + b, t);
+      }
+    }
+}
+
+// ---- per-structure finalisation: energy normalisation, AtomRef, stress scaling ---------------------
+struct FinalizeArgs {
+  const float* lattice;       // [B,9]
+  const int* atom_off;        // [B+1]
+  int n_struct;
+  int is_intensive, has_composition, want_stress;
+  const float *energy_sum, *comp_sum;
+  float* energy_out;          // [B]
+  float* virial;              // [B,9] in: dE/d eps, out: stress in GPa
+  float* volume;              // [B]
+};
+
+__global__ void k_finalize(FinalizeArgs p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.n_struct) return;
+  const float* L = p.lattice + 9 * b;
+  const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
+  const float vol = L[0] * cx + L[1] * cy + L[2] * cz;                 // model.py:834-836
+  p.volume[b] = vol;
+  const float n = (float)(p.atom_off[b + 1] - p.atom_off[b]);
+  float e = p.energy_sum[b];
+  if (p.is_intensive) e = e / n;                                        // model.py:538-540
+  if (p.has_composition) e += p.is_intensive ? p.comp_sum[b] / n : p.comp_sum[b];   // model.py:378
+  p.energy_out[b] = e;
+  if (p.want_stress) {
+    const float scale = 1.0f / vol * EV_A3_TO_GPA;                      // model.py:532
+    for (int k = 0; k < 9; ++k) p.virial[9 * b + k] *= scale;
+  }
+}
+
+}  // namespace chg

@@ -1,0 +1,180 @@
+"""Thin Python owner of a ``chg_engine`` / ``chg_batch`` (include/chgnet_hip.h)."""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from chgnet_amd import _lib
+from chgnet_amd.pack import D, PackedBatch, PackedWeights, pack_batch
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_float_p)
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_int_p)
+
+
+class DeviceBatch:
+    """A packed batch resident in HBM together with all its workspace."""
+
+    def __init__(self, engine: "Engine", packed: PackedBatch) -> None:
+        self.engine = engine
+        self.packed = packed
+        self.handle = ctypes.c_void_p()
+        self._host = self._host_struct(packed)
+        engine._check(engine.lib.chg_batch_upload(engine.handle, ctypes.byref(self._host), ctypes.byref(self.handle)))
+
+    @staticmethod
+    def _host_struct(pb: PackedBatch) -> _lib.BatchHost:
+        h = _lib.BatchHost()
+        h.n_struct, h.n_atoms, h.n_directed = pb.n_struct, pb.n_atoms, pb.n_directed
+        h.n_undirected, h.n_angles, h.n_bnodes = pb.n_undirected, pb.n_angles, pb.n_bnodes
+        for name in ("frac", "lattice", "e_image"):
+            setattr(h, name, _fp(pb.arrays[name]))
+        for name in ("z", "atom_owner", "atom_off", "e_center", "e_nbr", "e_d2u", "e_owner", "u_u2d", "u_bnode",
+                     "bn_und", "a_ctr", "a_b1c", "a_b2c", "a_d1", "a_d2"):
+            setattr(h, name, _ip(pb.arrays[name]))
+        return h
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.engine.lib.chg_batch_device_bytes(self.handle))
+
+    def update_geometry(self, frac=None, lattice=None) -> None:
+        f = np.ascontiguousarray(frac, dtype=np.float32) if frac is not None else None
+        l = np.ascontiguousarray(lattice, dtype=np.float32) if lattice is not None else None
+        self.engine._check(self.engine.lib.chg_batch_update_geometry(
+            self.engine.handle, self.handle, _fp(f) if f is not None else None, _fp(l) if l is not None else None))
+
+    def free(self) -> None:
+        if self.handle:
+            self.engine.lib.chg_batch_free(self.engine.handle, self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Engine:
+    """One engine per GPU; not thread-safe (serialise calls per engine)."""
+
+    def __init__(self, weights: PackedWeights, device: int = 0) -> None:
+        self.lib = _lib.load()
+        self.weights = weights
+        self.device = device
+        desc = _lib.ModelDesc(weights.n_conv, weights.cutoff_coeff, int(weights.is_intensive), int(weights.has_composition),
+                              weights.atom_graph_cutoff, weights.bond_graph_cutoff, weights.blob.size)
+        self.handle = ctypes.c_void_p()
+        blob = np.ascontiguousarray(weights.blob, dtype=np.float32)
+        status = self.lib.chg_engine_create(ctypes.byref(desc), _fp(blob), int(device), ctypes.byref(self.handle))
+        if status != 0:
+            msg = self.lib.chg_last_error(self.handle).decode() if self.handle else ""
+            if self.handle:
+                self.lib.chg_engine_destroy(self.handle)
+                self.handle = ctypes.c_void_p()
+            raise RuntimeError(f"chg_engine_create failed with status {status}: {msg or 'no usable gfx950 device'}")
+
+    def _check(self, status: int) -> None:
+        if status != 0:
+            raise RuntimeError(f"chgnet_hip error {status}: {self.lib.chg_last_error(self.handle).decode()}")
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.chg_engine_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------
+    def upload(self, graphs_or_packed) -> DeviceBatch:
+        packed = graphs_or_packed if isinstance(graphs_or_packed, PackedBatch) else pack_batch(graphs_or_packed)
+        return DeviceBatch(self, packed)
+
+    def predict(self, batch: DeviceBatch, task: str = "efsm") -> None:
+        """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""
+        self._check(self.lib.chg_predict(self.handle, batch.handle, _lib.task_mask(task)))
+
+    def synchronize(self) -> None:
+        self._check(self.lib.chg_synchronize(self.handle))
+
+    def download(self, batch: DeviceBatch, task: str = "efsm", *, site_energies=False, atom_feas=False,
+                 crystal_feas=False) -> dict:
+        """Copy results to host; returns batch-wide arrays (split per structure by the caller)."""
+        pb = batch.packed
+        out = {"e": np.empty(pb.n_struct, np.float32)}
+        o = _lib.OutHost()
+        o.energy = _fp(out["e"])
+        if "f" in task:
+            out["f"] = np.empty((pb.n_atoms, 3), np.float32)
+            o.force = _fp(out["f"])
+        if "s" in task:
+            out["s"] = np.empty((pb.n_struct, 3, 3), np.float32)
+            o.stress = _fp(out["s"])
+        if "m" in task:
+            out["m"] = np.empty(pb.n_atoms, np.float32)
+            o.magmom = _fp(out["m"])
+        if site_energies:
+            out["site_energies"] = np.empty(pb.n_atoms, np.float32)
+            o.site_energy = _fp(out["site_energies"])
+        if atom_feas:
+            out["atom_fea"] = np.empty((pb.n_atoms, D), np.float32)
+            o.atom_fea = _fp(out["atom_fea"])
+        if crystal_feas:
+            out["crystal_fea"] = np.empty((pb.n_struct, D), np.float32)
+            o.crystal_fea = _fp(out["crystal_fea"])
+        self._check(self.lib.chg_batch_download(self.handle, batch.handle, ctypes.byref(o)))
+        return out
+
+    # ---- timing / profiling on the engine's own stream ------------------------------------------------
+    def timer_start(self) -> None:
+        self._check(self.lib.chg_timer_start(self.handle))
+
+    def timer_stop_ms(self) -> float:
+        ms = ctypes.c_float()
+        self._check(self.lib.chg_timer_stop_ms(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on: bool) -> None:
+        self._check(self.lib.chg_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self) -> None:
+        self._check(self.lib.chg_profile_reset(self.handle))
+
+    def profile_read(self) -> dict:
+        out = {}
+        buf = ctypes.create_string_buffer(64)
+        for i in range(self.lib.chg_profile_count(self.handle)):
+            n, ms = ctypes.c_int64(), ctypes.c_double()
+            self._check(self.lib.chg_profile_read(self.handle, i, buf, 64, ctypes.byref(n), ctypes.byref(ms)))
+            out[buf.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
+    def debug_fetch(self, batch: DeviceBatch, name: str, shape) -> np.ndarray:
+        n = int(np.prod(shape))
+        dst = np.empty(max(n, 1), np.float32)
+        got = ctypes.c_int64()
+        self._check(self.lib.chg_debug_fetch(self.handle, batch.handle, name.encode(), _fp(dst), n, ctypes.byref(got)))
+        if got.value != n:
+            raise RuntimeError(f"debug_fetch({name}): expected {n} floats, device buffer has {got.value}")
+        return dst[:n].reshape(shape)
+
+    def test_rows_gemm(self, x: np.ndarray, wt: np.ndarray, bias: np.ndarray | None) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        wt = np.ascontiguousarray(wt, np.float32)
+        rows, k = x.shape
+        nout = wt.shape[0]
+        y = np.empty((rows, nout), np.float32)
+        b = np.ascontiguousarray(bias, np.float32) if bias is not None else None
+        self._check(self.lib.chg_test_rows_gemm(self.handle, _fp(x), _fp(wt), _fp(b) if b is not None else None, _fp(y), rows, k, nout))
+        return y

@@ -1,0 +1,280 @@
+"""``CHGNet`` -- host-side mirror of the reference model API for the inference path.
+
+Same constructor keywords, ``predict_structure`` / ``predict_graph`` signatures, task
+strings, error types/messages, output keys, dtypes and units as reference
+chgnet/model/model.py:544-665, and the same (de)serialisation surface
+(``as_dict`` / ``from_dict`` / ``from_file`` / ``load``, model.py:667-745).  All
+arithmetic happens in the gfx950 HIP engine (``chgnet_amd.engine``); there is no torch
+module graph and no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+from collections.abc import Sequence
+
+import numpy as np
+
+from chgnet_amd import VALID_TASKS
+from chgnet_amd.graph import CrystalGraph, CrystalGraphConverter
+from chgnet_amd.pack import D, N_ELEM, NUM_ANGULAR, NUM_RADIAL, check_model_args, pack_batch, pack_weights
+
+module_dir = os.path.dirname(os.path.abspath(__file__))
+
+_DEFAULT_ARGS = dict(
+    atom_fea_dim=64, bond_fea_dim=64, angle_fea_dim=64, composition_model="MPtrj", num_radial=31, num_angular=31,
+    n_conv=4, atom_conv_hidden_dim=64, update_bond=True, bond_conv_hidden_dim=64, update_angle=True,
+    angle_layer_hidden_dim=0, conv_dropout=0, read_out="ave", mlp_hidden_dims=(64, 64, 64), mlp_dropout=0,
+    mlp_first=True, is_intensive=True, non_linearity="silu", atom_graph_cutoff=6, bond_graph_cutoff=3,
+    graph_converter_algorithm="fast", cutoff_coeff=8, learnable_rbf=True, gMLP_norm="layer", readout_norm="layer",
+    version=None,
+)
+
+
+def _is_structure(obj) -> bool:
+    """pymatgen Structure or ours: anything with frac_coords + lattice that is not a sequence of them."""
+    return hasattr(obj, "frac_coords") and hasattr(obj, "lattice")
+
+
+def _is_graph(obj) -> bool:
+    return isinstance(obj, CrystalGraph) or (hasattr(obj, "atom_graph") and hasattr(obj, "bond_graph"))
+
+
+def random_state_dict(model_args: dict, seed: int = 0) -> dict:
+    """Randomly initialised parameters with the shapes of the reference ``state_dict``
+    (SURVEY 8.0); uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch's Linear default."""
+    rng = np.random.default_rng(seed)
+    L = int(model_args.get("n_conv", 4))
+    sd: dict[str, np.ndarray] = {}
+
+    def lin(name, out, inp, bias=True):
+        k = 1.0 / math.sqrt(inp)
+        sd[name + ".weight"] = rng.uniform(-k, k, (out, inp)).astype(np.float32)
+        if bias:
+            sd[name + ".bias"] = rng.uniform(-k, k, out).astype(np.float32)
+
+    def ln(name):
+        sd[name + ".weight"] = np.ones(D, np.float32)
+        sd[name + ".bias"] = np.zeros(D, np.float32)
+
+    if model_args.get("composition_model", "MPtrj") is not None:
+        sd["composition_model.fc.weight"] = np.zeros((1, N_ELEM), np.float32)
+    sd["atom_embedding.embedding.weight"] = rng.normal(0, 1, (N_ELEM, D)).astype(np.float32)
+    sd["bond_basis_expansion.rbf_expansion_ag.frequencies"] = (np.pi * np.arange(1, NUM_RADIAL + 1)).astype(np.float32)
+    sd["bond_basis_expansion.rbf_expansion_bg.frequencies"] = (np.pi * np.arange(1, NUM_RADIAL + 1)).astype(np.float32)
+    sd["angle_basis_expansion.fourier_expansion.frequencies"] = np.arange(1, (NUM_ANGULAR - 1) // 2 + 1).astype(np.float32)
+    for n in ("bond_embedding", "bond_weights_ag", "bond_weights_bg"):
+        lin(n, D, NUM_RADIAL, bias=False)
+    lin("angle_embedding", D, NUM_ANGULAR, bias=False)
+    mlp_out_bias = bool(model_args.get("mlp_out_bias", False))
+    for l in range(L):
+        p = f"atom_conv_layers.{l}"
+        for br in ("mlp_core", "mlp_gate"):
+            lin(f"{p}.twoBody_atom.{br}.layers.0", D, 3 * D)
+            lin(f"{p}.twoBody_atom.{br}.layers.3", D, D)
+        ln(f"{p}.twoBody_atom.bn1")
+        ln(f"{p}.twoBody_atom.bn2")
+        lin(f"{p}.mlp_out.layers.1", D, D, bias=mlp_out_bias)
+    for l in range(L - 1):
+        p = f"bond_conv_layers.{l}"
+        for br in ("mlp_core", "mlp_gate"):
+            lin(f"{p}.twoBody_bond.{br}.layers.0", D, 4 * D)
+            lin(f"{p}.twoBody_bond.{br}.layers.3", D, D)
+        ln(f"{p}.twoBody_bond.bn1")
+        ln(f"{p}.twoBody_bond.bn2")
+        lin(f"{p}.mlp_out.layers.1", D, D, bias=mlp_out_bias)
+        p = f"angle_layers.{l}"
+        for br in ("mlp_core", "mlp_gate"):
+            lin(f"{p}.twoBody_bond.{br}.layers.1", D, 4 * D)
+        ln(f"{p}.twoBody_bond.bn1")
+        ln(f"{p}.twoBody_bond.bn2")
+    lin("site_wise", 1, D)
+    ln("readout_norm")
+    for k in (0, 2, 4):
+        lin(f"mlp.layers.{k}", D, D)
+    lin("mlp.layers.7", 1, D)
+    return sd
+
+
+class CHGNet:
+    """Crystal Hamiltonian Graph neural Network, inference path on MI355X."""
+
+    def __init__(self, *, state_dict: dict | None = None, use_device: str | int | None = None, seed: int = 0, **kwargs) -> None:
+        args = dict(_DEFAULT_ARGS)
+        args.update(kwargs)
+        if args.get("version") is None:
+            args.pop("version", None)
+        self.model_args = args
+        check_model_args(args)
+        self.atom_fea_dim = args["atom_fea_dim"]
+        self.bond_fea_dim = args["bond_fea_dim"]
+        self.is_intensive = args["is_intensive"]
+        self.n_conv = args["n_conv"]
+        self.mlp_first = True
+        self.graph_converter = CrystalGraphConverter(
+            atom_graph_cutoff=args["atom_graph_cutoff"], bond_graph_cutoff=args["bond_graph_cutoff"],
+            algorithm=args.get("graph_converter_algorithm", "fast"), verbose=args.pop("converter_verbose", False))
+        self._state_dict = {k: _to_numpy(v) for k, v in (state_dict or random_state_dict(args, seed)).items()}
+        if args.get("composition_model") is None:
+            self._state_dict.pop("composition_model.fc.weight", None)
+        self.composition_model = "AtomRef" if "composition_model.fc.weight" in self._state_dict else None
+        self._weights = pack_weights(self._state_dict, args)
+        self._device = _parse_device(use_device)
+        self._engine = None
+        version_str = f" v{self.version}" if self.version else ""
+        print(f"CHGNet{version_str} initialized with {self.n_params:,} parameters")
+
+    # ---- properties mirrored from the reference (model.py:320-328) --------------------------------
+    @property
+    def version(self) -> str | None:
+        return self.model_args.get("version")
+
+    @property
+    def n_params(self) -> int:
+        return int(sum(v.size for v in self._state_dict.values()))
+
+    @property
+    def device(self) -> str:
+        return f"cuda:{self._device}"
+
+    def state_dict(self) -> dict:
+        return self._state_dict
+
+    @property
+    def engine(self):
+        """The HIP engine, created on first use; raises if the extension or a gfx950 GPU is missing."""
+        if self._engine is None:
+            from chgnet_amd.engine import Engine
+
+            self._engine = Engine(self._weights, self._device)
+        return self._engine
+
+    def to(self, device) -> "CHGNet":
+        dev = _parse_device(device)
+        if dev != self._device:
+            self._device = dev
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = None
+        return self
+
+    def eval(self) -> "CHGNet":
+        return self
+
+    # ---- prediction (model.py:544-665) ---------------------------------------------------------------
+    def predict_structure(self, structure, *, task: str = "efsm", return_site_energies: bool = False,
+                          return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16):
+        """Predict from structure(s) (pymatgen ``Structure`` or ``chgnet_amd.Structure``)."""
+        if self.graph_converter is None:
+            raise ValueError("graph_converter cannot be None!")
+        single = _is_structure(structure)
+        structures = [structure] if single else structure
+        graphs = [self.graph_converter(struct) for struct in structures]
+        out = self.predict_graph(graphs, task=task, return_site_energies=return_site_energies,
+                                 return_atom_feas=return_atom_feas, return_crystal_feas=return_crystal_feas,
+                                 batch_size=batch_size)
+        return out
+
+    def predict_graph(self, graph, *, task: str = "efsm", return_site_energies: bool = False,
+                      return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16):
+        """Predict from CrystalGraph(s).
+
+        Returns a dict (single graph) or list of dicts with float32 numpy arrays:
+        e () eV/atom, f (n,3) eV/A, s (3,3) GPa, m (n,) mu_B, and optionally
+        site_energies (n,), atom_fea (n,64), crystal_fea (64,).
+        """
+        if not (_is_graph(graph) or isinstance(graph, Sequence)):
+            raise TypeError(f"{type(graph)=} must be CrystalGraph or list of CrystalGraphs")
+        valid_tasks = VALID_TASKS
+        if task not in valid_tasks:
+            raise ValueError(f"Invalid {task=}. Must be one of {valid_tasks}.")
+        graphs = [graph] if _is_graph(graph) else list(graph)
+        predictions: list[dict] = [{} for _ in range(len(graphs))]
+        n_steps = math.ceil(len(graphs) / batch_size)
+        eng = self.engine
+        for step in range(n_steps):
+            chunk = graphs[batch_size * step: batch_size * (step + 1)]
+            packed = pack_batch(chunk)
+            batch = eng.upload(packed)
+            try:
+                eng.predict(batch, task)
+                res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,
+                                   crystal_feas=return_crystal_feas)
+            finally:
+                batch.free()
+            off = packed.atom_off
+            for i in range(len(chunk)):
+                pred = predictions[step * batch_size + i]
+                sl = slice(off[i], off[i + 1])
+                pred["e"] = res["e"][i]
+                for key in ("f", "m", "site_energies", "atom_fea"):
+                    if key in res:
+                        pred[key] = res[key][sl].copy()
+                for key in ("s", "crystal_fea"):
+                    if key in res:
+                        pred[key] = res[key][i].copy()
+        return predictions[0] if len(graphs) == 1 else predictions
+
+    # ---- (de)serialisation (model.py:667-745) ----------------------------------------------------------
+    def as_dict(self) -> dict:
+        return {"state_dict": self._state_dict, "model_args": self.model_args}
+
+    def todict(self) -> dict:
+        return {"model_name": type(self).__name__, "model_args": self.model_args}
+
+    @classmethod
+    def from_dict(cls, dct: dict, **kwargs) -> "CHGNet":
+        return cls(state_dict=dct["state_dict"], **dct["model_args"], **kwargs)
+
+    @classmethod
+    def from_file(cls, path: str, **kwargs) -> "CHGNet":
+        """Read a reference checkpoint: ``torch.save({"model": {"state_dict", "model_args"}, ...})``."""
+        import torch  # noqa: PLC0415  (only the pickle reader; no torch compute)
+
+        state = torch.load(path, map_location="cpu", weights_only=False)
+        return cls.from_dict(state["model"], **kwargs)
+
+    @classmethod
+    def load(cls, *, model_name: str = "0.3.0", use_device: str | None = None, check_cuda_mem: bool = False,  # noqa: ARG003
+             verbose: bool = True, checkpoint_dir: str | None = None) -> "CHGNet":
+        """Load a pretrained checkpoint (same names as the reference, model.py:718-736).  The
+        ``.pth.tar`` blobs are not shipped with this repository: point ``checkpoint_dir`` (or
+        ``$CHGNET_CHECKPOINT_DIR``) at a reference ``chgnet/pretrained`` directory."""
+        rel = {
+            "0.3.0": "0.3.0/chgnet_0.3.0_e29f68s314m37.pth.tar",
+            "0.2.0": "0.2.0/chgnet_0.2.0_e30f77s348m32.pth.tar",
+            "r2scan": "r2scan/chgnet_r2scan_transfer_learning_e15f36s161m23.pth.tar",
+        }.get(model_name)
+        if rel is None:
+            raise ValueError(f"Unknown {model_name=}")
+        root = checkpoint_dir or os.environ.get("CHGNET_CHECKPOINT_DIR") or os.path.join(module_dir, "pretrained")
+        path = os.path.join(root, rel)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"checkpoint {path} not found (set CHGNET_CHECKPOINT_DIR)")
+        model = cls.from_file(path, mlp_out_bias=model_name == "0.2.0", version=model_name, use_device=use_device)
+        if verbose:
+            print(f"CHGNet will run on {model.device}")
+        return model
+
+
+def _to_numpy(v) -> np.ndarray:
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+
+
+def _parse_device(use_device) -> int:
+    """``None``/"cuda"/"cuda:N"/N -> GPU ordinal (env CHGNET_DEVICE like common_utils.py:27; LOCAL_RANK
+    for one-process-per-GPU launches).  CPU / MPS are not available in this engine."""
+    use_device = use_device if use_device is not None else os.environ.get("CHGNET_DEVICE")
+    if use_device is None:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    if isinstance(use_device, int):
+        return use_device
+    s = str(use_device)
+    if s in ("cuda", "hip", "gpu"):
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    if s.startswith("cuda:"):
+        return int(s.split(":", 1)[1])
+    raise ValueError(f"chgnet_amd runs on MI355X GPUs only; cannot use device {use_device!r}")

@@ -1,0 +1,305 @@
+"""Host-side packing: list[CrystalGraph] -> one SoA batch, state_dict -> one fp32 blob.
+
+The packed batch is what replaces the reference's per-graph Python loop
+``BatchedGraph.from_graphs`` (model.py:820-899): all index offsetting happens here, once,
+in numpy; geometry and basis functions are evaluated on the device.
+
+Extra index arrays (not in the reference) that the kernels use:
+  * ``bn_und`` / ``u_bnode`` -- compact numbering of the undirected bonds that are nodes of
+    the bond graph (appear in ``bond_graph[:,1]`` or ``[:,3]``); only those bonds are ever
+    updated by BondConv (layers.py:252-258), so per-layer bond features and the per-bond
+    partial products live in arrays of ``Eb`` rows (~15 % of ``Eu``);
+  * global (batch-wide) directed / undirected indices with per-structure offsets applied.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from chgnet_amd.graph.crystalgraph import CrystalGraph
+
+D = 64          # atom = bond = angle feature width of every released CHGNet
+NUM_RADIAL = 31
+NUM_ANGULAR = 31
+N_ELEM = 94
+
+
+@dataclass
+class PackedBatch:
+    n_struct: int
+    n_atoms: int
+    n_directed: int
+    n_undirected: int
+    n_angles: int
+    n_bnodes: int
+    arrays: dict = field(default_factory=dict)   # name -> contiguous numpy array
+
+    def __getattr__(self, name):
+        try:
+            return self.__dict__["arrays"][name]
+        except KeyError as exc:
+            raise AttributeError(name) from exc
+
+
+def pack_batch(graphs) -> PackedBatch:
+    """Concatenate graphs into one disjoint-union batch with global indices."""
+    graphs = [CrystalGraph.from_reference(g) for g in graphs]
+    B = len(graphs)
+    n_at = np.array([len(g.atomic_number) for g in graphs], dtype=np.int64)
+    n_ed = np.array([len(g.atom_graph) for g in graphs], dtype=np.int64)
+    n_un = np.array([len(g.undirected2directed) for g in graphs], dtype=np.int64)
+    n_an = np.array([len(g.bond_graph) for g in graphs], dtype=np.int64)
+    a_off = np.concatenate([[0], np.cumsum(n_at)])
+    e_off = np.concatenate([[0], np.cumsum(n_ed)])
+    u_off = np.concatenate([[0], np.cumsum(n_un)])
+    g_off = np.concatenate([[0], np.cumsum(n_an)])
+    N, Ed, Eu, A = int(a_off[-1]), int(e_off[-1]), int(u_off[-1]), int(g_off[-1])
+    if max(N, Ed, Eu, A) >= 2**31 - 1:
+        raise ValueError("batch too large for int32 indexing")
+
+    def cat(parts, dtype, shape_tail=()):
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return np.zeros((0, *shape_tail), dtype=dtype)
+        return np.ascontiguousarray(np.concatenate(parts), dtype=dtype)
+
+    arr = {}
+    arr["z"] = cat([g.atomic_number for g in graphs], np.int32)
+    arr["frac"] = cat([g.atom_frac_coord for g in graphs], np.float32, (3,))
+    arr["lattice"] = np.ascontiguousarray(np.stack([g.lattice for g in graphs]) if B else np.zeros((0, 3, 3)), dtype=np.float32)
+    arr["atom_owner"] = np.repeat(np.arange(B, dtype=np.int32), n_at)
+    arr["e_center"] = cat([g.atom_graph[:, 0] + a_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["e_nbr"] = cat([g.atom_graph[:, 1] + a_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["e_image"] = cat([g.neighbor_image for g in graphs], np.float32, (3,))
+    arr["e_d2u"] = cat([g.directed2undirected + u_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["e_owner"] = np.repeat(np.arange(B, dtype=np.int32), n_ed)
+    arr["u_u2d"] = cat([g.undirected2directed + e_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["a_ctr"] = cat([g.bond_graph[:, 0] + a_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["a_b1"] = cat([g.bond_graph[:, 1] + u_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["a_d1"] = cat([g.bond_graph[:, 2] + e_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["a_b2"] = cat([g.bond_graph[:, 3] + u_off[i] for i, g in enumerate(graphs)], np.int32)
+    arr["a_d2"] = cat([g.bond_graph[:, 4] + e_off[i] for i, g in enumerate(graphs)], np.int32)
+
+    # compact numbering of bond-graph nodes (monotone in the undirected index, so the
+    # angle rows stay sorted by their owning bond: graph.py:283-327 emits them that way)
+    is_node = np.zeros(Eu, dtype=bool)
+    is_node[arr["a_b1"]] = True
+    is_node[arr["a_b2"]] = True
+    bn_und = np.flatnonzero(is_node).astype(np.int32)
+    u_bnode = np.full(Eu, -1, dtype=np.int32)
+    u_bnode[bn_und] = np.arange(len(bn_und), dtype=np.int32)
+    arr["bn_und"] = bn_und
+    arr["u_bnode"] = u_bnode
+    arr["a_b1c"] = u_bnode[arr["a_b1"]].astype(np.int32) if A else np.zeros(0, np.int32)
+    arr["a_b2c"] = u_bnode[arr["a_b2"]].astype(np.int32) if A else np.zeros(0, np.int32)
+
+    arr["atom_off"] = a_off.astype(np.int32)
+    arr["edge_off"] = e_off.astype(np.int32)
+    arr["und_off"] = u_off.astype(np.int32)
+    arr["ang_off"] = g_off.astype(np.int32)
+    return PackedBatch(B, N, Ed, Eu, A, int(len(bn_und)), arr)
+
+
+# ---------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------
+SUPPORTED_MODEL_ARGS = {
+    "atom_fea_dim": 64, "bond_fea_dim": 64, "angle_fea_dim": 64, "num_radial": 31, "num_angular": 31,
+    "atom_conv_hidden_dim": 64, "bond_conv_hidden_dim": 64, "angle_layer_hidden_dim": 0,
+    "update_bond": True, "update_angle": True, "mlp_first": True, "non_linearity": "silu",
+    "gMLP_norm": "layer", "readout_norm": "layer", "conv_dropout": 0, "mlp_dropout": 0,
+}
+
+
+def check_model_args(model_args: dict) -> None:
+    """The engine implements the architecture family of every released checkpoint
+    (0.2.0 / 0.3.0 / r2scan: pretrained/*/README.md); anything else is rejected loudly."""
+    for key, want in SUPPORTED_MODEL_ARGS.items():
+        got = model_args.get(key, want)
+        if isinstance(want, bool) or isinstance(want, str) or want is None:
+            ok = got == want
+        else:
+            ok = (list(got) == [want] if isinstance(got, (list, tuple)) else got == want)
+        if not ok:
+            raise NotImplementedError(f"chgnet_amd engine does not implement {key}={got!r} (supports {want!r})")
+    hid = model_args.get("mlp_hidden_dims", (64, 64, 64))
+    if list(hid) != [64, 64, 64]:
+        raise NotImplementedError(f"mlp_hidden_dims={hid!r} not implemented (supports (64, 64, 64))")
+    if model_args.get("conv_norm") is not None:
+        raise NotImplementedError("conv_norm is not implemented")
+    if model_args.get("final_mlp", "MLP") not in {"normal", "MLP"}:
+        raise NotImplementedError("gated final_mlp is not implemented")
+    if int(model_args.get("n_conv", 4)) < 2:
+        raise NotImplementedError("n_conv must be >= 2")
+
+
+def _f32(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+
+
+@dataclass
+class PackedWeights:
+    blob: np.ndarray            # float32 [n_values]
+    offsets: dict               # name -> (offset, shape)
+    n_conv: int
+    atom_graph_cutoff: float
+    bond_graph_cutoff: float
+    cutoff_coeff: int
+    is_intensive: bool
+    has_composition: bool
+
+    def get(self, name: str) -> np.ndarray:
+        off, shape = self.offsets[name]
+        return self.blob[off:off + int(np.prod(shape))].reshape(shape)
+
+
+def weight_layout(n_conv: int) -> list[tuple[str, tuple]]:
+    """Names and shapes of every tensor in the blob, in blob order.  The C side
+    (csrc/weights.h) derives the same table from ``n_conv``; both must agree."""
+    lay: list[tuple[str, tuple]] = [
+        ("atomref", (N_ELEM,)), ("emb", (N_ELEM, D)),
+        ("freq_ag", (NUM_RADIAL,)), ("freq_bg", (NUM_RADIAL,)), ("freq_ang", ((NUM_ANGULAR - 1) // 2,)),
+        ("w_bond_emb", (D, NUM_RADIAL)), ("w_wag", (D, NUM_RADIAL)), ("w_wbg", (D, NUM_RADIAL)),
+        ("w_ang_emb", (D, NUM_ANGULAR)),
+    ]
+    gated_tail = [("w2c", (D, D)), ("b2c", (D,)), ("w2g", (D, D)), ("b2g", (D,)),
+                  ("w2c_t", (D, D)), ("w2g_t", (D, D))]
+    ln = [("ln1_g", (D,)), ("ln1_b", (D,)), ("ln2_g", (D,)), ("ln2_b", (D,))]
+    for l in range(n_conv):
+        p = f"ac{l}."
+        lay += [(p + "w_cn", (4 * D, D)),      # rows 0..127: centre block (core|gate), 128..255: neighbour block
+                (p + "w_bond", (2 * D, D)),    # bond block (core|gate)
+                (p + "b1", (2 * D,)),
+                *[(p + n, s) for n, s in gated_tail], *[(p + n, s) for n, s in ln],
+                (p + "w_out", (D, D)), (p + "b_out", (D,)),
+                (p + "w_out_t", (D, D)),       # [in,out] for G(agg) = G(h') . Wout
+                (p + "w_cn_t", (2, D, 2 * D)), # [block][in][128]: G(h_atom) += GPc . Wc + GPn . Wn
+                (p + "w_bond_t", (D, 2 * D))]
+    for l in range(n_conv - 1):
+        p = f"bc{l}."
+        lay += [(p + "w_bij", (4 * D, D)),     # rows 0..127: bond_i block, 128..255: bond_j block
+                (p + "w_ang", (2 * D, D)), (p + "w_ctr", (2 * D, D)), (p + "b1", (2 * D,)),
+                *[(p + n, s) for n, s in gated_tail], *[(p + n, s) for n, s in ln],
+                (p + "w_out", (D, D)), (p + "b_out", (D,)), (p + "w_out_t", (D, D)),
+                (p + "w_bij_t", (2, D, 2 * D)), (p + "w_ang_t", (D, 2 * D)), (p + "w_ctr_t", (D, 2 * D))]
+    for l in range(n_conv - 1):
+        p = f"au{l}."
+        lay += [(p + "w_bij", (4 * D, D)), (p + "w_ang", (2 * D, D)), (p + "w_ctr", (2 * D, D)), (p + "b1", (2 * D,)),
+                *[(p + n, s) for n, s in ln],
+                (p + "w_bij_t", (2, D, 2 * D)), (p + "w_ang_t", (D, 2 * D)), (p + "w_ctr_t", (D, 2 * D))]
+    lay += [("site_w", (D,)), ("site_b", (1,)), ("ro_ln_g", (D,)), ("ro_ln_b", (D,)),
+            ("mlp_w0", (D, D)), ("mlp_b0", (D,)), ("mlp_w1", (D, D)), ("mlp_b1", (D,)),
+            ("mlp_w2", (D, D)), ("mlp_b2", (D,)), ("mlp_w3", (D,)), ("mlp_b3", (1,)),
+            ("mlp_w0_t", (D, D)), ("mlp_w1_t", (D, D)), ("mlp_w2_t", (D, D))]
+    return lay
+
+
+def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeights:
+    """Re-lay the reference ``state_dict`` for the kernels."""
+    model_args = dict(model_args or {})
+    check_model_args(model_args)
+    sd = {k: _f32(v) for k, v in state_dict.items()}
+    n_conv = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("atom_conv_layers."))
+    vals: dict[str, np.ndarray] = {}
+
+    has_comp = "composition_model.fc.weight" in sd
+    vals["atomref"] = sd["composition_model.fc.weight"].reshape(-1) if has_comp else np.zeros(N_ELEM, np.float32)
+    vals["emb"] = sd["atom_embedding.embedding.weight"]
+    vals["freq_ag"] = sd["bond_basis_expansion.rbf_expansion_ag.frequencies"]
+    vals["freq_bg"] = sd["bond_basis_expansion.rbf_expansion_bg.frequencies"]
+    vals["freq_ang"] = sd["angle_basis_expansion.fourier_expansion.frequencies"]
+    vals["w_bond_emb"] = sd["bond_embedding.weight"]
+    vals["w_wag"] = sd["bond_weights_ag.weight"]
+    vals["w_wbg"] = sd["bond_weights_bg.weight"]
+    vals["w_ang_emb"] = sd["angle_embedding.weight"]
+
+    def cg(prefix, name):  # stack core | gate along the output axis
+        return np.concatenate([sd[f"{prefix}.mlp_core.{name}"], sd[f"{prefix}.mlp_gate.{name}"]], axis=0)
+
+    def gated_tail(p, prefix):
+        vals[p + "w2c"] = sd[f"{prefix}.mlp_core.layers.3.weight"]
+        vals[p + "b2c"] = sd[f"{prefix}.mlp_core.layers.3.bias"]
+        vals[p + "w2g"] = sd[f"{prefix}.mlp_gate.layers.3.weight"]
+        vals[p + "b2g"] = sd[f"{prefix}.mlp_gate.layers.3.bias"]
+        vals[p + "w2c_t"] = vals[p + "w2c"].T
+        vals[p + "w2g_t"] = vals[p + "w2g"].T
+
+    def ln(p, prefix):
+        vals[p + "ln1_g"], vals[p + "ln1_b"] = sd[f"{prefix}.bn1.weight"], sd[f"{prefix}.bn1.bias"]
+        vals[p + "ln2_g"], vals[p + "ln2_b"] = sd[f"{prefix}.bn2.weight"], sd[f"{prefix}.bn2.bias"]
+
+    def mlp_out(p, prefix):
+        vals[p + "w_out"] = sd[f"{prefix}.mlp_out.layers.1.weight"]
+        vals[p + "b_out"] = sd.get(f"{prefix}.mlp_out.layers.1.bias", np.zeros(D, np.float32))
+        vals[p + "w_out_t"] = vals[p + "w_out"].T
+
+    for l in range(n_conv):
+        p, pre = f"ac{l}.", f"atom_conv_layers.{l}.twoBody_atom"
+        w1 = cg(pre, "layers.0.weight")                       # [128, 192], columns [centre | bond | nbr] (layers.py:116)
+        vals[p + "w_cn"] = np.concatenate([w1[:, 0:D], w1[:, 2 * D:3 * D]], axis=0)
+        vals[p + "w_bond"] = w1[:, D:2 * D]
+        vals[p + "b1"] = cg(pre, "layers.0.bias")
+        gated_tail(p, pre)
+        ln(p, pre)
+        mlp_out(p, f"atom_conv_layers.{l}")
+        vals[p + "w_cn_t"] = np.stack([vals[p + "w_cn"][:2 * D].T, vals[p + "w_cn"][2 * D:].T])
+        vals[p + "w_bond_t"] = vals[p + "w_bond"].T
+    for l in range(n_conv - 1):
+        p, pre = f"bc{l}.", f"bond_conv_layers.{l}.twoBody_bond"
+        w1 = cg(pre, "layers.0.weight")                       # [128, 256], columns [bond_i | bond_j | angle | centre] (layers.py:241-243)
+        vals[p + "w_bij"] = np.concatenate([w1[:, 0:D], w1[:, D:2 * D]], axis=0)
+        vals[p + "w_ang"] = w1[:, 2 * D:3 * D]
+        vals[p + "w_ctr"] = w1[:, 3 * D:4 * D]
+        vals[p + "b1"] = cg(pre, "layers.0.bias")
+        gated_tail(p, pre)
+        ln(p, pre)
+        mlp_out(p, f"bond_conv_layers.{l}")
+        vals[p + "w_bij_t"] = np.stack([vals[p + "w_bij"][:2 * D].T, vals[p + "w_bij"][2 * D:].T])
+        for n in ("w_ang", "w_ctr"):
+            vals[p + n + "_t"] = vals[p + n].T
+    for l in range(n_conv - 1):
+        p, pre = f"au{l}.", f"angle_layers.{l}.twoBody_bond"
+        w1 = cg(pre, "layers.1.weight")                       # single Linear (functions.py:72-73), same column order (layers.py:351-353)
+        vals[p + "w_bij"] = np.concatenate([w1[:, 0:D], w1[:, D:2 * D]], axis=0)
+        vals[p + "w_ang"] = w1[:, 2 * D:3 * D]
+        vals[p + "w_ctr"] = w1[:, 3 * D:4 * D]
+        vals[p + "b1"] = cg(pre, "layers.1.bias")
+        ln(p, pre)
+        vals[p + "w_bij_t"] = np.stack([vals[p + "w_bij"][:2 * D].T, vals[p + "w_bij"][2 * D:].T])
+        for n in ("w_ang", "w_ctr"):
+            vals[p + n + "_t"] = vals[p + n].T
+    vals["site_w"] = sd["site_wise.weight"].reshape(-1)
+    vals["site_b"] = sd["site_wise.bias"].reshape(-1)
+    vals["ro_ln_g"], vals["ro_ln_b"] = sd["readout_norm.weight"], sd["readout_norm.bias"]
+    for i, k in enumerate((0, 2, 4)):
+        vals[f"mlp_w{i}"] = sd[f"mlp.layers.{k}.weight"]
+        vals[f"mlp_b{i}"] = sd[f"mlp.layers.{k}.bias"]
+        vals[f"mlp_w{i}_t"] = vals[f"mlp_w{i}"].T
+    vals["mlp_w3"] = sd["mlp.layers.7.weight"].reshape(-1)
+    vals["mlp_b3"] = sd["mlp.layers.7.bias"].reshape(-1)
+
+    offsets, chunks, pos = {}, [], 0
+    for name, shape in weight_layout(n_conv):
+        v = np.ascontiguousarray(vals[name], dtype=np.float32)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"weight {name}: expected shape {shape}, got {v.shape}")
+        pad = (-pos) % 4                                     # keep every tensor 16-byte aligned
+        if pad:
+            chunks.append(np.zeros(pad, np.float32))
+            pos += pad
+        offsets[name] = (pos, tuple(shape))
+        chunks.append(v.reshape(-1))
+        pos += v.size
+    blob = np.concatenate(chunks)
+    return PackedWeights(
+        blob=blob, offsets=offsets, n_conv=n_conv,
+        atom_graph_cutoff=float(model_args.get("atom_graph_cutoff", 6)),
+        bond_graph_cutoff=float(model_args.get("bond_graph_cutoff", 3)),
+        cutoff_coeff=int(model_args.get("cutoff_coeff", 8)),
+        is_intensive=bool(model_args.get("is_intensive", True)),
+        has_composition=has_comp,
+    )

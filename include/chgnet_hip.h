@@ -1,0 +1,133 @@
+/* chgnet_hip.h -- C-ABI of the MI355X (gfx950) CHGNet engine (libchgnet_hip.so).
+ *
+ * The reference has no FFI for this path: its boundary is the Python class API
+ *   CHGNet.predict_graph / forward      chgnet/model/model.py:593-665, 330-387
+ *   BatchedGraph.from_graphs            chgnet/model/model.py:792-913
+ *   CHGNet._compute                     chgnet/model/model.py:389-542
+ * This header is what a ctypes/cffi binding inside that class binds instead of running the
+ * torch modules.  Entry points:
+ *
+ *   chg_engine_create   <- CHGNet.__init__/load_state_dict (weights re-laid by pack.py)
+ *   chg_batch_upload    <- [g.to(device) for g in graphs] + index offsetting of from_graphs
+ *                          (model.py:640-644, 856-857, 873-877)
+ *   chg_predict         <- from_graphs geometry/bases + _compute + the two autograd.grad sweeps
+ *                          (model.py:826-871, 427-540, 517-535) + AtomRef (model.py:356-358,378)
+ *   chg_batch_download  <- tensor.cpu().detach().numpy() per key (model.py:651-663)
+ *
+ * Conventions: plain C types only; every function returns 0 or a negative chg_status and
+ * never throws; chg_last_error() gives the text of the last failure on that engine.  One
+ * engine per GPU; calls on one engine must be serialised by the caller; engines on different
+ * devices are independent (one process or thread per GPU).  Host buffers belong to the
+ * caller, device memory to the library.  All floating point is fp32, all indices int32.
+ */
+#ifndef CHGNET_HIP_H
+#define CHGNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  CHG_OK = 0,
+  CHG_EINVAL = -1,     /* bad argument */
+  CHG_EHIP = -2,       /* HIP runtime error (text in chg_last_error) */
+  CHG_ENOMEM = -3,     /* device or host allocation failed */
+  CHG_ENODEV = -4,     /* no usable gfx950 device */
+  CHG_EUNSUPPORTED = -5
+} chg_status;
+
+/* task bits (reference task strings "e","ef","em","efs","efsm": chgnet/__init__.py:15) */
+enum {
+  CHG_TASK_E = 1u,
+  CHG_TASK_F = 2u,
+  CHG_TASK_S = 4u,
+  CHG_TASK_M = 8u
+};
+
+typedef struct chg_engine chg_engine;
+typedef struct chg_batch chg_batch;
+
+typedef struct chg_model_desc {
+  int32_t n_conv;              /* 4 for every released checkpoint */
+  int32_t cutoff_coeff;        /* envelope exponent p (8 for 0.3.0) */
+  int32_t is_intensive;
+  int32_t has_composition;     /* AtomRef present */
+  float atom_graph_cutoff;     /* 6 A */
+  float bond_graph_cutoff;     /* 3 A */
+  int64_t n_weights;           /* length of the blob in floats; layout = chgnet_amd/pack.py:weight_layout */
+} chg_model_desc;
+
+/* Packed batch of B structures in global (batch-wide) numbering: chgnet_amd/pack.py:pack_batch. */
+typedef struct chg_batch_host {
+  int32_t n_struct, n_atoms, n_directed, n_undirected, n_angles, n_bnodes;
+  const int32_t* z;            /* [N]     atomic numbers                          */
+  const float* frac;           /* [N,3]   fractional coordinates                  */
+  const float* lattice;        /* [B,3,3] rows a,b,c                              */
+  const int32_t* atom_owner;   /* [N]     structure index                         */
+  const int32_t* atom_off;     /* [B+1]                                           */
+  const int32_t* e_center;     /* [Ed]    atom_graph[:,0]                         */
+  const int32_t* e_nbr;        /* [Ed]    atom_graph[:,1]                         */
+  const float* e_image;        /* [Ed,3]  neighbor_image                          */
+  const int32_t* e_d2u;        /* [Ed]    directed2undirected                     */
+  const int32_t* e_owner;      /* [Ed]    structure index                         */
+  const int32_t* u_u2d;        /* [Eu]    undirected2directed                     */
+  const int32_t* u_bnode;      /* [Eu]    compact bond-graph node id or -1        */
+  const int32_t* bn_und;       /* [Eb]    undirected index of each node           */
+  const int32_t* a_ctr;        /* [A]     bond_graph[:,0]                         */
+  const int32_t* a_b1c;        /* [A]     node id of bond_graph[:,1]              */
+  const int32_t* a_b2c;        /* [A]     node id of bond_graph[:,3]              */
+  const int32_t* a_d1;         /* [A]     bond_graph[:,2]                         */
+  const int32_t* a_d2;         /* [A]     bond_graph[:,4]                         */
+} chg_batch_host;
+
+/* Host destinations for chg_batch_download; null pointers are skipped. */
+typedef struct chg_out_host {
+  float* energy;        /* [B]    eV/atom if is_intensive else eV (incl. AtomRef) */
+  float* force;         /* [N,3]  eV/A            (needs CHG_TASK_F)              */
+  float* stress;        /* [B,9]  GPa             (needs CHG_TASK_S)              */
+  float* magmom;        /* [N]    mu_B            (needs CHG_TASK_M)              */
+  float* site_energy;   /* [N]    eV, incl. AtomRef site shift                    */
+  float* atom_fea;      /* [N,64] atom features before the last AtomConv          */
+  float* crystal_fea;   /* [B,64]                                                 */
+} chg_out_host;
+
+int chg_device_count(void);
+int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int device, chg_engine** out);
+int chg_engine_destroy(chg_engine* eng);
+const char* chg_last_error(const chg_engine* eng);
+
+int chg_batch_upload(chg_engine* eng, const chg_batch_host* host, chg_batch** out);
+/* new positions / cells on an unchanged graph topology (MD with a Verlet-skin graph) */
+int chg_batch_update_geometry(chg_engine* eng, chg_batch* batch, const float* frac, const float* lattice);
+int chg_batch_free(chg_engine* eng, chg_batch* batch);
+int64_t chg_batch_device_bytes(const chg_batch* batch);
+
+/* Asynchronous on the engine's stream; results stay in HBM until downloaded. */
+int chg_predict(chg_engine* eng, chg_batch* batch, uint32_t task_mask);
+int chg_synchronize(chg_engine* eng);
+int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* out);
+
+/* Wall time of the stream between two marks, from HIP events recorded on the engine's stream. */
+int chg_timer_start(chg_engine* eng);
+int chg_timer_stop_ms(chg_engine* eng, float* elapsed_ms);
+
+/* Per-kernel profile: when enabled every launch is bracketed by HIP events on the engine's
+ * stream.  chg_profile_read returns, for entry i, the kernel label, launch count and total ms. */
+int chg_profile_enable(chg_engine* eng, int on);
+int chg_profile_reset(chg_engine* eng);
+int chg_profile_count(chg_engine* eng);
+int chg_profile_read(chg_engine* eng, int i, char* label, int label_cap, int64_t* launches, double* total_ms);
+
+/* Copy a named intermediate device buffer of the last chg_predict to the host (tests only).
+ * Returns the number of floats written in *n_written; CHG_EINVAL if the name is unknown. */
+int chg_debug_fetch(chg_engine* eng, chg_batch* batch, const char* name, float* dst, int64_t capacity, int64_t* n_written);
+
+/* Self-test of the MFMA tile primitives: Y[rows,nout] = X[rows,k] . Wt[nout,k]^T + bias (k, nout in {64,128}). */
+int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const float* bias, float* y, int rows, int k, int nout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHGNET_HIP_H */
