@@ -12,7 +12,7 @@ c_float_p = ctypes.POINTER(ctypes.c_float)
 TASK_BITS = {"e": 1, "f": 2, "s": 4, "m": 8}
 
 EXPORTED_SYMBOLS = (
-    "chg_device_count", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
+    "chg_device_count", "chg_weights_required", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
     "chg_batch_upload", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
@@ -68,6 +68,8 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(f"chgnet_amd: cannot load HIP extension {path}: {exc}") from exc
     vp = ctypes.c_void_p
     lib.chg_device_count.restype = ctypes.c_int
+    lib.chg_weights_required.argtypes = [ctypes.c_int32]
+    lib.chg_weights_required.restype = ctypes.c_int64
     lib.chg_engine_create.argtypes = [ctypes.POINTER(ModelDesc), c_float_p, ctypes.c_int, ctypes.POINTER(vp)]
     lib.chg_engine_destroy.argtypes = [vp]
     lib.chg_last_error.argtypes = [vp]

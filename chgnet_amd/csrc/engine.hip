@@ -602,6 +602,12 @@ int chg_device_count(void) {
   return n;
 }
 
+int64_t chg_weights_required(int32_t n_conv) {
+  if (n_conv < 2 || n_conv > MAX_CONV) return -1;
+  Weights probe{};
+  return (int64_t)layout_weights(nullptr, n_conv, probe);
+}
+
 int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int device, chg_engine** out) {
   if (!desc || !weights_blob || !out) return CHG_EINVAL;
   if (desc->n_conv < 2 || desc->n_conv > MAX_CONV) return CHG_EUNSUPPORTED;

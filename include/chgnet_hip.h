@@ -94,6 +94,8 @@ typedef struct chg_out_host {
 } chg_out_host;
 
 int chg_device_count(void);
+/* Length in floats of the weight blob for an n_conv-block model (same table as pack.py:weight_layout). */
+int64_t chg_weights_required(int32_t n_conv);
 int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int device, chg_engine** out);
 int chg_engine_destroy(chg_engine* eng);
 const char* chg_last_error(const chg_engine* eng);

@@ -1,0 +1,71 @@
+"""N > 1 path on CPU: 2 ranks over gloo, the CPU oracle standing in for the per-rank GPU engine."""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chgnet_amd.distributed import shard_indices, structure_cost
+from conftest import GOLDEN, REPO, load_case
+
+NAMES = ["limno2", "noangle", "s16tri", "s40", "li9co7o16"]
+
+
+def test_shard_indices_balance_and_cover():
+    rng = np.random.default_rng(0)
+    costs = rng.uniform(1, 50, size=1000)
+    for world in (1, 2, 4, 8):
+        shards = shard_indices(costs, world)
+        assert sorted(i for s in shards for i in s) == list(range(1000))
+        loads = np.array([costs[s].sum() for s in shards])
+        assert loads.max() / loads.mean() < 1.01
+    assert shard_indices([], 2) == [[], []]
+    assert shard_indices([3.0], 4) == [[0], [], [], []]
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chgnet_amd.distributed import predict_sharded
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    weights = dict(np.load(os.path.join(GOLDEN, "weights_seed0.npz")))
+    oracle = OracleCHGNet(weights)
+    graphs = [load_case(n)[0] for n in NAMES]
+    local, energies = predict_sharded(lambda gs, task: oracle.predict_graph(list(gs), task, batch_size=16), graphs, task="ef")
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), energies=energies, owned=np.array(sorted(local)),
+             **{f"f{i}": p["f"] for i, p in local.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_allgather(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # both ranks hold the full, identical energy table in original order
+    assert np.array_equal(r0["energies"], r1["energies"])
+    want = np.array([float(load_case(n)[1]["out_e"]) for n in NAMES], dtype=np.float32)
+    assert np.abs(r0["energies"] - want).max() < 3e-6
+    # shards are disjoint, cover everything, and are balanced by the cost proxy
+    owned0, owned1 = set(r0["owned"].tolist()), set(r1["owned"].tolist())
+    assert owned0 | owned1 == set(range(len(NAMES))) and not (owned0 & owned1)
+    costs = np.array([structure_cost(load_case(n)[0]) for n in NAMES])
+    loads = [costs[sorted(o)].sum() for o in (owned0, owned1)]
+    assert max(loads) <= sum(loads) * 0.75
+    # forces stay rank-local and match the reference goldens
+    for r in (r0, r1):
+        for i in r["owned"]:
+            assert np.abs(r[f"f{i}"] - load_case(NAMES[i])[1]["out_f"]).max() < 3e-6

@@ -1,0 +1,138 @@
+"""Native graph builder (csrc/host_graph.cpp) vs the reference's graph semantics."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from chgnet_amd import CrystalGraphConverter, Structure
+from chgnet_amd.graph.converter import build_graph_arrays, graph_arrays_from_neighbors
+from chgnet_amd.graph.structure import Lattice
+from conftest import GOLDEN, load_case
+
+
+def limno2() -> Structure:
+    _, d = load_case("limno2")
+    return Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"])
+
+
+def test_toy_bigraph_known_answers():
+    """Known-answer vectors of reference tests/test_graph.py:52-97 (3 nodes, 8 directed edges incl. a
+    periodic self-pair), fed through the from-neighbours entry point."""
+    center = [0, 0, 1, 1, 1, 1, 2, 2]
+    nbr = [1, 2, 0, 2, 1, 1, 0, 1]
+    image = [[0, 0, 0]] * 4 + [[0, 0, 1], [0, 0, -1]] + [[0, 0, 0]] * 2
+    dist = [1, 2, 1, 5, 4, 4, 2, 5]
+    g = graph_arrays_from_neighbors(3, center, nbr, image, dist, r_bond=7)
+    assert len(g["atom_graph"]) == 8 and len(g["undirected2directed"]) == 4
+    assert g["atom_graph"][0].tolist() == [0, 1] and g["atom_graph"][1].tolist() == [0, 2]
+    assert g["atom_graph"][2].tolist() == [1, 0] and g["atom_graph"][6].tolist() == [2, 0]
+    assert g["directed2undirected"][:3].tolist() == [0, 1, 0]
+    bg = g["bond_graph"]
+    assert len(bg) == 16
+    assert bg[0].tolist() == [0, 0, 0, 1, 1]
+    assert bg[5].tolist() == [2, 1, 6, 2, 7]
+    assert bg[10].tolist() == [1, 3, 4, 0, 2]
+    assert g["undirected2directed"][:3].tolist() == [0, 1, 3]
+
+
+def test_limno2_count_goldens():
+    """Counts asserted by reference tests/test_crystal_graph.py:22-65 (cutoffs 5 / 3)."""
+    g = CrystalGraphConverter(atom_graph_cutoff=5, bond_graph_cutoff=3)(limno2())
+    assert g.composition == "Li2 Mn2 O4"
+    assert g.atomic_number.tolist() == [3, 3, 25, 25, 8, 8, 8, 8]
+    assert g.atom_frac_coord.shape == (8, 3)
+    assert g.atom_graph.shape == (384, 2)
+    for atom in (0, 4, 7):
+        assert (g.atom_graph[:, 0] == atom).sum() == 48
+    assert (g.atom_graph[:, 1] == 0).sum() == 48
+    assert g.bond_graph.shape == (744, 5)
+    assert (g.bond_graph[:, 0] == 1).sum() == 72
+    assert g.lattice.shape == (3, 3)
+    assert g.undirected2directed.shape == (192,) and g.directed2undirected.shape == (384,)
+    assert g.atom_graph.dtype == np.int32 and g.neighbor_image.dtype == np.float32
+
+
+def test_supercell_count_goldens():
+    """2x3x4 supercell: reference tests/test_crystal_graph.py:255-303."""
+    g = CrystalGraphConverter(atom_graph_cutoff=5, bond_graph_cutoff=3)(limno2().make_supercell([2, 3, 4]))
+    assert g.atom_graph.shape == (9216, 2)
+    assert g.bond_graph.shape == (17856, 5)
+    assert g.undirected2directed.shape == (4608,)
+    assert (g.atom_graph[:, 0] == 4).sum() == 48 and (g.atom_graph[:, 1] == 100).sum() == 48
+
+
+@pytest.mark.parametrize("name", ["limno2", "s16tri", "noangle"])
+def test_indexing_bit_exact_vs_reference_converter(name):
+    """Same (shuffled) neighbour list in -> element-for-element the graph the reference's
+    CrystalGraphConverter produced (tests/golden/graph_*.npz)."""
+    d = np.load(os.path.join(GOLDEN, f"graph_{name}.npz"))
+    g = graph_arrays_from_neighbors(int(d["n_atoms"]), d["nl_center"], d["nl_neighbor"], d["nl_image"], d["nl_distance"], r_bond=3)
+    assert np.array_equal(g["atom_graph"], d["atom_graph"])
+    assert np.array_equal(g["directed2undirected"], d["directed2undirected"])
+    assert np.array_equal(g["undirected2directed"], d["undirected2directed"])
+    assert np.array_equal(g["bond_graph"].reshape(-1, 5), d["bond_graph"].reshape(-1, 5))
+    assert np.array_equal(g["image"].astype(np.float32), d["neighbor_image"])
+
+
+def test_graph_invariants_and_sortedness():
+    s = limno2().make_supercell([2, 2, 1]).perturb(0.03, np.random.default_rng(1))
+    a = build_graph_arrays(s.frac_coords, s.lattice.matrix, 6.0, 3.0)
+    ag, d2u, u2d, bg = a["atom_graph"], a["directed2undirected"], a["undirected2directed"], a["bond_graph"]
+    assert len(ag) == 2 * len(u2d)
+    assert np.all(np.diff(ag[:, 0]) >= 0)                       # centre-major
+    assert np.all(np.bincount(d2u) == 2)                        # every bond has exactly two directions
+    assert np.array_equal(d2u[u2d], np.arange(len(u2d)))
+    assert np.all(np.diff(bg[:, 1]) >= 0)                       # angles sorted by owning bond
+    assert np.array_equal(ag[bg[:, 2], 0], bg[:, 0]) and np.array_equal(ag[bg[:, 4], 0], bg[:, 0])
+    assert np.array_equal(d2u[bg[:, 2]], bg[:, 1]) and np.array_equal(d2u[bg[:, 4]], bg[:, 3])
+    assert np.all(bg[:, 2] != bg[:, 4])
+    # reverse edge has the negated image and the same length
+    for k in range(0, len(u2d), 97):
+        e1, e2 = np.flatnonzero(d2u == k)
+        assert np.array_equal(a["image"][e1], -a["image"][e2]) and abs(a["distance"][e1] - a["distance"][e2]) < 1e-9
+        assert ag[e1, 0] == ag[e2, 1] and ag[e1, 1] == ag[e2, 0]
+    # distances agree with the geometry
+    cart = s.cart_coords
+    v = cart[ag[:, 1]] + a["image"] @ s.lattice.matrix - cart[ag[:, 0]]
+    assert np.abs(np.linalg.norm(v, axis=1) - a["distance"]).max() < 1e-9
+    assert a["distance"].max() < 6.0 and a["distance"].min() > 1e-8
+
+
+def test_unwrapped_fractional_coordinates_give_the_same_bonds():
+    s = limno2()
+    shifted = Structure(s.lattice, s.atomic_numbers, s.frac_coords + np.array([[1, -2, 0]] * 4 + [[0, 0, 3]] * 4))
+    a = build_graph_arrays(s.frac_coords, s.lattice.matrix, 5.0, 3.0)
+    b = build_graph_arrays(shifted.frac_coords, shifted.lattice.matrix, 5.0, 3.0)
+    assert len(a["atom_graph"]) == len(b["atom_graph"]) and len(a["bond_graph"]) == len(b["bond_graph"])
+    assert np.allclose(np.sort(a["distance"]), np.sort(b["distance"]), atol=1e-9)
+
+
+@pytest.mark.parametrize("on_isolated_atoms", ["ignore", "warn", "error"])
+def test_isolated_atom_policy(on_isolated_atoms, capsys):
+    """reference tests/test_converter.py:65-100 (NaCl, a = 4 A, 5x strain -> both atoms isolated)."""
+    nacl = Structure(Lattice(np.eye(3) * 4.0), ["Na", "Cl"], [[0, 0, 0], [0.5, 0.5, 0.5]]).apply_strain(5)
+    atom_graph_cutoff = 5
+    conv = CrystalGraphConverter(atom_graph_cutoff=atom_graph_cutoff, bond_graph_cutoff=3, on_isolated_atoms=on_isolated_atoms)
+    graph_id = "strained"
+    err_msg = (f"Structure {graph_id=} has 2 isolated atom(s) with {atom_graph_cutoff=}. "
+               f"CHGNet calculation will likely go wrong")
+    if on_isolated_atoms == "error":
+        with pytest.raises(ValueError, match="has 2 isolated atom") as exc:
+            conv.forward(nacl, graph_id=graph_id)
+        assert err_msg in str(exc.value)
+    else:
+        g = conv.forward(nacl, graph_id=graph_id)
+        assert len(g.atom_graph) == 0 and g.num_isolated_atoms == 2
+        out, err = capsys.readouterr()
+        assert out == ""
+        assert (err_msg in err) if on_isolated_atoms == "warn" else err == ""
+
+
+def test_graph_builder_error_codes():
+    with pytest.raises(ValueError, match="singular lattice|invalid argument"):
+        build_graph_arrays(np.zeros((1, 3)), np.zeros((3, 3)), 5.0, 3.0)
+    with pytest.raises(ValueError, match="not complete|2 \\* number"):
+        graph_arrays_from_neighbors(2, [0], [1], [[0, 0, 0]], [1.0], r_bond=3)   # dangling directed edge

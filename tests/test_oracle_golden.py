@@ -1,0 +1,90 @@
+"""The CPU oracle is pinned to outputs of the unmodified reference (tests/golden, make_golden.py)."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case
+from oracle.chgnet_oracle import OracleCHGNet
+
+CASES = ["limno2", "s40", "s16tri", "noangle", "li9co7o16"]
+# torch CPU kernels pick different summation orders for different thread counts / batch shapes;
+# the fixtures were written single-threaded.  Observed oracle-vs-fixture noise is <= 1.2e-5.
+TOL = {"e": 2e-6, "f": 2e-6, "s": 5e-6, "m": 3e-6, "site_energies": 3e-6, "atom_fea": 1e-5, "crystal_fea": 5e-5}
+
+
+@pytest.fixture(scope="module")
+def oracle(golden_weights):
+    torch.set_num_threads(1)
+    return OracleCHGNet(golden_weights)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference_outputs(oracle, name):
+    g, d = load_case(name)
+    out = oracle.predict_graph(g, "efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+    for key, tol in TOL.items():
+        ref = d["out_" + key]
+        assert out[key].shape == ref.shape
+        err = float(np.abs(out[key] - ref).max()) if ref.size else 0.0
+        assert err <= tol, f"{name}:{key} {err:.2e}"
+
+
+def test_oracle_batched_equals_reference_batched(oracle):
+    d = np.load(os.path.join(GOLDEN, "batch_mixed.npz"))
+    order = [str(x) for x in d["order"]]
+    outs = oracle.predict_graph([load_case(n)[0] for n in order], "efsm", return_site_energies=True,
+                                return_atom_feas=True, return_crystal_feas=True)
+    for n, o in zip(order, outs):
+        for key, tol in TOL.items():
+            ref = d[f"{n}_{key}"]
+            err = float(np.abs(o[key] - ref).max()) if ref.size else 0.0
+            assert err <= tol, f"{n}:{key} {err:.2e}"
+
+
+def test_oracle_task_keys(oracle):
+    g, _ = load_case("limno2")
+    assert set(oracle.predict_graph(g, "e")) == {"e"}
+    assert set(oracle.predict_graph(g, "ef")) == {"e", "f"}
+    assert set(oracle.predict_graph(g, "em")) == {"e", "m"}
+    assert set(oracle.predict_graph(g, "efs")) == {"e", "f", "s"}
+
+
+def test_documented_pretrained_targets_are_recorded():
+    """The 0.3.0 checkpoint is absent offline (.MISSING_LARGE_BLOBS); the reference's own goldens
+    (tests/test_model.py:68-119) are kept here as documented targets for a box that has the blob."""
+    from golden import pretrained_targets as t
+
+    assert abs(t.LIMNO2_E - (-7.36769)) < 1e-9 and len(t.LIMNO2_MAGMOM) == 8
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/chgnet"), reason="live reference only in the build container")
+def test_oracle_matches_live_reference_on_fresh_input(golden_weights):
+    """Fresh random structure, reference imported from /root/reference (never on the GPU box)."""
+    from oracle._refimport import load_reference
+
+    load_reference()
+    from chgnet.graph.crystalgraph import CrystalGraph as RefGraph
+    from chgnet.model.model import CHGNet as RefCHGNet
+
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    torch.set_num_threads(1)
+    model = RefCHGNet()
+    model.load_state_dict({k: torch.tensor(v) for k, v in golden_weights.items()})
+    rng = np.random.default_rng(99)
+    s = Structure(Lattice(np.diag([4.1, 4.4, 5.0]) + rng.normal(0, 0.2, (3, 3))), [3, 8, 25, 8, 27], rng.random((5, 3)))
+    g = CrystalGraphConverter()(s)
+    rg = RefGraph(atomic_number=torch.tensor(g.atomic_number), atom_frac_coord=torch.tensor(g.atom_frac_coord),
+                  atom_graph=torch.tensor(g.atom_graph), neighbor_image=torch.tensor(g.neighbor_image),
+                  directed2undirected=torch.tensor(g.directed2undirected), undirected2directed=torch.tensor(g.undirected2directed),
+                  bond_graph=torch.tensor(g.bond_graph), lattice=torch.tensor(g.lattice), atom_graph_cutoff=6, bond_graph_cutoff=3)
+    ref = model.predict_graph(rg, task="efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+    out = OracleCHGNet(golden_weights).predict_graph(g, "efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+    for key in ref:
+        assert np.abs(out[key] - ref[key]).max() <= 5 * TOL[key], key
