@@ -1,0 +1,102 @@
+"""``CHGNetCalculator`` -- the ASE-facing surface of the reference
+(chgnet/model/dynamics.py:58-181) on top of the HIP engine.
+
+ASE is an optional dependency (absent in the build container): when it imports, the class derives
+from ``ase.calculators.calculator.Calculator`` so ASE optimisers / MD drivers can use it unchanged;
+otherwise a minimal base with the same ``results`` / ``get_*`` contract is used so that the
+in-repo MD smoke driver and the tests still work.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from chgnet_amd.graph.structure import Lattice, Structure
+from chgnet_amd.model import CHGNet
+
+GPA_TO_EV_A3 = 1.0 / 160.21766208   # ase.units.GPa
+
+try:  # pragma: no cover - exercised only where ASE is installed
+    from ase.calculators.calculator import Calculator, all_changes, all_properties
+
+    HAVE_ASE = True
+except ImportError:
+    HAVE_ASE = False
+    all_changes, all_properties = [], []
+
+    class Calculator:  # minimal stand-in with ASE's attribute contract
+        def __init__(self, **kwargs) -> None:  # noqa: ARG002
+            self.results: dict = {}
+            self.atoms = None
+
+        def calculate(self, atoms=None, properties=None, system_changes=None) -> None:  # noqa: ARG002
+            self.atoms = atoms
+
+        def get_potential_energy(self, atoms=None):
+            self.calculate(atoms)
+            return self.results["energy"]
+
+        def get_forces(self, atoms=None):
+            self.calculate(atoms)
+            return self.results["forces"]
+
+        def get_stress(self, atoms=None):
+            self.calculate(atoms)
+            return self.results["stress"]
+
+
+def atoms_to_structure(atoms) -> Structure:
+    """ASE ``Atoms`` (or anything with get_cell / get_scaled_positions / get_atomic_numbers) or one
+    of our / pymatgen's structures -> ``Structure`` (replaces AseAtomsAdaptor, dynamics.py:156)."""
+    if hasattr(atoms, "frac_coords") and hasattr(atoms, "lattice"):
+        return atoms
+    cell = np.asarray(atoms.get_cell()[:] if hasattr(atoms.get_cell(), "__getitem__") else atoms.get_cell())
+    return Structure(Lattice(cell), np.asarray(atoms.get_atomic_numbers()), np.asarray(atoms.get_scaled_positions(wrap=False)))
+
+
+class CHGNetCalculator(Calculator):
+    """CHGNet Calculator for ASE applications."""
+
+    implemented_properties = ("energy", "forces", "stress", "magmoms", "energies")
+
+    def __init__(self, model: CHGNet | None = None, *, use_device: str | None = None, check_cuda_mem: bool = False,  # noqa: ARG002
+                 stress_weight: float = GPA_TO_EV_A3, on_isolated_atoms: str = "warn", return_site_energies: bool = False,
+                 **kwargs) -> None:
+        super().__init__(**kwargs)
+        if model is None:
+            self.model = CHGNet.load(verbose=False, use_device=use_device)
+        else:
+            self.model = model.to(use_device) if use_device is not None else model
+        self.device = self.model.device
+        self.model.graph_converter.set_isolated_atom_response(on_isolated_atoms)
+        self.stress_weight = stress_weight
+        self.return_site_energies = return_site_energies
+        print(f"CHGNet will run on {self.device}")
+
+    @classmethod
+    def from_file(cls, path: str, use_device: str | None = None, **kwargs) -> "CHGNetCalculator":
+        return cls(model=CHGNet.from_file(path), use_device=use_device, **kwargs)
+
+    @property
+    def version(self) -> str | None:
+        return self.model.version
+
+    @property
+    def n_params(self) -> int:
+        return self.model.n_params
+
+    def calculate(self, atoms=None, properties=None, system_changes=None, task: str = "efsm") -> None:
+        properties = properties or all_properties
+        system_changes = system_changes or all_changes
+        super().calculate(atoms=atoms, properties=properties, system_changes=system_changes)
+        structure = atoms_to_structure(atoms)
+        graph = self.model.graph_converter(structure)
+        pred = self.model.predict_graph(graph, task=task, return_crystal_feas=True,
+                                        return_site_energies=self.return_site_energies)
+        extensive_factor = len(structure) if self.model.is_intensive else 1
+        key_map = {"e": ("energy", extensive_factor), "f": ("forces", 1), "m": ("magmoms", 1), "s": ("stress", self.stress_weight)}
+        self.results.update({long_key: pred[key] * factor for key, (long_key, factor) in key_map.items() if key in pred})
+        self.results["free_energy"] = self.results["energy"]
+        self.results["crystal_fea"] = pred["crystal_fea"]
+        if self.return_site_energies:
+            self.results["energies"] = pred["site_energies"]
