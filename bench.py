@@ -104,12 +104,14 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     from chgnet_amd.engine import Engine
     from chgnet_amd.pack import pack_batch, pack_weights

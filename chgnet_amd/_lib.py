@@ -49,7 +49,7 @@ _LIB = None
 def hip_lib_path() -> str:
     from chgnet_amd.build import HIP_LIB
 
-    return HIP_LIB
+    return os.environ.get("CHGNET_HIP_LIB", HIP_LIB)   # override: kernel timing experiments only
 
 
 def load() -> ctypes.CDLL:

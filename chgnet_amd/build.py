@@ -70,6 +70,14 @@ def build_hip(force: bool = False) -> str:
     return HIP_LIB
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """Experiment build (timing studies only): libchgnet_hip_<name>.so with extra -D flags."""
+    out = os.path.join(LIB_DIR, f"libchgnet_hip_{name}.so")
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    _run([hipcc_path(), *HIP_FLAGS, *[f"-D{d}" for d in defines], f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", out])
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_graph(force)
     build_hip(force)

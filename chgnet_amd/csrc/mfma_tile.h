@@ -218,6 +218,9 @@ __device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) {
 template <int W>
 __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride, int key, int nvalid, float* __restrict__ dst,
                                                   int ldd, int lane) {
+#ifdef CHG_EXP_NO_SEG_ATOMICS   // timing experiment only: wrong results
+  return;
+#endif
   constexpr int NC = W / 64;
   float acc[NC];
 #pragma unroll
@@ -250,6 +253,9 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
 template <int W>
 __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, int key, int nvalid, float* __restrict__ dst,
                                                int ldd, int lane) {
+#ifdef CHG_EXP_NO_ROW_ATOMICS   // timing experiment only (tests/gpu_experiments.sh): wrong results
+  return;
+#endif
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr) {
     if (rr < nvalid) {
@@ -273,7 +279,11 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
 #pragma unroll 4
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
     const int rr = 2 * it + hw;
+#ifdef CHG_EXP_NO_GATHER        // timing experiment only: every row reads table row 0 (cache-resident)
+    const int r0 = 0, r1 = 0, r2 = 0;
+#else
     const int r0 = __shfl(i0, rr), r1 = __shfl(i1, rr), r2 = __shfl(i2, rr);
+#endif
     f32x4 a = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0 * ld0 + 4 * t);
     const f32x4 b = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1 * ld1 + 4 * t);
     const f32x4 c = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2 * ld2 + 4 * t);

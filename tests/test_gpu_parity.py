@@ -223,3 +223,23 @@ def test_tasks_and_api_surface(hip_engine, golden_weights):
         model.predict_graph(g, task="xyz")
     with pytest.raises(TypeError):
         model.predict_graph(3)
+
+
+def test_calculator_surface(hip_engine, golden_weights):
+    """ASE-calculator contract (reference dynamics.py:129-181): extensive energy, 3x3 stress in eV/A^3."""
+    from chgnet_amd import Structure
+    from chgnet_amd.calculator import CHGNetCalculator
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.model import CHGNet
+
+    _, d = load_case("limno2")
+    s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"])
+    calc = CHGNetCalculator(CHGNet(state_dict=golden_weights), return_site_energies=True)
+    calc.calculate(s)
+    r = calc.results
+    assert set(r) >= {"energy", "forces", "stress", "magmoms", "free_energy", "crystal_fea", "energies"}
+    assert abs(r["energy"] - 8 * float(d["out_e"])) < 8 * TOL["e"]
+    assert np.abs(r["forces"] - d["out_f"]).max() < TOL["f"]
+    assert np.abs(r["stress"] - d["out_s"] / 160.21766208).max() < TOL["s"] / 160
+    assert r["stress"].shape == (3, 3) and r["energies"].shape == (8,)
+    assert calc.n_params == 412525
