@@ -43,9 +43,14 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-// ---- activations (IEEE division / expf: parity first) -------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
+// ---- activations -------------------------------------------------------------------------------
+// sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp
+// each) -- 4 VALU instructions instead of ~22 for expf + IEEE division, which made the conv kernels
+// VALU-bound (profiles/r01 notes).  Saturates correctly: x -> -inf gives rcp(inf) = 0, x -> +inf gives 1.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 // d/dx silu(x) = s (1 + x (1 - s))
 __device__ __forceinline__ float dsiluf_(float x) {
   const float s = sigmoidf_(x);
@@ -159,7 +164,7 @@ __device__ __forceinline__ float ln_normalize(f32x16 (&c)[2]) {
       c[ft][r] -= mu;
       v += c[ft][r] * c[ft][r];
     }
-  const float rstd = 1.0f / sqrtf(pair_sum(v) * (1.0f / 64.0f) + LN_EPS);
+  const float rstd = __builtin_amdgcn_rsqf(pair_sum(v) * (1.0f / 64.0f) + LN_EPS);
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
