@@ -1,9 +1,9 @@
 // kernels_conv.h -- message-passing kernels of the CHGNet hot path, forward and reverse.
 //
 // Reference ops replaced (file:line relative to /root/reference/chgnet):
-//   AtomConv.forward     model/layers.py:113-132   -> k_atomconv_fwd  / k_atomconv_bwd
-//   BondConv.forward     model/layers.py:238-260   -> k_bondconv_fwd  / k_bondconv_bwd
-//   AngleUpdate.forward  model/layers.py:348-360   -> k_angleupd_fwd  / k_angleupd_bwd
+//   AtomConv.forward     model/layers.py:113-132   -> k_atomconv<fwd>  / k_atomconv<bwd>
+//   BondConv.forward     model/layers.py:238-260   -> k_angle<hidden,fwd> / k_angle<hidden,bwd>
+//   AngleUpdate.forward  model/layers.py:348-360   -> k_angle<single,fwd> / k_angle<single,bwd>
 //   GatedMLP.forward     model/functions.py:177-183 (shared body: gated_forward / gated_backward)
 //   aggregate            model/functions.py:10-40  -> segmented column sums (rows arrive sorted by owner)
 //   nn.Linear partial products + mlp_out + residual -> k_rows_gemm
@@ -27,109 +27,93 @@ struct GatedW {            // global pointers into the weight blob
   const float *w2c, *b2c, *w2g, *b2g, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 };
 
-__device__ __forceinline__ void stage_gated_vecs(float* vecs, const GatedW& g, bool hidden, int tid) {
+__device__ __forceinline__ void stage_gated_vecs(float* vecs, const GatedW& gw, bool hidden, int tid) {
   if (hidden) {
-    stage_vector(vecs + 0 * D, g.b2c, D, tid);
-    stage_vector(vecs + 1 * D, g.b2g, D, tid);
+    stage_vector(vecs + 0 * D, gw.b2c, D, tid);
+    stage_vector(vecs + 1 * D, gw.b2g, D, tid);
   }
-  stage_vector(vecs + 2 * D, g.ln1_g, D, tid);
-  stage_vector(vecs + 3 * D, g.ln1_b, D, tid);
-  stage_vector(vecs + 4 * D, g.ln2_g, D, tid);
-  stage_vector(vecs + 5 * D, g.ln2_b, D, tid);
+  stage_vector(vecs + 2 * D, gw.ln1_g, D, tid);
+  stage_vector(vecs + 3 * D, gw.ln1_b, D, tid);
+  stage_vector(vecs + 4 * D, gw.ln2_g, D, tid);
+  stage_vector(vecs + 5 * D, gw.ln2_b, D, tid);
 }
 
-// z (pre-activation of the first layer, 128 = core|gate) -> normalised branches and activations.
+__device__ __forceinline__ V64 param64(const float* vec, int g) {
+  V64 p;
+  read_dl<VT>(vec, g, p.t);
+  return p;
+}
+
+// Forward state of one gated MLP row kept for the backward
+struct GatedState {
+  V64 xh1, xh2;   // LayerNorm-normalised branches (before affine)
+  V64 n1;         // affine core branch (input of silu)
+  V64 a1, a2;     // silu(n1), sigmoid(n2)
+  float rstd1, rstd2;
+};
+
+// z (pre-activation of the first layer, 128 = core|gate) -> activations.
 //   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
-//   xh* = LayerNorm-normalised (before affine), n1 = affine core branch, a1 = silu(n1), a2 = sigmoid(n2)
 template <bool HIDDEN>
-__device__ __forceinline__ void gated_forward(const f32x16 (&zc)[2], const f32x16 (&zg)[2], const float* W2c, const float* W2g,
-                                              const float* vecs, int j, int h, f32x16 (&xh1)[2], f32x16 (&xh2)[2], float& rstd1,
-                                              float& rstd2, f32x16 (&n1)[2], f32x16 (&a1)[2], f32x16 (&a2)[2]) {
+__device__ __forceinline__ void gated_forward(const V64& zc, const V64& zg, const float* W2c, const float* W2g, const float* vecs,
+                                              int j, int g, GatedState& s) {
   if (HIDDEN) {
-    f32x16 hc[2], hg[2], b[2];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        hc[ft][r] = siluf_(zc[ft][r]);
-        hg[ft][r] = siluf_(zg[ft][r]);
-      }
-    param_read_dl<2>(vecs + 0 * D, h, b);
-    xh1[0] = b[0];
-    xh1[1] = b[1];
-    gemm_dl<2, 2>(xh1, W2c, WS, hc, j, h);
-    param_read_dl<2>(vecs + 1 * D, h, b);
-    xh2[0] = b[0];
-    xh2[1] = b[1];
-    gemm_dl<2, 2>(xh2, W2g, WS, hg, j, h);
-  } else {
-    xh1[0] = zc[0];
-    xh1[1] = zc[1];
-    xh2[0] = zg[0];
-    xh2[1] = zg[1];
-  }
-  rstd1 = ln_normalize(xh1);
-  rstd2 = ln_normalize(xh2);
-  f32x16 g[2], b[2];
-  param_read_dl<2>(vecs + 2 * D, h, g);
-  param_read_dl<2>(vecs + 3 * D, h, b);
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      n1[ft][r] = xh1[ft][r] * g[ft][r] + b[ft][r];
-      a1[ft][r] = siluf_(n1[ft][r]);
+    V64 hc, hg;
+    CHG_EW(ft, r) {
+      hc.t[ft][r] = siluf_(zc.t[ft][r]);
+      hg.t[ft][r] = siluf_(zg.t[ft][r]);
     }
-  param_read_dl<2>(vecs + 4 * D, h, g);
-  param_read_dl<2>(vecs + 5 * D, h, b);
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a2[ft][r] = sigmoidf_(xh2[ft][r] * g[ft][r] + b[ft][r]);
+    s.xh1 = param64(vecs + 0 * D, g);
+    s.xh2 = param64(vecs + 1 * D, g);
+    gemm_dl<VT, VT>(s.xh1.t, W2c, WS, hc.t, j, g);
+    gemm_dl<VT, VT>(s.xh2.t, W2g, WS, hg.t, j, g);
+  } else {
+    s.xh1 = zc;
+    s.xh2 = zg;
+  }
+  s.rstd1 = ln_normalize(s.xh1);
+  s.rstd2 = ln_normalize(s.xh2);
+  {
+    const V64 gam = param64(vecs + 2 * D, g), bet = param64(vecs + 3 * D, g);
+    CHG_EW(ft, r) {
+      s.n1.t[ft][r] = s.xh1.t[ft][r] * gam.t[ft][r] + bet.t[ft][r];
+      s.a1.t[ft][r] = siluf_(s.n1.t[ft][r]);
+    }
+  }
+  {
+    const V64 gam = param64(vecs + 4 * D, g), bet = param64(vecs + 5 * D, g);
+    CHG_EW(ft, r) s.a2.t[ft][r] = sigmoidf_(s.xh2.t[ft][r] * gam.t[ft][r] + bet.t[ft][r]);
+  }
 }
 
 // gy = dE/d(a1*a2)  ->  gzc, gzg = dE/dz (128 wide)
 template <bool HIDDEN>
-__device__ __forceinline__ void gated_backward(const f32x16 (&gy)[2], const f32x16 (&zc)[2], const f32x16 (&zg)[2], const float* W2c,
-                                               const float* W2g, const float* vecs, int j, int h, const f32x16 (&xh1)[2],
-                                               const f32x16 (&xh2)[2], float rstd1, float rstd2, const f32x16 (&n1)[2],
-                                               const f32x16 (&a1)[2], const f32x16 (&a2)[2], f32x16 (&gzc)[2], f32x16 (&gzg)[2]) {
-  f32x16 gn1[2], gn2[2], gam[2];
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      gn1[ft][r] = gy[ft][r] * a2[ft][r] * dsiluf_(n1[ft][r]);
-      gn2[ft][r] = gy[ft][r] * a1[ft][r] * a2[ft][r] * (1.0f - a2[ft][r]);
-    }
-  param_read_dl<2>(vecs + 2 * D, h, gam);
-  ln_backward(gn1, gam, xh1, rstd1);
-  param_read_dl<2>(vecs + 4 * D, h, gam);
-  ln_backward(gn2, gam, xh2, rstd2);
+__device__ __forceinline__ void gated_backward(const V64& gy, const V64& zc, const V64& zg, const float* W2c, const float* W2g,
+                                               const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg) {
+  V64 gn1, gn2;
+  CHG_EW(ft, r) {
+    gn1.t[ft][r] = gy.t[ft][r] * s.a2.t[ft][r] * dsiluf_(s.n1.t[ft][r]);
+    gn2.t[ft][r] = gy.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r] * (1.0f - s.a2.t[ft][r]);
+  }
+  ln_backward(gn1, param64(vecs + 2 * D, g), s.xh1, s.rstd1);
+  ln_backward(gn2, param64(vecs + 4 * D, g), s.xh2, s.rstd2);
   if (HIDDEN) {
-    gzc[0] = zero16();
-    gzc[1] = zero16();
-    gzg[0] = zero16();
-    gzg[1] = zero16();
-    gemm_dl_t<2, 2>(gzc, W2c, WS, gn1, j, h);
-    gemm_dl_t<2, 2>(gzg, W2g, WS, gn2, j, h);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        gzc[ft][r] *= dsiluf_(zc[ft][r]);
-        gzg[ft][r] *= dsiluf_(zg[ft][r]);
-      }
+    gzc = zero64();
+    gzg = zero64();
+    gemm_dl_t<VT, VT>(gzc.t, W2c, WS, gn1.t, j, g);
+    gemm_dl_t<VT, VT>(gzg.t, W2g, WS, gn2.t, j, g);
+    CHG_EW(ft, r) {
+      gzc.t[ft][r] *= dsiluf_(zc.t[ft][r]);
+      gzg.t[ft][r] *= dsiluf_(zg.t[ft][r]);
+    }
   } else {
-    gzc[0] = gn1[0];
-    gzc[1] = gn1[1];
-    gzg[0] = gn2[0];
-    gzg[1] = gn2[1];
+    gzc = gn1;
+    gzg = gn2;
   }
 }
 
 // =============================================================================================
-// k_rows_gemm:  Y[o(r), yoff + n] (+)= sum_k X[i(r), xoff + k] * Wt[n][k] (+ bias[n]) (+ resid[o(r), n])
+// k_rows_gemm:  Y[o(r), n] (+)= sum_k X[i(r), k] * Wt[n][k] (+ bias[n]) (+ resid[o(r), n])
 //   K in {64,128}, NOUT in {64,128}; i(r) / o(r) optional row index maps (null = identity).
 // =============================================================================================
 struct RowsGemm {
@@ -150,12 +134,12 @@ struct RowsGemm {
 template <int K, int NOUT>
 __global__ __launch_bounds__(BLOCK) void k_rows_gemm(RowsGemm p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KS = K + PAD, KT = K / 32, NFT = NOUT / 32;
+  constexpr int KS = K + PAD, KT = K / 16, NFT = NOUT / 16;
   constexpr int XS = (K > NOUT ? K : NOUT) + PAD;  // tile stride: holds X (K wide) then Y (NOUT wide)
   float* W = smem;                          // [NOUT][KS]
   float* bias = W + NOUT * KS;              // [NOUT]
-  float* tiles = bias + NOUT;               // [WAVES][32][XS]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  float* tiles = bias + NOUT;               // [WAVES][16][XS]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_weights(W, p.Wt, NOUT, K, tid);
   for (int idx = tid; idx < NOUT; idx += BLOCK) bias[idx] = p.bias ? p.bias[idx] : 0.f;
   __syncthreads();
@@ -174,27 +158,29 @@ __global__ __launch_bounds__(BLOCK) void k_rows_gemm(RowsGemm p) {
     constexpr int LPR = K / 4, RPS = 64 / LPR;
     {
       const int sub = lane / LPR, t = lane % LPR;
-#pragma unroll 4
+      f32x4 v[TILE_ROWS / RPS];
+#pragma unroll
       for (int it = 0; it < TILE_ROWS / RPS; ++it) {
-        const int rr = RPS * it + sub;
-        const int r = __shfl(in_row, rr);
-        *reinterpret_cast<f32x4*>(T + rr * XS + 4 * t) = *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + 4 * t);
+        const int r = __shfl(in_row, RPS * it + sub);
+        v[it] = *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + 4 * t);
       }
+#pragma unroll
+      for (int it = 0; it < TILE_ROWS / RPS; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + sub) * XS + 4 * t) = v[it];
     }
     __builtin_amdgcn_wave_barrier();
-    f32x16 x[KT];
-    lds_read_dl<KT>(T, XS, j, h, 0, x);
-    f32x16 acc[NFT];
-    param_read_dl<NFT>(bias, h, acc);
-    gemm_dl<KT, NFT>(acc, W, KS, x, j, h);
+    f32x4 x[KT];
+    read_dl<KT>(T + j * XS, g, x);
+    f32x4 acc[NFT];
+    read_dl<NFT>(bias, g, acc);
+    gemm_dl<KT, NFT>(acc, W, KS, x, j, g);
     __builtin_amdgcn_wave_barrier();
-    lds_write_dl<NFT>(T, XS, j, h, 0, acc);
+    write_dl<NFT>(T + j * XS, g, acc);
     __builtin_amdgcn_wave_barrier();
     // Y tile -> global, NOUT/4 lanes per row
     constexpr int LPO = NOUT / 4, RPO = 64 / LPO;
     {
       const int sub = lane / LPO, t = lane % LPO;
-#pragma unroll 4
+#pragma unroll
       for (int it = 0; it < TILE_ROWS / RPO; ++it) {
         const int rr = RPO * it + sub;
         const int r = __shfl(out_row, rr);
@@ -243,12 +229,13 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv(AtomConvArgs p) {
   float* W2g = W2c + D * WS;
   float* vecs = W2g + D * WS;
   float* tiles = vecs + VEC_SLOTS * D;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_weights(W2c, p.gw.w2c, D, D, tid);
   stage_weights(W2g, p.gw.w2g, D, D, tid);
   stage_gated_vecs(vecs, p.gw, true, tid);
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
@@ -260,41 +247,36 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv(AtomConvArgs p) {
     const int e = row0 + (valid ? j : 0);
     const int c = p.e_center[e], n = p.e_nbr[e], k = p.e_d2u[e];
     gather_sum128(T, TS, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+    // per-row multipliers / incoming gradients: issued now, consumed after the MFMA phase
+    V64 wv, gm;
+    read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
+    if (BWD) read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
     __builtin_amdgcn_wave_barrier();
-    f32x16 zc[2], zg[2];
-    lds_read_dl<2>(T, TS, j, h, 0, zc);
-    lds_read_dl<2>(T, TS, j, h, D, zg);
-    f32x16 xh1[2], xh2[2], n1[2], a1[2], a2[2], wv[2];
-    float rstd1, rstd2;
-    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, h, xh1, xh2, rstd1, rstd2, n1, a1, a2);
-    glb_read_dl<2>(p.wag + (size_t)k * D, h, wv);
+    V64 zc, zg;
+    read_dl<VT>(Trow, g, zc.t);
+    read_dl<VT>(Trow + D, g, zg.t);
+    GatedState s;
+    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
     __builtin_amdgcn_wave_barrier();
     if (!BWD) {
-      f32x16 m[2];
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[ft][r] = a1[ft][r] * a2[ft][r] * wv[ft][r];
-      lds_write_dl<2>(T, TS, j, h, 0, m);
+      V64 m;
+      CHG_EW(ft, r) m.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r] * wv.t[ft][r];
+      write_dl<VT>(Trow, g, m.t);
       __builtin_amdgcn_wave_barrier();
       seg_colsum_atomic<D>(T, TS, valid ? c : -1, nvalid, p.agg, D, lane);
     } else {
-      f32x16 gm[2], gy[2], gw[2], gzc[2], gzg[2];
-      glb_read_dl<2>(p.GA + (size_t)c * D, h, gm);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          gw[ft][r] = gm[ft][r] * a1[ft][r] * a2[ft][r];   // dE/d wag[k]
-          gy[ft][r] = gm[ft][r] * wv[ft][r];
-        }
-      lds_write_dl<2>(T, TS, j, h, 0, gw);
+      V64 gy, gw, gzc, gzg;
+      CHG_EW(ft, r) {
+        gw.t[ft][r] = gm.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r];   // dE/d wag[k]
+        gy.t[ft][r] = gm.t[ft][r] * wv.t[ft][r];
+      }
+      write_dl<VT>(Trow, g, gw.t);
       __builtin_amdgcn_wave_barrier();
       row_atomic_add<D>(T, TS, valid ? k : -1, nvalid, p.Gwag, D, lane);
-      gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, h, xh1, xh2, rstd1, rstd2, n1, a1, a2, gzc, gzg);
+      gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
       __builtin_amdgcn_wave_barrier();
-      lds_write_dl<2>(T, TS, j, h, 0, gzc);
-      lds_write_dl<2>(T, TS, j, h, D, gzg);
+      write_dl<VT>(Trow, g, gzc.t);
+      write_dl<VT>(Trow + D, g, gzg.t);
       __builtin_amdgcn_wave_barrier();
       seg_colsum_atomic<2 * D>(T, TS, valid ? c : -1, nvalid, p.GP, 4 * D, lane);
       row_atomic_add<2 * D>(T, TS, valid ? n : -1, nvalid, p.GP + 2 * D, 4 * D, lane);
@@ -340,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
   float* W2g = W2c + (HIDDEN ? D * WS : 0);
   float* vecs = W2g + (HIDDEN ? D * WS : 0);
   float* tiles = vecs + VEC_SLOTS * D;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_weights(Wang, p.w_ang, 2 * D, D, tid);
   if (HIDDEN) {
     stage_weights(W2c, p.gw.w2c, D, D, tid);
@@ -349,6 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
   stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
   const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
@@ -359,76 +342,70 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
     const bool valid = j < nvalid;
     const int a = row0 + (valid ? j : 0);
     const int ctr = p.a_ctr[a], b1 = p.a_b1c[a], b2 = p.a_b2c[a];
-    // angle features of the tile -> D layout (B operand of the first contraction)
+    // table sum -> cols 0..127 of the tile, angle rows -> a second region is not needed: the angle
+    // features are consumed (B operand of the first contraction) before the table sum is written
     gather_rows64(T, TS, p.ang, a, lane);
+    V64 w1, w2, gu;
+    if (HIDDEN) {
+      read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
+      read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
+      if (BWD) read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
+    }
     __builtin_amdgcn_wave_barrier();
-    f32x16 x[2];
-    lds_read_dl<2>(T, TS, j, h, 0, x);
+    V64 x;
+    read_dl<VT>(Trow, g, x.t);
     __builtin_amdgcn_wave_barrier();
     gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
     __builtin_amdgcn_wave_barrier();
-    f32x16 z[4];
-    lds_read_dl<4>(T, TS, j, h, 0, z);
-    gemm_dl<2, 4>(z, Wang, WS, x, j, h);
-    f32x16 zc[2] = {z[0], z[1]}, zg[2] = {z[2], z[3]};
-    f32x16 xh1[2], xh2[2], n1[2], a1[2], a2[2];
-    float rstd1, rstd2;
-    gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, h, xh1, xh2, rstd1, rstd2, n1, a1, a2);
+    f32x4 z[2 * VT];
+    read_dl<2 * VT>(Trow, g, z);
+    gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+    V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
+    GatedState s;
+    gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, g, s);
     __builtin_amdgcn_wave_barrier();
-    f32x16 w1[2], w2[2];
-    if (HIDDEN) {
-      glb_read_dl<2>(p.wbgc + (size_t)b1 * D, h, w1);
-      glb_read_dl<2>(p.wbgc + (size_t)b2 * D, h, w2);
-    }
     if (!BWD) {
-      f32x16 y[2];
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          y[ft][r] = a1[ft][r] * a2[ft][r];
-          if (HIDDEN) y[ft][r] *= w1[ft][r] * w2[ft][r];
-          else y[ft][r] += x[ft][r];
-        }
-      lds_write_dl<2>(T, TS, j, h, 0, y);
+      V64 y;
+      CHG_EW(ft, r) {
+        y.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r];
+        if (HIDDEN) y.t[ft][r] *= w1.t[ft][r] * w2.t[ft][r];
+        else y.t[ft][r] += x.t[ft][r];
+      }
+      write_dl<VT>(Trow, g, y.t);
       __builtin_amdgcn_wave_barrier();
       if (HIDDEN) seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.out, D, lane);
       else scatter_rows64<false>(T, TS, p.out, a, nvalid, lane);
     } else {
-      f32x16 gy[2], gzc[2], gzg[2];
+      V64 gy, gzc, gzg;
       if (HIDDEN) {
-        f32x16 gu[2], g1[2], g2[2];
-        glb_read_dl<2>(p.Gagg + (size_t)b1 * D, h, gu);
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float y = a1[ft][r] * a2[ft][r];
-            g1[ft][r] = gu[ft][r] * y * w2[ft][r];      // dE/d wbgc[b1]
-            g2[ft][r] = gu[ft][r] * y * w1[ft][r];      // dE/d wbgc[b2]
-            gy[ft][r] = gu[ft][r] * w1[ft][r] * w2[ft][r];
-          }
-        lds_write_dl<2>(T, TS, j, h, 0, g1);
-        lds_write_dl<2>(T, TS, j, h, D, g2);
+        V64 g1, g2;
+        CHG_EW(ft, r) {
+          const float y = s.a1.t[ft][r] * s.a2.t[ft][r];
+          g1.t[ft][r] = gu.t[ft][r] * y * w2.t[ft][r];      // dE/d wbgc[b1]
+          g2.t[ft][r] = gu.t[ft][r] * y * w1.t[ft][r];      // dE/d wbgc[b2]
+          gy.t[ft][r] = gu.t[ft][r] * w1.t[ft][r] * w2.t[ft][r];
+        }
+        write_dl<VT>(Trow, g, g1.t);
+        write_dl<VT>(Trow + D, g, g2.t);
         __builtin_amdgcn_wave_barrier();
         seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.Gwbgc, D, lane);
         row_atomic_add<D>(T + D, TS, valid ? b2 : -1, nvalid, p.Gwbgc, D, lane);
       } else {
         gather_rows64(T, TS, p.Gang, a, lane);          // dE/d(new angle) of this tile
         __builtin_amdgcn_wave_barrier();
-        lds_read_dl<2>(T, TS, j, h, 0, gy);
+        read_dl<VT>(Trow, g, gy.t);
       }
       __builtin_amdgcn_wave_barrier();
-      gated_backward<HIDDEN>(gy, zc, zg, W2c, W2g, vecs, j, h, xh1, xh2, rstd1, rstd2, n1, a1, a2, gzc, gzg);
+      gated_backward<HIDDEN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
       // dE/d(angle in) += W_ang^T gz   (the residual identity is already in Gang)
-      f32x16 gz[4] = {gzc[0], gzc[1], gzg[0], gzg[1]};
-      f32x16 ga[2] = {zero16(), zero16()};
-      gemm_dl_t<4, 2>(ga, Wang, WS, gz, j, h);
-      lds_write_dl<2>(T, TS, j, h, 0, ga);
+      f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
+      V64 ga = zero64();
+      gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
+      write_dl<VT>(Trow, g, ga.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<true>(T, TS, p.Gang, a, nvalid, lane);
       __builtin_amdgcn_wave_barrier();
-      lds_write_dl<4>(T, TS, j, h, 0, gz);
+      write_dl<2 * VT>(Trow, g, gz);
       __builtin_amdgcn_wave_barrier();
       seg_colsum_atomic<2 * D>(T, TS, valid ? b1 : -1, nvalid, p.GR, 4 * D, lane);
       row_atomic_add<2 * D>(T, TS, valid ? b2 : -1, nvalid, p.GR + 2 * D, 4 * D, lane);
@@ -440,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
 
 // =============================================================================================
 // Readout: LayerNorm -> MLP 64-64-64-64-1 (silu) -> per-structure sums; and its reverse.
-//   model.py:497-509 (readout_norm, mlp, pooling), 477-487 (site_wise magmom lives in k_magmom)
+//   model.py:497-509 (readout_norm, mlp, pooling); the site_wise magmom head is k_magmom
 // =============================================================================================
 struct ReadoutArgs {
   const float* atom;       // [N,64] features after the last AtomConv
@@ -456,7 +433,7 @@ struct ReadoutArgs {
   float* Ga;               // [N,64] out: dE/d atom (null -> forward only)
 };
 
-constexpr size_t readout_lds() { return sizeof(float) * (3 * D * WS + 9 * D + WAVES * TILE_FLOATS); }
+constexpr size_t readout_lds() { return sizeof(float) * (3 * D * WS + 6 * D + WAVES * TILE_FLOATS); }
 
 __global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -464,8 +441,8 @@ __global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
   float* W1 = W0 + D * WS;
   float* W2 = W1 + D * WS;
   float* vecs = W2 + D * WS;  // ln_g ln_b b0 b1 b2 w3
-  float* tiles = vecs + 9 * D;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  float* tiles = vecs + 6 * D;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_weights(W0, p.w0, D, D, tid);
   stage_weights(W1, p.w1, D, D, tid);
   stage_weights(W2, p.w2, D, D, tid);
@@ -477,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
   stage_vector(vecs + 5 * D, p.w3, D, tid);
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
   const float b3 = p.b3[0];
   const int ntiles = (p.n_atoms + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
@@ -490,68 +468,42 @@ __global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
     const int owner = p.atom_owner[i];
     gather_rows64(T, TS, p.atom, i, lane);
     __builtin_amdgcn_wave_barrier();
-    f32x16 xh[2], x0[2], g[2], b[2];
-    lds_read_dl<2>(T, TS, j, h, 0, xh);
+    V64 xh, x0;
+    read_dl<VT>(Trow, g, xh.t);
     const float rstd = ln_normalize(xh);
-    param_read_dl<2>(vecs + 0 * D, h, g);
-    param_read_dl<2>(vecs + 1 * D, h, b);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x0[ft][r] = xh[ft][r] * g[ft][r] + b[ft][r];
+    const V64 gam = param64(vecs + 0 * D, g), bet = param64(vecs + 1 * D, g);
+    CHG_EW(ft, r) x0.t[ft][r] = xh.t[ft][r] * gam.t[ft][r] + bet.t[ft][r];
     __builtin_amdgcn_wave_barrier();
-    lds_write_dl<2>(T, TS, j, h, 0, x0);
+    write_dl<VT>(Trow, g, x0.t);
     __builtin_amdgcn_wave_barrier();
     seg_colsum_atomic<D>(T, TS, valid ? owner : -1, nvalid, p.crystal_fea, D, lane);
-    f32x16 l1[2], l2[2], l3[2], s[2];
-    param_read_dl<2>(vecs + 2 * D, h, l1);
-    gemm_dl<2, 2>(l1, W0, WS, x0, j, h);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[ft][r] = siluf_(l1[ft][r]);
-    param_read_dl<2>(vecs + 3 * D, h, l2);
-    gemm_dl<2, 2>(l2, W1, WS, s, j, h);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[ft][r] = siluf_(l2[ft][r]);
-    param_read_dl<2>(vecs + 4 * D, h, l3);
-    gemm_dl<2, 2>(l3, W2, WS, s, j, h);
-    f32x16 w3[2];
-    param_read_dl<2>(vecs + 5 * D, h, w3);
+    V64 l1 = param64(vecs + 2 * D, g), l2 = param64(vecs + 3 * D, g), l3 = param64(vecs + 4 * D, g), sv;
+    gemm_dl<VT, VT>(l1.t, W0, WS, x0.t, j, g);
+    CHG_EW(ft, r) sv.t[ft][r] = siluf_(l1.t[ft][r]);
+    gemm_dl<VT, VT>(l2.t, W1, WS, sv.t, j, g);
+    CHG_EW(ft, r) sv.t[ft][r] = siluf_(l2.t[ft][r]);
+    gemm_dl<VT, VT>(l3.t, W2, WS, sv.t, j, g);
+    const V64 w3 = param64(vecs + 5 * D, g);
     float site = 0.f;
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) site += w3[ft][r] * siluf_(l3[ft][r]);
-    site = pair_sum(site) + b3;
-    if (valid && h == 0) {
+    CHG_EW(ft, r) site += w3.t[ft][r] * siluf_(l3.t[ft][r]);
+    site = quad_sum(site) + b3;
+    if (valid && g == 0) {
       const float ref = p.has_composition ? p.atomref[p.z[i] - 1] : 0.f;
       p.site_energy[i] = site + ref;
       atomicAdd(p.energy + owner, site);
       if (p.has_composition) atomicAdd(p.comp_energy + owner, ref);
     }
     if (p.Ga) {
-      f32x16 g3[2], g2[2] = {zero16(), zero16()}, g1[2] = {zero16(), zero16()}, gx[2] = {zero16(), zero16()};
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g3[ft][r] = w3[ft][r] * dsiluf_(l3[ft][r]);
-      gemm_dl_t<2, 2>(g2, W2, WS, g3, j, h);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g2[ft][r] *= dsiluf_(l2[ft][r]);
-      gemm_dl_t<2, 2>(g1, W1, WS, g2, j, h);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g1[ft][r] *= dsiluf_(l1[ft][r]);
-      gemm_dl_t<2, 2>(gx, W0, WS, g1, j, h);
-      ln_backward(gx, g, xh, rstd);
+      V64 g3, g2 = zero64(), g1 = zero64(), gx = zero64();
+      CHG_EW(ft, r) g3.t[ft][r] = w3.t[ft][r] * dsiluf_(l3.t[ft][r]);
+      gemm_dl_t<VT, VT>(g2.t, W2, WS, g3.t, j, g);
+      CHG_EW(ft, r) g2.t[ft][r] *= dsiluf_(l2.t[ft][r]);
+      gemm_dl_t<VT, VT>(g1.t, W1, WS, g2.t, j, g);
+      CHG_EW(ft, r) g1.t[ft][r] *= dsiluf_(l1.t[ft][r]);
+      gemm_dl_t<VT, VT>(gx.t, W0, WS, g1.t, j, g);
+      ln_backward(gx, gam, xh, rstd);
       __builtin_amdgcn_wave_barrier();
-      lds_write_dl<2>(T, TS, j, h, 0, gx);
+      write_dl<VT>(Trow, g, gx.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, TS, p.Ga, i, nvalid, lane);
     }

@@ -1,18 +1,22 @@
 // mfma_tile.h -- wave-level building blocks shared by every gfx950 kernel of the engine.
 //
-// One wave (64 lanes) owns a tile of 32 rows (edges / angles / atoms / bonds) and keeps
-// feature vectors in the "D layout" of v_mfma_f32_32x32x2_f32:
+// One wave (64 lanes) owns a tile of 16 rows (edges / angles / atoms / bonds) and keeps feature
+// vectors in the accumulator ("D") layout of v_mfma_f32_16x16x4_f32:
 //
-//     lane = j + 32*h      j in [0,32) = tile row,  h in {0,1}
-//     x[ft][r]  (ft = 32-feature tile, r in [0,16))  holds feature
-//         F(ft,r,h) = 32*ft + 8*(r>>2) + 4*h + (r&3)      of row j
+//     lane = j + 16*g      j in [0,16) = tile row,  g in [0,4)
+//     x[ft][r]  (ft = 16-feature tile, r in [0,4))  holds feature  F(ft,r,g) = 16*ft + 4*g + r  of row j
 //
-// i.e. a 64-wide vector is split between lane j and lane j+32, each owning 8 groups of 4
-// consecutive floats (one float4 per (ft, r>>2)).  With the contraction index k enumerated
-// in that same order, the accumulator of one MFMA GEMM is directly the B operand of the
-// next one ("swapped" form D[f][row] = sum_k W[f][k] * X[row][k]: weights are the A operand,
-// rows are the columns of D), so chained layers never leave registers, and LayerNorm over
-// the 64 features of a row is an in-lane sum plus one exchange with lane^32.
+// i.e. a 64-wide vector is split over the 4 lanes {j, j+16, j+32, j+48}, each owning one float4 per
+// 16-feature tile (16 registers per lane).  With the contraction index k enumerated in that same order
+// the accumulator of one MFMA GEMM is directly the B operand of the next one ("swapped" form
+// D[f][row] = sum_k W[f][k] * X[row][k]: weights are the A operand, rows are the columns of D), so
+// chained layers never leave registers, and LayerNorm over the 64 features of a row is an in-lane sum
+// plus two cross-lane exchanges (lane^16, lane^32).
+//
+// Why 16-row tiles: the conv kernels were latency-bound at one 32-row wave per SIMD (478-512 VGPRs,
+// profiles/r01).  Halving the rows halves every per-lane vector, which fits the backward kernels in 256
+// VGPRs -> 8 waves per workgroup = 2 waves per SIMD, so one wave's gathers / VALU run under the other's
+// MFMAs, and a whole tile's gather (24 row loads) is in flight at once.
 //
 // fp32 MFMA is exact f32 (fmaf chain) at 64 FLOP/clk/SIMD; there is no xf32 on CDNA4.
 #pragma once
@@ -22,26 +26,24 @@
 
 namespace chg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int D = 64;            // feature width (atom = bond = angle)
-constexpr int TILE_ROWS = 32;    // rows per wave tile
-constexpr int WAVES = 4;         // waves per workgroup
+constexpr int TILE_ROWS = 16;    // rows per wave tile
+constexpr int WAVES = 8;         // waves per workgroup (2 per SIMD)
 constexpr int BLOCK = 64 * WAVES;
 constexpr int BLOCK_ROWS = TILE_ROWS * WAVES;
-constexpr int PAD = 4;           // floats of padding per LDS row: keeps 16-B alignment and makes
-                                 // ds_read_b128 over 32 consecutive rows conflict-free (row stride = 4 mod 64)
+constexpr int PAD = 4;           // floats of padding per LDS row: keeps 16-B alignment and spreads
+                                 // ds_read_b128 of consecutive rows over the banks (row stride = 4 mod 64)
+constexpr int VT = 4;            // 16-feature tiles per 64 features
 constexpr float LN_EPS = 1e-5f;
 
-__device__ __forceinline__ int dfeat(int ft, int r, int h) { return 32 * ft + 8 * (r >> 2) + 4 * h + (r & 3); }
+struct V64 { f32x4 t[VT]; };     // 64 features of one row, this lane's share (16 floats)
 
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) z[r] = 0.f;
-  return z;
-}
+__device__ __forceinline__ int dfeat(int ft, int r, int g) { return 16 * ft + 4 * g + r; }
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ V64 zero64() { return V64{{zero4(), zero4(), zero4(), zero4()}}; }
 
 // ---- activations -------------------------------------------------------------------------------
 // sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp
@@ -57,138 +59,87 @@ __device__ __forceinline__ float dsiluf_(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// elementwise loop over this lane's 16 floats of a 64-wide vector
+#define CHG_EW(ft, r) _Pragma("unroll") for (int ft = 0; ft < VT; ++ft) _Pragma("unroll") for (int r = 0; r < 4; ++r)
+
 // ---- D-layout loads / stores ---------------------------------------------------------------
-// LDS tile [32][stride] (or any row-major buffer): row j, features f0 + [0, 32*NT)
+// `row` points at feature 0 of the lane's row in a row-major buffer (LDS tile or global table)
 template <int NT>
-__device__ __forceinline__ void lds_read_dl(const float* tile, int stride, int j, int h, int f0, f32x16 (&x)[NT]) {
+__device__ __forceinline__ void read_dl(const float* row, int g, f32x4 (&x)[NT]) {
 #pragma unroll
-  for (int ft = 0; ft < NT; ++ft)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + j * stride + f0 + 32 * ft + 8 * q + 4 * h);
-      x[ft][4 * q + 0] = v[0];
-      x[ft][4 * q + 1] = v[1];
-      x[ft][4 * q + 2] = v[2];
-      x[ft][4 * q + 3] = v[3];
-    }
+  for (int ft = 0; ft < NT; ++ft) x[ft] = *reinterpret_cast<const f32x4*>(row + 16 * ft + 4 * g);
 }
-
 template <int NT>
-__device__ __forceinline__ void lds_write_dl(float* tile, int stride, int j, int h, int f0, const f32x16 (&x)[NT]) {
+__device__ __forceinline__ void write_dl(float* row, int g, const f32x4 (&x)[NT]) {
 #pragma unroll
-  for (int ft = 0; ft < NT; ++ft)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v;
-      v[0] = x[ft][4 * q + 0];
-      v[1] = x[ft][4 * q + 1];
-      v[2] = x[ft][4 * q + 2];
-      v[3] = x[ft][4 * q + 3];
-      *reinterpret_cast<f32x4*>(tile + j * stride + f0 + 32 * ft + 8 * q + 4 * h) = v;
-    }
-}
-
-// per-lane global row pointer (each lane reads its own row): features [0, 32*NT)
-template <int NT>
-__device__ __forceinline__ void glb_read_dl(const float* __restrict__ row, int h, f32x16 (&x)[NT]) {
-#pragma unroll
-  for (int ft = 0; ft < NT; ++ft)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * ft + 8 * q + 4 * h);
-      x[ft][4 * q + 0] = v[0];
-      x[ft][4 * q + 1] = v[1];
-      x[ft][4 * q + 2] = v[2];
-      x[ft][4 * q + 3] = v[3];
-    }
-}
-
-// a 64*NT/2-float parameter vector (bias / gamma / beta), same for every row
-template <int NT>
-__device__ __forceinline__ void param_read_dl(const float* vec, int h, f32x16 (&x)[NT]) {
-  lds_read_dl<NT>(vec, 0, 0, h, 0, x);
+  for (int ft = 0; ft < NT; ++ft) *reinterpret_cast<f32x4*>(row + 16 * ft + 4 * g) = x[ft];
 }
 
 // ---- MFMA GEMMs in swapped form ---------------------------------------------------------------
-// acc[fo] (fo < NFT) += W[32*fo + i][k] * x[k]   for k over 32*KT inputs held in D layout.
-// W: LDS, row-major [out][ws] (ws = K + PAD): the A operand of lane (i,h) is read as float4.
+// acc[fo] (fo < NFT) += W[16*fo + i][k] * x[k]   for k over 16*KT inputs held in D layout.
+// W: LDS, row-major [out][ws] (ws = K + PAD): the A operand of lane (i,g) is read as float4.
+// Consecutive MFMAs go to different accumulators (16x16x4: 32-cycle issue, 40-cycle dependent latency).
 template <int KT, int NFT>
-__device__ __forceinline__ void gemm_dl(f32x16 (&acc)[NFT], const float* W, int ws, const f32x16 (&x)[KT], int i, int h) {
+__device__ __forceinline__ void gemm_dl(f32x4 (&acc)[NFT], const float* W, int ws, const f32x4 (&x)[KT], int i, int g) {
+  const float* wbase = W + i * ws + 4 * g;
 #pragma unroll
-  for (int fo = 0; fo < NFT; ++fo) {
-    const float* wrow = W + (32 * fo + i) * ws + 4 * h;
+  for (int kt = 0; kt < KT; ++kt) {
+    f32x4 w[NFT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int fo = 0; fo < NFT; ++fo) w[fo] = *reinterpret_cast<const f32x4*>(wbase + 16 * fo * ws + 16 * kt);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + 32 * kt + 8 * q);
-        acc[fo] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[kt][4 * q + 0], acc[fo], 0, 0, 0);
-        acc[fo] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[kt][4 * q + 1], acc[fo], 0, 0, 0);
-        acc[fo] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[kt][4 * q + 2], acc[fo], 0, 0, 0);
-        acc[fo] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[kt][4 * q + 3], acc[fo], 0, 0, 0);
-      }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[fo][r], x[kt][r], acc[fo], 0, 0, 0);
   }
 }
 
-// Transposed use of the same LDS copy: acc[fo] += W[k][32*fo + i] * x[k]  (W row-major [k][ws]).
+// Transposed use of the same LDS copy: acc[fo] += W[k][16*fo + i] * x[k]  (W row-major [k][ws]).
 // Lanes i are consecutive in memory -> ds_read_b32, conflict-free.
 template <int KT, int NFT>
-__device__ __forceinline__ void gemm_dl_t(f32x16 (&acc)[NFT], const float* W, int ws, const f32x16 (&x)[KT], int i, int h) {
+__device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int ws, const f32x4 (&x)[KT], int i, int g) {
 #pragma unroll
-  for (int fo = 0; fo < NFT; ++fo)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int r = 0; r < 4; ++r) {
+      const float* wrow = W + dfeat(kt, r, g) * ws + i;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float w = W[dfeat(kt, r, h) * ws + 32 * fo + i];
-        acc[fo] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x[kt][r], acc[fo], 0, 0, 0);
-      }
+      for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * fo], x[kt][r], acc[fo], 0, 0, 0);
+    }
 }
 
-// ---- LayerNorm over the 64 features of a row (2 tiles in D layout) ---------------------------
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32); }
+// ---- LayerNorm over the 64 features of a row (spread over 4 lanes) ------------------------------
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
 
 // in: c (pre-norm).  out: c <- xhat, returns rstd.
-__device__ __forceinline__ float ln_normalize(f32x16 (&c)[2]) {
+__device__ __forceinline__ float ln_normalize(V64& c) {
   float s = 0.f;
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += c[ft][r];
-  const float mu = pair_sum(s) * (1.0f / 64.0f);
+  CHG_EW(ft, r) s += c.t[ft][r];
+  const float mu = quad_sum(s) * (1.0f / 64.0f);
   float v = 0.f;
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      c[ft][r] -= mu;
-      v += c[ft][r] * c[ft][r];
-    }
-  const float rstd = __builtin_amdgcn_rsqf(pair_sum(v) * (1.0f / 64.0f) + LN_EPS);
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[ft][r] *= rstd;
+  CHG_EW(ft, r) {
+    c.t[ft][r] -= mu;
+    v += c.t[ft][r] * c.t[ft][r];
+  }
+  const float rstd = __builtin_amdgcn_rsqf(quad_sum(v) * (1.0f / 64.0f) + LN_EPS);
+  CHG_EW(ft, r) c.t[ft][r] *= rstd;
   return rstd;
 }
 
 // LayerNorm backward: gy <- rstd * (gx - mean(gx) - xhat * mean(gx*xhat)),  gx = gy * gamma
-__device__ __forceinline__ void ln_backward(f32x16 (&gy)[2], const f32x16 (&gamma)[2], const f32x16 (&xhat)[2], float rstd) {
+__device__ __forceinline__ void ln_backward(V64& gy, const V64& gamma, const V64& xhat, float rstd) {
   float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      gy[ft][r] *= gamma[ft][r];
-      s1 += gy[ft][r];
-      s2 += gy[ft][r] * xhat[ft][r];
-    }
-  const float m1 = pair_sum(s1) * (1.0f / 64.0f);
-  const float m2 = pair_sum(s2) * (1.0f / 64.0f);
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gy[ft][r] = rstd * (gy[ft][r] - m1 - xhat[ft][r] * m2);
+  CHG_EW(ft, r) {
+    gy.t[ft][r] *= gamma.t[ft][r];
+    s1 += gy.t[ft][r];
+    s2 += gy.t[ft][r] * xhat.t[ft][r];
+  }
+  const float m1 = quad_sum(s1) * (1.0f / 64.0f);
+  const float m2 = quad_sum(s2) * (1.0f / 64.0f);
+  CHG_EW(ft, r) gy.t[ft][r] = rstd * (gy.t[ft][r] - m1 - xhat.t[ft][r] * m2);
 }
 
 // ---- LDS staging of a row-major weight matrix [rows][K] -> [rows][K+PAD] ------------------------
@@ -217,7 +168,7 @@ __device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) {
 }
 
 // ---- segmented reductions over the rows of a wave tile -----------------------------------------
-// tile: [32][stride] LDS, W columns; lane `rr` holds the (sorted-run) key of row rr in `key`
+// tile: [16][stride] LDS, W columns; lane `rr` holds the (sorted-run) key of row rr in `key`
 // (key < 0: skip).  Runs of equal keys are summed per column and flushed with one fp32 atomic
 // per (run, column); runs that continue in another tile meet in memory.
 template <int W>
@@ -258,7 +209,7 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
 template <int W>
 __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, int key, int nvalid, float* __restrict__ dst,
                                                int ldd, int lane) {
-#ifdef CHG_EXP_NO_ROW_ATOMICS   // timing experiment only (tests/gpu_experiments.sh): wrong results
+#ifdef CHG_EXP_NO_ROW_ATOMICS   // timing experiment only: wrong results
   return;
 #endif
 #pragma unroll
@@ -273,15 +224,17 @@ __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, in
   }
 }
 
-// ---- row-spread gather: sum of up to three table rows, 128 floats wide, into an LDS tile ---------
+// ---- row-spread gather: sum of three table rows, 128 floats wide, into an LDS tile ---------------
 // Half-wave `hw` (32 lanes) handles one row per step; lane t loads float4 #t of the 512-B row, so
-// every load instruction covers two full rows.  Lane rr (< 32) holds the three row indices of tile
-// row rr; they must be valid (clamped) even for rows past the end of the problem.
+// every load instruction covers two full rows and all 24 loads of a tile are in flight together.
+// Lane rr (< 16) holds the three row indices of tile row rr; they must be valid (clamped) even for
+// rows past the end of the problem.
 __device__ __forceinline__ void gather_sum128(float* tile, int stride, const float* __restrict__ t0, int i0,
                                               const float* __restrict__ t1, int i1, const float* __restrict__ t2, int i2,
                                               int ld0, int ld1, int ld2, int lane) {
   const int hw = lane >> 5, t = lane & 31;
-#pragma unroll 4
+  f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
+#pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
     const int rr = 2 * it + hw;
 #ifdef CHG_EXP_NO_GATHER        // timing experiment only: every row reads table row 0 (cache-resident)
@@ -289,24 +242,28 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
 #else
     const int r0 = __shfl(i0, rr), r1 = __shfl(i1, rr), r2 = __shfl(i2, rr);
 #endif
-    f32x4 a = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0 * ld0 + 4 * t);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1 * ld1 + 4 * t);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2 * ld2 + 4 * t);
-    a += b;
-    a += c;
-    *reinterpret_cast<f32x4*>(tile + rr * stride + 4 * t) = a;
+    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0 * ld0 + 4 * t);
+    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1 * ld1 + 4 * t);
+    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2 * ld2 + 4 * t);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    const int rr = 2 * it + hw;
+    *reinterpret_cast<f32x4*>(tile + rr * stride + 4 * t) = (a[it] + b[it]) + c[it];
   }
 }
 
-// contiguous or gathered 64-wide rows into an LDS tile (half-wave per row pair: 16 lanes per row)
+// contiguous or gathered 64-wide rows into an LDS tile (16 lanes per row, 4 rows per step)
 __device__ __forceinline__ void gather_rows64(float* tile, int stride, const float* __restrict__ src, int idx, int lane) {
-  const int sub = lane >> 4, t = lane & 15;   // 4 rows per step
-#pragma unroll 4
+  const int sub = lane >> 4, t = lane & 15;
+  f32x4 v[TILE_ROWS / 4];
+#pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
-    const int rr = 4 * it + sub;
-    const int r = __shfl(idx, rr);
-    *reinterpret_cast<f32x4*>(tile + rr * stride + 4 * t) = *reinterpret_cast<const f32x4*>(src + (size_t)r * D + 4 * t);
+    const int r = __shfl(idx, 4 * it + sub);
+    v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r * D + 4 * t);
   }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = v[it];
 }
 
 // LDS tile (64 wide) -> global rows (coalesced 256-B rows), plain store or read-modify-write add
@@ -314,7 +271,7 @@ template <bool ACCUM>
 __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid,
                                                int lane) {
   const int sub = lane >> 4, t = lane & 15;
-#pragma unroll 4
+#pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
     const int rr = 4 * it + sub;
     const int r = __shfl(idx, rr);
