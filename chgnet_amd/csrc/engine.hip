@@ -71,7 +71,7 @@ struct chg_batch {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   // inputs
-  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
+  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *p_center, *p_nbr, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
   float *frac, *lattice, *e_image;
   // geometry / features
   float* cart;
@@ -80,11 +80,17 @@ struct chg_batch {
   float* atom[MAX_CONV + 1];
   float* hbc[MAX_CONV + 1];
   float* ang[MAX_CONV];
-  float *P, *Q, *R, *S, *agg, *aggB;
+  // first-layer partial-product tables, one set per layer so the reverse sweep reuses the forward's
+  float* Pl[MAX_CONV];          // AtomConv l: [N,256]
+  float* Ql[MAX_CONV];          // AtomConv l: [Eu,128]
+  float* Rl[2 * MAX_CONV];      // BondConv l (slot l) / AngleUpdate l (slot L+l): [Eb,256]
+  float* Sl[2 * MAX_CONV];      // same slots: [N,128]
+  float *agg, *aggB;
   // outputs
   float *energy_sum, *comp_sum, *energy, *site_energy, *magmom, *crystal_fea, *force, *virial, *volume;
   // reverse sweep
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
+  float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
   std::map<std::string, std::pair<const float*, size_t>> named;
 };
@@ -268,17 +274,18 @@ inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4
 // tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half),  Q = h_bond^l . Wb^T
 int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
-  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, b->P, 4 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn + 2 * D * D, nullptr, nullptr, 0, b->P + 2 * D, 4 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, nullptr, nullptr, 0, b->Q, 2 * D, nullptr, b->Eu, 0));
+  float *P = b->Pl[l], *Q = b->Ql[l];
+  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, P, 4 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn + 2 * D * D, nullptr, nullptr, 0, P + 2 * D, 4 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
   if (b->Eb > 0 && b->hbc[l] != b->hbc[0])   // bond-graph nodes carry layer-l features
-    TRY(rows_gemm(eng, "gemm_Qnode", 64, 128, b->hbc[l], D, nullptr, w.w_bond, nullptr, nullptr, 0, b->Q, 2 * D, b->bn_und, b->Eb, 0));
+    TRY(rows_gemm(eng, "gemm_Qnode", 64, 128, b->hbc[l], D, nullptr, w.w_bond, nullptr, nullptr, 0, Q, 2 * D, b->bn_und, b->Eb, 0));
   return CHG_OK;
 }
 
 AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   AtomConvArgs a{};
-  a.P = b->P; a.Q = b->Q; a.wag = b->wag;
+  a.P = b->Pl[l]; a.Q = b->Ql[l]; a.wag = b->wag;
   a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_d2u = b->e_d2u; a.n_edges = b->Ed;
   a.gw = eng->w.ac[l].g;
   a.agg = b->agg; a.GA = b->GA; a.GP = b->GP; a.GQ = b->GQ; a.Gwag = b->Gwag;
@@ -291,7 +298,7 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   if (b->Ed > 0) {
     TRY(atomconv_tables(eng, b, l));
     LaunchScope ls(eng, "atomconv_fwd");
-    hipLaunchKernelGGL((k_atomconv<false>), dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
+    hipLaunchKernelGGL(k_atomconv_fwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
     HIP_TRY(eng, hipGetLastError());
   }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
@@ -301,13 +308,14 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
 int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
   if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
-  TRY(atomconv_tables(eng, b, l));
   TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
   TRY(zero(eng, b->GP, sizeof(float) * (size_t)b->N * 4 * D));
-  TRY(zero(eng, b->GQ, sizeof(float) * (size_t)b->Eu * 2 * D));
-  {
+  {  // pair-ordered edge list: GQ and Gwag rows are owned by one tile each (no zeroing, no atomics)
+    AtomConvArgs a = atomconv_args(eng, b, l);
+    a.e_center = b->p_center;
+    a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL((k_atomconv<true>), dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
+    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -319,15 +327,16 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
 
 // ---- BondConv / AngleUpdate ----------------------------------------------------------------------------
 // tables: S = atom . Wctr^T + b1 (per atom),  R = hbc . [Wi;Wj]^T (per bond-graph node)
-int angle_tables(chg_engine* eng, chg_batch* b, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
-  TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, b->S, 2 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij, nullptr, nullptr, 0, b->R, 4 * D, nullptr, b->Eb, 0));
-  return rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij + 2 * D * D, nullptr, nullptr, 0, b->R + 2 * D, 4 * D, nullptr, b->Eb, 0);
+int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
+  float *S = b->Sl[slot], *R = b->Rl[slot];
+  TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0));
+  TRY(rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0));
+  return rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij + 2 * D * D, nullptr, nullptr, 0, R + 2 * D, 4 * D, nullptr, b->Eb, 0);
 }
 
-AngleArgs angle_args(chg_batch* b, const float* ang, const float* w_ang, const GatedW& g, float* out) {
+AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_ang, const GatedW& g, float* out) {
   AngleArgs a{};
-  a.R = b->R; a.S = b->S; a.ang = ang; a.wbgc = b->wbgc;
+  a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.ang = ang; a.wbgc = b->wbgc;
   a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
   a.w_ang = w_ang; a.gw = g; a.out = out;
   a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR; a.GS = b->GS; a.Gwbgc = b->Gwbgc;
@@ -345,17 +354,17 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
 
 int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   const BCW& w = eng->w.bc[l];
-  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
+  TRY(angle_tables(eng, b, l, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
   TRY(zero(eng, b->aggB, sizeof(float) * (size_t)b->Eb * D));
-  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, b->aggB))));
+  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, b->aggB))));
   // hbc[l+1] = agg . Wout^T + b_out + hbc[l]          (layers.py:255-260)
   return rows_gemm(eng, "gemm_out", 64, 64, b->aggB, D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
 }
 
 int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
   const AUW& w = eng->w.au[l];
-  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
-  return launch_angle<false, false>(eng, "angleupd_fwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
+  TRY(angle_tables(eng, b, b->L + l, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
+  return launch_angle<false, false>(eng, "angleupd_fwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
 }
 
 // scatter of the table gradients back to atoms / bond nodes
@@ -367,20 +376,18 @@ int angle_table_grads(chg_engine* eng, chg_batch* b, const float* w_bij_t, const
 
 int bondconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   const BCW& w = eng->w.bc[l];
-  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
   TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, w.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, b->Eb, 0));
   TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
   TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
-  TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, nullptr))));
+  TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, nullptr))));
   return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
 }
 
 int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
   const AUW& w = eng->w.au[l];
-  TRY(angle_tables(eng, b, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
   TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
   TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
-  TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, b->ang[l], w.w_ang, w.g, nullptr))));
+  TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, nullptr))));
   return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
 }
 
@@ -448,9 +455,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   TRY(atomconv_fwd(eng, b, L - 1));
 
   // ---- readout (model.py:497-509) and its adjoint ----
-  TRY(zero(eng, b->energy_sum, sizeof(float) * b->B));
-  TRY(zero(eng, b->comp_sum, sizeof(float) * b->B));
-  TRY(zero(eng, b->crystal_fea, sizeof(float) * (size_t)b->B * D));
+  TRY(zero(eng, b->zero1, (size_t)((char*)b->zero1_end - (char*)b->zero1)));
   {
     ReadoutArgs r{};
     r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = b->N;
@@ -466,10 +471,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
 
   // ---- reverse sweep: dE/dv_e ----
   if (want_grad) {
-    TRY(zero(eng, b->Gb, sizeof(float) * (size_t)b->Eu * D));
-    TRY(zero(eng, b->Gwag, sizeof(float) * (size_t)b->Eu * D));
-    TRY(zero(eng, b->Gwbgc, sizeof(float) * (size_t)b->Eb * D));
-    TRY(zero(eng, b->Gang, sizeof(float) * (size_t)b->A * D));
+    TRY(zero(eng, b->zero2, (size_t)((char*)b->zero2_end - (char*)b->zero2)));
     TRY(atomconv_bwd(eng, b, L - 1));
     for (int l = L - 2; l >= 0; --l) {
       if (b->A > 0) {
@@ -478,9 +480,6 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
       }
       TRY(atomconv_bwd(eng, b, l));
     }
-    TRY(zero(eng, b->Gu, sizeof(float) * (size_t)b->Ed * 4));
-    TRY(zero(eng, b->force, sizeof(float) * (size_t)b->N * 3));
-    TRY(zero(eng, b->virial, sizeof(float) * (size_t)b->B * 9));
     if (b->Ed > 0) {
       { LaunchScope ls(eng, "bond_embed_bwd");
         hipLaunchKernelGGL((k_bond_embed<true>), dim3(wave_grid(eng, b->Eu)), dim3(256), 0, st, bond_embed_args(eng, b)); }
@@ -529,6 +528,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   const int L = b->L;
   b->z = c.take<int>(N); b->atom_owner = c.take<int>(N); b->atom_off = c.take<int>(B + 1);
   b->e_center = c.take<int>(Ed); b->e_nbr = c.take<int>(Ed); b->e_d2u = c.take<int>(Ed); b->e_owner = c.take<int>(Ed);
+  b->p_center = c.take<int>(Ed); b->p_nbr = c.take<int>(Ed);
   b->u_u2d = c.take<int>(Eu); b->u_bnode = c.take<int>(Eu); b->bn_und = c.take<int>(Eb);
   b->a_ctr = c.take<int>(A); b->a_b1c = c.take<int>(A); b->a_b2c = c.take<int>(A); b->a_d1 = c.take<int>(A); b->a_d2 = c.take<int>(A);
   b->frac = c.take<float>(3 * N); b->lattice = c.take<float>(9 * B); b->e_image = c.take<float>(3 * Ed);
@@ -537,15 +537,23 @@ void carve(chg_batch* b, char* base, size_t& total) {
   for (int l = 0; l <= L; ++l) b->atom[l] = c.take<float>(N * D);
   for (int l = 0; l < L; ++l) b->hbc[l] = (A > 0 || l == 0) ? c.take<float>(Eb * D) : nullptr;
   for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
-  b->P = c.take<float>(N * 4 * D); b->Q = c.take<float>(Eu * 2 * D); b->R = c.take<float>(Eb * 4 * D); b->S = c.take<float>(N * 2 * D);
+  for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
+  for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
   b->agg = c.take<float>(N * D); b->aggB = c.take<float>(Eb * D);
-  b->energy_sum = c.take<float>(B); b->comp_sum = c.take<float>(B); b->energy = c.take<float>(B);
-  b->site_energy = c.take<float>(N); b->magmom = c.take<float>(N); b->crystal_fea = c.take<float>(B * D);
-  b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B); b->volume = c.take<float>(B);
-  b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D); b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D);
-  b->Gwbgc = c.take<float>(Eb * D); b->Gang = c.take<float>(A * D); b->GP = c.take<float>(N * 4 * D); b->GQ = c.take<float>(Eu * 2 * D);
+  b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
+  // zero group 1 (cleared with one memset before the readout)
+  b->zero1 = c.take<float>(0);
+  b->energy_sum = c.take<float>(B); b->comp_sum = c.take<float>(B); b->crystal_fea = c.take<float>(B * D);
+  b->zero1_end = c.take<float>(0);
+  // zero group 2 (cleared with one memset before the reverse sweep)
+  b->zero2 = c.take<float>(0);
+  b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D); b->Gwbgc = c.take<float>(Eb * D); b->Gang = c.take<float>(A * D);
+  b->Gu = c.take<float>(4 * Ed); b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B);
+  b->zero2_end = c.take<float>(0);
+  b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D);
+  b->GP = c.take<float>(N * 4 * D); b->GQ = c.take<float>(Eu * 2 * D);
   b->GR = c.take<float>(Eb * 4 * D); b->GS = c.take<float>(N * 2 * D); b->Gagg = c.take<float>(Eb * D);
-  b->Grk = c.take<float>(Eu); b->Gu = c.take<float>(4 * Ed);
+  b->Grk = c.take<float>(Eu);
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
   total = (c.pos + 255) & ~size_t(255);
 }
@@ -561,7 +569,7 @@ void register_names(chg_batch* b) {
   for (int l = 0; l <= b->L; ++l) m["atom" + std::to_string(l)] = {b->atom[l], N * D};
   for (int l = 0; l < b->L; ++l) m["hbc" + std::to_string(l)] = {b->hbc[l], Eb * D};
   for (int l = 0; l < b->L - 1; ++l) m["ang" + std::to_string(l)] = {b->ang[l], A * D};
-  m["P"] = {b->P, N * 4 * D}; m["Q"] = {b->Q, Eu * 2 * D}; m["R"] = {b->R, Eb * 4 * D}; m["S"] = {b->S, N * 2 * D};
+  for (int l = 0; l < b->L; ++l) { m["P" + std::to_string(l)] = {b->Pl[l], N * 4 * D}; m["Q" + std::to_string(l)] = {b->Ql[l], Eu * 2 * D}; }
   m["agg"] = {b->agg, N * D}; m["aggB"] = {b->aggB, Eb * D};
   m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
   m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
@@ -643,8 +651,8 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
-  if ((s = set_lds(eng, k_atomconv<false>, atomconv_lds()))) return s;
-  if ((s = set_lds(eng, k_atomconv<true>, atomconv_lds()))) return s;
+  if ((s = set_lds(eng, k_atomconv_fwd, atomconv_lds()))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<false, false>, angle_lds<false>()))) return s;
@@ -695,7 +703,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
 #define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
   UP(z, N); UP(atom_owner, N); UP(atom_off, B + 1); UP(frac, 3 * N); UP(lattice, 9 * B);
-  UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed);
+  UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed); UP(p_center, Ed); UP(p_nbr, Ed);
   UP(u_u2d, Eu); UP(u_bnode, Eu); UP(bn_und, Eb);
   UP(a_ctr, A); UP(a_b1c, A); UP(a_b2c, A); UP(a_d1, A); UP(a_d2, A);
 #undef UP

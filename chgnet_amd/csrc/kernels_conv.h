@@ -222,8 +222,7 @@ struct AtomConvArgs {
 
 constexpr size_t atomconv_lds() { return sizeof(float) * (2 * D * WS + VEC_SLOTS * D + WAVES * TILE_FLOATS); }
 
-template <bool BWD>
-__global__ __launch_bounds__(BLOCK) void k_atomconv(AtomConvArgs p) {
+__global__ __launch_bounds__(BLOCK) void k_atomconv_fwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2c = smem;
   float* W2g = W2c + D * WS;
@@ -247,10 +246,8 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv(AtomConvArgs p) {
     const int e = row0 + (valid ? j : 0);
     const int c = p.e_center[e], n = p.e_nbr[e], k = p.e_d2u[e];
     gather_sum128(T, TS, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
-    // per-row multipliers / incoming gradients: issued now, consumed after the MFMA phase
-    V64 wv, gm;
+    V64 wv;   // issued now, consumed after the MFMA phase
     read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
-    if (BWD) read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
     __builtin_amdgcn_wave_barrier();
     V64 zc, zg;
     read_dl<VT>(Trow, g, zc.t);
@@ -258,29 +255,110 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv(AtomConvArgs p) {
     GatedState s;
     gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
     __builtin_amdgcn_wave_barrier();
-    if (!BWD) {
-      V64 m;
-      CHG_EW(ft, r) m.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r] * wv.t[ft][r];
-      write_dl<VT>(Trow, g, m.t);
-      __builtin_amdgcn_wave_barrier();
-      seg_colsum_atomic<D>(T, TS, valid ? c : -1, nvalid, p.agg, D, lane);
-    } else {
-      V64 gy, gw, gzc, gzg;
-      CHG_EW(ft, r) {
-        gw.t[ft][r] = gm.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r];   // dE/d wag[k]
-        gy.t[ft][r] = gm.t[ft][r] * wv.t[ft][r];
+    V64 m;
+    CHG_EW(ft, r) m.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r] * wv.t[ft][r];
+    write_dl<VT>(Trow, g, m.t);
+    __builtin_amdgcn_wave_barrier();
+    seg_colsum_atomic<D>(T, TS, valid ? c : -1, nvalid, p.agg, D, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Adjoint of AtomConv over the PAIR-ORDERED edge list: rows 2k and 2k+1 are the two directions of
+// undirected bond k (pack.py: p_center / p_nbr).  Both directions of a bond then sit in one tile, so
+//   dE/dQ[k], dE/dw_ag[k]        = sum of the two rows            -> plain stores, no atomics
+//   dE/dP[c1] (c1 = centre of the even row, nondecreasing in k)    -> segmented column sums
+//   dE/dP[c2]                                                      -> one coalesced atomic row per bond
+// which cuts the scattered fp32 atomics from 320 to 128 per directed bond (profiles/r01 notes: row
+// atomics were 55 % of the centre-ordered version of this kernel).
+__global__ __launch_bounds__(BLOCK) void k_atomconv_bwd(AtomConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W2c = smem;
+  float* W2g = W2c + D * WS;
+  float* vecs = W2g + D * WS;
+  float* tiles = vecs + VEC_SLOTS * D;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  stage_weights(W2c, p.gw.w2c, D, D, tid);
+  stage_weights(W2g, p.gw.w2g, D, D, tid);
+  stage_gated_vecs(vecs, p.gw, true, tid);
+  __syncthreads();
+  float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
+  const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
+    if (nvalid <= 0) continue;
+    const bool valid = j < nvalid;
+    const int row = row0 + (valid ? j : 0);
+    const int c = p.e_center[row], n = p.e_nbr[row], k = row >> 1;   // pair-ordered index arrays
+    gather_sum128(T, TS, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+    V64 wv, gm;
+    read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
+    read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
+    __builtin_amdgcn_wave_barrier();
+    V64 zc, zg;
+    read_dl<VT>(Trow, g, zc.t);
+    read_dl<VT>(Trow + D, g, zg.t);
+    GatedState s;
+    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
+    V64 gy, gw, gzc, gzg;
+    CHG_EW(ft, r) {
+      gw.t[ft][r] = gm.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r];   // dE/d wag[k], this direction
+      gy.t[ft][r] = gm.t[ft][r] * wv.t[ft][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    write_dl<VT>(Trow, g, gw.t);
+    __builtin_amdgcn_wave_barrier();
+    {  // Gwag[k] += gw(2b) + gw(2b+1): this tile owns those rows of Gwag
+      const int k0 = row0 >> 1;
+#pragma unroll
+      for (int b = 0; b < TILE_ROWS / 2; ++b)
+        if (2 * b < nvalid) {
+          float* dst = p.Gwag + (size_t)(k0 + b) * D + lane;
+          *dst += T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
+        }
+    }
+    gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+    __builtin_amdgcn_wave_barrier();
+    write_dl<VT>(Trow, g, gzc.t);
+    write_dl<VT>(Trow + D, g, gzg.t);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int k0 = row0 >> 1;
+      // lane's column pair (lane, lane+64) of the 128-wide gz rows
+      float acc_c0 = 0.f, acc_c1 = 0.f, acc_n0 = 0.f, acc_n1 = 0.f;   // running sums for atom c1 (sorted side)
+      int cur = __builtin_amdgcn_readlane(c, 0);
+#pragma unroll
+      for (int b = 0; b < TILE_ROWS / 2; ++b) {
+        if (2 * b < nvalid) {
+          const float e0 = T[(2 * b) * TS + lane], e1 = T[(2 * b) * TS + 64 + lane];           // gz of direction c1 -> c2
+          const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];   // gz of direction c2 -> c1
+          // dE/dQ[k]
+          float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
+          q[0] = e0 + o0;
+          q[64] = e1 + o1;
+          // atom c1: centre part <- even row, neighbour part <- odd row; runs of equal c1 are contiguous
+          const int c1 = __builtin_amdgcn_readlane(c, 2 * b);
+          if (c1 != cur) {
+            float* d = p.GP + (size_t)cur * 4 * D + lane;
+            atomicAdd(d, acc_c0); atomicAdd(d + 64, acc_c1); atomicAdd(d + 128, acc_n0); atomicAdd(d + 192, acc_n1);
+            acc_c0 = acc_c1 = acc_n0 = acc_n1 = 0.f;
+            cur = c1;
+          }
+          acc_c0 += e0; acc_c1 += e1; acc_n0 += o0; acc_n1 += o1;
+          // atom c2 (unsorted): centre part <- odd row, neighbour part <- even row
+          const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
+          float* d2 = p.GP + (size_t)c2 * 4 * D + lane;
+#ifndef CHG_EXP_NO_ROW_ATOMICS
+          atomicAdd(d2, o0); atomicAdd(d2 + 64, o1); atomicAdd(d2 + 128, e0); atomicAdd(d2 + 192, e1);
+#endif
+        }
       }
-      write_dl<VT>(Trow, g, gw.t);
-      __builtin_amdgcn_wave_barrier();
-      row_atomic_add<D>(T, TS, valid ? k : -1, nvalid, p.Gwag, D, lane);
-      gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
-      __builtin_amdgcn_wave_barrier();
-      write_dl<VT>(Trow, g, gzc.t);
-      write_dl<VT>(Trow + D, g, gzg.t);
-      __builtin_amdgcn_wave_barrier();
-      seg_colsum_atomic<2 * D>(T, TS, valid ? c : -1, nvalid, p.GP, 4 * D, lane);
-      row_atomic_add<2 * D>(T, TS, valid ? n : -1, nvalid, p.GP + 2 * D, 4 * D, lane);
-      row_atomic_add<2 * D>(T, TS, valid ? k : -1, nvalid, p.GQ, 2 * D, lane);
+      float* d = p.GP + (size_t)cur * 4 * D + lane;
+      atomicAdd(d, acc_c0); atomicAdd(d + 64, acc_c1); atomicAdd(d + 128, acc_n0); atomicAdd(d + 192, acc_n1);
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -9,6 +9,9 @@ Extra index arrays (not in the reference) that the kernels use:
     the bond graph (appear in ``bond_graph[:,1]`` or ``[:,3]``); only those bonds are ever
     updated by BondConv (layers.py:252-258), so per-layer bond features and the per-bond
     partial products live in arrays of ``Eb`` rows (~15 % of ``Eu``);
+  * ``p_center`` / ``p_nbr`` -- the directed edges re-listed in bond-pair order (rows 2k, 2k+1 are the
+    two directions of undirected bond k) for the AtomConv adjoint, where both directions of a bond
+    must sit in one tile so that their gradients can be summed without atomics;
   * global (batch-wide) directed / undirected indices with per-structure offsets applied.
 """
 
@@ -94,6 +97,16 @@ def pack_batch(graphs) -> PackedBatch:
     arr["u_bnode"] = u_bnode
     arr["a_b1c"] = u_bnode[arr["a_b1"]].astype(np.int32) if A else np.zeros(0, np.int32)
     arr["a_b2c"] = u_bnode[arr["a_b2"]].astype(np.int32) if A else np.zeros(0, np.int32)
+
+    # pair-ordered edge list for the AtomConv adjoint: rows 2k, 2k+1 = the two directions of bond k
+    # (first = undirected2directed[k], whose centre is nondecreasing in k)
+    first = arr["u_u2d"].astype(np.int64)
+    order = np.argsort(arr["e_d2u"], kind="stable")           # the two directed edges of bond k sit at 2k, 2k+1
+    pair = order.reshape(Eu, 2) if Eu else np.zeros((0, 2), np.int64)
+    second = np.where(pair[:, 0] == first, pair[:, 1], pair[:, 0]) if Eu else np.zeros(0, np.int64)
+    rows = np.stack([first, second], axis=1).reshape(-1) if Eu else np.zeros(0, np.int64)
+    arr["p_center"] = np.ascontiguousarray(arr["e_center"][rows], dtype=np.int32)
+    arr["p_nbr"] = np.ascontiguousarray(arr["e_nbr"][rows], dtype=np.int32)
 
     arr["atom_off"] = a_off.astype(np.int32)
     arr["edge_off"] = e_off.astype(np.int32)
