@@ -423,12 +423,6 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
     // table sum -> cols 0..127 of the tile, angle rows -> a second region is not needed: the angle
     // features are consumed (B operand of the first contraction) before the table sum is written
     gather_rows64(T, TS, p.ang, a, lane);
-    V64 w1, w2, gu;
-    if (HIDDEN) {
-      read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
-      read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
-      if (BWD) read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
-    }
     __builtin_amdgcn_wave_barrier();
     V64 x;
     read_dl<VT>(Trow, g, x.t);
@@ -442,6 +436,11 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
     GatedState s;
     gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, g, s);
     __builtin_amdgcn_wave_barrier();
+    V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
+    if (HIDDEN) {
+      read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
+      read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
+    }
     if (!BWD) {
       V64 y;
       CHG_EW(ft, r) {
@@ -456,7 +455,8 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
     } else {
       V64 gy, gzc, gzg;
       if (HIDDEN) {
-        V64 g1, g2;
+        V64 g1, g2, gu;
+        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
         CHG_EW(ft, r) {
           const float y = s.a1.t[ft][r] * s.a2.t[ft][r];
           g1.t[ft][r] = gu.t[ft][r] * y * w2.t[ft][r];      // dE/d wbgc[b1]

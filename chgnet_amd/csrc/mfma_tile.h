@@ -181,25 +181,23 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
   float acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = 0.f;
-  int cur = __builtin_amdgcn_readlane(key, 0);
+  int cur = __builtin_amdgcn_readlane(key, 0);   // row 0 is always valid (nvalid >= 1)
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr) {
-    if (rr < nvalid) {
-      const int kk = __builtin_amdgcn_readlane(key, rr);
-      if (kk != cur) {
-        if (cur >= 0) {
+    const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
+    if (kk != cur) {
+      if (cur >= 0) {
 #pragma unroll
-          for (int c = 0; c < NC; ++c) atomicAdd(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
-        cur = kk;
+        for (int c = 0; c < NC; ++c) atomicAdd(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
       }
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] += tile[rr * stride + 64 * c + lane];
+      for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+      cur = kk;
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] += tile[rr * stride + 64 * c + lane];
   }
-  if (cur >= 0 && nvalid > 0) {
+  if (cur >= 0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) atomicAdd(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
   }
@@ -214,12 +212,10 @@ __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, in
 #endif
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr) {
-    if (rr < nvalid) {
-      const int kk = __builtin_amdgcn_readlane(key, rr);
-      if (kk >= 0) {
+    const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
+    if (kk >= 0) {
 #pragma unroll
-        for (int c = 0; c < W / 64; ++c) atomicAdd(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
-      }
+      for (int c = 0; c < W / 64; ++c) atomicAdd(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
     }
   }
 }
