@@ -87,7 +87,7 @@ struct chg_batch {
   float* Sl[2 * MAX_CONV];      // same slots: [N,128]
   float *agg, *aggB;
   // outputs
-  float *energy_sum, *comp_sum, *energy, *site_energy, *magmom, *crystal_fea, *force, *virial, *volume;
+  float *energy, *site_energy, *site_raw, *magmom, *crystal_fea, *force, *virial, *volume;
   // reverse sweep
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
@@ -462,7 +462,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
     r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
     r.has_composition = eng->desc.has_composition;
-    r.site_energy = b->site_energy; r.energy = b->energy_sum; r.comp_energy = b->comp_sum; r.crystal_fea = b->crystal_fea;
+    r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
     r.Ga = want_grad ? b->Ga : nullptr;
     LaunchScope ls(eng, "readout");
     hipLaunchKernelGGL(k_readout, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
@@ -500,7 +500,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     FinalizeArgs f{};
     f.lattice = b->lattice; f.atom_off = b->atom_off; f.n_struct = b->B;
     f.is_intensive = eng->desc.is_intensive; f.has_composition = eng->desc.has_composition; f.want_stress = want_s;
-    f.energy_sum = b->energy_sum; f.comp_sum = b->comp_sum; f.energy_out = b->energy; f.virial = b->virial; f.volume = b->volume;
+    f.site_raw = b->site_raw; f.z = b->z; f.atomref = eng->w.atomref; f.energy_out = b->energy; f.virial = b->virial; f.volume = b->volume;
     LaunchScope ls(eng, "finalize");
     hipLaunchKernelGGL(k_finalize, g1(b->B), dim3(256), 0, st, f);
     HIP_TRY(eng, hipGetLastError());
@@ -540,10 +540,10 @@ void carve(chg_batch* b, char* base, size_t& total) {
   for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
   for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
   b->agg = c.take<float>(N * D); b->aggB = c.take<float>(Eb * D);
-  b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
+  b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
   // zero group 1 (cleared with one memset before the readout)
   b->zero1 = c.take<float>(0);
-  b->energy_sum = c.take<float>(B); b->comp_sum = c.take<float>(B); b->crystal_fea = c.take<float>(B * D);
+  b->crystal_fea = c.take<float>(B * D);
   b->zero1_end = c.take<float>(0);
   // zero group 2 (cleared with one memset before the reverse sweep)
   b->zero2 = c.take<float>(0);
@@ -574,7 +574,7 @@ void register_names(chg_batch* b) {
   m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
   m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
   m["GR"] = {b->GR, Eb * 4 * D}; m["GS"] = {b->GS, N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
-  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["energy_sum"] = {b->energy_sum, B};
+  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B};
 }
 
 template <class T>

@@ -505,8 +505,7 @@ struct ReadoutArgs {
   const float *ln_g, *ln_b, *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3, *atomref;
   int has_composition;
   float* site_energy;      // [N]  (includes the AtomRef shift when has_composition)
-  float* energy;           // [B]  zeroed: sum of site energies (without AtomRef)
-  float* comp_energy;      // [B]  zeroed: sum of AtomRef site shifts
+  float* site_raw;         // [N]  model part only; summed per structure (in order, fp64) by k_finalize
   float* crystal_fea;      // [B,64] zeroed
   float* Ga;               // [N,64] out: dE/d atom (null -> forward only)
 };
@@ -568,8 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
     if (valid && g == 0) {
       const float ref = p.has_composition ? p.atomref[p.z[i] - 1] : 0.f;
       p.site_energy[i] = site + ref;
-      atomicAdd(p.energy + owner, site);
-      if (p.has_composition) atomicAdd(p.comp_energy + owner, ref);
+      p.site_raw[i] = site;
     }
     if (p.Ga) {
       V64 g3, g2 = zero64(), g1 = zero64(), gx = zero64();

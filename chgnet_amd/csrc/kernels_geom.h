@@ -305,7 +305,9 @@ struct FinalizeArgs {
   const int* atom_off;        // [B+1]
   int n_struct;
   int is_intensive, has_composition, want_stress;
-  const float *energy_sum, *comp_sum;
+  const float* site_raw;      // [N] model site energies
+  const int* z;               // [N]
+  const float* atomref;       // [94]
   float* energy_out;          // [B]
   float* virial;              // [B,9] in: dE/d eps, out: stress in GPa
   float* volume;              // [B]
@@ -318,11 +320,18 @@ __global__ void k_finalize(FinalizeArgs p) {
   const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
   const float vol = L[0] * cx + L[1] * cy + L[2] * cz;                 // model.py:834-836
   p.volume[b] = vol;
-  const float n = (float)(p.atom_off[b + 1] - p.atom_off[b]);
-  float e = p.energy_sum[b];
-  if (p.is_intensive) e = e / n;                                        // model.py:538-540
-  if (p.has_composition) e += p.is_intensive ? p.comp_sum[b] / n : p.comp_sum[b];   // model.py:378
-  p.energy_out[b] = e;
+  // per-structure sums in atom order and fp64: the result does not depend on where the structure
+  // sits in the batch (fp32 atomics in arrival order cost several ulp of the ~300 eV total)
+  const int a0 = p.atom_off[b], a1 = p.atom_off[b + 1];
+  double es = 0.0, cs = 0.0;
+  for (int i = a0; i < a1; ++i) {
+    es += (double)p.site_raw[i];
+    if (p.has_composition) cs += (double)p.atomref[p.z[i] - 1];
+  }
+  const double n = (double)(a1 - a0);
+  double e = p.is_intensive ? es / n : es;                              // model.py:538-540
+  if (p.has_composition) e += p.is_intensive ? cs / n : cs;             // model.py:378
+  p.energy_out[b] = (float)e;
   if (p.want_stress) {
     const float scale = 1.0f / vol * EV_A3_TO_GPA;                      // model.py:532
     for (int k = 0; k < 9; ++k) p.virial[9 * b + k] *= scale;

@@ -243,3 +243,156 @@ def test_calculator_surface(hip_engine, golden_weights):
     assert np.abs(r["stress"] - d["out_s"] / 160.21766208).max() < TOL["s"] / 160
     assert r["stress"].shape == (3, 3) and r["energies"].shape == (8,)
     assert calc.n_params == 412525
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases and full-size properties
+# ---------------------------------------------------------------------------------------------------
+def _oracle(golden_weights, graphs, task="efsm", dtype=None):
+    import torch
+
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    torch.set_num_threads(8)
+    m = OracleCHGNet(golden_weights, dtype=dtype or torch.float32)
+    return m.predict_graph(list(graphs), task, return_site_energies=True, return_atom_feas=True,
+                           return_crystal_feas=True, batch_size=len(graphs))
+
+
+def test_isolated_atoms(hip_engine, golden_weights):
+    """Atoms without any bond (reference tests/test_model.py:210-219, converter 'ignore' policy):
+    a fully isolated cell (Ed = 0) and one batched next to a normal structure."""
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+    lone = conv(Structure(Lattice(np.eye(3) * 20.0), ["H", "O"], [[0, 0, 0], [0.5, 0.5, 0.5]]))
+    assert len(lone.atom_graph) == 0
+    normal = load_case("limno2")[0]
+    for graphs in ([lone], [normal, lone], [lone, normal]):
+        batch, res = _predict(hip_engine, graphs)
+        outs = _split(res, batch.packed)
+        batch.free()
+        refs = _oracle(golden_weights, graphs)
+        for o, r in zip(outs, refs):
+            for key in ("e", "f", "s", "m", "site_energies"):
+                assert np.isfinite(o[key]).all()
+                assert np.abs(o[key] - r[key]).max() < TOL[key], key
+    # energy of an isolated cell does not depend on the cell size
+    big = conv(Structure(Lattice(np.eye(3) * 30.0), ["H", "O"], [[0, 0, 0], [0.5, 0.5, 0.5]]))
+    batch, res = _predict(hip_engine, [lone, big])
+    batch.free()
+    assert abs(res["e"][0] - res["e"][1]) < 1e-6 and np.abs(res["f"]).max() == 0.0
+
+
+def test_zero_length_bond_gives_nan_like_the_reference(hip_engine):
+    """reference tests/test_encoders.py:83-96: a zero-length bond makes the bases NaN."""
+    from chgnet_amd.graph.crystalgraph import CrystalGraph
+
+    g = CrystalGraph(atomic_number=[8, 8], atom_frac_coord=[[0.1, 0.1, 0.1], [0.1, 0.1, 0.1]], atom_graph=[[0, 1], [1, 0]],
+                     atom_graph_cutoff=6, neighbor_image=np.zeros((2, 3)), directed2undirected=[0, 0], undirected2directed=[0],
+                     bond_graph=np.zeros((0, 5)), bond_graph_cutoff=3, lattice=np.eye(3) * 5)
+    batch, res = _predict(hip_engine, [g])
+    batch.free()
+    assert np.isnan(res["e"]).all() and np.isnan(res["f"]).all()
+
+
+def test_large_structure_256_atoms(hip_engine, golden_weights):
+    """Li9Co7O16 2x2x2 (256 atoms, 28,480 directed bonds, 67,008 angles: config 4's MD cell)."""
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    _, d = load_case("li9co7o16")
+    s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell([2, 2, 2])
+    g = CrystalGraphConverter()(s)
+    assert len(g.atomic_number) == 256 and len(g.atom_graph) > 28000
+    batch, res = _predict(hip_engine, [g])
+    out = _split(res, batch.packed)[0]
+    batch.free()
+    ref = _oracle(golden_weights, [g])[0]
+    for key in ("e", "f", "s", "m", "site_energies"):
+        assert np.abs(out[key] - ref[key]).max() < 2 * TOL[key], key
+    # supercell of the 32-atom golden case: same energy per atom / stress, forces tiled 8x
+    assert abs(out["e"] - float(d["out_e"])) < TOL["e"]
+    assert np.abs(out["f"] - np.repeat(d["out_f"], 8, axis=0)).max() < 2 * TOL["f"]
+
+
+def test_ragged_batch_10_to_100_atoms_vs_oracle(hip_engine, golden_weights):
+    """SURVEY C3-like ragged batch: random orthorhombic cells, 10-100 atoms, mixed species."""
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    rng = np.random.default_rng(12345)
+    conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+    graphs = []
+    for _ in range(12):
+        n = int(rng.integers(10, 101))
+        vol = n / 0.103
+        a = vol ** (1 / 3) * rng.uniform(0.85, 1.15)
+        b = vol ** (1 / 3) * rng.uniform(0.85, 1.15)
+        lat = np.diag([a, b, vol / (a * b)])
+        pos = []
+        while len(pos) < n:      # min-distance rejection 1.6 A (periodic)
+            p = rng.random(3)
+            if all(np.linalg.norm(((p - q + 0.5) % 1.0 - 0.5) @ lat) > 1.6 for q in pos):
+                pos.append(p)
+        graphs.append(conv(Structure(Lattice(lat), rng.choice([3, 25, 27, 8], size=n), np.array(pos))))
+    batch, res = _predict(hip_engine, graphs)
+    outs = _split(res, batch.packed)
+    batch.free()
+    refs = _oracle(golden_weights, graphs)
+    for o, r in zip(outs, refs):
+        for key in ("e", "f", "s", "m"):
+            assert np.abs(o[key] - r[key]).max() < 2 * TOL[key], key
+
+
+def test_full_size_batch_properties(hip_engine, golden_weights):
+    """BASELINE configs[1] at full size (1024 x 40 atoms): properties that need no oracle at scale --
+    duplicates agree bit-for-bit on E, permuting the batch permutes the results, net force vanishes,
+    and a sample of structures matches the oracle."""
+    import bench
+
+    graphs = bench.build_workload(512, 0)
+    graphs = graphs + graphs[::-1]                       # 1024 structures, every one twice, mirrored order
+    batch, res = _predict(hip_engine, graphs, task="efs")
+    outs = _split(res, batch.packed)
+    batch.free()
+    n = len(graphs)
+    e = np.array([o["e"] for o in outs])
+    assert np.isfinite(e).all()
+    assert np.abs(e[:512] - e[::-1][:512]).max() < 2e-6           # same structure, different batch position
+    for i in (0, 17, 300, 511):
+        assert np.abs(outs[i]["f"] - outs[n - 1 - i]["f"]).max() < 2e-6
+        assert np.abs(outs[i]["s"] - outs[n - 1 - i]["s"]).max() < 2e-5
+    fsum = np.array([np.abs(o["f"].sum(0)).max() for o in outs])
+    assert fsum.max() < 2e-4                                     # translation invariance
+    asym = np.array([np.abs(o["s"] - o["s"].T).max() for o in outs])
+    assert asym.max() < 2e-4                                     # rotation invariance -> symmetric stress
+    sample = [3, 77, 400]
+    refs = _oracle(golden_weights, [graphs[i] for i in sample], task="efs")
+    for i, r in zip(sample, refs):
+        assert abs(outs[i]["e"] - r["e"]) < TOL["e"]
+        assert np.abs(outs[i]["f"] - r["f"]).max() < TOL["f"]
+        assert np.abs(outs[i]["s"] - r["s"]).max() < TOL["s"]
+
+
+def test_update_geometry_reuses_topology(hip_engine):
+    """chg_batch_update_geometry: new positions / cell on the same graph == a fresh upload."""
+    from chgnet_amd.graph.crystalgraph import CrystalGraph
+
+    g, d = load_case("s16tri")
+    rng = np.random.default_rng(8)
+    frac2 = (d["atom_frac_coord"] + rng.normal(0, 1e-3, d["atom_frac_coord"].shape)).astype(np.float32)
+    lat2 = (d["lattice"] * 1.002).astype(np.float32)
+    g2 = CrystalGraph(atomic_number=g.atomic_number, atom_frac_coord=frac2, atom_graph=g.atom_graph, atom_graph_cutoff=6,
+                      neighbor_image=g.neighbor_image, directed2undirected=g.directed2undirected,
+                      undirected2directed=g.undirected2directed, bond_graph=g.bond_graph, bond_graph_cutoff=3, lattice=lat2)
+    batch, _ = _predict(hip_engine, [g])
+    batch.update_geometry(frac2, lat2[None])
+    hip_engine.predict(batch, "efs")
+    moved = hip_engine.download(batch, "efs")
+    batch.free()
+    batch2, fresh = _predict(hip_engine, [g2], task="efs")
+    batch2.free()
+    for key in ("e", "f", "s"):
+        assert np.abs(moved[key] - fresh[key]).max() < 1e-6, key
