@@ -34,7 +34,7 @@ class BatchHost(ctypes.Structure):
         ("n_undirected", ctypes.c_int32), ("n_angles", ctypes.c_int32), ("n_bnodes", ctypes.c_int32),
         ("z", c_int_p), ("frac", c_float_p), ("lattice", c_float_p), ("atom_owner", c_int_p), ("atom_off", c_int_p),
         ("e_center", c_int_p), ("e_nbr", c_int_p), ("e_image", c_float_p), ("e_d2u", c_int_p), ("e_owner", c_int_p),
-        ("p_center", c_int_p), ("p_nbr", c_int_p),
+        ("e_rev", c_int_p), ("p_center", c_int_p), ("p_nbr", c_int_p),
         ("u_u2d", c_int_p), ("u_bnode", c_int_p), ("bn_und", c_int_p),
         ("a_ctr", c_int_p), ("a_b1c", c_int_p), ("a_b2c", c_int_p), ("a_d1", c_int_p), ("a_d2", c_int_p),
     ]

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kernels_conv.h"
+#include "kernels_embed.h"
 #include "kernels_geom.h"
 
 using namespace chg;
@@ -71,7 +72,7 @@ struct chg_batch {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   // inputs
-  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *p_center, *p_nbr, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
+  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *e_rev, *p_center, *p_nbr, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
   float *frac, *lattice, *e_image;
   // geometry / features
   float* cart;
@@ -391,9 +392,9 @@ int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
   return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
 }
 
-BondEmbedArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
+BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
   const Weights& w = eng->w;
-  BondEmbedArgs a{};
+  BondEmbedTArgs a{};
   a.ev = b->ev; a.u_u2d = b->u_u2d; a.u_bnode = b->u_bnode; a.n_und = b->Eu;
   a.freq_ag = w.freq_ag; a.freq_bg = w.freq_bg; a.w_emb = w.w_bond_emb; a.w_ag = w.w_wag; a.w_bg = w.w_wbg;
   a.rc_ag = eng->desc.atom_graph_cutoff; a.rc_bg = eng->desc.bond_graph_cutoff;
@@ -404,8 +405,8 @@ BondEmbedArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
   return a;
 }
 
-AngleEmbedArgs angle_embed_args(chg_engine* eng, chg_batch* b) {
-  AngleEmbedArgs a{};
+AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b) {
+  AngleEmbedTArgs a{};
   a.eu = b->eu; a.a_d1 = b->a_d1; a.a_d2 = b->a_d2; a.n_angles = b->A;
   a.freq = eng->w.freq_ang; a.w_emb = eng->w.w_ang_emb;
   a.ang0 = b->ang[0]; a.Gang = b->Gang; a.Gu = b->Gu;
@@ -426,11 +427,11 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     { LaunchScope ls(eng, "edge_geom");
       hipLaunchKernelGGL(k_edge_geom, g1(b->Ed), dim3(256), 0, st, b->cart, b->lattice, b->e_center, b->e_nbr, b->e_image, b->e_owner, b->ev, b->eu, b->Ed); }
     { LaunchScope ls(eng, "bond_embed_fwd");
-      hipLaunchKernelGGL((k_bond_embed<false>), dim3(wave_grid(eng, b->Eu)), dim3(256), 0, st, bond_embed_args(eng, b)); }
+      hipLaunchKernelGGL((k_bond_embed_t<false>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
   }
   if (b->A > 0) {
     LaunchScope ls(eng, "angle_embed_fwd");
-    hipLaunchKernelGGL((k_angle_embed<false>), dim3(wave_grid(eng, b->A)), dim3(256), 0, st, angle_embed_args(eng, b));
+    hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
   }
   { LaunchScope ls(eng, "atom_embed");
     hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
@@ -482,14 +483,14 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     }
     if (b->Ed > 0) {
       { LaunchScope ls(eng, "bond_embed_bwd");
-        hipLaunchKernelGGL((k_bond_embed<true>), dim3(wave_grid(eng, b->Eu)), dim3(256), 0, st, bond_embed_args(eng, b)); }
+        hipLaunchKernelGGL((k_bond_embed_t<true>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
       if (b->A > 0) {
         LaunchScope ls(eng, "angle_embed_bwd");
-        hipLaunchKernelGGL((k_angle_embed<true>), dim3(wave_grid(eng, b->A)), dim3(256), 0, st, angle_embed_args(eng, b));
+        hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
       }
       ForceArgs f{};
       f.ev = b->ev; f.eu = b->eu; f.Gu = b->Gu; f.Grk = b->Grk;
-      f.e_center = b->e_center; f.e_nbr = b->e_nbr; f.e_d2u = b->e_d2u; f.e_owner = b->e_owner; f.u_u2d = b->u_u2d;
+      f.e_center = b->e_center; f.e_d2u = b->e_d2u; f.e_owner = b->e_owner; f.e_rev = b->e_rev; f.u_u2d = b->u_u2d;
       f.n_edges = b->Ed; f.force = b->force; f.virial = b->virial;
       LaunchScope ls(eng, "edge_force");
       hipLaunchKernelGGL(k_edge_force, g1(b->Ed), dim3(256), 0, st, f);
@@ -528,7 +529,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   const int L = b->L;
   b->z = c.take<int>(N); b->atom_owner = c.take<int>(N); b->atom_off = c.take<int>(B + 1);
   b->e_center = c.take<int>(Ed); b->e_nbr = c.take<int>(Ed); b->e_d2u = c.take<int>(Ed); b->e_owner = c.take<int>(Ed);
-  b->p_center = c.take<int>(Ed); b->p_nbr = c.take<int>(Ed);
+  b->e_rev = c.take<int>(Ed); b->p_center = c.take<int>(Ed); b->p_nbr = c.take<int>(Ed);
   b->u_u2d = c.take<int>(Eu); b->u_bnode = c.take<int>(Eu); b->bn_und = c.take<int>(Eb);
   b->a_ctr = c.take<int>(A); b->a_b1c = c.take<int>(A); b->a_b2c = c.take<int>(A); b->a_d1 = c.take<int>(A); b->a_d2 = c.take<int>(A);
   b->frac = c.take<float>(3 * N); b->lattice = c.take<float>(9 * B); b->e_image = c.take<float>(3 * Ed);
@@ -658,6 +659,10 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_angle<false, false>, angle_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
   if ((s = set_lds(eng, k_readout, readout_lds()))) return s;
+  if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_embed_t<true>, angle_embed_lds()))) return s;
   return CHG_OK;
 }
 
@@ -703,7 +708,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
 #define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
   UP(z, N); UP(atom_owner, N); UP(atom_off, B + 1); UP(frac, 3 * N); UP(lattice, 9 * B);
-  UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed); UP(p_center, Ed); UP(p_nbr, Ed);
+  UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed); UP(e_rev, Ed); UP(p_center, Ed); UP(p_nbr, Ed);
   UP(u_u2d, Eu); UP(u_bnode, Eu); UP(bn_und, Eb);
   UP(a_ctr, A); UP(a_b1c, A); UP(a_b2c, A); UP(a_d1, A); UP(a_d2, A);
 #undef UP

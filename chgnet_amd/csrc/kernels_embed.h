@@ -1,0 +1,243 @@
+// kernels_embed.h -- basis functions + 31->64 embeddings on MFMA tiles, forward and adjoint.
+//
+// Reference ops replaced (file:line relative to /root/reference/chgnet):
+//   RadialBessel x CutoffPolynomial for both cutoffs   model/basis.py:108-116, 197-206
+//   bond_embedding / bond_weights_ag / bond_weights_bg  model/model.py:435-437  (3 x Linear(31->64))
+//   AngleEncoder (acos, Fourier) + angle_embedding      model/encoders.py:144-146, basis.py:33-40, model.py:439
+//   their adjoints w.r.t. the bond length / the two unit vectors (model.py:517-535 via autograd)
+//
+// One wave = 16 bonds (or angles).  The 31 basis functions (padded to K = 32) are evaluated directly
+// in the B-operand layout of v_mfma_f32_16x16x4_f32 -- lane (row j, g) owns basis indices
+// k = 16*kt + 4*g + r -- so every lane evaluates 8 sin/cos per row instead of one lane per basis
+// function with 33 lanes idle, and the 31x64 contraction runs on the matrix core.  Bases are never
+// written to memory.
+#pragma once
+
+#include "kernels_geom.h"
+#include "mfma_tile.h"
+
+namespace chg {
+
+constexpr int KB = 32;            // basis count padded to a multiple of 16
+constexpr int WSB = KB + PAD;     // LDS row stride of a [64][32] embedding weight
+constexpr int ETS = D + PAD;      // LDS tile row stride (64-wide rows)
+
+// [64][31] global -> [64][WSB] LDS, column 31 zero
+__device__ __forceinline__ void stage_embed_weight(float* dst, const float* __restrict__ src, int tid) {
+  for (int idx = tid; idx < D * KB; idx += BLOCK) {
+    const int f = idx / KB, k = idx - f * KB;
+    dst[f * WSB + k] = k < NRAD ? src[f * NRAD + k] : 0.f;
+  }
+}
+
+struct BondEmbedTArgs {
+  const f32x4* ev;            // [Ed] (v, r)
+  const int* u_u2d;           // [Eu]
+  const int* u_bnode;         // [Eu] compact bond-node index or -1
+  int n_und;
+  const float *freq_ag, *freq_bg;   // [31]
+  const float *w_emb, *w_ag, *w_bg; // [64][31]
+  float rc_ag, rc_bg;
+  Envelope env;
+  float *hb0, *wag, *wbgc;    // fwd out: [Eu,64], [Eu,64], [Eb,64]
+  const float *Gb, *Gwag, *Gwbgc;   // bwd in
+  float* Grk;                 // bwd out [Eu] dE/d r_k
+};
+
+constexpr size_t bond_embed_lds() { return sizeof(float) * (3 * D * WSB + WAVES * TILE_ROWS * ETS); }
+
+template <bool BWD>
+__global__ __launch_bounds__(BLOCK) void k_bond_embed_t(BondEmbedTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* We = smem;
+  float* Wa = We + D * WSB;
+  float* Wb = Wa + D * WSB;
+  float* tiles = Wb + D * WSB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  stage_embed_weight(We, p.w_emb, tid);
+  stage_embed_weight(Wa, p.w_ag, tid);
+  stage_embed_weight(Wb, p.w_bg, tid);
+  // this lane's 8 basis indices k = 16*kt + 4*g + r and their frequencies (k = 31 is padding)
+  float f6[2][4], f3[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * kt + 4 * g + r;
+      f6[kt][r] = k < NRAD ? p.freq_ag[k] : 0.f;
+      f3[kt][r] = k < NRAD ? p.freq_bg[k] : 0.f;
+    }
+  __syncthreads();
+  float* T = tiles + wave * TILE_ROWS * ETS;
+  float* Trow = T + j * ETS;
+  const int ntiles = (p.n_und + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_und - row0);
+    if (nvalid <= 0) continue;
+    const bool valid = j < nvalid;
+    const int k = row0 + (valid ? j : 0);
+    const float rlen = p.ev[p.u_u2d[k]][3];
+    const int node = p.u_bnode[k];
+    f32x4 x6[2], x3[2], d6[2], d3[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool pad = 16 * kt + 4 * g + r >= NRAD;
+        float v, dv;
+        rbf_eval(rlen, p.rc_ag, f6[kt][r], p.env, v, dv);
+        x6[kt][r] = pad ? 0.f : v;
+        d6[kt][r] = pad ? 0.f : dv;
+        rbf_eval(rlen, p.rc_bg, f3[kt][r], p.env, v, dv);
+        x3[kt][r] = pad ? 0.f : v;
+        d3[kt][r] = pad ? 0.f : dv;
+      }
+    if (!BWD) {
+      V64 h = zero64();
+      gemm_dl<2, VT>(h.t, We, WSB, x6, j, g);
+      write_dl<VT>(Trow, g, h.t);
+      __builtin_amdgcn_wave_barrier();
+      scatter_rows64<false>(T, ETS, p.hb0, k, nvalid, lane);
+      __builtin_amdgcn_wave_barrier();
+      h = zero64();
+      gemm_dl<2, VT>(h.t, Wa, WSB, x6, j, g);
+      write_dl<VT>(Trow, g, h.t);
+      __builtin_amdgcn_wave_barrier();
+      scatter_rows64<false>(T, ETS, p.wag, k, nvalid, lane);
+      __builtin_amdgcn_wave_barrier();
+      if (__any(valid && node >= 0)) {
+        h = zero64();
+        gemm_dl<2, VT>(h.t, Wb, WSB, x3, j, g);
+        write_dl<VT>(Trow, g, h.t);
+        __builtin_amdgcn_wave_barrier();
+        // rows that are bond-graph nodes go to their compact slot; others are dropped
+        const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+        for (int it = 0; it < TILE_ROWS / 4; ++it) {
+          const int rr = 4 * it + sub;
+          const int nd = __shfl(node, rr);
+          if (rr < nvalid && nd >= 0)
+            *reinterpret_cast<f32x4*>(p.wbgc + (size_t)nd * D + 4 * t) = *reinterpret_cast<const f32x4*>(T + rr * ETS + 4 * t);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // t6 = We^T Gb[k] + Wa^T Gwag[k],  t3 = Wb^T Gwbgc[node]   (64 -> 32 each), then dot with d(basis)/dr
+      f32x4 t6[2] = {zero4(), zero4()}, t3[2] = {zero4(), zero4()};
+      V64 gin;
+      gather_rows64(T, ETS, p.Gb, k, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<VT>(Trow, g, gin.t);
+      gemm_dl_t<VT, 2>(t6, We, WSB, gin.t, j, g);
+      __builtin_amdgcn_wave_barrier();
+      gather_rows64(T, ETS, p.Gwag, k, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<VT>(Trow, g, gin.t);
+      gemm_dl_t<VT, 2>(t6, Wa, WSB, gin.t, j, g);
+      __builtin_amdgcn_wave_barrier();
+      if (__any(valid && node >= 0)) {
+        read_dl<VT>(p.Gwbgc + (size_t)(node >= 0 ? node : 0) * D, g, gin.t);
+        if (node < 0) gin = zero64();
+        gemm_dl_t<VT, 2>(t3, Wb, WSB, gin.t, j, g);
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += t6[kt][r] * d6[kt][r] + t3[kt][r] * d3[kt][r];
+      acc = quad_sum(acc);
+      if (valid && g == 0) p.Grk[k] = acc;
+    }
+  }
+}
+
+struct AngleEmbedTArgs {
+  const f32x4* eu;            // [Ed] unit vectors
+  const int *a_d1, *a_d2;     // [A] directed edges of the two bonds
+  int n_angles;
+  const float* freq;          // [15]
+  const float* w_emb;         // [64][31]
+  float* ang0;                // fwd out [A,64]
+  const float* Gang;          // bwd in  [A,64]
+  float* Gu;                  // bwd out [Ed,4] zeroed, dE/d unit vectors
+};
+
+constexpr size_t angle_embed_lds() { return sizeof(float) * (D * WSB + WAVES * TILE_ROWS * ETS); }
+
+template <bool BWD>
+__global__ __launch_bounds__(BLOCK) void k_angle_embed_t(AngleEmbedTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* We = smem;
+  float* tiles = We + D * WSB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  stage_embed_weight(We, p.w_emb, tid);
+  // basis index k = 16*kt + 4*g + r:  k = 0 const, 1..15 sin(f_{k-1} t), 16..30 cos(f_{k-16} t), 31 padding
+  float fs[4], fc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ks = 4 * g + r;            // kt = 0 : sin of freq[ks - 1]
+    fs[r] = (ks >= 1) ? p.freq[ks - 1] : 0.f;
+    fc[r] = (ks < NFREQ) ? p.freq[ks] : 0.f;   // kt = 1 : cos of freq[ks]   (ks = 15 is the padding column)
+  }
+  __syncthreads();
+  float* T = tiles + wave * TILE_ROWS * ETS;
+  float* Trow = T + j * ETS;
+  const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_angles - row0);
+    if (nvalid <= 0) continue;
+    const bool valid = j < nvalid;
+    const int a = row0 + (valid ? j : 0);
+    const int d1 = p.a_d1[a], d2 = p.a_d2[a];
+    const f32x4 u1 = p.eu[d1], u2 = p.eu[d2];
+    const float cosv = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]) * KAPPA;   // encoders.py:144
+    const float theta = acosf(cosv);
+    f32x4 x[2], dx[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ks = 4 * g + r;
+      float sn, cs;
+      sincosf(fs[r] * theta, &sn, &cs);
+      x[0][r] = ks == 0 ? INV_SQRT_2 * INV_SQRT_PI : sn * INV_SQRT_PI;
+      dx[0][r] = ks == 0 ? 0.f : fs[r] * cs * INV_SQRT_PI;
+      sincosf(fc[r] * theta, &sn, &cs);
+      x[1][r] = ks < NFREQ ? cs * INV_SQRT_PI : 0.f;
+      dx[1][r] = ks < NFREQ ? -fc[r] * sn * INV_SQRT_PI : 0.f;
+    }
+    if (!BWD) {
+      V64 h = zero64();
+      gemm_dl<2, VT>(h.t, We, WSB, x, j, g);
+      write_dl<VT>(Trow, g, h.t);
+      __builtin_amdgcn_wave_barrier();
+      scatter_rows64<false>(T, ETS, p.ang0, a, nvalid, lane);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      f32x4 t[2] = {zero4(), zero4()};
+      V64 gin;
+      gather_rows64(T, ETS, p.Gang, a, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<VT>(Trow, g, gin.t);
+      gemm_dl_t<VT, 2>(t, We, WSB, gin.t, j, g);
+      __builtin_amdgcn_wave_barrier();
+      float gtheta = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gtheta += t[kt][r] * dx[kt][r];
+      gtheta = quad_sum(gtheta);
+      const float gcos = -gtheta / sqrtf(1.0f - cosv * cosv) * KAPPA;
+      if (valid && g < 3) {   // lane g handles cartesian component g of this row
+        atomicAdd(p.Gu + 4 * (size_t)d1 + g, gcos * u2[g]);
+        atomicAdd(p.Gu + 4 * (size_t)d2 + g, gcos * u1[g]);
+      }
+    }
+  }
+}
+
+}  // namespace chg

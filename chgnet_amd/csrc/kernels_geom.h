@@ -8,8 +8,7 @@
 //   AtomEmbedding                               model/model.py:432-434
 //   site_wise magmom head                       model/model.py:484-487
 //   autograd of all of the above w.r.t. positions / strain  model/model.py:517-535
-// Bases are never materialised: each kernel evaluates them in registers and contracts them
-// with the 31x64 embedding weights immediately.
+// (basis functions + 31->64 embeddings live in kernels_embed.h)
 #pragma once
 
 #include "mfma_tile.h"
@@ -100,130 +99,6 @@ __device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope
   dval = de * base + e * dbase;
 }
 
-struct BondEmbedArgs {
-  const f32x4* ev;            // [Ed]
-  const int* u_u2d;           // [Eu]
-  const int* u_bnode;         // [Eu] compact bond-node index or -1
-  int n_und;
-  const float *freq_ag, *freq_bg;   // [31]
-  const float *w_emb, *w_ag, *w_bg; // [64][31]
-  float rc_ag, rc_bg;
-  Envelope env;
-  float *hb0, *wag, *wbgc;    // fwd out: [Eu,64], [Eu,64], [Eb,64]
-  // backward
-  const float *Gb, *Gwag, *Gwbgc;
-  float* Grk;                 // [Eu] dE/d r_k
-};
-
-// one wave per undirected bond (grid-stride), lane = output feature; lanes 0..30 also evaluate basis j
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_bond_embed(BondEmbedArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  float we[NRAD], wa[NRAD], wb[NRAD];
-#pragma unroll
-  for (int jj = 0; jj < NRAD; ++jj) {
-    we[jj] = p.w_emb[lane * NRAD + jj];
-    wa[jj] = p.w_ag[lane * NRAD + jj];
-    wb[jj] = p.w_bg[lane * NRAD + jj];
-  }
-  const int jb = lane < NRAD ? lane : 0;
-  const float f6 = p.freq_ag[jb], f3 = p.freq_bg[jb];
-  for (int k = wave; k < p.n_und; k += nwaves) {
-    const float r = p.ev[p.u_u2d[k]][3];
-    const int node = p.u_bnode[k];
-    float v6, d6, v3, d3;
-    rbf_eval(r, p.rc_ag, f6, p.env, v6, d6);
-    rbf_eval(r, p.rc_bg, f3, p.env, v3, d3);
-    if (!BWD) {
-      float h0 = 0.f, h1 = 0.f, h2 = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < NRAD; ++jj) {
-        const float b6 = bcast(v6, jj), b3 = bcast(v3, jj);
-        h0 = fmaf(b6, we[jj], h0);
-        h1 = fmaf(b6, wa[jj], h1);
-        h2 = fmaf(b3, wb[jj], h2);
-      }
-      p.hb0[(size_t)k * D + lane] = h0;
-      p.wag[(size_t)k * D + lane] = h1;
-      if (node >= 0) p.wbgc[(size_t)node * D + lane] = h2;
-    } else {
-      const float g0 = p.Gb[(size_t)k * D + lane], g1 = p.Gwag[(size_t)k * D + lane];
-      const float g2 = node >= 0 ? p.Gwbgc[(size_t)node * D + lane] : 0.f;
-      float t = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < NRAD; ++jj) {
-        const float b6 = bcast(d6, jj), b3 = bcast(d3, jj);
-        t = fmaf(fmaf(g0, we[jj], g1 * wa[jj]), b6, t);
-        t = fmaf(g2 * wb[jj], b3, t);
-      }
-      t = wave_sum(t);
-      if (lane == 0) p.Grk[k] = t;
-    }
-  }
-}
-
-struct AngleEmbedArgs {
-  const f32x4* eu;            // [Ed] unit vectors
-  const int *a_d1, *a_d2;     // [A] directed edges of the two bonds
-  int n_angles;
-  const float* freq;          // [15]
-  const float* w_emb;         // [64][31]
-  float* ang0;                // fwd out [A,64]
-  const float* Gang;          // bwd in  [A,64]
-  float* Gu;                  // bwd out [Ed,4] zeroed, dE/d unit vectors
-};
-
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_angle_embed(AngleEmbedArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  float w[NANG];
-#pragma unroll
-  for (int jj = 0; jj < NANG; ++jj) w[jj] = p.w_emb[lane * NANG + jj];
-  // lane jj evaluates basis jj: 0 -> const, 1..15 -> sin(g t), 16..30 -> cos(g t)   (basis.py:35-40)
-  const int fi = lane == 0 ? 0 : (lane <= NFREQ ? lane - 1 : (lane < NANG ? lane - 1 - NFREQ : 0));
-  const float g = p.freq[fi];
-  for (int a = wave; a < p.n_angles; a += nwaves) {
-    const int d1 = p.a_d1[a], d2 = p.a_d2[a];
-    const f32x4 u1 = p.eu[d1], u2 = p.eu[d2];
-    const float cosv = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]) * KAPPA;
-    const float theta = acosf(cosv);
-    float sn, cs;
-    sincosf(g * theta, &sn, &cs);
-    float val, dval;
-    if (lane == 0) {
-      val = INV_SQRT_2 * INV_SQRT_PI;
-      dval = 0.f;
-    } else if (lane <= NFREQ) {
-      val = sn * INV_SQRT_PI;
-      dval = g * cs * INV_SQRT_PI;
-    } else {
-      val = cs * INV_SQRT_PI;
-      dval = -g * sn * INV_SQRT_PI;
-    }
-    if (!BWD) {
-      float hsum = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < NANG; ++jj) hsum = fmaf(bcast(val, jj), w[jj], hsum);
-      p.ang0[(size_t)a * D + lane] = hsum;
-    } else {
-      const float ga = p.Gang[(size_t)a * D + lane];
-      float t = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < NANG; ++jj) t = fmaf(bcast(dval, jj), w[jj], t);
-      const float gtheta = wave_sum(t * ga);
-      const float gcos = -gtheta / sqrtf(1.0f - cosv * cosv) * KAPPA;
-      if (lane < 3) {
-        atomicAdd(reinterpret_cast<float*>(p.Gu + 0) + 4 * (size_t)d1 + lane, gcos * u2[lane]);
-        atomicAdd(reinterpret_cast<float*>(p.Gu + 0) + 4 * (size_t)d2 + lane, gcos * u1[lane]);
-      }
-    }
-  }
-}
-
 // ---- atom embedding ------------------------------------------------------------------------------
 __global__ void k_atom_embed(const int* __restrict__ z, const float* __restrict__ emb, float* __restrict__ out, int n_atoms) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,37 +125,63 @@ struct ForceArgs {
   const f32x4 *ev, *eu;
   const float* Gu;            // [Ed,4]
   const float* Grk;           // [Eu]
-  const int *e_center, *e_nbr, *e_d2u, *e_owner, *u_u2d;
+  const int *e_center, *e_d2u, *e_owner, *e_rev, *u_u2d;
   int n_edges;
   float* force;               // [N,3] zeroed
   float* virial;              // [B,9] zeroed
 };
 
+// dE/dv of one directed edge: lengths enter only via the representative edge u2d[k]
+__device__ __forceinline__ void edge_gv(const ForceArgs& p, int e, float (&gv)[3], f32x4& vr) {
+  vr = p.ev[e];
+  const f32x4 u = p.eu[e];
+  const int k = p.e_d2u[e];
+  const float gr = (p.u_u2d[k] == e) ? p.Grk[k] : 0.f;
+  const f32x4 gu = *reinterpret_cast<const f32x4*>(p.Gu + 4 * (size_t)e);
+  const float dotp = gu[0] * u[0] + gu[1] * u[1] + gu[2] * u[2];
+  const float inv_r = 1.0f / vr[3];
+#pragma unroll
+  for (int k3 = 0; k3 < 3; ++k3) gv[k3] = gr * u[k3] + (gu[k3] - dotp * u[k3]) * inv_r;
+}
+
+// F_i = -sum_{c_e = i} gv_e + sum_{n_e = i} gv_e, and every edge with n_e = i is the reverse of an edge
+// with c_e = i, so each thread forms gv_rev(e) - gv_e for its own edge and the force is a segmented sum
+// over runs of equal centre (edges are centre-major): a wave-level segmented scan and one atomic per
+// run end replace 6 same-address atomics per edge.  Any edge order stays correct (shorter runs).
 __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool valid = e < p.n_edges;
-  float gv[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
-  int owner = -1;
+  float gv[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  int owner = -1, key = -1;
   if (valid) {
-    const f32x4 vr = p.ev[e], u = p.eu[e];
-    const int k = p.e_d2u[e];
-    const float gr = (p.u_u2d[k] == e) ? p.Grk[k] : 0.f;   // lengths enter only via the representative edge
-    const float g0 = p.Gu[4 * (size_t)e], g1 = p.Gu[4 * (size_t)e + 1], g2 = p.Gu[4 * (size_t)e + 2];
-    const float dotp = g0 * u[0] + g1 * u[1] + g2 * u[2];
-    const float inv_r = 1.0f / vr[3];
-    gv[0] = gr * u[0] + (g0 - dotp * u[0]) * inv_r;
-    gv[1] = gr * u[1] + (g1 - dotp * u[1]) * inv_r;
-    gv[2] = gr * u[2] + (g2 - dotp * u[2]) * inv_r;
-    v[0] = vr[0];
-    v[1] = vr[1];
-    v[2] = vr[2];
-    owner = p.e_owner[e];
-    const int c = p.e_center[e], n = p.e_nbr[e];
+    f32x4 vr, vr2;
+    float gr2[3];
+    edge_gv(p, e, gv, vr);
+    edge_gv(p, p.e_rev[e], gr2, vr2);
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3) {
-      atomicAdd(p.force + 3 * (size_t)c + k3, -gv[k3]);
-      atomicAdd(p.force + 3 * (size_t)n + k3, gv[k3]);
+      d[k3] = gr2[k3] - gv[k3];
+      v[k3] = vr[k3];
     }
+    owner = p.e_owner[e];
+    key = p.e_center[e];
+  }
+  // segmented inclusive scan over runs of equal key
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int k2 = __shfl_up(key, off);
+    const float t0 = __shfl_up(d[0], off), t1 = __shfl_up(d[1], off), t2 = __shfl_up(d[2], off);
+    if (lane >= off && k2 == key) {
+      d[0] += t0;
+      d[1] += t1;
+      d[2] += t2;
+    }
+  }
+  const int knext = __shfl_down(key, 1);
+  if (valid && (lane == 63 || knext != key)) {
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) atomicAdd(p.force + 3 * (size_t)key + k3, d[k3]);
   }
   // virial: dE/d eps[a][b] = sum_e v_e[a] * gv_e[b]; reduce across the wave when it sits in one structure
   const int first = __builtin_amdgcn_readfirstlane(owner);
@@ -292,7 +193,7 @@ __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
       const float t = v[a] * gv[b];
       if (uniform) {
         const float s = wave_sum(t);
-        if ((threadIdx.x & 63) == 0 && first >= 0) atomicAdd(p.virial + 9 * (size_t)first + 3 * a + b, s);
+        if (lane == 0 && first >= 0) atomicAdd(p.virial + 9 * (size_t)first + 3 * a + b, s);
       } else if (valid) {
         atomicAdd(p.virial + 9 * (size_t)owner + 3 * a + b, t);
       }

@@ -35,7 +35,7 @@ class DeviceBatch:
         h.n_undirected, h.n_angles, h.n_bnodes = pb.n_undirected, pb.n_angles, pb.n_bnodes
         for name in ("frac", "lattice", "e_image"):
             setattr(h, name, _fp(pb.arrays[name]))
-        for name in ("z", "atom_owner", "atom_off", "e_center", "e_nbr", "e_d2u", "e_owner", "p_center", "p_nbr", "u_u2d", "u_bnode",
+        for name in ("z", "atom_owner", "atom_off", "e_center", "e_nbr", "e_d2u", "e_owner", "e_rev", "p_center", "p_nbr", "u_u2d", "u_bnode",
                      "bn_und", "a_ctr", "a_b1c", "a_b2c", "a_d1", "a_d2"):
             setattr(h, name, _ip(pb.arrays[name]))
         return h

@@ -105,6 +105,10 @@ def pack_batch(graphs) -> PackedBatch:
     pair = order.reshape(Eu, 2) if Eu else np.zeros((0, 2), np.int64)
     second = np.where(pair[:, 0] == first, pair[:, 1], pair[:, 0]) if Eu else np.zeros(0, np.int64)
     rows = np.stack([first, second], axis=1).reshape(-1) if Eu else np.zeros(0, np.int64)
+    e_rev = np.empty(Ed, dtype=np.int32)                      # the opposite direction of every directed edge
+    e_rev[first] = second
+    e_rev[second] = first
+    arr["e_rev"] = e_rev
     arr["p_center"] = np.ascontiguousarray(arr["e_center"][rows], dtype=np.int32)
     arr["p_nbr"] = np.ascontiguousarray(arr["e_nbr"][rows], dtype=np.int32)
 

@@ -72,6 +72,7 @@ typedef struct chg_batch_host {
   const float* e_image;        /* [Ed,3]  neighbor_image                          */
   const int32_t* e_d2u;        /* [Ed]    directed2undirected                     */
   const int32_t* e_owner;      /* [Ed]    structure index                         */
+  const int32_t* e_rev;        /* [Ed]    index of the opposite directed edge     */
   const int32_t* p_center;     /* [Ed]    centre atom, bond-pair order (rows 2k,2k+1 = bond k) */
   const int32_t* p_nbr;        /* [Ed]    neighbour atom, bond-pair order         */
   const int32_t* u_u2d;        /* [Eu]    undirected2directed                     */
