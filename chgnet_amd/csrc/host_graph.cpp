@@ -29,8 +29,8 @@ inline void cross3(const double* a, const double* b, double* o) {
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// Brute-force periodic neighbour search, exact for any cell shape: along each lattice
-// axis the number of images needed is ceil(r / h_axis), h_axis = V / |a_j x a_k|.
+// All-pairs periodic neighbour search, exact for any cell shape: along lattice axis k only the
+// images with |df_k + image_k| <= r / h_k (h_k = V / |a_i x a_j|, the plane spacing) are visited.
 int neighbor_list(int32_t n, const double* frac, const double* L, double r, double tol,
                   NeighborRows& rows) {
   const double *a = L, *b = L + 3, *c = L + 6;
@@ -44,9 +44,8 @@ int neighbor_list(int32_t n, const double* frac, const double* L, double r, doub
       std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
       std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
       std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
-  int reach[3];
-  for (int k = 0; k < 3; ++k) reach[k] = static_cast<int>(std::ceil(r / h[k])) + 1;
   const double r2 = r * r;
+  const double reach[3] = {r / h[0], r / h[1], r / h[2]};   // in fractional units along each axis
 
   // cartesian coordinates (row-vector convention: x = frac @ L)
   std::vector<double> cart(3 * static_cast<size_t>(n));
@@ -56,12 +55,14 @@ int neighbor_list(int32_t n, const double* frac, const double* L, double r, doub
 
   for (int32_t i = 0; i < n; ++i) {
     for (int32_t j = 0; j < n; ++j) {
-      // image window centred on the fractional separation so unwrapped inputs work
+      // |(df + image)_k| * h_k is the distance to the lattice plane family k, hence <= the pair
+      // distance: only images with |df_k + image_k| <= r / h_k can be inside the cutoff (exact bound,
+      // valid for unwrapped fractional coordinates too)
       int lo[3], hi[3];
       for (int k = 0; k < 3; ++k) {
-        const double df = frac[3 * i + k] - frac[3 * j + k];
-        lo[k] = static_cast<int>(std::floor(df)) - reach[k];
-        hi[k] = static_cast<int>(std::ceil(df)) + reach[k];
+        const double df = frac[3 * j + k] - frac[3 * i + k];
+        lo[k] = static_cast<int>(std::ceil(-df - reach[k] - 1e-9));
+        hi[k] = static_cast<int>(std::floor(-df + reach[k] + 1e-9));
       }
       for (int ia = lo[0]; ia <= hi[0]; ++ia)
         for (int ib = lo[1]; ib <= hi[1]; ++ib)
