@@ -196,7 +196,17 @@ def main() -> None:
                                 frac=round(gbs / PEAK_HBM_GBS, 4))
             roofline.update(units_per_launch=int(units), flop_per_unit=flop_u, bytes_per_unit=byte_u,
                             algorithmic_gbs=round(gbs, 1), algorithmic_tflops=round(tflops, 3))
-        roofline["traffic"] = None   # PMC pass: profiles/ (FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs)
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE runs, summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction)
+        roofline["traffic"] = None
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as fh:
+                pmc = json.load(fh)
+            if dom in pmc:
+                roofline["traffic"] = pmc[dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = pmc[dom]["profile"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "structures/s (energy+force+stress) on batched ~50-atom crystals",
             "value": round(value, 2), "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
