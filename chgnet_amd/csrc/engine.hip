@@ -64,6 +64,7 @@ struct chg_engine {
   std::map<std::string, int> prof_index;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
+  std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
   int num_cus = 256;
 };
 
@@ -674,6 +675,7 @@ int chg_engine_destroy(chg_engine* eng) {
   for (auto e : eng->event_pool) hipEventDestroy(e);
   if (eng->t0) hipEventDestroy(eng->t0);
   if (eng->t1) hipEventDestroy(eng->t1);
+  for (auto& a : eng->arena_pool) hipFree(a.first);
   if (eng->d_weights) hipFree(eng->d_weights);
   if (eng->stream) hipStreamDestroy(eng->stream);
   delete eng;
@@ -696,12 +698,25 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   b->L = eng->desc.n_conv;
   size_t total = 0;
   carve(b, nullptr, total);
-  if (hipMalloc(&b->arena, total) != hipSuccess) {
-    eng->err = "chg_batch_upload: hipMalloc of " + std::to_string(total) + " bytes failed";
-    delete b;
-    return CHG_ENOMEM;
+  // reuse a released arena when one is large enough (repeated predict_graph / MD steps would
+  // otherwise pay a hipMalloc + hipFree of GBs per call)
+  int best = -1;
+  for (int i = 0; i < (int)eng->arena_pool.size(); ++i)
+    if (eng->arena_pool[i].second >= total && (best < 0 || eng->arena_pool[i].second < eng->arena_pool[best].second)) best = i;
+  if (best >= 0) {
+    b->arena = eng->arena_pool[best].first;
+    b->arena_bytes = eng->arena_pool[best].second;
+    eng->arena_pool.erase(eng->arena_pool.begin() + best);
+  } else {
+    for (auto& a : eng->arena_pool) hipFree(a.first);   // nothing fits: drop the cache before growing
+    eng->arena_pool.clear();
+    if (hipMalloc(&b->arena, total) != hipSuccess) {
+      eng->err = "chg_batch_upload: hipMalloc of " + std::to_string(total) + " bytes failed";
+      delete b;
+      return CHG_ENOMEM;
+    }
+    b->arena_bytes = total;
   }
-  b->arena_bytes = total;
   carve(b, b->arena, total);
   register_names(b);
   int s = CHG_OK;
@@ -731,7 +746,10 @@ int chg_batch_update_geometry(chg_engine* eng, chg_batch* b, const float* frac, 
 int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (!b) return CHG_OK;
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
-  if (b->arena) hipFree(b->arena);
+  if (b->arena) {
+    if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
+    else hipFree(b->arena);
+  }
   delete b;
   return CHG_OK;
 }
