@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -65,6 +66,7 @@ struct chg_engine {
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
+  bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
   int num_cus = 256;
 };
 
@@ -94,6 +96,11 @@ struct chg_batch {
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
+  // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
+  // ~170 launches per call make small batches (MD: one structure) launch-bound otherwise
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_task = 0;
+  int eager_calls = 0;        // the first call of a (batch, task) runs eagerly: one-shot batches never pay a capture
   std::map<std::string, std::pair<const float*, size_t>> named;
 };
 
@@ -628,6 +635,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   *out = eng;  // returned even on failure so that chg_last_error is readable; destroy it either way
   eng->device = device;
   eng->desc = *desc;
+  if (const char* g = std::getenv("CHGNET_HIP_GRAPHS")) eng->use_graphs = std::string(g) != "0";
   HIP_TRY(eng, hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(eng, hipGetDeviceProperties(&prop, device));
@@ -746,6 +754,7 @@ int chg_batch_update_geometry(chg_engine* eng, chg_batch* b, const float* frac, 
 int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (!b) return CHG_OK;
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
+  if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
   if (b->arena) {
     if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
     else hipFree(b->arena);
@@ -759,7 +768,30 @@ int64_t chg_batch_device_bytes(const chg_batch* b) { return b ? (int64_t)b->aren
 int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   if (!eng || !b) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
-  return run_predict(eng, b, task_mask | CHG_TASK_E);
+  const uint32_t task = task_mask | CHG_TASK_E;
+  if (eng->profiling || !eng->use_graphs) return run_predict(eng, b, task);   // per-kernel events need eager launches
+  if (b->graph_task != task) {
+    if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
+    b->graph_exec = nullptr;
+    b->graph_task = task;
+    b->eager_calls = 0;
+  }
+  if (!b->graph_exec && b->eager_calls++ == 0) return run_predict(eng, b, task);
+  if (!b->graph_exec) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(eng, hipStreamBeginCapture(eng->stream, hipStreamCaptureModeThreadLocal));
+    const int s = run_predict(eng, b, task);
+    const hipError_t e = hipStreamEndCapture(eng->stream, &graph);
+    if (s != CHG_OK) { if (graph) hipGraphDestroy(graph); return s; }
+    if (e != hipSuccess) { eng->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return CHG_EHIP; }
+    const hipError_t ei = hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ei != hipSuccess) { b->graph_exec = nullptr; eng->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ei); return CHG_EHIP; }
+    b->graph_task = task;
+  }
+  HIP_TRY(eng, hipGraphLaunch(b->graph_exec, eng->stream));
+  b->last_task = task;
+  return CHG_OK;
 }
 
 int chg_synchronize(chg_engine* eng) {
