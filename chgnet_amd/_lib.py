@@ -13,7 +13,7 @@ TASK_BITS = {"e": 1, "f": 2, "s": 4, "m": 8}
 
 EXPORTED_SYMBOLS = (
     "chg_device_count", "chg_weights_required", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
-    "chg_batch_upload", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
+    "chg_batch_upload", "chg_batch_build", "chg_debug_fetch_i32", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
     "chg_debug_fetch", "chg_test_rows_gemm",
@@ -38,6 +38,11 @@ class BatchHost(ctypes.Structure):
         ("u_u2d", c_int_p), ("u_bnode", c_int_p), ("bn_und", c_int_p),
         ("a_ctr", c_int_p), ("a_b1c", c_int_p), ("a_b2c", c_int_p), ("a_d1", c_int_p), ("a_d2", c_int_p),
     ]
+
+
+class StructsHost(ctypes.Structure):
+    _fields_ = [("n_struct", ctypes.c_int32), ("n_atoms", ctypes.c_int32), ("z", c_int_p),
+                ("frac", ctypes.POINTER(ctypes.c_double)), ("lattice", ctypes.POINTER(ctypes.c_double)), ("atom_off", c_int_p)]
 
 
 class OutHost(ctypes.Structure):
@@ -76,6 +81,9 @@ def load() -> ctypes.CDLL:
     lib.chg_last_error.argtypes = [vp]
     lib.chg_last_error.restype = ctypes.c_char_p
     lib.chg_batch_upload.argtypes = [vp, ctypes.POINTER(BatchHost), ctypes.POINTER(vp)]
+    lib.chg_batch_build.argtypes = [vp, ctypes.POINTER(StructsHost), ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                    ctypes.POINTER(vp), c_int_p]
+    lib.chg_debug_fetch_i32.argtypes = [vp, vp, ctypes.c_char_p, c_int_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     lib.chg_batch_update_geometry.argtypes = [vp, vp, c_float_p, c_float_p]
     lib.chg_batch_free.argtypes = [vp, vp]
     lib.chg_batch_device_bytes.argtypes = [vp]

@@ -26,6 +26,9 @@
 #include "kernels_conv.h"
 #include "kernels_embed.h"
 #include "kernels_geom.h"
+#include "kernels_graph.h"
+
+#include <hipcub/hipcub.hpp>
 
 using namespace chg;
 
@@ -102,6 +105,7 @@ struct chg_batch {
   uint32_t graph_task = 0;
   int eager_calls = 0;        // the first call of a (batch, task) runs eagerly: one-shot batches never pay a capture
   std::map<std::string, std::pair<const float*, size_t>> named;
+  std::map<std::string, std::pair<const int*, size_t>> named_i32;
 };
 
 namespace {
@@ -584,6 +588,14 @@ void register_names(chg_batch* b) {
   m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
   m["GR"] = {b->GR, Eb * 4 * D}; m["GS"] = {b->GS, N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
   m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B};
+  m["frac"] = {b->frac, 3 * N}; m["lattice"] = {b->lattice, 9 * B}; m["e_image"] = {b->e_image, 3 * Ed};
+  auto& mi = b->named_i32;
+  mi.clear();
+  mi["z"] = {b->z, N}; mi["atom_owner"] = {b->atom_owner, N}; mi["atom_off"] = {b->atom_off, B + 1};
+  mi["e_center"] = {b->e_center, Ed}; mi["e_nbr"] = {b->e_nbr, Ed}; mi["e_d2u"] = {b->e_d2u, Ed}; mi["e_owner"] = {b->e_owner, Ed};
+  mi["e_rev"] = {b->e_rev, Ed}; mi["p_center"] = {b->p_center, Ed}; mi["p_nbr"] = {b->p_nbr, Ed};
+  mi["u_u2d"] = {b->u_u2d, Eu}; mi["u_bnode"] = {b->u_bnode, Eu}; mi["bn_und"] = {b->bn_und, Eb};
+  mi["a_ctr"] = {b->a_ctr, A}; mi["a_b1c"] = {b->a_b1c, A}; mi["a_b2c"] = {b->a_b2c, A}; mi["a_d1"] = {b->a_d1, A}; mi["a_d2"] = {b->a_d2, A};
 }
 
 template <class T>
@@ -607,6 +619,200 @@ int set_lds(chg_engine* eng, K kernel, size_t bytes) {
 }
 
 }  // namespace
+
+
+// ---- device-side graph construction ------------------------------------------------------------------
+struct TmpPool {   // scratch device allocations of one chg_batch_build call
+  std::vector<void*> ptrs;
+  template <class T>
+  T* get(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return static_cast<T*>(p);
+  }
+  ~TmpPool() { for (void* p : ptrs) hipFree(p); }
+};
+
+int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
+  if (n <= 0) return CHG_OK;
+  size_t bytes = 0;
+  HIP_TRY(eng, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n, eng->stream));
+  void* work = tmp.get<char>(bytes);
+  if (!work) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  HIP_TRY(eng, hipcub::DeviceScan::ExclusiveSum(work, bytes, in, out, n, eng->stream));
+  return CHG_OK;
+}
+
+int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
+  int best = -1;
+  for (int i = 0; i < (int)eng->arena_pool.size(); ++i)
+    if (eng->arena_pool[i].second >= total && (best < 0 || eng->arena_pool[i].second < eng->arena_pool[best].second)) best = i;
+  if (best >= 0) {
+    b->arena = eng->arena_pool[best].first;
+    b->arena_bytes = eng->arena_pool[best].second;
+    eng->arena_pool.erase(eng->arena_pool.begin() + best);
+    return CHG_OK;
+  }
+  for (auto& a : eng->arena_pool) hipFree(a.first);   // nothing fits: drop the cache before growing
+  eng->arena_pool.clear();
+  if (hipMalloc(&b->arena, total) != hipSuccess) {
+    eng->err = "hipMalloc of " + std::to_string(total) + " bytes failed";
+    return CHG_ENOMEM;
+  }
+  b->arena_bytes = total;
+  return CHG_OK;
+}
+
+template <class T>
+int d2d(chg_engine* eng, T* dst, const T* src, size_t n) {
+  if (n == 0) return CHG_OK;
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, eng->stream));
+  return CHG_OK;
+}
+
+int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double tol, chg_batch** out,
+                          int32_t* counts_out) {
+  const int B = h->n_struct, N = h->n_atoms;
+  hipStream_t st = eng->stream;
+  // per-structure constants and float64 cartesian coordinates, computed exactly as host_graph.cpp does
+  std::vector<double> reach(3 * (size_t)B), cart(3 * (size_t)N);
+  std::vector<int> owner(N);
+  for (int b = 0; b < B; ++b) {
+    const double* L = h->lattice + 9 * b;
+    const double *a = L, *bb = L + 3, *c = L + 6;
+    const double bc[3] = {bb[1] * c[2] - bb[2] * c[1], bb[2] * c[0] - bb[0] * c[2], bb[0] * c[1] - bb[1] * c[0]};
+    const double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+    const double ab[3] = {a[1] * bb[2] - a[2] * bb[1], a[2] * bb[0] - a[0] * bb[2], a[0] * bb[1] - a[1] * bb[0]};
+    const double vol = a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2];
+    if (!(std::fabs(vol) > 1e-12)) { eng->err = "graph build: singular lattice"; return CHG_EINVAL; }
+    const double hk[3] = {std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
+                          std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
+                          std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
+    for (int k = 0; k < 3; ++k) reach[3 * b + k] = r_atom / hk[k];
+    for (int i = h->atom_off[b]; i < h->atom_off[b + 1]; ++i) {
+      owner[i] = b;
+      for (int k = 0; k < 3; ++k)
+        cart[3 * i + k] = h->frac[3 * i] * a[k] + h->frac[3 * i + 1] * bb[k] + h->frac[3 * i + 2] * c[k];
+    }
+  }
+  TmpPool tmp;
+  double* d_cart = tmp.get<double>(3 * (size_t)N);
+  double* d_frac = tmp.get<double>(3 * (size_t)N);
+  double* d_lat = tmp.get<double>(9 * (size_t)B);
+  double* d_reach = tmp.get<double>(3 * (size_t)B);
+  int* d_owner = tmp.get<int>(N);
+  int* d_aoff = tmp.get<int>(B + 1);
+  int* d_ccnt = tmp.get<int>(N + 1);
+  int* d_coff = tmp.get<int>(N + 1);
+  int* d_flags = tmp.get<int>(4);   // [0] unpaired-edge error, [1] isolated atoms
+  if (!d_cart || !d_frac || !d_lat || !d_reach || !d_owner || !d_aoff || !d_ccnt || !d_coff || !d_flags) {
+    eng->err = "graph build: scratch allocation failed";
+    return CHG_ENOMEM;
+  }
+  HIP_TRY(eng, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemcpyAsync(d_frac, h->frac, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemcpyAsync(d_lat, h->lattice, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemcpyAsync(d_reach, reach.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemcpyAsync(d_owner, owner.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemcpyAsync(d_aoff, h->atom_off, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+  HIP_TRY(eng, hipMemsetAsync(d_ccnt, 0, sizeof(int) * (N + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
+
+  NlArgs nl{};
+  nl.cart = d_cart; nl.frac = d_frac; nl.lattice = d_lat; nl.reach = d_reach; nl.atom_owner = d_owner; nl.atom_off = d_aoff;
+  nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt;
+  const dim3 wave_per_atom((unsigned)((N + 3) / 4));
+  hipLaunchKernelGGL((k_neighbors<false>), wave_per_atom, dim3(256), 0, st, nl);
+  TRY(exclusive_scan(eng, tmp, d_ccnt, d_coff, N + 1));
+  int Ed = 0;
+  HIP_TRY(eng, hipMemcpyAsync(&Ed, d_coff + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(eng, hipStreamSynchronize(st));
+  if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
+  const int Eu = Ed / 2;
+
+  int* e_center = tmp.get<int>(Ed); int* e_nbr = tmp.get<int>(Ed); int* e_img = tmp.get<int>(3 * (size_t)Ed);
+  float* e_image = tmp.get<float>(3 * (size_t)Ed); double* e_dist = tmp.get<double>(Ed); int* e_owner = tmp.get<int>(Ed);
+  int* e_rev = tmp.get<int>(Ed); int* e_d2u = tmp.get<int>(Ed); int* is_first = tmp.get<int>(Ed + 1); int* first_scan = tmp.get<int>(Ed + 1);
+  int* p_center = tmp.get<int>(Ed); int* p_nbr = tmp.get<int>(Ed);
+  int* u_u2d = tmp.get<int>(Eu); int* short_cnt = tmp.get<int>(N); int* ang_cnt = tmp.get<int>(Eu + 1); int* ang_off = tmp.get<int>(Eu + 1);
+  int* is_node = tmp.get<int>(Eu + 1); int* node_scan = tmp.get<int>(Eu + 1); int* u_bnode = tmp.get<int>(Eu);
+  if (!e_center || !e_nbr || !e_img || !e_image || !e_dist || !e_owner || !e_rev || !e_d2u || !is_first || !first_scan || !p_center ||
+      !p_nbr || !u_u2d || !short_cnt || !ang_cnt || !ang_off || !is_node || !node_scan || !u_bnode) {
+    eng->err = "graph build: scratch allocation failed";
+    return CHG_ENOMEM;
+  }
+  int A = 0, Eb = 0, flags[4] = {0, 0, 0, 0};
+  int *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr, *bn_und = nullptr;
+  HIP_TRY(eng, hipMemsetAsync(ang_cnt, 0, sizeof(int) * (Eu + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(is_node, 0, sizeof(int) * (Eu + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(is_first, 0, sizeof(int) * (Ed + 1), st));
+  if (Ed > 0) {
+    nl.center_off = d_coff; nl.e_center = e_center; nl.e_nbr = e_nbr; nl.e_img = e_img; nl.e_image = e_image; nl.e_dist = e_dist;
+    nl.e_owner = e_owner;
+    hipLaunchKernelGGL((k_neighbors<true>), wave_per_atom, dim3(256), 0, st, nl);
+    hipLaunchKernelGGL(k_reverse, g1(Ed), dim3(256), 0, st, e_center, e_nbr, e_img, d_coff, Ed, e_rev, is_first, d_flags);
+    TRY(exclusive_scan(eng, tmp, is_first, first_scan, Ed + 1));
+    hipLaunchKernelGGL(k_undirected, g1(Ed), dim3(256), 0, st, e_center, e_nbr, e_rev, is_first, first_scan, Ed, e_d2u, u_u2d, p_center, p_nbr);
+  }
+  hipLaunchKernelGGL(k_short_count, g1(N), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1);
+  if (Eu > 0) {
+    hipLaunchKernelGGL(k_angle_count, g1(Eu), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, Eu, r_bond, ang_cnt);
+    TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, Eu + 1));
+    HIP_TRY(eng, hipMemcpyAsync(&A, ang_off + Eu, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(eng, hipStreamSynchronize(st));
+  if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
+  a_ctr = tmp.get<int>(A); a_b1 = tmp.get<int>(A); a_d1 = tmp.get<int>(A); a_b2 = tmp.get<int>(A); a_d2 = tmp.get<int>(A);
+  if (!a_ctr || !a_b1 || !a_d1 || !a_b2 || !a_d2) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  if (A > 0) {
+    hipLaunchKernelGGL(k_angle_fill, g1(Eu), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, Eu, r_bond, a_ctr, a_b1,
+                       a_d1, a_b2, a_d2, is_node);
+    TRY(exclusive_scan(eng, tmp, is_node, node_scan, Eu + 1));
+    HIP_TRY(eng, hipMemcpyAsync(&Eb, node_scan + Eu, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipStreamSynchronize(st));
+  }
+  bn_und = tmp.get<int>(Eb);
+  if (!bn_und) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  if (Eu > 0) {
+    if (A == 0) HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (Eu + 1), st));
+    hipLaunchKernelGGL(k_bond_nodes, g1(Eu), dim3(256), 0, st, is_node, node_scan, Eu, u_bnode, bn_und);
+  }
+  HIP_TRY(eng, hipGetLastError());
+
+  // the batch itself: same arena layout as an uploaded batch, filled by device-to-device copies
+  chg_batch* b = new (std::nothrow) chg_batch();
+  if (!b) return CHG_ENOMEM;
+  b->B = B; b->N = N; b->Ed = Ed; b->Eu = Eu; b->A = A; b->Eb = Eb; b->L = eng->desc.n_conv;
+  size_t total = 0;
+  carve(b, nullptr, total);
+  int s = acquire_arena(eng, b, total);
+  if (s != CHG_OK) { delete b; return s; }
+  carve(b, b->arena, total);
+  register_names(b);
+  s = h2d(eng, b->z, h->z, (size_t)N);
+  if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
+  if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
+  if (s == CHG_OK) {
+    hipLaunchKernelGGL(k_f64_to_f32, g1(3 * (int64_t)N), dim3(256), 0, st, d_frac, b->frac, 3 * N);
+    hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
+  }
+#define CP(dst, src, n) if (s == CHG_OK) s = d2d(eng, b->dst, src, (size_t)(n))
+  CP(e_center, e_center, Ed); CP(e_nbr, e_nbr, Ed); CP(e_d2u, e_d2u, Ed); CP(e_owner, e_owner, Ed); CP(e_rev, e_rev, Ed);
+  CP(p_center, p_center, Ed); CP(p_nbr, p_nbr, Ed); CP(e_image, e_image, 3 * (size_t)Ed);
+  CP(u_u2d, u_u2d, Eu); CP(u_bnode, u_bnode, Eu); CP(bn_und, bn_und, Eb);
+  CP(a_ctr, a_ctr, A); CP(a_d1, a_d1, A); CP(a_d2, a_d2, A);
+#undef CP
+  if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
+  if (s == CHG_OK && hipStreamSynchronize(st) != hipSuccess) { eng->err = "graph build: synchronisation failed"; s = CHG_EHIP; }
+  if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
+  if (counts_out) {
+    counts_out[0] = Ed; counts_out[1] = Eu; counts_out[2] = A; counts_out[3] = Eb; counts_out[4] = flags[1]; counts_out[5] = 0;
+  }
+  *out = b;
+  return CHG_OK;
+}
 
 // =====================================================================================================
 // C-ABI
@@ -706,24 +912,9 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   b->L = eng->desc.n_conv;
   size_t total = 0;
   carve(b, nullptr, total);
-  // reuse a released arena when one is large enough (repeated predict_graph / MD steps would
-  // otherwise pay a hipMalloc + hipFree of GBs per call)
-  int best = -1;
-  for (int i = 0; i < (int)eng->arena_pool.size(); ++i)
-    if (eng->arena_pool[i].second >= total && (best < 0 || eng->arena_pool[i].second < eng->arena_pool[best].second)) best = i;
-  if (best >= 0) {
-    b->arena = eng->arena_pool[best].first;
-    b->arena_bytes = eng->arena_pool[best].second;
-    eng->arena_pool.erase(eng->arena_pool.begin() + best);
-  } else {
-    for (auto& a : eng->arena_pool) hipFree(a.first);   // nothing fits: drop the cache before growing
-    eng->arena_pool.clear();
-    if (hipMalloc(&b->arena, total) != hipSuccess) {
-      eng->err = "chg_batch_upload: hipMalloc of " + std::to_string(total) + " bytes failed";
-      delete b;
-      return CHG_ENOMEM;
-    }
-    b->arena_bytes = total;
+  {
+    const int sa = acquire_arena(eng, b, total);
+    if (sa != CHG_OK) { delete b; return sa; }
   }
   carve(b, b->arena, total);
   register_names(b);
@@ -738,6 +929,25 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "chg_batch_upload: sync failed"; s = CHG_EHIP; }
   if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
   *out = b;
+  return CHG_OK;
+}
+
+int chg_batch_build(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double numerical_tol, chg_batch** out,
+                    int32_t* counts_out) {
+  if (!eng || !h || !out || !h->z || !h->frac || !h->lattice || !h->atom_off || h->n_struct <= 0 || h->n_atoms <= 0 || !(r_atom > 0))
+    return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  return build_batch_on_device(eng, h, r_atom, r_bond, numerical_tol, out, counts_out);
+}
+
+int chg_debug_fetch_i32(chg_engine* eng, chg_batch* b, const char* name, int32_t* dst, int64_t capacity, int64_t* n_written) {
+  if (!eng || !b || !name || !dst) return CHG_EINVAL;
+  auto it = b->named_i32.find(name);
+  if (it == b->named_i32.end()) { eng->err = std::string("chg_debug_fetch_i32: unknown buffer ") + name; return CHG_EINVAL; }
+  const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  if (n) HIP_TRY(eng, hipMemcpy(dst, it->second.first, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (n_written) *n_written = (int64_t)n;
   return CHG_OK;
 }
 

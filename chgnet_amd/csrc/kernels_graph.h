@@ -1,0 +1,245 @@
+// kernels_graph.h -- crystal-graph construction on the device.
+//
+// Replaces, for structures that are already on their way to the GPU, the host path
+//   Structure.get_neighbor_list        chgnet/graph/converter.py:132-134   (pymatgen, un-vendored)
+//   create_graph / Graph.add_edge      fast_converter_libraries/create_graph.c:135-203, graph/graph.py:132-224
+//   Graph.adjacency_list               graph/graph.py:226-247
+//   Graph.line_graph_adjacency_list    graph/graph.py:249-328
+// and the index offsetting of BatchedGraph.from_graphs (model/model.py:856-857, 873-877), writing the
+// packed batch arrays (pack.py) directly in HBM.
+//
+// Contract: bit-for-bit the arrays chgnet_amd/csrc/host_graph.cpp + pack.py produce.  The neighbour
+// search therefore repeats the host's float64 arithmetic operation by operation (explicit
+// round-to-nearest mul/add, no FMA contraction), lists neighbours centre-major in (neighbour, image)
+// lexicographic order, numbers undirected bonds by first appearance and enumerates angles in the
+// reference's order (owning bond, end 0 then end 1, the centre's edges in row order).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chg {
+
+struct NlArgs {
+  const double* cart;        // [N,3] float64 cartesian coordinates (computed on the host like host_graph.cpp)
+  const double* frac;        // [N,3]
+  const double* lattice;     // [B,9]
+  const double* reach;       // [B,3]  r / plane spacing per axis
+  const int* atom_owner;     // [N]
+  const int* atom_off;       // [B+1]
+  int n_atoms;
+  double r2, tol;
+  // count pass
+  int* center_cnt;           // [N]
+  // fill pass
+  const int* center_off;     // [N+1]
+  int* e_center;
+  int* e_nbr;
+  int* e_img;                // [Ed,3] int
+  float* e_image;            // [Ed,3] float (engine input)
+  double* e_dist;            // [Ed]
+  int* e_owner;
+};
+
+__device__ __forceinline__ double sq_dist(const double* __restrict__ cart, const double* __restrict__ L, int i, int j, int ia, int ib,
+                                          int ic) {
+  double d2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // host: dx = cart[j][k] + ia*a[k] + ib*b[k] + ic*c[k] - cart[i][k]   (left to right, every op rounded)
+    double t = __dadd_rn(cart[3 * j + k], __dmul_rn((double)ia, L[k]));
+    t = __dadd_rn(t, __dmul_rn((double)ib, L[3 + k]));
+    t = __dadd_rn(t, __dmul_rn((double)ic, L[6 + k]));
+    const double dx = __dsub_rn(t, cart[3 * i + k]);
+    d2 = __dadd_rn(d2, __dmul_rn(dx, dx));
+  }
+  return d2;
+}
+
+// image window of the pair (i, j): host_graph.cpp neighbor_list
+__device__ __forceinline__ void image_window(const NlArgs& p, const double* reach, int i, int j, int (&lo)[3], int (&hi)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double df = __dsub_rn(p.frac[3 * j + k], p.frac[3 * i + k]);
+    lo[k] = (int)ceil(__dsub_rn(__dsub_rn(-df, reach[k]), 1e-9));
+    hi[k] = (int)floor(__dadd_rn(__dadd_rn(-df, reach[k]), 1e-9));
+  }
+}
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  total = __shfl(incl, 63);
+  return incl - v;
+}
+
+// one wave per centre atom; lanes stride over the neighbour atoms j of the same structure
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_neighbors(NlArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= p.n_atoms) return;
+  const int b = p.atom_owner[i];
+  const int a0 = p.atom_off[b], n = p.atom_off[b + 1] - a0;
+  const double* L = p.lattice + 9 * b;
+  const double* reach = p.reach + 3 * b;
+  int running = FILL ? p.center_off[i] : 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int jj = j0 + lane;
+    const int j = a0 + jj;
+    int cnt = 0;
+    int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+    if (jj < n) {
+      image_window(p, reach, i, j, lo, hi);
+      for (int ia = lo[0]; ia <= hi[0]; ++ia)
+        for (int ib = lo[1]; ib <= hi[1]; ++ib)
+          for (int ic = lo[2]; ic <= hi[2]; ++ic) {
+            const double d2 = sq_dist(p.cart, L, i, j, ia, ib, ic);
+            if (d2 < p.r2 && sqrt(d2) > p.tol) ++cnt;
+          }
+    }
+    int total;
+    const int excl = wave_excl_scan(cnt, lane, total);
+    if (FILL && cnt > 0) {
+      int w = running + excl;
+      for (int ia = lo[0]; ia <= hi[0]; ++ia)
+        for (int ib = lo[1]; ib <= hi[1]; ++ib)
+          for (int ic = lo[2]; ic <= hi[2]; ++ic) {
+            const double d2 = sq_dist(p.cart, L, i, j, ia, ib, ic);
+            if (d2 < p.r2) {
+              const double d = sqrt(d2);
+              if (d > p.tol) {
+                p.e_center[w] = i;
+                p.e_nbr[w] = j;
+                p.e_img[3 * w] = ia; p.e_img[3 * w + 1] = ib; p.e_img[3 * w + 2] = ic;
+                p.e_image[3 * w] = (float)ia; p.e_image[3 * w + 1] = (float)ib; p.e_image[3 * w + 2] = (float)ic;
+                p.e_dist[w] = d;
+                p.e_owner[w] = b;
+                ++w;
+              }
+            }
+          }
+    }
+    running += total;
+  }
+  if (!FILL && lane == 0) p.center_cnt[i] = running;
+}
+
+// reverse edge of every directed edge by binary search in the neighbour's (nbr, image)-sorted range
+__global__ void k_reverse(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_img,
+                          const int* __restrict__ center_off, int n_edges, int* __restrict__ e_rev, int* __restrict__ is_first,
+                          int* __restrict__ err) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int i = e_center[e], j = e_nbr[e];
+  const int t0 = -e_img[3 * e], t1 = -e_img[3 * e + 1], t2 = -e_img[3 * e + 2];
+  int lo = center_off[j], hi = center_off[j + 1] - 1, found = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int n = e_nbr[mid], m0 = e_img[3 * mid], m1 = e_img[3 * mid + 1], m2 = e_img[3 * mid + 2];
+    int cmp = n < i ? -1 : (n > i ? 1 : 0);
+    if (cmp == 0) cmp = m0 < t0 ? -1 : (m0 > t0 ? 1 : 0);
+    if (cmp == 0) cmp = m1 < t1 ? -1 : (m1 > t1 ? 1 : 0);
+    if (cmp == 0) cmp = m2 < t2 ? -1 : (m2 > t2 ? 1 : 0);
+    if (cmp == 0) { found = mid; break; }
+    if (cmp < 0) lo = mid + 1; else hi = mid - 1;
+  }
+  if (found < 0) { atomicExch(err, 1); found = e; }   // unpaired directed edge: graph.py:273-278 raises
+  e_rev[e] = found;
+  is_first[e] = e < found ? 1 : 0;   // undirected index = order of first appearance (create_graph.c:152-189)
+}
+
+__global__ void k_undirected(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_rev,
+                             const int* __restrict__ is_first, const int* __restrict__ first_scan, int n_edges, int* __restrict__ e_d2u,
+                             int* __restrict__ u_u2d, int* __restrict__ p_center, int* __restrict__ p_nbr) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges || !is_first[e]) return;
+  const int k = first_scan[e], s = e_rev[e];
+  u_u2d[k] = e;
+  e_d2u[e] = k;
+  e_d2u[s] = k;
+  p_center[2 * k] = e_center[e]; p_nbr[2 * k] = e_nbr[e];
+  p_center[2 * k + 1] = e_center[s]; p_nbr[2 * k + 1] = e_nbr[s];
+}
+
+// per centre: number of edges strictly shorter than the bond-graph cutoff (graph.py:313 uses '<')
+__global__ void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
+                              int* __restrict__ short_cnt, int* __restrict__ n_isolated) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  int c = 0;
+  for (int e = center_off[i]; e < center_off[i + 1]; ++e) c += e_dist[e] < r_bond ? 1 : 0;
+  short_cnt[i] = c;
+  if (center_off[i + 1] == center_off[i]) atomicAdd(n_isolated, 1);
+}
+
+// angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
+__global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
+                              const double* __restrict__ e_dist, const int* __restrict__ short_cnt, int n_und, double r_bond,
+                              int* __restrict__ ang_cnt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_und) return;
+  const int f = u_u2d[k], s = e_rev[f];
+  int c = 0;
+  if (!(e_dist[f] > r_bond)) {   // note '>' on the first directed edge's distance (graph.py:289)
+    c += short_cnt[e_center[f]] - (e_dist[f] < r_bond ? 1 : 0);
+    c += short_cnt[e_center[s]] - (e_dist[s] < r_bond ? 1 : 0);
+  }
+  ang_cnt[k] = c;
+}
+
+__global__ void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
+                             const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
+                             const int* __restrict__ ang_off, int n_und, double r_bond, int* __restrict__ a_ctr, int* __restrict__ a_b1,
+                             int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2, int* __restrict__ is_node) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_und) return;
+  if (ang_off[k + 1] == ang_off[k]) return;
+  const int f = u_u2d[k];
+  const int des[2] = {f, e_rev[f]};
+  int w = ang_off[k];
+  for (int end = 0; end < 2; ++end) {
+    const int de = des[end], ctr = e_center[de];
+    for (int other = center_off[ctr]; other < center_off[ctr + 1]; ++other) {
+      if (other == de) continue;
+      if (e_dist[other] < r_bond) {
+        const int b2 = e_d2u[other];
+        a_ctr[w] = ctr; a_b1[w] = k; a_d1[w] = de; a_b2[w] = b2; a_d2[w] = other;
+        is_node[b2] = 1;
+        ++w;
+      }
+    }
+  }
+  is_node[k] = 1;
+}
+
+__global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, int n_und, int* __restrict__ u_bnode,
+                             int* __restrict__ bn_und) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_und) return;
+  if (is_node[k]) {
+    u_bnode[k] = node_scan[k];
+    bn_und[node_scan[k]] = k;
+  } else {
+    u_bnode[k] = -1;
+  }
+}
+
+__global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restrict__ a_b2, const int* __restrict__ u_bnode, int n_ang,
+                                int* __restrict__ a_b1c, int* __restrict__ a_b2c) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_ang) return;
+  a_b1c[a] = u_bnode[a_b1[a]];
+  a_b2c[a] = u_bnode[a_b2[a]];
+}
+
+__global__ void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = (float)src[t];
+}
+
+}  // namespace chg

@@ -21,9 +21,12 @@ def _ip(a: np.ndarray):
 class DeviceBatch:
     """A packed batch resident in HBM together with all its workspace."""
 
-    def __init__(self, engine: "Engine", packed: PackedBatch) -> None:
+    def __init__(self, engine: "Engine", packed: PackedBatch, handle=None) -> None:
         self.engine = engine
         self.packed = packed
+        if handle is not None:          # built on the device (Engine.build_batch)
+            self.handle = handle
+            return
         self.handle = ctypes.c_void_p()
         self._host = self._host_struct(packed)
         engine._check(engine.lib.chg_batch_upload(engine.handle, ctypes.byref(self._host), ctypes.byref(self.handle)))
@@ -100,6 +103,36 @@ class Engine:
     def upload(self, graphs_or_packed) -> DeviceBatch:
         packed = graphs_or_packed if isinstance(graphs_or_packed, PackedBatch) else pack_batch(graphs_or_packed)
         return DeviceBatch(self, packed)
+
+    def build_batch(self, structures, atom_graph_cutoff: float = 6.0, bond_graph_cutoff: float = 3.0,
+                    numerical_tol: float = 1e-8) -> DeviceBatch:
+        """Structures -> device-resident batch with the graph built ON the GPU (chg_batch_build):
+        same arrays, bit for bit, as ``CrystalGraphConverter`` + ``pack_batch`` + ``upload``.
+        ``batch.packed.n_isolated`` holds the number of atoms without any neighbour."""
+        structures = list(structures)
+        n_at = np.array([len(s) for s in structures], dtype=np.int64)
+        a_off = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int32)
+        z = np.ascontiguousarray(np.concatenate([[site.specie.Z for site in s] for s in structures]), dtype=np.int32)
+        frac = np.ascontiguousarray(np.concatenate([np.asarray(s.frac_coords, dtype=np.float64).reshape(-1, 3) for s in structures]))
+        lattice = np.ascontiguousarray(np.stack([np.asarray(s.lattice.matrix, dtype=np.float64) for s in structures]))
+        host = _lib.StructsHost(len(structures), int(a_off[-1]), _ip(z), frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                lattice.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ip(a_off))
+        handle = ctypes.c_void_p()
+        counts = np.zeros(6, dtype=np.int32)
+        self._check(self.lib.chg_batch_build(self.handle, ctypes.byref(host), float(atom_graph_cutoff), float(bond_graph_cutoff),
+                                             float(numerical_tol), ctypes.byref(handle), _ip(counts)))
+        packed = PackedBatch(len(structures), int(a_off[-1]), int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3]),
+                             {"z": z, "atom_off": a_off, "frac": frac.astype(np.float32), "lattice": lattice.astype(np.float32)})
+        packed.n_isolated = int(counts[4])
+        return DeviceBatch(self, packed, handle=handle)
+
+    def debug_fetch_i32(self, batch: DeviceBatch, name: str, n: int) -> np.ndarray:
+        dst = np.empty(max(int(n), 1), np.int32)
+        got = ctypes.c_int64()
+        self._check(self.lib.chg_debug_fetch_i32(self.handle, batch.handle, name.encode(), _ip(dst), int(n), ctypes.byref(got)))
+        if got.value != n:
+            raise RuntimeError(f"debug_fetch_i32({name}): expected {n} ints, device buffer has {got.value}")
+        return dst[:n]
 
     def predict(self, batch: DeviceBatch, task: str = "efsm") -> None:
         """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""

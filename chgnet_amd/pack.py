@@ -38,6 +38,7 @@ class PackedBatch:
     n_angles: int
     n_bnodes: int
     arrays: dict = field(default_factory=dict)   # name -> contiguous numpy array
+    n_isolated: int = 0
 
     def __getattr__(self, name):
         try:

@@ -104,6 +104,22 @@ int chg_engine_destroy(chg_engine* eng);
 const char* chg_last_error(const chg_engine* eng);
 
 int chg_batch_upload(chg_engine* eng, const chg_batch_host* host, chg_batch** out);
+
+/* Structures only (no graph): the periodic neighbour list, bond numbering and bond graph are built on
+ * the device, bit-for-bit the arrays of chg_graph_build (include/chgnet_graph.h) + pack.py.  Replaces
+ * CrystalGraphConverter.forward (chgnet/graph/converter.py:102-190) for structures headed to the GPU. */
+typedef struct chg_structs_host {
+  int32_t n_struct, n_atoms;
+  const int32_t* z;           /* [N]                                  */
+  const double* frac;         /* [N,3]   float64 fractional coordinates (unwrapped is fine) */
+  const double* lattice;      /* [B,3,3] float64, rows a,b,c          */
+  const int32_t* atom_off;    /* [B+1]                                */
+} chg_structs_host;
+/* counts_out[6] = { n_directed, n_undirected, n_angles, n_bnodes, n_isolated_atoms, 0 } */
+int chg_batch_build(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
+                    chg_batch** out, int32_t* counts_out);
+/* int32 index array of a batch by pack.py name (e_center, e_nbr, e_d2u, u_u2d, a_ctr, ...) -- tests only */
+int chg_debug_fetch_i32(chg_engine* eng, chg_batch* batch, const char* name, int32_t* dst, int64_t capacity, int64_t* n_written);
 /* new positions / cells on an unchanged graph topology (MD with a Verlet-skin graph) */
 int chg_batch_update_geometry(chg_engine* eng, chg_batch* batch, const float* frac, const float* lattice);
 int chg_batch_free(chg_engine* eng, chg_batch* batch);

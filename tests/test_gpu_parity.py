@@ -429,3 +429,88 @@ def test_calculator_skin_fast_path_is_exact(hip_engine, golden_weights):
         for l in range(3):
             w02[f"bond_conv_layers.{l}.mlp_out.layers.1.bias"] = np.zeros(64, np.float32)
         CHGNetCalculator(CHGNet(state_dict=w02, mlp_out_bias=True), skin=0.4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# device-side graph construction: bit-exact vs the host builder
+# ---------------------------------------------------------------------------------------------------
+INT_ARRAYS = {"z": "n_atoms", "atom_owner": "n_atoms", "e_center": "n_directed", "e_nbr": "n_directed", "e_d2u": "n_directed",
+              "e_owner": "n_directed", "e_rev": "n_directed", "p_center": "n_directed", "p_nbr": "n_directed",
+              "u_u2d": "n_undirected", "u_bnode": "n_undirected", "bn_und": "n_bnodes", "a_ctr": "n_angles", "a_b1c": "n_angles",
+              "a_b2c": "n_angles", "a_d1": "n_angles", "a_d2": "n_angles"}
+
+
+def _structures_for_graph_tests():
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    out = []
+    for name in ("limno2", "s16tri", "noangle", "li9co7o16"):
+        _, d = load_case(name)
+        out.append(Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]))
+    out.append(out[0].make_supercell([2, 1, 2]).perturb(0.03, np.random.default_rng(2)))
+    out.append(Structure(Lattice(np.eye(3) * 20.0), ["H", "O"], [[0, 0, 0], [0.5, 0.5, 0.5]]))       # isolated atoms
+    out.append(Structure(out[1].lattice, out[1].atomic_numbers, out[1].frac_coords + np.array([2.0, -1.0, 3.0])))  # unwrapped
+    out.append(Structure(Lattice(np.eye(3) * 2.5), ["Fe"], [[0.1, 0.2, 0.3]]))                        # periodic self-pairs
+    return out
+
+
+def test_device_graph_build_is_bit_exact(hip_engine):
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.pack import pack_batch
+
+    structs = _structures_for_graph_tests()
+    conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+    want = pack_batch([conv(s) for s in structs])
+    batch = hip_engine.build_batch(structs, 6.0, 3.0)
+    got = batch.packed
+    for attr in ("n_struct", "n_atoms", "n_directed", "n_undirected", "n_angles", "n_bnodes"):
+        assert getattr(got, attr) == getattr(want, attr), attr
+    assert got.n_isolated == 2
+    for name, count in INT_ARRAYS.items():
+        dev = hip_engine.debug_fetch_i32(batch, name, getattr(want, count))
+        assert np.array_equal(dev, want.arrays[name]), name
+    img = hip_engine.debug_fetch(batch, "e_image", (want.n_directed, 3))
+    assert np.array_equal(img, want.e_image)
+    assert np.array_equal(hip_engine.debug_fetch(batch, "frac", (want.n_atoms, 3)), want.frac)
+    assert np.array_equal(hip_engine.debug_fetch(batch, "lattice", (want.n_struct, 9)).reshape(-1, 3, 3), want.lattice)
+    # and the prediction from the device-built batch equals the one from the uploaded host graph
+    hip_engine.predict(batch, "efsm")
+    r_dev = hip_engine.download(batch, "efsm")
+    batch.free()
+    up = hip_engine.upload(want)
+    hip_engine.predict(up, "efsm")
+    r_up = hip_engine.download(up, "efsm")
+    up.free()
+    for key in ("e", "f", "s", "m"):
+        assert np.allclose(r_dev[key], r_up[key], rtol=0, atol=2e-6, equal_nan=True), key
+
+
+def test_device_graph_build_other_cutoffs_and_workload(hip_engine):
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.pack import pack_batch
+
+    structs = _structures_for_graph_tests()[:5]
+    conv = CrystalGraphConverter(atom_graph_cutoff=5, bond_graph_cutoff=3, on_isolated_atoms="ignore")
+    want = pack_batch([conv(s) for s in structs])
+    batch = hip_engine.build_batch(structs, 5.0, 3.0)
+    for name, count in INT_ARRAYS.items():
+        assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+    batch.free()
+    # 64 structures of the bench workload
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    lat = Lattice.from_parameters(2.868779, 4.634475, 5.832507, 90, 90, 90)
+    frac = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
+            [0.5, 0, 0.3608245], [0, 0.5, 0.0985135], [0.5, 0, 0.9014865], [0, 0.5, 0.6391755]]
+    base = Structure(lat, ["Li", "Li", "Mn", "Mn", "O", "O", "O", "O"], frac).make_supercell([5, 1, 1])
+    ss = [base.perturb(0.01, np.random.default_rng(i)) for i in range(64)]
+    conv6 = CrystalGraphConverter()
+    want = pack_batch([conv6(s) for s in ss])
+    batch = hip_engine.build_batch(ss)
+    assert batch.packed.n_directed == want.n_directed and batch.packed.n_angles == want.n_angles
+    for name, count in INT_ARRAYS.items():
+        assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+    batch.free()
