@@ -115,10 +115,9 @@ class CHGNetCalculator(Calculator):
         if self.skin > 0:
             pred = self._predict_resident(structure, task)
         else:
-            graph = self.model.graph_converter(structure)
-            self.n_graph_builds += 1
-            pred = self.model.predict_graph(graph, task=task, return_crystal_feas=True,
-                                            return_site_energies=self.return_site_energies)
+            self.n_graph_builds += 1   # graph rebuilt every call like dynamics.py:156-157, but on the device
+            pred = self.model.predict_structure(structure, task=task, return_crystal_feas=True,
+                                                return_site_energies=self.return_site_energies)
         extensive_factor = len(structure) if self.model.is_intensive else 1
         key_map = {"e": ("energy", extensive_factor), "f": ("forces", 1), "m": ("magmoms", 1), "s": ("stress", self.stress_weight)}
         self.results.update({long_key: pred[key] * factor for key, (long_key, factor) in key_map.items() if key in pred})
@@ -130,7 +129,6 @@ class CHGNetCalculator(Calculator):
     # ---- device-resident fast path (skin > 0) ----------------------------------------------------------
     def _predict_resident(self, structure, task: str) -> dict:
         from chgnet_amd import VALID_TASKS
-        from chgnet_amd.pack import pack_batch
 
         if task not in VALID_TASKS:
             raise ValueError(f"Invalid {task=}. Must be one of {VALID_TASKS}.")
@@ -148,9 +146,11 @@ class CHGNetCalculator(Calculator):
         else:
             if res is not None:
                 res["batch"].free()
-            graph = self._skin_converter(structure)
+            conv = self._skin_converter
             self.n_graph_builds += 1
-            batch = eng.upload(pack_batch([graph]))
+            batch = eng.build_batch([structure], conv.atom_graph_cutoff, conv.bond_graph_cutoff)
+            if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
+                conv(structure)   # phrases the reference's isolated-atom error / warning
             res = self._resident = {"z": z, "lattice": lattice.copy(), "cart": cart.copy(), "batch": batch}
         eng.predict(res["batch"], task)
         out = eng.download(res["batch"], task, site_energies=self.return_site_energies, crystal_feas=True)

@@ -169,12 +169,29 @@ class CHGNet:
         if self.graph_converter is None:
             raise ValueError("graph_converter cannot be None!")
         single = _is_structure(structure)
-        structures = [structure] if single else structure
-        graphs = [self.graph_converter(struct) for struct in structures]
-        out = self.predict_graph(graphs, task=task, return_site_energies=return_site_energies,
-                                 return_atom_feas=return_atom_feas, return_crystal_feas=return_crystal_feas,
-                                 batch_size=batch_size)
-        return out
+        structures = [structure] if single else list(structure)
+        valid_tasks = VALID_TASKS
+        if task not in valid_tasks:
+            raise ValueError(f"Invalid {task=}. Must be one of {valid_tasks}.")
+        # Graphs are built on the GPU (chg_batch_build: bit-for-bit the arrays of the host converter, see
+        # tests/test_gpu_parity.py::test_device_graph_build_is_bit_exact); the host converter is only
+        # consulted to phrase the reference's isolated-atom error / warning for the offending structure.
+        conv, eng = self.graph_converter, self.engine
+        predictions: list[dict] = []
+        for start in range(0, len(structures), batch_size):
+            chunk = structures[start:start + batch_size]
+            batch = eng.build_batch(chunk, conv.atom_graph_cutoff, conv.bond_graph_cutoff)
+            try:
+                if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
+                    for struct in chunk:          # raises ValueError / prints the warning like converter.py:161-174
+                        conv(struct)
+                eng.predict(batch, task)
+                res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,
+                                   crystal_feas=return_crystal_feas)
+            finally:
+                batch.free()
+            predictions.extend(_split_results(res, batch.packed.atom_off, len(chunk)))
+        return predictions[0] if single else predictions
 
     def predict_graph(self, graph, *, task: str = "efsm", return_site_energies: bool = False,
                       return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16):
@@ -203,17 +220,8 @@ class CHGNet:
                                    crystal_feas=return_crystal_feas)
             finally:
                 batch.free()
-            off = packed.atom_off
-            for i in range(len(chunk)):
-                pred = predictions[step * batch_size + i]
-                sl = slice(off[i], off[i + 1])
-                pred["e"] = res["e"][i]
-                for key in ("f", "m", "site_energies", "atom_fea"):
-                    if key in res:
-                        pred[key] = res[key][sl].copy()
-                for key in ("s", "crystal_fea"):
-                    if key in res:
-                        pred[key] = res[key][i].copy()
+            for i, pred in enumerate(_split_results(res, packed.atom_off, len(chunk))):
+                predictions[step * batch_size + i] = pred
         return predictions[0] if len(graphs) == 1 else predictions
 
     # ---- (de)serialisation (model.py:667-745) ----------------------------------------------------------
@@ -256,6 +264,22 @@ class CHGNet:
         if verbose:
             print(f"CHGNet will run on {model.device}")
         return model
+
+
+def _split_results(res: dict, atom_off, n: int) -> list[dict]:
+    """Batch-wide result arrays -> one dict per structure (reference model.py:651-663)."""
+    out = []
+    for i in range(n):
+        sl = slice(atom_off[i], atom_off[i + 1])
+        pred = {"e": res["e"][i]}
+        for key in ("f", "m", "site_energies", "atom_fea"):
+            if key in res:
+                pred[key] = res[key][sl].copy()
+        for key in ("s", "crystal_fea"):
+            if key in res:
+                pred[key] = res[key][i].copy()
+        out.append(pred)
+    return out
 
 
 def _to_numpy(v) -> np.ndarray:

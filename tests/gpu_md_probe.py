@@ -16,6 +16,8 @@ s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]
 calc = CHGNetCalculator(CHGNet(state_dict=W))
 md = BerendsenNVT(s, calc, temperature_K=1000.0, timestep_fs=2.0, task="ef")
 md.run(5)
+t = time.perf_counter(); calc.model.predict_structure(md.structure, task="ef"); tps = time.perf_counter() - t
+print(f"predict_structure (device graph build + predict + download) {tps*1e3:.2f} ms", flush=True)
 t = time.perf_counter(); g = calc.model.graph_converter(md.structure); tg = time.perf_counter() - t
 t = time.perf_counter(); calc.model.predict_graph(g, task="ef"); tp = time.perf_counter() - t
 print(f"graph build {tg*1e3:.2f} ms, predict_graph (pack+upload+predict+download) {tp*1e3:.2f} ms, N={len(s)} Ed={len(g.atom_graph)} A={len(g.bond_graph)}", flush=True)

@@ -514,3 +514,26 @@ def test_device_graph_build_other_cutoffs_and_workload(hip_engine):
     for name, count in INT_ARRAYS.items():
         assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
     batch.free()
+
+
+def test_predict_structure_uses_device_graphs_and_matches_predict_graph(hip_engine, golden_weights, capsys):
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.model import CHGNet
+
+    model = CHGNet(state_dict=golden_weights)
+    structs = _structures_for_graph_tests()[:4]
+    via_struct = model.predict_structure(structs, task="efsm", batch_size=3)
+    via_graph = model.predict_graph([CrystalGraphConverter()(s) for s in structs], task="efsm", batch_size=3)
+    for a, b in zip(via_struct, via_graph):
+        assert set(a) == set(b) == {"e", "f", "s", "m"}
+        for key in a:
+            assert np.abs(a[key] - b[key]).max() < 2e-6, key
+    single = model.predict_structure(structs[0])
+    assert isinstance(single, dict) and abs(single["e"] - via_graph[0]["e"]) < 2e-6
+    lone = _structures_for_graph_tests()[5]
+    with pytest.raises(ValueError, match="has 2 isolated atom"):
+        model.predict_structure(lone)
+    model.graph_converter.set_isolated_atom_response("warn")
+    capsys.readouterr()
+    out = model.predict_structure([structs[0], lone])
+    assert "has 2 isolated atom" in capsys.readouterr()[1] and np.isfinite(out[1]["e"])
