@@ -46,6 +46,18 @@ KERNEL_MODEL = {
 }
 
 
+def workload_structures(n_struct: int, first_seed: int):
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    lat = Lattice.from_parameters(2.868779, 4.634475, 5.832507, 90, 90, 90)
+    species = ["Li", "Li", "Mn", "Mn", "O", "O", "O", "O"]
+    frac = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
+            [0.5, 0, 0.3608245], [0, 0.5, 0.0985135], [0.5, 0, 0.9014865], [0, 0.5, 0.6391755]]
+    base = Structure(lat, species, frac).make_supercell([5, 1, 1])
+    return [base.perturb(0.01, np.random.default_rng(first_seed + i)) for i in range(n_struct)]
+
+
 def build_workload(n_struct: int, first_seed: int):
     from chgnet_amd import CrystalGraphConverter, Structure
     from chgnet_amd.graph.structure import Lattice
@@ -174,6 +186,18 @@ def main() -> None:
     prof = eng.profile_read()
     eng.profile(False)
 
+    # secondary, informative only: structures on the host -> graph built on the device -> E/F/S on the host
+    structs = workload_structures(args.structures, first_seed=rank * args.structures)
+    e2e = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        b2 = eng.build_batch(structs)
+        eng.predict(b2, "efs")
+        eng.download(b2, "efs")
+        e2e.append(time.perf_counter() - t0)
+        b2.free()
+    e2e_ms = 1e3 * min(e2e)
+
     line = None
     if rank == 0:
         total_ms = sum(ms for _, ms in prof.values()) or 1.0
@@ -218,6 +242,8 @@ def main() -> None:
                        "weights": "random-init 0.3.0 architecture (tests/golden/weights_seed0.npz)",
                        "parallelism": f"structures sharded over {world} GPU(s), RCCL all-gather of energies only"},
             "device_ms_per_step": round(dev_ms, 3),
+            "end_to_end": {"what": "host structures -> device graph build (chg_batch_build) -> predict -> E/F/S on host, per GPU",
+                           "ms": round(e2e_ms, 3), "structures_per_s": round(args.structures / (e2e_ms * 1e-3), 1)},
             "device_bytes": batch.device_bytes,
             "roofline": roofline,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in ranked},
