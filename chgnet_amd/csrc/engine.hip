@@ -35,6 +35,10 @@ using namespace chg;
 namespace {
 
 constexpr int MAX_CONV = 8;
+#ifndef CHG_FWD_WAVES
+#define CHG_FWD_WAVES 8
+#endif
+constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
 
 struct GatedPtrs { GatedW g; };
 
@@ -230,8 +234,8 @@ int collect_profile(chg_engine* eng) {
   return CHG_OK;
 }
 
-int grid_for(int rows, int max_blocks) {
-  int ntiles = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
+int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS) {
+  int ntiles = (rows + block_rows - 1) / block_rows;
   int g = std::min(ntiles, max_blocks);
   if (g >= 8) g &= ~7;  // multiple of 8: tile_range keeps neighbouring ranges on one XCD
   return std::max(g, 1);
@@ -311,7 +315,11 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   if (b->Ed > 0) {
     TRY(atomconv_tables(eng, b, l));
     LaunchScope ls(eng, "atomconv_fwd");
-    hipLaunchKernelGGL(k_atomconv_fwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, atomconv_args(eng, b, l));
+    const size_t lds = atomconv_lds<FWD_WAVES>();
+    AtomConvArgs a = atomconv_args(eng, b, l);
+    a.e_center = b->p_center;   // bond-pair order
+    a.e_nbr = b->p_nbr;
+    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(grid_for(b->Ed, 2 * eng->num_cus, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
@@ -328,7 +336,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds(), eng->stream, a);
+    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -356,11 +364,11 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   return a;
 }
 
-template <bool HIDDEN, bool BWD>
+template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
-  const size_t lds = angle_lds<HIDDEN>();
-  hipLaunchKernelGGL((k_angle<HIDDEN, BWD>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, a);
+  const size_t lds = angle_lds<HIDDEN, NW>();
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, 2 * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, a);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
@@ -377,7 +385,7 @@ int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
 int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
   const AUW& w = eng->w.au[l];
   TRY(angle_tables(eng, b, b->L + l, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
-  return launch_angle<false, false>(eng, "angleupd_fwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
+  return launch_angle<false, false, FWD_WAVES>(eng, "angleupd_fwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
 }
 
 // scatter of the table gradients back to atoms / bond nodes
@@ -867,11 +875,11 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
-  if ((s = set_lds(eng, k_atomconv_fwd, atomconv_lds()))) return s;
-  if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds()))) return s;
+  if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, atomconv_lds<FWD_WAVES>()))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds<WAVES>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
-  if ((s = set_lds(eng, k_angle<false, false>, angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
   if ((s = set_lds(eng, k_readout, readout_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;

@@ -220,9 +220,12 @@ struct AtomConvArgs {
   float* Gwag;         // [Eu,64] accumulated over layers
 };
 
-constexpr size_t atomconv_lds() { return sizeof(float) * (2 * D * WS + VEC_SLOTS * D + WAVES * TILE_FLOATS); }
+template <int NW = WAVES>
+constexpr size_t atomconv_lds() { return sizeof(float) * (2 * D * WS + VEC_SLOTS * D + NW * TILE_FLOATS); }
 
-__global__ __launch_bounds__(BLOCK) void k_atomconv_fwd(AtomConvArgs p) {
+// NW waves per workgroup: the forward kernel needs only ~106 VGPRs, so 12 waves (3 per SIMD) fit
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_atomconv_fwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2c = smem;
   float* W2g = W2c + D * WS;
@@ -235,19 +238,42 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_fwd(AtomConvArgs p) {
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int ntiles = (p.n_edges + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
   int tb, te;
   tile_range(ntiles, tb, te);
+  // Software pipeline over tiles: the row gather of tile t+1 (24 loads) is issued before tile t's MFMA /
+  // VALU phase and committed to LDS after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of
+  // wave time with the gather issued and awaited in place.)
+  const int tstride = TILE_ROWS * NW;
+  auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_edges - 1); };
+  GatherRegs gr;
+  V64 wv_nx;
+  int c_nx = 0, n_nx = 0, c_n2 = 0, n_n2 = 0;
+  if (tb < te) {
+    const int r0 = row_of(tb);
+    c_nx = p.e_center[r0]; n_nx = p.e_nbr[r0];
+    gather_issue128(gr, p.P, c_nx, p.P + 2 * D, n_nx, p.Q, r0 >> 1, 4 * D, 4 * D, 2 * D, lane);
+    read_dl<VT>(p.wag + (size_t)(r0 >> 1) * D, g, wv_nx.t);
+    const int r1 = row_of(tb + 1);
+    c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
+  }
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
-    const int nvalid = min(TILE_ROWS, p.n_edges - row0);
+    const int row0 = tile * tstride + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
+    // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): Q[k] and w_ag[k] are fetched once per bond
+    const int c = c_nx;
+    const V64 wv = wv_nx;
+    gather_commit128(gr, T, TS, lane);
+    c_nx = c_n2; n_nx = n_n2;
+    if (tile + 1 < te) {
+      const int r1 = row_of(tile + 1);
+      gather_issue128(gr, p.P, c_nx, p.P + 2 * D, n_nx, p.Q, r1 >> 1, 4 * D, 4 * D, 2 * D, lane);
+      read_dl<VT>(p.wag + (size_t)(r1 >> 1) * D, g, wv_nx.t);
+      const int r2 = row_of(tile + 2);
+      c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
+    }
     if (nvalid <= 0) continue;
     const bool valid = j < nvalid;
-    const int e = row0 + (valid ? j : 0);
-    const int c = p.e_center[e], n = p.e_nbr[e], k = p.e_d2u[e];
-    gather_sum128(T, TS, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
-    V64 wv;   // issued now, consumed after the MFMA phase
-    read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
     __builtin_amdgcn_wave_barrier();
     V64 zc, zg;
     read_dl<VT>(Trow, g, zc.t);
@@ -259,7 +285,24 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_fwd(AtomConvArgs p) {
     CHG_EW(ft, r) m.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r] * wv.t[ft][r];
     write_dl<VT>(Trow, g, m.t);
     __builtin_amdgcn_wave_barrier();
-    seg_colsum_atomic<D>(T, TS, valid ? c : -1, nvalid, p.agg, D, lane);
+    {  // even rows: centre c1 is nondecreasing in k -> segmented sum; odd rows: one atomic row each
+      float acc = 0.f;
+      int cur = __builtin_amdgcn_readlane(c, 0);
+#pragma unroll
+      for (int b = 0; b < TILE_ROWS / 2; ++b) {
+        if (2 * b < nvalid) {
+          const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
+          if (c1 != cur) {
+            atomicAdd(p.agg + (size_t)cur * D + lane, acc);
+            acc = 0.f;
+            cur = c1;
+          }
+          acc += T[(2 * b) * TS + lane];
+          atomicAdd(p.agg + (size_t)c2 * D + lane, T[(2 * b + 1) * TS + lane]);
+        }
+      }
+      atomicAdd(p.agg + (size_t)cur * D + lane, acc);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -385,15 +428,15 @@ struct AngleArgs {
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
 };
 
-template <bool HIDDEN>
+template <bool HIDDEN, int NW = WAVES>
 constexpr size_t angle_lds() {
-  return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + WAVES * TILE_FLOATS);
+  return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + NW * TILE_FLOATS);
 }
 
 // HIDDEN = true: BondConv (gated MLP with one hidden layer, weighted, aggregated over the owning bond)
 // HIDDEN = false: AngleUpdate (single gated layer, residual on the angle itself)
-template <bool HIDDEN, bool BWD>
-__global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
+template <bool HIDDEN, bool BWD, int NW = WAVES>
+__global__ __launch_bounds__(64 * NW) void k_angle(AngleArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wang = smem;                                  // [128][WS]
   float* W2c = Wang + 2 * D * WS;
@@ -410,11 +453,11 @@ __global__ __launch_bounds__(BLOCK) void k_angle(AngleArgs p) {
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int ntiles = (p.n_angles + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
   int tb, te;
   tile_range(ntiles, tb, te);
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int row0 = tile * (TILE_ROWS * NW) + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     if (nvalid <= 0) continue;
     const bool valid = j < nvalid;

@@ -146,13 +146,13 @@ __device__ __forceinline__ void ln_backward(V64& gy, const V64& gamma, const V64
 __device__ __forceinline__ void stage_weights(float* dst, const float* __restrict__ src, int rows, int K, int tid) {
   const int ws = K + PAD;
   const int k4 = K / 4;
-  for (int idx = tid; idx < rows * k4; idx += BLOCK) {
+  for (int idx = tid; idx < rows * k4; idx += (int)blockDim.x) {
     const int rr = idx / k4, c4 = idx - rr * k4;
     *reinterpret_cast<f32x4*>(dst + rr * ws + 4 * c4) = *reinterpret_cast<const f32x4*>(src + rr * K + 4 * c4);
   }
 }
 __device__ __forceinline__ void stage_vector(float* dst, const float* __restrict__ src, int n, int tid) {
-  for (int idx = tid; idx < n; idx += BLOCK) dst[idx] = src[idx];
+  for (int idx = tid; idx < n; idx += (int)blockDim.x) dst[idx] = src[idx];
 }
 
 // ---- tile scheduling: contiguous tile ranges per workgroup, neighbouring ranges on one XCD -------
@@ -229,18 +229,24 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
                                               const float* __restrict__ t1, int i1, const float* __restrict__ t2, int i2,
                                               int ld0, int ld1, int ld2, int lane) {
   const int hw = lane >> 5, t = lane & 31;
-  f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
+  // all index shuffles first (independent ds_bpermutes, one wait), then all 24 row loads back to back:
+  // interleaving shuffle -> wait -> load serialised the issue of the gather (~100 cycles per row)
+  int r0[TILE_ROWS / 2], r1[TILE_ROWS / 2], r2[TILE_ROWS / 2];
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
     const int rr = 2 * it + hw;
 #ifdef CHG_EXP_NO_GATHER        // timing experiment only: every row reads table row 0 (cache-resident)
-    const int r0 = 0, r1 = 0, r2 = 0;
+    r0[it] = r1[it] = r2[it] = 0;
 #else
-    const int r0 = __shfl(i0, rr), r1 = __shfl(i1, rr), r2 = __shfl(i2, rr);
+    r0[it] = __shfl(i0, rr); r1[it] = __shfl(i1, rr); r2[it] = __shfl(i2, rr);
 #endif
-    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0 * ld0 + 4 * t);
-    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1 * ld1 + 4 * t);
-    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2 * ld2 + 4 * t);
+  }
+  f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
+    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
+    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
@@ -249,15 +255,42 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
   }
 }
 
+// The same gather split in two so that the loads of tile t+1 can be in flight while tile t computes:
+// issue (registers only) ... commit (sum + LDS write).
+struct GatherRegs { f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2]; };
+
+__device__ __forceinline__ void gather_issue128(GatherRegs& gr, const float* __restrict__ t0, int i0, const float* __restrict__ t1,
+                                                int i1, const float* __restrict__ t2, int i2, int ld0, int ld1, int ld2, int lane) {
+  const int hw = lane >> 5, t = lane & 31;
+  int r0[TILE_ROWS / 2], r1[TILE_ROWS / 2], r2[TILE_ROWS / 2];
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    const int rr = 2 * it + hw;
+    r0[it] = __shfl(i0, rr); r1[it] = __shfl(i1, rr); r2[it] = __shfl(i2, rr);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
+    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
+  }
+}
+__device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* tile, int stride, int lane) {
+  const int hw = lane >> 5, t = lane & 31;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it)
+    *reinterpret_cast<f32x4*>(tile + (2 * it + hw) * stride + 4 * t) = (gr.a[it] + gr.b[it]) + gr.c[it];
+}
+
 // contiguous or gathered 64-wide rows into an LDS tile (16 lanes per row, 4 rows per step)
 __device__ __forceinline__ void gather_rows64(float* tile, int stride, const float* __restrict__ src, int idx, int lane) {
   const int sub = lane >> 4, t = lane & 15;
   f32x4 v[TILE_ROWS / 4];
+  int r[TILE_ROWS / 4];
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) {
-    const int r = __shfl(idx, 4 * it + sub);
-    v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r * D + 4 * t);
-  }
+  for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r[it] * D + 4 * t);
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = v[it];
 }
