@@ -9,7 +9,6 @@ attributes).
 
 from __future__ import annotations
 
-import pickle
 from typing import Any
 
 import numpy as np
@@ -95,15 +94,35 @@ class CrystalGraph:
     def from_dict(cls, dic: dict[str, Any]) -> "CrystalGraph":
         return cls(**dic)
 
-    def save(self, fname: str = "CrystalGraph.pkl") -> str:
-        with open(fname, "wb") as fh:
-            pickle.dump(self.to_dict(), fh)
-        return fname
+    def save(self, fname: str | None = None, save_dir: str = ".") -> str:
+        """Save in the reference's on-disk format (crystalgraph.py:138-155): ``torch.save`` of the
+        ``to_dict()`` dictionary with tensor values, so files are interchangeable both ways
+        (``GraphData`` caches, dataset.py:400-402).  torch is used as the (de)serialiser only."""
+        import os
+
+        import torch
+
+        if fname is not None:
+            save_name = os.path.join(save_dir, fname)
+        elif self.graph_id is not None:
+            save_name = os.path.join(save_dir, f"{self.graph_id}.pt")
+        else:
+            save_name = os.path.join(save_dir, f"{self.composition}.pt")
+        dic = self.to_dict()
+        for key in _FIELDS:
+            dic[key] = torch.from_numpy(np.ascontiguousarray(dic[key]))
+        torch.save(dic, f=save_name)
+        return save_name
 
     @classmethod
     def from_file(cls, file_name: str) -> "CrystalGraph":
-        with open(file_name, "rb") as fh:
-            return cls.from_dict(pickle.load(fh))  # noqa: S301
+        """Load a graph written by ``save`` here or by the reference (a dict of tensors)."""
+        import torch
+
+        obj = torch.load(file_name, map_location="cpu", weights_only=False)
+        if isinstance(obj, dict):
+            return cls.from_dict(obj)
+        return cls.from_reference(obj)       # a pickled reference CrystalGraph object
 
     @property
     def num_isolated_atoms(self) -> int:
@@ -114,9 +133,10 @@ class CrystalGraph:
         composition = self.composition
         atom_graph_cutoff = self.atom_graph_cutoff
         bond_graph_cutoff = self.bond_graph_cutoff
+        n_atoms = len(self.atomic_number)
         atom_graph_len = len(self.atom_graph)
         bond_graph_len = len(self.bond_graph)
         return (
             f"CrystalGraph({composition=}, {atom_graph_cutoff=}, {bond_graph_cutoff=}, "
-            f"atom_graph.shape[0]={atom_graph_len}, bond_graph.shape[0]={bond_graph_len})"
+            f"{n_atoms=}, {atom_graph_len=}, {bond_graph_len=})"
         )

@@ -136,3 +136,27 @@ def test_graph_builder_error_codes():
         build_graph_arrays(np.zeros((1, 3)), np.zeros((3, 3)), 5.0, 3.0)
     with pytest.raises(ValueError, match="not complete|2 \\* number"):
         graph_arrays_from_neighbors(2, [0], [1], [[0, 0, 0]], [1.0], r_bond=3)   # dangling directed edge
+
+
+def test_crystal_graph_file_round_trip_and_reference_format(tmp_path):
+    """On-disk format of reference crystalgraph.py:138-167: torch.save(to_dict()) with tensor values."""
+    import torch
+
+    g, _ = load_case("s16tri")
+    path = g.save(fname="g.pt", save_dir=str(tmp_path))
+    raw = torch.load(path, weights_only=False)
+    assert isinstance(raw, dict) and isinstance(raw["atom_graph"], torch.Tensor) and raw["atom_graph"].dtype == torch.int32
+    assert raw["atom_frac_coord"].dtype == torch.float32 and raw["atom_graph_cutoff"] == 6
+    from chgnet_amd import CrystalGraph
+
+    g2 = CrystalGraph.from_file(path)
+    for key in ("atomic_number", "atom_frac_coord", "atom_graph", "neighbor_image", "directed2undirected",
+                "undirected2directed", "bond_graph", "lattice"):
+        assert np.array_equal(getattr(g, key), getattr(g2, key)), key
+    assert repr(g2).startswith("CrystalGraph(composition=") and "n_atoms=16" in repr(g2)
+    # a file written the way the reference writes it (tensor dict incl. grad-tracking floats) loads too
+    ref_style = {k: (torch.tensor(v, requires_grad=v.dtype == np.float32) if isinstance(v, np.ndarray) else v)
+                 for k, v in g.to_dict().items()}
+    torch.save(ref_style, tmp_path / "ref.pt")
+    g3 = CrystalGraph.from_file(str(tmp_path / "ref.pt"))
+    assert np.array_equal(g3.bond_graph, g.bond_graph) and g3.lattice.dtype == np.float32
