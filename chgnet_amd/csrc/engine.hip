@@ -74,6 +74,8 @@ struct chg_engine {
   std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
   bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
+  char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
+  size_t scratch_bytes = 0, scratch_wanted = 0;
   int num_cus = 256;
 };
 
@@ -630,16 +632,39 @@ int set_lds(chg_engine* eng, K kernel, size_t bytes) {
 
 
 // ---- device-side graph construction ------------------------------------------------------------------
-struct TmpPool {   // scratch device allocations of one chg_batch_build call
-  std::vector<void*> ptrs;
+struct TmpPool {   // scratch device memory of one chg_batch_build call: bump allocation from the engine's
+                   // grow-only scratch buffer; requests that do not fit fall back to hipMalloc and make the
+                   // buffer grow before the next call
+  chg_engine* eng;
+  size_t pos = 0, overflow = 0;
+  std::vector<void*> extra;
+  explicit TmpPool(chg_engine* e) : eng(e) {
+    if (eng->scratch_wanted > eng->scratch_bytes) {
+      if (eng->scratch) hipFree(eng->scratch);
+      eng->scratch = nullptr;
+      eng->scratch_bytes = 0;
+      const size_t want = eng->scratch_wanted + eng->scratch_wanted / 4;
+      if (hipMalloc(&eng->scratch, want) == hipSuccess) eng->scratch_bytes = want; else eng->scratch = nullptr;
+    }
+  }
   template <class T>
   T* get(size_t n) {
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~size_t(255);
+    if (pos + bytes <= eng->scratch_bytes) {
+      T* p = reinterpret_cast<T*>(eng->scratch + pos);
+      pos += bytes;
+      return p;
+    }
+    overflow += bytes;
     void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    ptrs.push_back(p);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    extra.push_back(p);
     return static_cast<T*>(p);
   }
-  ~TmpPool() { for (void* p : ptrs) hipFree(p); }
+  ~TmpPool() {
+    for (void* p : extra) hipFree(p);
+    if (overflow) eng->scratch_wanted = std::max(eng->scratch_wanted, pos + overflow);
+  }
 };
 
 int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
@@ -704,7 +729,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
         cart[3 * i + k] = h->frac[3 * i] * a[k] + h->frac[3 * i + 1] * bb[k] + h->frac[3 * i + 2] * c[k];
     }
   }
-  TmpPool tmp;
+  TmpPool tmp(eng);
   double* d_cart = tmp.get<double>(3 * (size_t)N);
   double* d_frac = tmp.get<double>(3 * (size_t)N);
   double* d_lat = tmp.get<double>(9 * (size_t)B);
@@ -898,6 +923,7 @@ int chg_engine_destroy(chg_engine* eng) {
   if (eng->t0) hipEventDestroy(eng->t0);
   if (eng->t1) hipEventDestroy(eng->t1);
   for (auto& a : eng->arena_pool) hipFree(a.first);
+  if (eng->scratch) hipFree(eng->scratch);
   if (eng->d_weights) hipFree(eng->d_weights);
   if (eng->stream) hipStreamDestroy(eng->stream);
   delete eng;
