@@ -160,3 +160,38 @@ def test_crystal_graph_file_round_trip_and_reference_format(tmp_path):
     torch.save(ref_style, tmp_path / "ref.pt")
     g3 = CrystalGraph.from_file(str(tmp_path / "ref.pt"))
     assert np.array_equal(g3.bond_graph, g.bond_graph) and g3.lattice.dtype == np.float32
+
+
+def _cases_for_native_reference():
+    rng = np.random.default_rng(5)
+    out = []
+    for name in ("limno2", "s16tri", "noangle", "li9co7o16"):
+        _, d = load_case(name)
+        out.append(Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]))
+    out.append(out[0].make_supercell([3, 2, 1]).perturb(0.02, rng))
+    out.append(Structure(Lattice(np.eye(3) * 2.5), ["Fe"], [[0.1, 0.2, 0.3]]))          # periodic self-pairs only
+    out.append(Structure(Lattice([[3.1, 0.2, 0.0], [0.4, 2.9, 0.3], [0.1, 0.5, 3.3]]), ["Li", "O"], [[0, 0, 0], [0.45, 0.55, 0.5]]))
+    return out
+
+
+def test_builder_matches_the_references_compiled_c_algorithm():
+    """oracle/_ref: the reference's create_graph.c compiled from where it lies (`make -C oracle`), fed the
+    same neighbour list (in our order and in a shuffled order): every array identical."""
+    from oracle import ref_graph
+
+    if not ref_graph.available() and ref_graph.build() is None:
+        pytest.skip("oracle/_ref/libref_graph.so not built and /root/reference absent")
+    rng = np.random.default_rng(3)
+    for s in _cases_for_native_reference():
+        for r_atom, r_bond in ((6.0, 3.0), (5.0, 3.0), (4.0, 4.0)):
+            a = build_graph_arrays(s.frac_coords, s.lattice.matrix, r_atom, r_bond)
+            nl = {"center": a["atom_graph"][:, 0].astype(np.int64), "neighbor": a["atom_graph"][:, 1].astype(np.int64),
+                  "image": a["image"].astype(np.int64), "distance": a["distance"]}
+            for shuffle in (False, True):
+                if shuffle and len(nl["center"]):
+                    perm = np.concatenate([rng.permutation(np.flatnonzero(nl["center"] == c)) for c in range(len(s))])
+                    nl = {k: v[perm] for k, v in nl.items()}
+                ref = ref_graph.reference_graph(len(s), nl["center"], nl["neighbor"], nl["image"], nl["distance"], r_bond)
+                got = graph_arrays_from_neighbors(len(s), nl["center"], nl["neighbor"], nl["image"], nl["distance"], r_bond)
+                for key in ("atom_graph", "directed2undirected", "undirected2directed", "bond_graph"):
+                    assert np.array_equal(got[key].reshape(ref[key].shape), ref[key]), (key, r_atom, r_bond, shuffle)
