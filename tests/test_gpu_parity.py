@@ -537,3 +537,43 @@ def test_predict_structure_uses_device_graphs_and_matches_predict_graph(hip_engi
     capsys.readouterr()
     out = model.predict_structure([structs[0], lone])
     assert "has 2 isolated atom" in capsys.readouterr()[1] and np.isfinite(out[1]["e"])
+
+
+def test_c_abi_error_paths(hip_engine):
+    """Status codes + chg_last_error instead of crashes for bad arguments."""
+    import ctypes
+
+    from chgnet_amd import _lib
+    from chgnet_amd.pack import pack_batch
+
+    pb = pack_batch([load_case("limno2")[0]])
+    bad = pack_batch([load_case("limno2")[0]])
+    bad.n_directed += 1                                    # Ed != 2 Eu
+    with pytest.raises(RuntimeError, match="inconsistent counts"):
+        hip_engine.upload(bad)
+    with pytest.raises(RuntimeError, match="unknown buffer"):
+        b = hip_engine.upload(pb)
+        try:
+            hip_engine.debug_fetch(b, "no_such_buffer", (1,))
+        finally:
+            b.free()
+    lib = hip_engine.lib
+    assert lib.chg_predict(None, None, 7) == -1             # CHG_EINVAL, no crash
+    assert lib.chg_batch_upload(hip_engine.handle, None, None) == -1
+    # wrong blob length is rejected at engine creation with a readable message
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.pack import PackedWeights
+
+    w = hip_engine.weights
+    short = PackedWeights(w.blob[:-8].copy(), w.offsets, w.n_conv, w.atom_graph_cutoff, w.bond_graph_cutoff, w.cutoff_coeff,
+                          w.is_intensive, w.has_composition)
+    with pytest.raises(RuntimeError, match="layout needs"):
+        Engine(short, 0)
+    with pytest.raises(RuntimeError, match="chg_engine_create failed"):
+        Engine(w, 99)                                       # no such device
+    # singular lattice in the device graph build
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+
+    with pytest.raises(RuntimeError, match="singular lattice"):
+        hip_engine.build_batch([Structure(Lattice(np.zeros((3, 3))), ["H"], [[0, 0, 0]])])
