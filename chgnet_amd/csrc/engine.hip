@@ -42,7 +42,7 @@ constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light f
 
 struct GatedPtrs { GatedW g; };
 
-struct ACW { const float *w_cn, *w_bond, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
+struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
 struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
 struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };
 
@@ -153,7 +153,7 @@ size_t layout_weights(const float* base, int L, Weights& w) {
   w.w_bond_emb = c.take(D * NRAD); w.w_wag = c.take(D * NRAD); w.w_wbg = c.take(D * NRAD); w.w_ang_emb = c.take(D * NANG);
   for (int l = 0; l < L; ++l) {
     ACW& a = w.ac[l];
-    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D);
+    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D); a.q_bias = c.take(2 * D);
     take_gated_tail(c, a.g, dummy1, dummy2);
     take_ln(c, a.g);
     a.w_out = c.take(D * D); a.b_out = c.take(D); a.w_out_t = c.take(D * D);
@@ -296,7 +296,9 @@ int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   float *P = b->Pl[l], *Q = b->Ql[l];
   TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, P, 4 * D, nullptr, b->N, 0));
   TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn + 2 * D * D, nullptr, nullptr, 0, P + 2 * D, 4 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
+  // q_bias: constant shift of the bonds outside the bond graph when mlp_out has a bias (0.2.0 only; zero otherwise);
+  // the reference runs BondConv only when the batch has angles (model.py:460)
+  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, b->A > 0 ? w.q_bias : nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
   if (b->Eb > 0 && b->hbc[l] != b->hbc[0])   // bond-graph nodes carry layer-l features
     TRY(rows_gemm(eng, "gemm_Qnode", 64, 128, b->hbc[l], D, nullptr, w.w_bond, nullptr, nullptr, 0, Q, 2 * D, b->bn_und, b->Eb, 0));
   return CHG_OK;

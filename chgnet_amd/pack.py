@@ -192,6 +192,7 @@ def weight_layout(n_conv: int) -> list[tuple[str, tuple]]:
         lay += [(p + "w_cn", (4 * D, D)),      # rows 0..127: centre block (core|gate), 128..255: neighbour block
                 (p + "w_bond", (2 * D, D)),    # bond block (core|gate)
                 (p + "b1", (2 * D,)),
+                (p + "q_bias", (2 * D,)),      # W_bond . (sum of earlier BondConv mlp_out biases): see pack_weights
                 *[(p + n, s) for n, s in gated_tail], *[(p + n, s) for n, s in ln],
                 (p + "w_out", (D, D)), (p + "b_out", (D,)),
                 (p + "w_out_t", (D, D)),       # [in,out] for G(agg) = G(h') . Wout
@@ -290,6 +291,16 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
         vals[p + "w_bij_t"] = np.stack([vals[p + "w_bij"][:2 * D].T, vals[p + "w_bij"][2 * D:].T])
         for n in ("w_ang", "w_ctr"):
             vals[p + n + "_t"] = vals[p + n].T
+    # mlp_out_bias (0.2.0 checkpoint only): the reference aggregates BondConv messages over ALL bonds
+    # (layers.py:252-258, num_owner=len(bond_feas)), so every bond -- also those that own no angle --
+    # gains the mlp_out bias in every BondConv layer.  Bonds outside the bond graph keep their
+    # embedding in the engine, so their layer-l features are hb0 + sum_{m<l} b_out[m]; the constant
+    # part enters AtomConv l through Q as this bias row.
+    shift = np.zeros(D, np.float64)
+    for l in range(n_conv):
+        vals[f"ac{l}.q_bias"] = (vals[f"ac{l}.w_bond"].astype(np.float64) @ shift).astype(np.float32)
+        if l < n_conv - 1:
+            shift = shift + vals[f"bc{l}.b_out"].astype(np.float64)
     vals["site_w"] = sd["site_wise.weight"].reshape(-1)
     vals["site_b"] = sd["site_wise.bias"].reshape(-1)
     vals["ro_ln_g"], vals["ro_ln_b"] = sd["readout_norm.weight"], sd["readout_norm.bias"]

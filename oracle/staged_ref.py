@@ -157,7 +157,12 @@ class StagedModel:
         hbc = [hb0[bn]]
 
         def hb_full(l):
+            # bonds outside the bond graph keep their embedding, plus -- only for models with an mlp_out
+            # bias (0.2.0) and only when the batch has angles -- the biases of the earlier BondConv layers
             h = hb0.copy()
+            if A:
+                for m in range(l):
+                    h = h + W(f"bc{m}.b_out")
             h[bn] = hbc[l]
             return h
 

@@ -577,3 +577,36 @@ def test_c_abi_error_paths(hip_engine):
 
     with pytest.raises(RuntimeError, match="singular lattice"):
         hip_engine.build_batch([Structure(Lattice(np.zeros((3, 3))), ["H"], [[0, 0, 0]])])
+
+
+@pytest.mark.parametrize("variant", ["n_conv3", "mlp_out_bias_0.2.0", "not_intensive_no_atomref"])
+def test_architecture_family_variants_vs_oracle(variant):
+    """Other members of the supported architecture family (random weights): 3 interaction blocks, the
+    0.2.0 checkpoint's mlp_out biases, extensive energy without AtomRef."""
+    import torch
+
+    from chgnet_amd.model import CHGNet, random_state_dict
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    args = {"n_conv3": dict(n_conv=3), "mlp_out_bias_0.2.0": dict(mlp_out_bias=True),
+            "not_intensive_no_atomref": dict(is_intensive=False, composition_model=None)}[variant]
+    sd = random_state_dict({"n_conv": 4, **args}, seed=11)
+    rng = np.random.default_rng(12)
+    for k, v in sd.items():                    # move LayerNorm affine / frequencies / biases off their defaults
+        if ".bn" in k or k.startswith("readout_norm") or k.endswith("frequencies") or k.endswith("mlp_out.layers.1.bias"):
+            sd[k] = (v + 0.1 * rng.normal(size=v.shape)).astype(np.float32)
+    if "composition_model.fc.weight" in sd:
+        sd["composition_model.fc.weight"] = rng.normal(-5, 2, (1, 94)).astype(np.float32)
+    if args.get("composition_model", "x") is None:
+        sd.pop("composition_model.fc.weight", None)
+    model = CHGNet(state_dict=sd, **args)
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    got = model.predict_graph(graphs, task="efsm", return_site_energies=True, return_crystal_feas=True)
+    torch.set_num_threads(4)
+    oracle = OracleCHGNet(sd, is_intensive=args.get("is_intensive", True))
+    want = oracle.predict_graph(graphs, "efsm", return_site_energies=True, return_crystal_feas=True)
+    scale_e = 1.0 if args.get("is_intensive", True) else 16.0
+    for g_, w_ in zip(got, want):
+        assert abs(g_["e"] - w_["e"]) < TOL["e"] * scale_e
+        for key in ("f", "s", "m", "site_energies"):
+            assert np.abs(g_[key] - w_[key]).max() < TOL[key], (variant, key)
