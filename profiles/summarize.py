@@ -16,9 +16,9 @@ SRC = os.path.join(REPO, "gpurun_out", "prof")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 LABELS = {  # kernel-name substring -> bench.py label
-    "k_angle<true, true>": "bondconv_bwd", "k_angle<true, false>": "bondconv_fwd",
-    "k_angle<false, true>": "angleupd_bwd", "k_angle<false, false>": "angleupd_fwd",
-    "k_atomconv<true>": "atomconv_bwd", "k_atomconv<false>": "atomconv_fwd",
+    "k_angle<true, true": "bondconv_bwd", "k_angle<true, false": "bondconv_fwd",
+    "k_angle<false, true": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",
+    "k_atomconv_bwd": "atomconv_bwd", "k_atomconv_fwd": "atomconv_fwd",
 }
 
 shutil.copy(os.path.join(SRC, "ktrace_kernel_stats.csv"), os.path.join(REPO, "profiles", f"{tag}_kernel_stats.csv"))
