@@ -40,8 +40,6 @@ constexpr int MAX_CONV = 8;
 #endif
 constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
 
-struct GatedPtrs { GatedW g; };
-
 struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
 struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
 struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };

@@ -19,12 +19,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _predict(engine, graphs, task="efsm"):
+    """Upload, run, download; the caller frees the batch (some tests fetch intermediates from it)."""
     batch = engine.upload(graphs)
-    try:
-        engine.predict(batch, task)
-        res = engine.download(batch, task, site_energies=True, atom_feas=True, crystal_feas=True)
-    finally:
-        pass
+    engine.predict(batch, task)
+    res = engine.download(batch, task, site_energies=True, atom_feas=True, crystal_feas=True)
     return batch, res
 
 
@@ -150,13 +148,12 @@ def test_random_structures_vs_oracle(hip_engine, golden_weights):
         if dmin < 1.2:   # random gas with near-contacts: 1/r terms amplify fp32 noise in any implementation
             continue
         graphs.append(conv(s))
-    keep = graphs
-    batch, res = _predict(hip_engine, keep)
+    batch, res = _predict(hip_engine, graphs)
     outs = _split(res, batch.packed)
     batch.free()
-    o64 = OracleCHGNet(golden_weights, dtype=torch.float64).predict_graph(keep, "efsm", return_site_energies=True,
+    o64 = OracleCHGNet(golden_weights, dtype=torch.float64).predict_graph(graphs, "efsm", return_site_energies=True,
                                                                          return_atom_feas=True, return_crystal_feas=True, batch_size=64)
-    o32 = OracleCHGNet(golden_weights).predict_graph(keep, "efsm", return_site_energies=True, return_atom_feas=True,
+    o32 = OracleCHGNet(golden_weights).predict_graph(graphs, "efsm", return_site_energies=True, return_atom_feas=True,
                                                      return_crystal_feas=True, batch_size=64)
     for got, r64, r32 in zip(outs, o64, o32):
         for key in ("e", "f", "s", "m"):
