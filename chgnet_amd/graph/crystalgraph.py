@@ -117,9 +117,9 @@ class CrystalGraph:
     @classmethod
     def from_file(cls, file_name: str) -> "CrystalGraph":
         """Load a graph written by ``save`` here or by the reference (a dict of tensors)."""
-        import torch
+        from ..safe_load import load_torch_file
 
-        obj = torch.load(file_name, map_location="cpu", weights_only=False)
+        obj = load_torch_file(file_name)
         if isinstance(obj, dict):
             return cls.from_dict(obj)
         return cls.from_reference(obj)       # a pickled reference CrystalGraph object

@@ -238,9 +238,9 @@ class CHGNet:
     @classmethod
     def from_file(cls, path: str, **kwargs) -> "CHGNet":
         """Read a reference checkpoint: ``torch.save({"model": {"state_dict", "model_args"}, ...})``."""
-        import torch  # noqa: PLC0415  (only the pickle reader; no torch compute)
+        from .safe_load import load_torch_file  # noqa: PLC0415  (restricted unpickler, SURVEY §8f-4)
 
-        state = torch.load(path, map_location="cpu", weights_only=False)
+        state = load_torch_file(path)
         return cls.from_dict(state["model"], **kwargs)
 
     @classmethod
