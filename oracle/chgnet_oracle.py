@@ -225,13 +225,13 @@ class OracleCHGNet:
         out["e"] = e
 
         def split(t, offs):
-            return [t[offs[i]:offs[i + 1]].detach().numpy() for i in range(B)]
+            return [t[offs[i]:offs[i + 1]].detach().cpu().numpy() for i in range(B)]
 
-        res = {"e": [x for x in out["e"].detach().numpy()]}
+        res = {"e": [x for x in out["e"].detach().cpu().numpy()]}
         if "f" in task:
             res["f"] = split(out["f"], a_off)
         if "s" in task:
-            res["s"] = [x for x in out["s"].detach().numpy()]
+            res["s"] = [x for x in out["s"].detach().cpu().numpy()]
         if "m" in task:
             res["m"] = split(magmom, a_off)
         if return_site_energies:
@@ -239,9 +239,9 @@ class OracleCHGNet:
         if return_atom_feas:
             res["atom_fea"] = split(atom_fea_out, a_off)
         if return_crystal_feas:
-            res["crystal_fea"] = [x for x in crystal.detach().numpy()]
+            res["crystal_fea"] = [x for x in crystal.detach().cpu().numpy()]
         if return_intermediates:
-            res["intermediates"] = {k: v.detach().numpy() for k, v in inter.items()}
+            res["intermediates"] = {k: v.detach().cpu().numpy() for k, v in inter.items()}
         return res
 
     def predict_graph(self, graph, task="efsm", *, return_site_energies=False, return_atom_feas=False,
