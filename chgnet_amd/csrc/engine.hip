@@ -904,8 +904,8 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds<WAVES>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
-  if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
   if ((s = set_lds(eng, k_readout, readout_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;

@@ -54,6 +54,8 @@ struct GatedState {
 
 // z (pre-activation of the first layer, 128 = core|gate) -> activations.
 //   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
+// z (pre-activation of the first layer, 128 = core|gate) -> activations.
+//   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
 template <bool HIDDEN>
 __device__ __forceinline__ void gated_forward(const V64& zc, const V64& zg, const float* W2c, const float* W2g, const float* vecs,
                                               int j, int g, GatedState& s) {
@@ -132,7 +134,7 @@ struct RowsGemm {
 };
 
 template <int K, int NOUT>
-__global__ __launch_bounds__(BLOCK) void k_rows_gemm(RowsGemm p) {
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KS = K + PAD, KT = K / 16, NFT = NOUT / 16;
   constexpr int XS = (K > NOUT ? K : NOUT) + PAD;  // tile stride: holds X (K wide) then Y (NOUT wide)
@@ -225,7 +227,7 @@ constexpr size_t atomconv_lds() { return sizeof(float) * (2 * D * WS + VEC_SLOTS
 
 // NW waves per workgroup: the forward kernel needs only ~106 VGPRs, so 12 waves (3 per SIMD) fit
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_atomconv_fwd(AtomConvArgs p) {
+__global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2c = smem;
   float* W2g = W2c + D * WS;
@@ -293,15 +295,15 @@ __global__ __launch_bounds__(64 * NW) void k_atomconv_fwd(AtomConvArgs p) {
         if (2 * b < nvalid) {
           const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
           if (c1 != cur) {
-            atomicAdd(p.agg + (size_t)cur * D + lane, acc);
+            tile_atomic_add(p.agg + (size_t)cur * D + lane, acc);
             acc = 0.f;
             cur = c1;
           }
           acc += T[(2 * b) * TS + lane];
-          atomicAdd(p.agg + (size_t)c2 * D + lane, T[(2 * b + 1) * TS + lane]);
+          tile_atomic_add(p.agg + (size_t)c2 * D + lane, T[(2 * b + 1) * TS + lane]);
         }
       }
-      atomicAdd(p.agg + (size_t)cur * D + lane, acc);
+      tile_atomic_add(p.agg + (size_t)cur * D + lane, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -314,13 +316,97 @@ __global__ __launch_bounds__(64 * NW) void k_atomconv_fwd(AtomConvArgs p) {
 //   dE/dP[c2]                                                      -> one coalesced atomic row per bond
 // which cuts the scattered fp32 atomics from 320 to 128 per directed bond (profiles/r01 notes: row
 // atomics were 55 % of the centre-ordered version of this kernel).
-__global__ __launch_bounds__(BLOCK) void k_atomconv_bwd(AtomConvArgs p) {
+// Scatter of one AtomConv-adjoint tile (gz rows in LDS, pair order).  Lane owns columns
+// (lane, lane+64) of the 128-wide rows.  dE/dQ[k] is a plain store (the tile owns bond k);
+// atom c2 (unsorted side) gets one atomic row per bond; atom c1 (sorted side) gets run sums.
+// General form: any number of valid rows, any number of c1 runs; branches around the atomics.
+__device__ __forceinline__ void acbwd_scatter_any(const float* T, int c, int nvalid, int k0, const AtomConvArgs& p, int lane) {
+  float acc_c0 = 0.f, acc_c1 = 0.f, acc_n0 = 0.f, acc_n1 = 0.f;
+  int cur = __builtin_amdgcn_readlane(c, 0);
+#pragma unroll
+  for (int b = 0; b < TILE_ROWS / 2; ++b) {
+    if (2 * b < nvalid) {
+      const float e0 = T[(2 * b) * TS + lane], e1 = T[(2 * b) * TS + 64 + lane];           // gz of direction c1 -> c2
+      const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];   // gz of direction c2 -> c1
+      float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
+      q[0] = e0 + o0;
+      q[64] = e1 + o1;
+      const int c1 = __builtin_amdgcn_readlane(c, 2 * b);
+      if (c1 != cur) {
+        float* d = p.GP + (size_t)cur * 4 * D + lane;
+        tile_atomic_add(d, acc_c0); tile_atomic_add(d + 64, acc_c1); tile_atomic_add(d + 128, acc_n0); tile_atomic_add(d + 192, acc_n1);
+        acc_c0 = acc_c1 = acc_n0 = acc_n1 = 0.f;
+        cur = c1;
+      }
+      acc_c0 += e0; acc_c1 += e1; acc_n0 += o0; acc_n1 += o1;   // centre part <- even row, neighbour part <- odd row
+      const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
+      float* d2 = p.GP + (size_t)c2 * 4 * D + lane;              // centre part <- odd row, neighbour part <- even row
+      tile_atomic_add(d2, o0); tile_atomic_add(d2 + 64, o1); tile_atomic_add(d2 + 128, e0); tile_atomic_add(d2 + 192, e1);
+    }
+  }
+  float* d = p.GP + (size_t)cur * 4 * D + lane;
+  tile_atomic_add(d, acc_c0); tile_atomic_add(d + 64, acc_c1); tile_atomic_add(d + 128, acc_n0); tile_atomic_add(d + 192, acc_n1);
+}
+
+// Full tiles (16 valid rows): a fixed instruction sequence.  s_waitcnt vmcnt counts in order, so
+// when the number of atomics issued after a load is known at compile time the wait for that load
+// leaves them in flight; any branch around an atomic turns that wait into vmcnt(0).  The two
+// leading c1 runs go to two fixed slots (an absent second run adds 0.0 next to the first); a
+// third run in one 8-bond tile (an atom with < 8 bonds) takes the branch at the end.
+__device__ __forceinline__ void acbwd_store_gq_full(const float* T, int k0, const AtomConvArgs& p, int lane) {
+#pragma unroll
+  for (int b = 0; b < TILE_ROWS / 2; ++b) {
+    float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
+    q[0] = T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
+    q[64] = T[(2 * b) * TS + 64 + lane] + T[(2 * b + 1) * TS + 64 + lane];
+  }
+}
+__device__ __forceinline__ void acbwd_scatter_full(const float* T, int c, const AtomConvArgs& p, int lane) {
+  constexpr int NB = TILE_ROWS / 2;
+  int c1[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) c1[b] = __builtin_amdgcn_readlane(c, 2 * b);
+  unsigned bd = 0;   // bit b: bond b starts a new c1 run
+#pragma unroll
+  for (int b = 1; b < NB; ++b) bd |= (c1[b] != c1[b - 1] ? 1u : 0u) << b;
+  const int e1 = bd ? __builtin_ctz(bd) : NB;
+  const unsigned bd2 = bd & (bd - 1);
+  const int e2 = bd2 ? __builtin_ctz(bd2) : NB;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float e0 = T[(2 * b) * TS + lane], e1v = T[(2 * b) * TS + 64 + lane];
+    const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];
+    const float w0 = b < e1 ? 1.f : 0.f, w1 = (b >= e1 && b < e2) ? 1.f : 0.f;   // wave-uniform
+    s0[0] += w0 * e0; s0[1] += w0 * e1v; s0[2] += w0 * o0; s0[3] += w0 * o1;
+    s1[0] += w1 * e0; s1[1] += w1 * e1v; s1[2] += w1 * o0; s1[3] += w1 * o1;
+    const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
+    float* d2 = p.GP + (size_t)c2 * 4 * D + lane;
+    tile_atomic_add(d2, o0); tile_atomic_add(d2 + 64, o1); tile_atomic_add(d2 + 128, e0); tile_atomic_add(d2 + 192, e1v);
+  }
+  const int key1 = __builtin_amdgcn_readlane(c, 2 * min(e1, NB - 1));
+  float* d0 = p.GP + (size_t)c1[0] * 4 * D + lane;
+  float* d1 = p.GP + (size_t)key1 * 4 * D + lane;
+  tile_atomic_add(d0, s0[0]); tile_atomic_add(d0 + 64, s0[1]); tile_atomic_add(d0 + 128, s0[2]); tile_atomic_add(d0 + 192, s0[3]);
+  tile_atomic_add(d1, s1[0]); tile_atomic_add(d1 + 64, s1[1]); tile_atomic_add(d1 + 128, s1[2]); tile_atomic_add(d1 + 192, s1[3]);
+  if (e2 < NB) {   // rare: bonds of a third (fourth, ...) run, one row each
+    for (int b = e2; b < NB; ++b) {
+      const int a = __builtin_amdgcn_readlane(c, 2 * b);
+      float* d = p.GP + (size_t)a * 4 * D + lane;
+      tile_atomic_add(d, T[(2 * b) * TS + lane]); tile_atomic_add(d + 64, T[(2 * b) * TS + 64 + lane]);
+      tile_atomic_add(d + 128, T[(2 * b + 1) * TS + lane]); tile_atomic_add(d + 192, T[(2 * b + 1) * TS + 64 + lane]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2c = smem;
   float* W2g = W2c + D * WS;
   float* vecs = W2g + D * WS;
   float* tiles = vecs + VEC_SLOTS * D;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   stage_weights(W2c, p.gw.w2c, D, D, tid);
   stage_weights(W2g, p.gw.w2g, D, D, tid);
   stage_gated_vecs(vecs, p.gw, true, tid);
@@ -330,14 +416,25 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_bwd(AtomConvArgs p) {
   const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
+  if (tb >= te) return;
+  const int last_row = p.n_edges - 1;
+  int c, n, k;
+  {
+    const int row = min(tb * BLOCK_ROWS + wave * TILE_ROWS + j, last_row);
+    c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
+    GatherRegs gr;
+    gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+    gather_commit128(gr, T, TS, lane);
+  }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
-    if (nvalid <= 0) continue;
-    const bool valid = j < nvalid;
-    const int row = row0 + (valid ? j : 0);
-    const int c = p.e_center[row], n = p.e_nbr[row], k = row >> 1;   // pair-ordered index arrays
-    gather_sum128(T, TS, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+    if (nvalid <= 0) break;                                 // waves past the end of the last tile
+    int cn, nn, kn;                                         // the next tile's rows (clamped: harmless reads at the range end)
+    {
+      const int row = min(row0 + BLOCK_ROWS + j, last_row);
+      cn = p.e_center[row]; nn = p.e_nbr[row]; kn = row >> 1;
+    }
     V64 wv, gm;
     read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
     read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
@@ -347,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_bwd(AtomConvArgs p) {
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
     gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
+    asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
     CHG_EW(ft, r) {
       gw.t[ft][r] = gm.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r];   // dE/d wag[k], this direction
@@ -355,55 +453,46 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_bwd(AtomConvArgs p) {
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gw.t);
     __builtin_amdgcn_wave_barrier();
-    {  // Gwag[k] += gw(2b) + gw(2b+1): this tile owns those rows of Gwag
-      const int k0 = row0 >> 1;
+    const int k0 = row0 >> 1;
+    {  // Gwag[k] += gw(2b) + gw(2b+1): this tile owns those rows of Gwag (all loads first: one round trip)
+      float* dst = p.Gwag + (size_t)k0 * D + lane;
+      const int nb = nvalid >> 1;
+      float prev[TILE_ROWS / 2];
 #pragma unroll
-      for (int b = 0; b < TILE_ROWS / 2; ++b)
-        if (2 * b < nvalid) {
-          float* dst = p.Gwag + (size_t)(k0 + b) * D + lane;
-          *dst += T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
-        }
+      for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] = dst[(size_t)min(b, nb - 1) * D];
+#pragma unroll
+      for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] += T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
+      if (nvalid == TILE_ROWS) {
+#pragma unroll
+        for (int b = 0; b < TILE_ROWS / 2; ++b) dst[(size_t)b * D] = prev[b];
+      } else {
+#pragma unroll
+        for (int b = 0; b < TILE_ROWS / 2; ++b)
+          if (b < nb) dst[(size_t)b * D] = prev[b];
+      }
     }
     gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
     __builtin_amdgcn_wave_barrier();
-    {
-      const int k0 = row0 >> 1;
-      // lane's column pair (lane, lane+64) of the 128-wide gz rows
-      float acc_c0 = 0.f, acc_c1 = 0.f, acc_n0 = 0.f, acc_n1 = 0.f;   // running sums for atom c1 (sorted side)
-      int cur = __builtin_amdgcn_readlane(c, 0);
-#pragma unroll
-      for (int b = 0; b < TILE_ROWS / 2; ++b) {
-        if (2 * b < nvalid) {
-          const float e0 = T[(2 * b) * TS + lane], e1 = T[(2 * b) * TS + 64 + lane];           // gz of direction c1 -> c2
-          const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];   // gz of direction c2 -> c1
-          // dE/dQ[k]
-          float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
-          q[0] = e0 + o0;
-          q[64] = e1 + o1;
-          // atom c1: centre part <- even row, neighbour part <- odd row; runs of equal c1 are contiguous
-          const int c1 = __builtin_amdgcn_readlane(c, 2 * b);
-          if (c1 != cur) {
-            float* d = p.GP + (size_t)cur * 4 * D + lane;
-            atomicAdd(d, acc_c0); atomicAdd(d + 64, acc_c1); atomicAdd(d + 128, acc_n0); atomicAdd(d + 192, acc_n1);
-            acc_c0 = acc_c1 = acc_n0 = acc_n1 = 0.f;
-            cur = c1;
-          }
-          acc_c0 += e0; acc_c1 += e1; acc_n0 += o0; acc_n1 += o1;
-          // atom c2 (unsorted): centre part <- odd row, neighbour part <- even row
-          const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
-          float* d2 = p.GP + (size_t)c2 * 4 * D + lane;
-#ifndef CHG_EXP_NO_ROW_ATOMICS
-          atomicAdd(d2, o0); atomicAdd(d2 + 64, o1); atomicAdd(d2 + 128, e0); atomicAdd(d2 + 192, e1);
-#endif
-        }
-      }
-      float* d = p.GP + (size_t)cur * 4 * D + lane;
-      atomicAdd(d, acc_c0); atomicAdd(d + 64, acc_c1); atomicAdd(d + 128, acc_n0); atomicAdd(d + 192, acc_n1);
+    // Order matters: stores, then the NEXT tile's gathers, then this tile's atomics, then the wait
+    // for the gathers (gather_commit128) -- see acbwd_scatter_full.
+    if (nvalid == TILE_ROWS) {
+      acbwd_store_gq_full(T, k0, p, lane);
+      GatherRegs gr;
+      gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
+      acbwd_scatter_full(T, c, p, lane);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gr, T, TS, lane);
+    } else {
+      acbwd_scatter_any(T, c, nvalid, k0, p, lane);
+      GatherRegs gr;
+      gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gr, T, TS, lane);
     }
-    __builtin_amdgcn_wave_barrier();
+    c = cn; n = nn; k = kn;
   }
 }
 
@@ -436,7 +525,7 @@ constexpr size_t angle_lds() {
 // HIDDEN = true: BondConv (gated MLP with one hidden layer, weighted, aggregated over the owning bond)
 // HIDDEN = false: AngleUpdate (single gated layer, residual on the angle itself)
 template <bool HIDDEN, bool BWD, int NW = WAVES>
-__global__ __launch_bounds__(64 * NW) void k_angle(AngleArgs p) {
+__global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wang = smem;                                  // [128][WS]
   float* W2c = Wang + 2 * D * WS;
@@ -462,8 +551,9 @@ __global__ __launch_bounds__(64 * NW) void k_angle(AngleArgs p) {
   constexpr bool LEAN = !HIDDEN && !BWD;
   const int tstride = TILE_ROWS * NW;
   auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_angles - 1); };
+  constexpr bool IDX_AHEAD = BWD || LEAN;   // indices of the next tile are loaded one tile ahead (3 registers)
   int ctr_nx = 0, b1_nx = 0, b2_nx = 0;
-  if (LEAN && tb < te) {
+  if (IDX_AHEAD && tb < te) {
     const int a0 = row_of(tb);
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
   }
@@ -471,7 +561,7 @@ __global__ __launch_bounds__(64 * NW) void k_angle(AngleArgs p) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
-    if (LEAN && tile + 1 < te) {
+    if (IDX_AHEAD && tile + 1 < te) {
       const int a1 = row_of(tile + 1);
       ctr_nx = p.a_ctr[a1]; b1_nx = p.a_b1c[a1]; b2_nx = p.a_b2c[a1];
     }
@@ -482,7 +572,7 @@ __global__ __launch_bounds__(64 * NW) void k_angle(AngleArgs p) {
     if (LEAN) {
       read_dl<VT>(p.ang + (size_t)a * D, g, x.t);
     } else {
-      ctr = p.a_ctr[a]; b1 = p.a_b1c[a]; b2 = p.a_b2c[a];
+      if (!IDX_AHEAD) { ctr = p.a_ctr[a]; b1 = p.a_b1c[a]; b2 = p.a_b2c[a]; }
       // the angle rows are consumed (B operand of the first contraction) before the table sum is written
       gather_rows64(T, TS, p.ang, a, lane);
       __builtin_amdgcn_wave_barrier();
@@ -574,7 +664,7 @@ struct ReadoutArgs {
 
 constexpr size_t readout_lds() { return sizeof(float) * (3 * D * WS + 6 * D + WAVES * TILE_FLOATS); }
 
-__global__ __launch_bounds__(BLOCK) void k_readout(ReadoutArgs p) {
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W0 = smem;
   float* W1 = W0 + D * WS;

@@ -47,7 +47,7 @@ struct BondEmbedTArgs {
 constexpr size_t bond_embed_lds() { return sizeof(float) * (3 * D * WSB + WAVES * TILE_ROWS * ETS); }
 
 template <bool BWD>
-__global__ __launch_bounds__(BLOCK) void k_bond_embed_t(BondEmbedTArgs p) {
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedTArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
   float* Wa = We + D * WSB;
@@ -168,7 +168,7 @@ struct AngleEmbedTArgs {
 constexpr size_t angle_embed_lds() { return sizeof(float) * (D * WSB + WAVES * TILE_ROWS * ETS); }
 
 template <bool BWD>
-__global__ __launch_bounds__(BLOCK) void k_angle_embed_t(AngleEmbedTArgs p) {
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
   float* tiles = We + D * WSB;

@@ -167,6 +167,25 @@ __device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) {
   end = begin + per + (lb < rem ? 1 : 0);
 }
 
+// The tile kernels run 8 waves per CU (LDS-limited), i.e. two per SIMD, whatever their register count:
+// telling the compiler lets its scheduler spend the 256-register budget on overlap instead of
+// trading instruction-level parallelism for an occupancy it cannot have.
+#ifdef CHG_EXP_NO_WAVES_ATTR
+#define CHG_TWO_WAVES
+#else
+#define CHG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+
+// fp32 add to global memory (global_atomic_add_f32, no return).  CHG_EXP_ATOMIC_AS_STORE: timing
+// experiment only (same addresses and instruction count as plain stores; wrong results).
+__device__ __forceinline__ void tile_atomic_add(float* p, float v) {
+#ifdef CHG_EXP_ATOMIC_AS_STORE
+  *p = v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+
 // ---- segmented reductions over the rows of a wave tile -----------------------------------------
 // tile: [16][stride] LDS, W columns; lane `rr` holds the (sorted-run) key of row rr in `key`
 // (key < 0: skip).  Runs of equal keys are summed per column and flushed with one fp32 atomic
@@ -188,7 +207,7 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
     if (kk != cur) {
       if (cur >= 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) atomicAdd(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
+        for (int c = 0; c < NC; ++c) tile_atomic_add(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = 0.f;
@@ -199,7 +218,7 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
   }
   if (cur >= 0) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) atomicAdd(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
+    for (int c = 0; c < NC; ++c) tile_atomic_add(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
   }
 }
 
@@ -215,7 +234,7 @@ __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, in
     const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
     if (kk >= 0) {
 #pragma unroll
-      for (int c = 0; c < W / 64; ++c) atomicAdd(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
+      for (int c = 0; c < W / 64; ++c) tile_atomic_add(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
     }
   }
 }
@@ -300,17 +319,22 @@ template <bool ACCUM>
 __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid,
                                                int lane) {
   const int sub = lane >> 4, t = lane & 15;
+  f32x4* p[TILE_ROWS / 4];
+  f32x4 v[TILE_ROWS / 4];
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) {
-    const int rr = 4 * it + sub;
-    const int r = __shfl(idx, rr);
-    if (rr < nvalid) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
-      f32x4* p = reinterpret_cast<f32x4*>(dst + (size_t)r * D + 4 * t);
-      if (ACCUM) v += *p;
-      *p = v;
-    }
+  for (int it = 0; it < TILE_ROWS / 4; ++it) p[it] = reinterpret_cast<f32x4*>(dst + (size_t)__shfl(idx, 4 * it + sub) * D + 4 * t);
+  if (ACCUM) {   // all loads first: one memory round trip for the tile, not one per step (idx of rows past nvalid is a valid row)
+#pragma unroll
+    for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *p[it];
+#pragma unroll
+    for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] += *reinterpret_cast<const f32x4*>(tile + (4 * it + sub) * stride + 4 * t);
+  } else {
+#pragma unroll
+    for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(tile + (4 * it + sub) * stride + 4 * t);
   }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it)
+    if (4 * it + sub < nvalid) *p[it] = v[it];
 }
 
 }  // namespace chg
