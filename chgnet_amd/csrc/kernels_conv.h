@@ -44,26 +44,29 @@ __device__ __forceinline__ V64 param64(const float* vec, int g) {
   return p;
 }
 
-// Forward state of one gated MLP row kept for the backward
+// Forward state of one gated MLP row kept for the backward (64 registers per lane: the affine
+// core n1 = xh1*g1+b1 is one FMA to recompute, and with sigmoid(n1) kept the backward needs no
+// transcendental for it)
 struct GatedState {
   V64 xh1, xh2;   // LayerNorm-normalised branches (before affine)
-  V64 n1;         // affine core branch (input of silu)
-  V64 a1, a2;     // silu(n1), sigmoid(n2)
+  V64 sg1, a2;    // sigmoid(n1), sigmoid(n2);  a1 = silu(n1) = n1 * sg1
   float rstd1, rstd2;
 };
 
-// z (pre-activation of the first layer, 128 = core|gate) -> activations.
+// z (pre-activation of the first layer, 128 = core|gate) -> y = silu(n1) * sigmoid(n2), plus the state.
 //   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
-// z (pre-activation of the first layer, 128 = core|gate) -> activations.
-//   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
+//   HIDDEN: zc, zg are replaced by silu'(zc), silu'(zg), which is all the backward needs of them.
 template <bool HIDDEN>
-__device__ __forceinline__ void gated_forward(const V64& zc, const V64& zg, const float* W2c, const float* W2g, const float* vecs,
-                                              int j, int g, GatedState& s) {
+__device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c, const float* W2g, const float* vecs,
+                                              int j, int g, GatedState& s, V64& y) {
   if (HIDDEN) {
     V64 hc, hg;
     CHG_EW(ft, r) {
-      hc.t[ft][r] = siluf_(zc.t[ft][r]);
-      hg.t[ft][r] = siluf_(zg.t[ft][r]);
+      const float sc = sigmoidf_(zc.t[ft][r]), sg = sigmoidf_(zg.t[ft][r]);
+      hc.t[ft][r] = zc.t[ft][r] * sc;
+      hg.t[ft][r] = zg.t[ft][r] * sg;
+      zc.t[ft][r] = sc * (1.0f + zc.t[ft][r] * (1.0f - sc));
+      zg.t[ft][r] = sg * (1.0f + zg.t[ft][r] * (1.0f - sg));
     }
     s.xh1 = param64(vecs + 0 * D, g);
     s.xh2 = param64(vecs + 1 * D, g);
@@ -76,28 +79,35 @@ __device__ __forceinline__ void gated_forward(const V64& zc, const V64& zg, cons
   s.rstd1 = ln_normalize(s.xh1);
   s.rstd2 = ln_normalize(s.xh2);
   {
-    const V64 gam = param64(vecs + 2 * D, g), bet = param64(vecs + 3 * D, g);
-    CHG_EW(ft, r) {
-      s.n1.t[ft][r] = s.xh1.t[ft][r] * gam.t[ft][r] + bet.t[ft][r];
-      s.a1.t[ft][r] = siluf_(s.n1.t[ft][r]);
-    }
-  }
-  {
     const V64 gam = param64(vecs + 4 * D, g), bet = param64(vecs + 5 * D, g);
     CHG_EW(ft, r) s.a2.t[ft][r] = sigmoidf_(s.xh2.t[ft][r] * gam.t[ft][r] + bet.t[ft][r]);
   }
+  {
+    const V64 gam = param64(vecs + 2 * D, g), bet = param64(vecs + 3 * D, g);
+    CHG_EW(ft, r) {
+      const float n1 = s.xh1.t[ft][r] * gam.t[ft][r] + bet.t[ft][r];
+      s.sg1.t[ft][r] = sigmoidf_(n1);
+      y.t[ft][r] = n1 * s.sg1.t[ft][r] * s.a2.t[ft][r];
+    }
+  }
 }
 
-// gy = dE/d(a1*a2)  ->  gzc, gzg = dE/dz (128 wide)
+// gy = dE/dy  ->  gzc, gzg = dE/dz (128 wide);  dzc, dzg: silu'(z) as left by gated_forward<true>
 template <bool HIDDEN>
-__device__ __forceinline__ void gated_backward(const V64& gy, const V64& zc, const V64& zg, const float* W2c, const float* W2g,
+__device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, const V64& dzg, const float* W2c, const float* W2g,
                                                const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg) {
   V64 gn1, gn2;
-  CHG_EW(ft, r) {
-    gn1.t[ft][r] = gy.t[ft][r] * s.a2.t[ft][r] * dsiluf_(s.n1.t[ft][r]);
-    gn2.t[ft][r] = gy.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r] * (1.0f - s.a2.t[ft][r]);
+  const V64 gam1 = param64(vecs + 2 * D, g);
+  {
+    const V64 bet1 = param64(vecs + 3 * D, g);
+    CHG_EW(ft, r) {
+      const float n1 = s.xh1.t[ft][r] * gam1.t[ft][r] + bet1.t[ft][r];
+      const float sg = s.sg1.t[ft][r], a2 = s.a2.t[ft][r];
+      gn1.t[ft][r] = gy.t[ft][r] * a2 * sg * (1.0f + n1 * (1.0f - sg));     // d silu
+      gn2.t[ft][r] = gy.t[ft][r] * n1 * sg * a2 * (1.0f - a2);
+    }
   }
-  ln_backward(gn1, param64(vecs + 2 * D, g), s.xh1, s.rstd1);
+  ln_backward(gn1, gam1, s.xh1, s.rstd1);
   ln_backward(gn2, param64(vecs + 4 * D, g), s.xh2, s.rstd2);
   if (HIDDEN) {
     gzc = zero64();
@@ -105,8 +115,8 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& zc, con
     gemm_dl_t<VT, VT>(gzc.t, W2c, WS, gn1.t, j, g);
     gemm_dl_t<VT, VT>(gzg.t, W2g, WS, gn2.t, j, g);
     CHG_EW(ft, r) {
-      gzc.t[ft][r] *= dsiluf_(zc.t[ft][r]);
-      gzg.t[ft][r] *= dsiluf_(zg.t[ft][r]);
+      gzc.t[ft][r] *= dzc.t[ft][r];
+      gzg.t[ft][r] *= dzg.t[ft][r];
     }
   } else {
     gzc = gn1;
@@ -281,10 +291,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     read_dl<VT>(Trow, g, zc.t);
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
-    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
+    V64 y;
+    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 m;
-    CHG_EW(ft, r) m.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r] * wv.t[ft][r];
+    CHG_EW(ft, r) m.t[ft][r] = y.t[ft][r] * wv.t[ft][r];
     write_dl<VT>(Trow, g, m.t);
     __builtin_amdgcn_wave_barrier();
     {  // even rows: centre c1 is nondecreasing in k -> segmented sum; odd rows: one atomic row each
@@ -443,11 +454,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     read_dl<VT>(Trow, g, zc.t);
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
-    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s);
+    V64 y;
+    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
     CHG_EW(ft, r) {
-      gw.t[ft][r] = gm.t[ft][r] * s.a1.t[ft][r] * s.a2.t[ft][r];   // dE/d wag[k], this direction
+      gw.t[ft][r] = gm.t[ft][r] * y.t[ft][r];   // dE/d wag[k], this direction
       gy.t[ft][r] = gm.t[ft][r] * wv.t[ft][r];
     }
     __builtin_amdgcn_wave_barrier();
@@ -586,7 +598,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     GatedState s;
-    gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, g, s);
+    V64 y;
+    gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
     if (HIDDEN) {
@@ -594,9 +607,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
     }
     if (!BWD) {
-      V64 y;
       CHG_EW(ft, r) {
-        y.t[ft][r] = s.a1.t[ft][r] * s.a2.t[ft][r];
         if (HIDDEN) y.t[ft][r] *= w1.t[ft][r] * w2.t[ft][r];
         else y.t[ft][r] += x.t[ft][r];
       }
@@ -610,9 +621,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         V64 g1, g2, gu;
         read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
         CHG_EW(ft, r) {
-          const float y = s.a1.t[ft][r] * s.a2.t[ft][r];
-          g1.t[ft][r] = gu.t[ft][r] * y * w2.t[ft][r];      // dE/d wbgc[b1]
-          g2.t[ft][r] = gu.t[ft][r] * y * w1.t[ft][r];      // dE/d wbgc[b2]
+          g1.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w2.t[ft][r];      // dE/d wbgc[b1]
+          g2.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w1.t[ft][r];      // dE/d wbgc[b2]
           gy.t[ft][r] = gu.t[ft][r] * w1.t[ft][r] * w2.t[ft][r];
         }
         write_dl<VT>(Trow, g, g1.t);
