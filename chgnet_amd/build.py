@@ -70,11 +70,11 @@ def build_hip(force: bool = False) -> str:
     return HIP_LIB
 
 
-def build_variant(name: str, defines: list[str]) -> str:
-    """Experiment build (timing studies only): libchgnet_hip_<name>.so with extra -D flags."""
+def build_variant(name: str, defines: list[str], extra_flags: list[str] | None = None) -> str:
+    """Experiment build (timing studies only): libchgnet_hip_<name>.so with extra -D / compiler flags."""
     out = os.path.join(LIB_DIR, f"libchgnet_hip_{name}.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    _run([hipcc_path(), *HIP_FLAGS, *[f"-D{d}" for d in defines], f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", out])
+    _run([hipcc_path(), *HIP_FLAGS, *(extra_flags or []), *[f"-D{d}" for d in defines], f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", out])
     return out
 
 
