@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from chgnet_amd.graph.structure import Lattice, Structure
+from chgnet_amd.graph.structure import Lattice, Structure, atomic_numbers_of
 from chgnet_amd.model import CHGNet
 
 GPA_TO_EV_A3 = 1.0 / 160.21766208   # ase.units.GPa
@@ -135,7 +135,7 @@ class CHGNetCalculator(Calculator):
         eng = self.model.engine
         lattice = np.asarray(structure.lattice.matrix, dtype=np.float64)
         frac = np.asarray(structure.frac_coords, dtype=np.float64)          # unwrapped: images stay valid
-        z = np.array([site.specie.Z for site in structure], dtype=np.int32)
+        z = atomic_numbers_of(structure)
         cart = frac @ lattice
         res = self._resident
         reuse = (res is not None and len(z) == len(res["z"]) and np.array_equal(z, res["z"])

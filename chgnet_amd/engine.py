@@ -7,6 +7,7 @@ import ctypes
 import numpy as np
 
 from chgnet_amd import _lib
+from chgnet_amd.graph.structure import atomic_numbers_of
 from chgnet_amd.pack import D, PackedBatch, PackedWeights, pack_batch
 
 
@@ -112,7 +113,7 @@ class Engine:
         structures = list(structures)
         n_at = np.array([len(s) for s in structures], dtype=np.int64)
         a_off = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int32)
-        z = np.ascontiguousarray(np.concatenate([[site.specie.Z for site in s] for s in structures]), dtype=np.int32)
+        z = np.ascontiguousarray(np.concatenate([atomic_numbers_of(s) for s in structures]), dtype=np.int32)
         frac = np.ascontiguousarray(np.concatenate([np.asarray(s.frac_coords, dtype=np.float64).reshape(-1, 3) for s in structures]))
         lattice = np.ascontiguousarray(np.stack([np.asarray(s.lattice.matrix, dtype=np.float64) for s in structures]))
         host = _lib.StructsHost(len(structures), int(a_off[-1]), _ip(z), frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),

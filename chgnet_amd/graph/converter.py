@@ -15,6 +15,7 @@ import sys
 import numpy as np
 
 from chgnet_amd.graph.crystalgraph import CrystalGraph
+from chgnet_amd.graph.structure import atomic_numbers_of
 
 _LIB = None
 
@@ -151,7 +152,7 @@ class CrystalGraphConverter:
     def forward(self, structure, graph_id=None, mp_id=None) -> CrystalGraph:
         """Structure (ours or pymatgen's) -> CrystalGraph (reference converter.py:102-190)."""
         n_atoms = len(structure)
-        atomic_number = np.array([site.specie.Z for site in structure], dtype=np.int32)
+        atomic_number = atomic_numbers_of(structure)
         frac = np.asarray(structure.frac_coords, dtype=np.float64).reshape(n_atoms, 3)
         lattice = np.asarray(structure.lattice.matrix, dtype=np.float64)
         arrays = build_graph_arrays(frac, lattice, self.atom_graph_cutoff, self.bond_graph_cutoff)

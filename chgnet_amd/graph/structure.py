@@ -165,3 +165,13 @@ class Structure:
 # rough electronegativity ranks for a pymatgen-like formula string (tracking only)
 _FORMULA_ORDER = {s: i for i, s in enumerate(
     "Cs K Rb Ba Na Sr Li Ca La Y Mg Sc Zr Hf Ti Mn Ta Nb V Al Zn Cr Cd In Ga Fe Co Cu Si Ni Ag Sn Hg Ge Bi B Sb Te Mo As P H Ir Ru Os Pd Pt Rh Pb W Au C Se S I Br N Cl O F".split())}
+
+
+def atomic_numbers_of(structure) -> np.ndarray:
+    """Z of every site of a structure-like object.  ``atomic_numbers`` (this module's and pymatgen's
+    structures have it) avoids a Python loop over sites, which for a thousand structures costs more
+    than building their graphs on the GPU; anything else is read site by site (``site.specie.Z``)."""
+    z = getattr(structure, "atomic_numbers", None)
+    if z is None:
+        z = [site.specie.Z for site in structure]
+    return np.asarray(z, dtype=np.int32)
