@@ -298,23 +298,30 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     CHG_EW(ft, r) m.t[ft][r] = y.t[ft][r] * wv.t[ft][r];
     write_dl<VT>(Trow, g, m.t);
     __builtin_amdgcn_wave_barrier();
-    {  // even rows: centre c1 is nondecreasing in k -> segmented sum; odd rows: one atomic row each
-      float acc = 0.f;
-      int cur = __builtin_amdgcn_readlane(c, 0);
+    {  // even rows: centre c1 is nondecreasing in k; odd rows: c2 is nondecreasing within one c1 (images of
+       // one neighbour are adjacent) -> run sums on both sides, one atomic row per run
+      float acc1 = 0.f, acc2 = 0.f;
+      int cur1 = __builtin_amdgcn_readlane(c, 0), cur2 = __builtin_amdgcn_readlane(c, 1);
 #pragma unroll
       for (int b = 0; b < TILE_ROWS / 2; ++b) {
         if (2 * b < nvalid) {
           const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
-          if (c1 != cur) {
-            tile_atomic_add(p.agg + (size_t)cur * D + lane, acc);
-            acc = 0.f;
-            cur = c1;
+          if (c1 != cur1) {
+            tile_atomic_add(p.agg + (size_t)cur1 * D + lane, acc1);
+            acc1 = 0.f;
+            cur1 = c1;
           }
-          acc += T[(2 * b) * TS + lane];
-          tile_atomic_add(p.agg + (size_t)c2 * D + lane, T[(2 * b + 1) * TS + lane]);
+          if (c2 != cur2) {
+            tile_atomic_add(p.agg + (size_t)cur2 * D + lane, acc2);
+            acc2 = 0.f;
+            cur2 = c2;
+          }
+          acc1 += T[(2 * b) * TS + lane];
+          acc2 += T[(2 * b + 1) * TS + lane];
         }
       }
-      tile_atomic_add(p.agg + (size_t)cur * D + lane, acc);
+      tile_atomic_add(p.agg + (size_t)cur1 * D + lane, acc1);
+      tile_atomic_add(p.agg + (size_t)cur2 * D + lane, acc2);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -330,10 +337,12 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
 // Scatter of one AtomConv-adjoint tile (gz rows in LDS, pair order).  Lane owns columns
 // (lane, lane+64) of the 128-wide rows.  dE/dQ[k] is a plain store (the tile owns bond k);
 // atom c2 (unsorted side) gets one atomic row per bond; atom c1 (sorted side) gets run sums.
-// General form: any number of valid rows, any number of c1 runs; branches around the atomics.
-__device__ __forceinline__ void acbwd_scatter_any(const float* T, int c, int nvalid, int k0, const AtomConvArgs& p, int lane) {
-  float acc_c0 = 0.f, acc_c1 = 0.f, acc_n0 = 0.f, acc_n1 = 0.f;
-  int cur = __builtin_amdgcn_readlane(c, 0);
+__device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid, int k0, const AtomConvArgs& p, int lane) {
+  // Both sides leave the tile as run sums: c1 is sorted along the pair order, and within one c1 the
+  // bonds are ordered by c2 (then image), so periodic images of one neighbour are adjacent too
+  // (small cells: ~3.5 distinct c2 per 8 bonds).  Fewer atomic rows matter: each is paid at the memory side.
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur1 = __builtin_amdgcn_readlane(c, 0), cur2 = __builtin_amdgcn_readlane(c, 1);
 #pragma unroll
   for (int b = 0; b < TILE_ROWS / 2; ++b) {
     if (2 * b < nvalid) {
@@ -342,72 +351,27 @@ __device__ __forceinline__ void acbwd_scatter_any(const float* T, int c, int nva
       float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
       q[0] = e0 + o0;
       q[64] = e1 + o1;
-      const int c1 = __builtin_amdgcn_readlane(c, 2 * b);
-      if (c1 != cur) {
-        float* d = p.GP + (size_t)cur * 4 * D + lane;
-        tile_atomic_add(d, acc_c0); tile_atomic_add(d + 64, acc_c1); tile_atomic_add(d + 128, acc_n0); tile_atomic_add(d + 192, acc_n1);
-        acc_c0 = acc_c1 = acc_n0 = acc_n1 = 0.f;
-        cur = c1;
+      const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
+      if (c1 != cur1) {
+        float* d = p.GP + (size_t)cur1 * 4 * D + lane;
+        tile_atomic_add(d, a1[0]); tile_atomic_add(d + 64, a1[1]); tile_atomic_add(d + 128, a1[2]); tile_atomic_add(d + 192, a1[3]);
+        a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+        cur1 = c1;
       }
-      acc_c0 += e0; acc_c1 += e1; acc_n0 += o0; acc_n1 += o1;   // centre part <- even row, neighbour part <- odd row
-      const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
-      float* d2 = p.GP + (size_t)c2 * 4 * D + lane;              // centre part <- odd row, neighbour part <- even row
-      tile_atomic_add(d2, o0); tile_atomic_add(d2 + 64, o1); tile_atomic_add(d2 + 128, e0); tile_atomic_add(d2 + 192, e1);
+      if (c2 != cur2) {
+        float* d = p.GP + (size_t)cur2 * 4 * D + lane;
+        tile_atomic_add(d, a2[0]); tile_atomic_add(d + 64, a2[1]); tile_atomic_add(d + 128, a2[2]); tile_atomic_add(d + 192, a2[3]);
+        a2[0] = a2[1] = a2[2] = a2[3] = 0.f;
+        cur2 = c2;
+      }
+      a1[0] += e0; a1[1] += e1; a1[2] += o0; a1[3] += o1;   // atom c1: centre part <- even row, neighbour part <- odd row
+      a2[0] += o0; a2[1] += o1; a2[2] += e0; a2[3] += e1;   // atom c2: centre part <- odd row, neighbour part <- even row
     }
   }
-  float* d = p.GP + (size_t)cur * 4 * D + lane;
-  tile_atomic_add(d, acc_c0); tile_atomic_add(d + 64, acc_c1); tile_atomic_add(d + 128, acc_n0); tile_atomic_add(d + 192, acc_n1);
-}
-
-// Full tiles (16 valid rows): a fixed instruction sequence.  s_waitcnt vmcnt counts in order, so
-// when the number of atomics issued after a load is known at compile time the wait for that load
-// leaves them in flight; any branch around an atomic turns that wait into vmcnt(0).  The two
-// leading c1 runs go to two fixed slots (an absent second run adds 0.0 next to the first); a
-// third run in one 8-bond tile (an atom with < 8 bonds) takes the branch at the end.
-__device__ __forceinline__ void acbwd_store_gq_full(const float* T, int k0, const AtomConvArgs& p, int lane) {
-#pragma unroll
-  for (int b = 0; b < TILE_ROWS / 2; ++b) {
-    float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
-    q[0] = T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
-    q[64] = T[(2 * b) * TS + 64 + lane] + T[(2 * b + 1) * TS + 64 + lane];
-  }
-}
-__device__ __forceinline__ void acbwd_scatter_full(const float* T, int c, const AtomConvArgs& p, int lane) {
-  constexpr int NB = TILE_ROWS / 2;
-  int c1[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) c1[b] = __builtin_amdgcn_readlane(c, 2 * b);
-  unsigned bd = 0;   // bit b: bond b starts a new c1 run
-#pragma unroll
-  for (int b = 1; b < NB; ++b) bd |= (c1[b] != c1[b - 1] ? 1u : 0u) << b;
-  const int e1 = bd ? __builtin_ctz(bd) : NB;
-  const unsigned bd2 = bd & (bd - 1);
-  const int e2 = bd2 ? __builtin_ctz(bd2) : NB;
-  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const float e0 = T[(2 * b) * TS + lane], e1v = T[(2 * b) * TS + 64 + lane];
-    const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];
-    const float w0 = b < e1 ? 1.f : 0.f, w1 = (b >= e1 && b < e2) ? 1.f : 0.f;   // wave-uniform
-    s0[0] += w0 * e0; s0[1] += w0 * e1v; s0[2] += w0 * o0; s0[3] += w0 * o1;
-    s1[0] += w1 * e0; s1[1] += w1 * e1v; s1[2] += w1 * o0; s1[3] += w1 * o1;
-    const int c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
-    float* d2 = p.GP + (size_t)c2 * 4 * D + lane;
-    tile_atomic_add(d2, o0); tile_atomic_add(d2 + 64, o1); tile_atomic_add(d2 + 128, e0); tile_atomic_add(d2 + 192, e1v);
-  }
-  const int key1 = __builtin_amdgcn_readlane(c, 2 * min(e1, NB - 1));
-  float* d0 = p.GP + (size_t)c1[0] * 4 * D + lane;
-  float* d1 = p.GP + (size_t)key1 * 4 * D + lane;
-  tile_atomic_add(d0, s0[0]); tile_atomic_add(d0 + 64, s0[1]); tile_atomic_add(d0 + 128, s0[2]); tile_atomic_add(d0 + 192, s0[3]);
-  tile_atomic_add(d1, s1[0]); tile_atomic_add(d1 + 64, s1[1]); tile_atomic_add(d1 + 128, s1[2]); tile_atomic_add(d1 + 192, s1[3]);
-  if (e2 < NB) {   // rare: bonds of a third (fourth, ...) run, one row each
-    for (int b = e2; b < NB; ++b) {
-      const int a = __builtin_amdgcn_readlane(c, 2 * b);
-      float* d = p.GP + (size_t)a * 4 * D + lane;
-      tile_atomic_add(d, T[(2 * b) * TS + lane]); tile_atomic_add(d + 64, T[(2 * b) * TS + 64 + lane]);
-      tile_atomic_add(d + 128, T[(2 * b + 1) * TS + lane]); tile_atomic_add(d + 192, T[(2 * b + 1) * TS + 64 + lane]);
-    }
-  }
+  float* d1 = p.GP + (size_t)cur1 * 4 * D + lane;
+  tile_atomic_add(d1, a1[0]); tile_atomic_add(d1 + 64, a1[1]); tile_atomic_add(d1 + 128, a1[2]); tile_atomic_add(d1 + 192, a1[3]);
+  float* d2 = p.GP + (size_t)cur2 * 4 * D + lane;
+  tile_atomic_add(d2, a2[0]); tile_atomic_add(d2 + 64, a2[1]); tile_atomic_add(d2 + 128, a2[2]); tile_atomic_add(d2 + 192, a2[3]);
 }
 
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
@@ -488,19 +452,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
     __builtin_amdgcn_wave_barrier();
-    // Order matters: stores, then the NEXT tile's gathers, then this tile's atomics, then the wait
-    // for the gathers (gather_commit128) -- see acbwd_scatter_full.
-    if (nvalid == TILE_ROWS) {
-      acbwd_store_gq_full(T, k0, p, lane);
+    {  // the next tile's gathers fly while this tile's run sums are formed and sent
       GatherRegs gr;
       gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
-      acbwd_scatter_full(T, c, p, lane);
-      __builtin_amdgcn_wave_barrier();
-      gather_commit128(gr, T, TS, lane);
-    } else {
-      acbwd_scatter_any(T, c, nvalid, k0, p, lane);
-      GatherRegs gr;
-      gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
+      acbwd_scatter(T, c, nvalid, k0, p, lane);
       __builtin_amdgcn_wave_barrier();
       gather_commit128(gr, T, TS, lane);
     }
