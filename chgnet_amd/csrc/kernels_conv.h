@@ -331,12 +331,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
 // undirected bond k (pack.py: p_center / p_nbr).  Both directions of a bond then sit in one tile, so
 //   dE/dQ[k], dE/dw_ag[k]        = sum of the two rows            -> plain stores, no atomics
 //   dE/dP[c1] (c1 = centre of the even row, nondecreasing in k)    -> segmented column sums
-//   dE/dP[c2]                                                      -> one coalesced atomic row per bond
-// which cuts the scattered fp32 atomics from 320 to 128 per directed bond (profiles/r01 notes: row
-// atomics were 55 % of the centre-ordered version of this kernel).
+//   dE/dP[c2] (nondecreasing inside one c1: images of a neighbour)  -> run sums, one atomic row per run
+// (profiles/r01 notes: row atomics were 55 % of the centre-ordered version of this kernel).
+//
 // Scatter of one AtomConv-adjoint tile (gz rows in LDS, pair order).  Lane owns columns
-// (lane, lane+64) of the 128-wide rows.  dE/dQ[k] is a plain store (the tile owns bond k);
-// atom c2 (unsorted side) gets one atomic row per bond; atom c1 (sorted side) gets run sums.
+// (lane, lane+64) of the 128-wide rows.  dE/dQ[k] is a plain store (the tile owns bond k).
 __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid, int k0, const AtomConvArgs& p, int lane) {
   // Both sides leave the tile as run sums: c1 is sorted along the pair order, and within one c1 the
   // bonds are ordered by c2 (then image), so periodic images of one neighbour are adjacent too
