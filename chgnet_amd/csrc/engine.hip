@@ -101,6 +101,7 @@ struct chg_batch {
   float *energy, *site_energy, *site_raw, *magmom, *crystal_fea, *force, *virial, *volume;
   // reverse sweep
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
+  float* phase = nullptr;   // CHG_PHASE_TIMING builds: per-phase shader-clock totals of the angle kernels
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
   // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
@@ -362,7 +363,7 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.ang = ang; a.wbgc = b->wbgc;
   a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
   a.w_ang = w_ang; a.gw = g; a.out = out;
-  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR; a.GS = b->GS; a.Gwbgc = b->Gwbgc;
+  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR; a.GS = b->GS; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
   return a;
 }
 
@@ -441,6 +442,9 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   const bool want_f = task & CHG_TASK_F, want_s = task & CHG_TASK_S, want_m = task & CHG_TASK_M;
   const bool want_grad = want_f || want_s;
   hipStream_t st = eng->stream;
+#ifdef CHG_PHASE_TIMING
+  HIP_TRY(eng, hipMemsetAsync(b->phase, 0, sizeof(float) * 64, st));
+#endif
 
   // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
   { LaunchScope ls(eng, "cart");
@@ -577,6 +581,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->GP = c.take<float>(N * 4 * D); b->GQ = c.take<float>(Eu * 2 * D);
   b->GR = c.take<float>(Eb * 4 * D); b->GS = c.take<float>(N * 2 * D); b->Gagg = c.take<float>(Eb * D);
   b->Grk = c.take<float>(Eu);
+  b->phase = c.take<float>(64);
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
   total = (c.pos + 255) & ~size_t(255);
 }
@@ -597,7 +602,7 @@ void register_names(chg_batch* b) {
   m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
   m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
   m["GR"] = {b->GR, Eb * 4 * D}; m["GS"] = {b->GS, N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
-  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B};
+  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["phase"] = {b->phase, 64};
   m["frac"] = {b->frac, 3 * N}; m["lattice"] = {b->lattice, 9 * B}; m["e_image"] = {b->e_image, 3 * Ed};
   auto& mi = b->named_i32;
   mi.clear();

@@ -481,12 +481,26 @@ struct AngleArgs {
   float* GR;           // [Eb,256] zeroed
   float* GS;           // [N,128] zeroed
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
+  float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
 };
 
 template <bool HIDDEN, int NW = WAVES>
 constexpr size_t angle_lds() {
   return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + NW * TILE_FLOATS);
 }
+
+// Phase timing (diagnostic builds, -DCHG_PHASE_TIMING): s_memtime deltas between the phases of a tile,
+// summed per wave and added to p.phase[base + i] at the end; read back with chg_debug_fetch("phase")
+// (tests/gpu_phase_probe.py).
+#ifdef CHG_PHASE_TIMING
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(); float ph_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define PH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += (float)(t_ - ph_t); ph_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#define PH_FLUSH(base) if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(p.phase + (base) + i_, ph_acc[i_]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
 
 // HIDDEN = true: BondConv (gated MLP with one hidden layer, weighted, aggregated over the owning bond)
 // HIDDEN = false: AngleUpdate (single gated layer, residual on the angle itself)
@@ -523,6 +537,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     const int a0 = row_of(tb);
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
   }
+  PH_DECL
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
@@ -545,16 +560,20 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       read_dl<VT>(Trow, g, x.t);
       __builtin_amdgcn_wave_barrier();
     }
+    PH(0)   // indices + angle rows
     gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
     __builtin_amdgcn_wave_barrier();
     f32x4 z[2 * VT];
     read_dl<2 * VT>(Trow, g, z);
+    PH(1)   // table gather
     gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
+    PH(2)   // W_ang contraction
     GatedState s;
     V64 y;
     gated_forward<HIDDEN>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
+    PH(3)   // gated forward
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
     if (HIDDEN) {
       read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       __builtin_amdgcn_wave_barrier();
       if (HIDDEN) seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.out, D, lane);
       else scatter_rows64<false>(T, TS, p.out, a, nvalid, lane);
+      PH(4)   // forward output
     } else {
       V64 gy, gzc, gzg;
       if (HIDDEN) {
@@ -590,23 +610,29 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         read_dl<VT>(Trow, g, gy.t);
       }
       __builtin_amdgcn_wave_barrier();
+      PH(4)   // weight rows / Gang rows, dE/dy, (BondConv) Gwbgc scatter
       gated_backward<HIDDEN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+      PH(5)   // gated backward
       // dE/d(angle in) += W_ang^T gz   (the residual identity is already in Gang)
       f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
       V64 ga = zero64();
       gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
       write_dl<VT>(Trow, g, ga.t);
       __builtin_amdgcn_wave_barrier();
+      PH(6)   // W_ang^T contraction
       scatter_rows64<true>(T, TS, p.Gang, a, nvalid, lane);
       __builtin_amdgcn_wave_barrier();
+      PH(7)   // Gang update
       write_dl<2 * VT>(Trow, g, gz);
       __builtin_amdgcn_wave_barrier();
       seg_colsum_atomic<2 * D>(T, TS, valid ? b1 : -1, nvalid, p.GR, 4 * D, lane);
       row_atomic_add<2 * D>(T, TS, valid ? b2 : -1, nvalid, p.GR + 2 * D, 4 * D, lane);
       seg_colsum_atomic<2 * D>(T, TS, valid ? ctr : -1, nvalid, p.GS, 2 * D, lane);
+      PH(8)   // GR / GS scatter
     }
     __builtin_amdgcn_wave_barrier();
   }
+  PH_FLUSH((HIDDEN ? 0 : 20) + (BWD ? 10 : 0))
 }
 
 // =============================================================================================

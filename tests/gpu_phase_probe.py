@@ -1,0 +1,25 @@
+"""Per-phase shader-clock breakdown of the angle kernels (needs a -DCHG_PHASE_TIMING build in CHGNET_HIP_LIB)."""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench
+from chgnet_amd.engine import Engine
+from chgnet_amd.pack import pack_batch, pack_weights
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+W = dict(np.load(os.path.join(REPO, "tests/golden/weights_seed0.npz")))
+pb = pack_batch(bench.build_workload(n, 0))
+eng = Engine(pack_weights(W), 0)
+os.environ["CHGNET_HIP_GRAPHS"] = "0"
+batch = eng.upload(pb)
+eng.predict(batch, "efs"); eng.synchronize()
+ph = eng.debug_fetch(batch, "phase", 64)
+names = {0: ["idx+ang rows", "table gather", "W_ang GEMM", "gated fwd", "output scatter"],
+         10: ["idx+ang rows", "table gather", "W_ang GEMM", "gated fwd", "rows+dE/dy+Gwbgc", "gated bwd", "W_ang^T GEMM", "Gang update", "GR/GS scatter"]}
+tiles = pb.n_angles / 16
+for base, label, launches in ((0, "bondconv_fwd", 3), (10, "bondconv_bwd", 3), (20, "angleupd_fwd", 2), (30, "angleupd_bwd", 2)):
+    v = ph[base:base + 10]
+    tot = v.sum()
+    print(f"{label}: {tot / (tiles * launches):8.0f} cycles per wave-tile")
+    for i, nm in enumerate(names[10 if base % 20 else 0]):
+        print(f"   {nm:20s} {v[i] / (tiles * launches):8.0f}  {100 * v[i] / tot:5.1f} %")
