@@ -96,8 +96,29 @@ __device__ __forceinline__ void gemm_dl(f32x4 (&acc)[NFT], const float* W, int w
 
 // Transposed use of the same LDS copy: acc[fo] += W[k][16*fo + i] * x[k]  (W row-major [k][ws]).
 // Lanes i are consecutive in memory -> ds_read_b32, conflict-free.
+// The 4 x NFT operand reads of a k-group are issued together and one group ahead of the MFMAs that
+// consume them.  Left to itself the scheduler sinks each read next to its MFMA (read -> wait -> 2
+// MFMAs -> read ...), which exposes the LDS latency on every pair: 1.9x slower than the forward form.
+// The empty asm is a use of the whole group: it pins the (counted) wait in front of the group's MFMAs.
+template <int NFT>
+__device__ __forceinline__ void gemm_t_load(float (&a)[4][NFT], const float* W, int ws, int kt, int i, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* wrow = W + dfeat(kt, r, g) * ws + i;
+#pragma unroll
+    for (int fo = 0; fo < NFT; ++fo) a[r][fo] = wrow[16 * fo];
+  }
+}
+template <int NFT>
+__device__ __forceinline__ void gemm_t_touch(float (&a)[4][NFT]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int fo = 0; fo < NFT; ++fo) asm volatile("" : "+v"(a[r][fo]));
+}
 template <int KT, int NFT>
 __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int ws, const f32x4 (&x)[KT], int i, int g) {
+#ifdef CHG_EXP_GEMM_T_PLAIN
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -106,6 +127,19 @@ __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int
 #pragma unroll
       for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * fo], x[kt][r], acc[fo], 0, 0, 0);
     }
+#else
+  float a[2][4][NFT];
+  gemm_t_load<NFT>(a[0], W, ws, 0, i, g);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) gemm_t_load<NFT>(a[(kt + 1) & 1], W, ws, kt + 1, i, g);
+    gemm_t_touch<NFT>(a[kt & 1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt & 1][r][fo], x[kt][r], acc[fo], 0, 0, 0);
+  }
+#endif
 }
 
 // ---- LayerNorm over the 64 features of a row (spread over 4 lanes) ------------------------------
