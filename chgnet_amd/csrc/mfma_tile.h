@@ -143,9 +143,23 @@ __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int
 }
 
 // ---- LayerNorm over the 64 features of a row (spread over 4 lanes) ------------------------------
+// Sum over the four 16-lane rows of a wave (the four lanes that share a tile row), result in all of
+// them.  gfx950's row swaps do it in the VALU: v_permlane16_swap exchanges the odd rows of one operand
+// with the even rows of the other (both copies of v: a + b = row0+row1 | row2+row3), v_permlane32_swap
+// the upper half of one with the lower half of the other.  Two ds_bpermute round trips through the LDS
+// crossbar before (CHG_EXP_QUAD_SHFL keeps that form for A/B).
 __device__ __forceinline__ float quad_sum(float v) {
+#ifdef CHG_EXP_QUAD_SHFL
   v += __shfl_xor(v, 16);
   return v + __shfl_xor(v, 32);
+#else
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned w = __float_as_uint(s);
+  const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+#endif
 }
 
 // in: c (pre-norm).  out: c <- xhat, returns rstd.
