@@ -532,24 +532,63 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   const int tstride = TILE_ROWS * NW;
   auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_angles - 1); };
   constexpr bool IDX_AHEAD = BWD || LEAN;   // indices of the next tile are loaded one tile ahead (3 registers)
+  // Forward variants: software-pipelined gathers.  The table rows and angle rows of tile t+1 are in
+  // flight (registers) while tile t is computed; its indices were loaded during tile t-1.
+#ifdef CHG_EXP_NO_PIPE_FWD
+  constexpr bool PIPE = false;
+#else
+  constexpr bool PIPE = !BWD;
+#endif
   int ctr_nx = 0, b1_nx = 0, b2_nx = 0;
-  if (IDX_AHEAD && tb < te) {
+  GatherRegs gr_p;
+  V64 x_p;
+  if (PIPE) {
+    if (tb >= te) return;
+    const int a0 = row_of(tb);
+    const int c0 = p.a_ctr[a0], i0 = p.a_b1c[a0], j0 = p.a_b2c[a0];
+    gather_issue128(gr_p, p.R, i0, p.R + 2 * D, j0, p.S, c0, 4 * D, 4 * D, 2 * D, lane);
+    read_dl<VT>(p.ang + (size_t)a0 * D, g, x_p.t);
+    ctr_nx = c0; b1_nx = i0; b2_nx = j0;
+  } else if (IDX_AHEAD && tb < te) {
     const int a0 = row_of(tb);
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
+  }
+  int ctr_n2 = 0, b1_n2 = 0, b2_n2 = 0;
+  if (PIPE && tb + 1 < te) {
+    const int a1 = row_of(tb + 1);
+    ctr_n2 = p.a_ctr[a1]; b1_n2 = p.a_b1c[a1]; b2_n2 = p.a_b2c[a1];
   }
   PH_DECL
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
-    if (IDX_AHEAD && tile + 1 < te) {
+    if (!PIPE && IDX_AHEAD && tile + 1 < te) {
       const int a1 = row_of(tile + 1);
       ctr_nx = p.a_ctr[a1]; b1_nx = p.a_b1c[a1]; b2_nx = p.a_b2c[a1];
     }
-    if (nvalid <= 0) continue;
+    if (nvalid <= 0) continue;   // only past the end of the last tile
     const bool valid = j < nvalid;
     const int a = row0 + (valid ? j : 0);
     V64 x;
+    f32x4 z[2 * VT];
+    if (PIPE) {
+      gather_commit128(gr_p, T, TS, lane);
+      x = x_p;
+      __builtin_amdgcn_wave_barrier();
+      read_dl<2 * VT>(Trow, g, z);
+      PH(0)
+      if (tile + 1 < te) {       // next tile: rows in flight during this tile's contractions
+        const int a1 = row_of(tile + 1);
+        gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane);
+        read_dl<VT>(p.ang + (size_t)a1 * D, g, x_p.t);
+        ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
+        if (tile + 2 < te) {
+          const int a2 = row_of(tile + 2);
+          ctr_n2 = p.a_ctr[a2]; b1_n2 = p.a_b1c[a2]; b2_n2 = p.a_b2c[a2];
+        }
+      }
+    } else {
     if (LEAN) {
       read_dl<VT>(p.ang + (size_t)a * D, g, x.t);
     } else {
@@ -563,8 +602,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     PH(0)   // indices + angle rows
     gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
     __builtin_amdgcn_wave_barrier();
-    f32x4 z[2 * VT];
     read_dl<2 * VT>(Trow, g, z);
+    }
     PH(1)   // table gather
     gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
