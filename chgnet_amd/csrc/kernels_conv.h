@@ -525,45 +525,36 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   const int ntiles = (p.n_angles + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
   int tb, te;
   tile_range(ntiles, tb, te);
-  // The lightest variant (AngleUpdate forward) runs its indices one tile ahead and reads the angle rows
-  // straight into the MFMA operand layout in the same round trip as the table gather (1.13 -> 0.98 ms);
-  // for the heavier variants the extra live registers cost more than the round trip saves (measured).
-  constexpr bool LEAN = !HIDDEN && !BWD;
   const int tstride = TILE_ROWS * NW;
   auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_angles - 1); };
-  constexpr bool IDX_AHEAD = BWD || LEAN;   // indices of the next tile are loaded one tile ahead (3 registers)
-  // Forward variants: software-pipelined gathers.  The table rows and angle rows of tile t+1 are in
-  // flight (registers) while tile t is computed; its indices were loaded during tile t-1.
-#ifdef CHG_EXP_NO_PIPE_FWD
-  constexpr bool PIPE = false;
-#else
+  if (tb >= te) return;
+  // Forward: software-pipelined gathers -- the table rows and angle rows of tile t+1 are in flight
+  // (registers) while tile t is computed, its indices were loaded during tile t-1 (angleupd_fwd
+  // 0.945 -> 0.871 ms).  Backward: indices one tile ahead only; with the adjoint's register load
+  // anything more costs spills (measured, profiles/r01_sq_counters.md).
   constexpr bool PIPE = !BWD;
-#endif
-  int ctr_nx = 0, b1_nx = 0, b2_nx = 0;
+  int ctr_nx, b1_nx, b2_nx;            // indices of the tile that is gathered next
+  int ctr_n2 = 0, b1_n2 = 0, b2_n2 = 0;   // forward: and of the one after it
   GatherRegs gr_p;
   V64 x_p;
-  if (PIPE) {
-    if (tb >= te) return;
-    const int a0 = row_of(tb);
-    const int c0 = p.a_ctr[a0], i0 = p.a_b1c[a0], j0 = p.a_b2c[a0];
-    gather_issue128(gr_p, p.R, i0, p.R + 2 * D, j0, p.S, c0, 4 * D, 4 * D, 2 * D, lane);
-    read_dl<VT>(p.ang + (size_t)a0 * D, g, x_p.t);
-    ctr_nx = c0; b1_nx = i0; b2_nx = j0;
-  } else if (IDX_AHEAD && tb < te) {
+  {
     const int a0 = row_of(tb);
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
-  }
-  int ctr_n2 = 0, b1_n2 = 0, b2_n2 = 0;
-  if (PIPE && tb + 1 < te) {
-    const int a1 = row_of(tb + 1);
-    ctr_n2 = p.a_ctr[a1]; b1_n2 = p.a_b1c[a1]; b2_n2 = p.a_b2c[a1];
+    if (PIPE) {
+      gather_issue128(gr_p, p.R, b1_nx, p.R + 2 * D, b2_nx, p.S, ctr_nx, 4 * D, 4 * D, 2 * D, lane);
+      read_dl<VT>(p.ang + (size_t)a0 * D, g, x_p.t);
+      if (tb + 1 < te) {
+        const int a1 = row_of(tb + 1);
+        ctr_n2 = p.a_ctr[a1]; b1_n2 = p.a_b1c[a1]; b2_n2 = p.a_b2c[a1];
+      }
+    }
   }
   PH_DECL
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
-    int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
-    if (!PIPE && IDX_AHEAD && tile + 1 < te) {
+    const int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
+    if (!PIPE && tile + 1 < te) {
       const int a1 = row_of(tile + 1);
       ctr_nx = p.a_ctr[a1]; b1_nx = p.a_b1c[a1]; b2_nx = p.a_b2c[a1];
     }
@@ -578,7 +569,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       __builtin_amdgcn_wave_barrier();
       read_dl<2 * VT>(Trow, g, z);
       PH(0)
-      if (tile + 1 < te) {       // next tile: rows in flight during this tile's contractions
+      if (tile + 1 < te) {
         const int a1 = row_of(tile + 1);
         gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane);
         read_dl<VT>(p.ang + (size_t)a1 * D, g, x_p.t);
@@ -589,20 +580,15 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         }
       }
     } else {
-    if (LEAN) {
-      read_dl<VT>(p.ang + (size_t)a * D, g, x.t);
-    } else {
-      if (!IDX_AHEAD) { ctr = p.a_ctr[a]; b1 = p.a_b1c[a]; b2 = p.a_b2c[a]; }
       // the angle rows are consumed (B operand of the first contraction) before the table sum is written
       gather_rows64(T, TS, p.ang, a, lane);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, x.t);
       __builtin_amdgcn_wave_barrier();
-    }
-    PH(0)   // indices + angle rows
-    gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
-    __builtin_amdgcn_wave_barrier();
-    read_dl<2 * VT>(Trow, g, z);
+      PH(0)   // indices + angle rows
+      gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<2 * VT>(Trow, g, z);
     }
     PH(1)   // table gather
     gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
