@@ -349,6 +349,29 @@ __device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* ti
     *reinterpret_cast<f32x4*>(tile + (2 * it + hw) * stride + 4 * t) = (gr.a[it] + gr.b[it]) + gr.c[it];
 }
 
+// The read half of a row-wise read-modify-write, issued early (its round trip then runs under the
+// contraction that produces the increment); scatter_rows64_add finishes it.
+struct Rows64 { f32x4 v[TILE_ROWS / 4]; };
+__device__ __forceinline__ void rows64_issue(Rows64& rr, const float* __restrict__ src, int idx, int lane) {
+  const int sub = lane >> 4, t = lane & 15;
+  int r[TILE_ROWS / 4];
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r[it] * D + 4 * t);
+}
+__device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid, int lane,
+                                                   const Rows64& old) {
+  const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) {
+    const int rr = 4 * it + sub;
+    const int r = __shfl(idx, rr);
+    if (rr < nvalid)
+      *reinterpret_cast<f32x4*>(dst + (size_t)r * D + 4 * t) = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
+  }
+}
+
 // contiguous or gathered 64-wide rows into an LDS tile (16 lanes per row, 4 rows per step)
 __device__ __forceinline__ void gather_rows64(float* tile, int stride, const float* __restrict__ src, int idx, int lane) {
   const int sub = lane >> 4, t = lane & 15;
