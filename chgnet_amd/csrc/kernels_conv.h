@@ -591,7 +591,13 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       read_dl<2 * VT>(Trow, g, z);
     }
     PH(1)   // table gather
+    Rows64 gy_rows;
+    if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
     gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+    if (BWD && !HIDDEN) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
+    }
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     PH(2)   // W_ang contraction
     GatedState s;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.Gwbgc, D, lane);
         row_atomic_add<D>(T + D, TS, valid ? b2 : -1, nvalid, p.Gwbgc, D, lane);
       } else {
-        gather_rows64(T, TS, p.Gang, a, lane);          // dE/d(new angle) of this tile
+        rows64_commit(gy_rows, T, TS, lane);             // dE/d(new angle) of this tile, issued above
         __builtin_amdgcn_wave_barrier();
         read_dl<VT>(Trow, g, gy.t);
       }

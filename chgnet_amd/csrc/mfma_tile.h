@@ -360,6 +360,11 @@ __device__ __forceinline__ void rows64_issue(Rows64& rr, const float* __restrict
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r[it] * D + 4 * t);
 }
+__device__ __forceinline__ void rows64_commit(const Rows64& rr, float* tile, int stride, int lane) {
+  const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = rr.v[it];
+}
 __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid, int lane,
                                                    const Rows64& old) {
   const int sub = lane >> 4, t = lane & 15;
