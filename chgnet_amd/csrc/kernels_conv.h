@@ -412,6 +412,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     V64 wv, gm;
     read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
     read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
+    const int k0 = row0 >> 1, nb = nvalid >> 1;
+    float* gwag_rows = p.Gwag + (size_t)k0 * D + lane;     // this tile owns these rows of Gwag: old values read here,
+    float prev[TILE_ROWS / 2];                             // under the forward recomputation
+#pragma unroll
+    for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] = gwag_rows[(size_t)min(b, nb - 1) * D];
     __builtin_amdgcn_wave_barrier();
     V64 zc, zg;
     read_dl<VT>(Trow, g, zc.t);
@@ -428,13 +433,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gw.t);
     __builtin_amdgcn_wave_barrier();
-    const int k0 = row0 >> 1;
-    {  // Gwag[k] += gw(2b) + gw(2b+1): this tile owns those rows of Gwag (all loads first: one round trip)
-      float* dst = p.Gwag + (size_t)k0 * D + lane;
-      const int nb = nvalid >> 1;
-      float prev[TILE_ROWS / 2];
-#pragma unroll
-      for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] = dst[(size_t)min(b, nb - 1) * D];
+    {  // Gwag[k] += gw(2b) + gw(2b+1)
+      float* dst = gwag_rows;
 #pragma unroll
       for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] += T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
       if (nvalid == TILE_ROWS) {
