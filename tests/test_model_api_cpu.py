@@ -66,3 +66,17 @@ def test_argument_errors(golden_weights):
         CHGNet(state_dict=golden_weights, use_device="cpu")
     with pytest.raises(NotImplementedError):
         CHGNet(state_dict=golden_weights, read_out="attn", mlp_first=False)
+
+
+def test_chunk_planner():
+    from chgnet_amd.model import _plan_chunks
+
+    # reference behaviour when the atom floor is off
+    assert _plan_chunks([8] * 5, 2, 0) == [(0, 2), (2, 4), (4, 5)]
+    # chunks grow to the atom floor, never below batch_size structures
+    assert _plan_chunks([10] * 10, 2, 45) == [(0, 5), (5, 10)]
+    assert _plan_chunks([100, 1, 1, 1], 1, 50) == [(0, 1), (1, 4)]
+    assert _plan_chunks([], 16, 100) == []
+    import pytest
+    with pytest.raises(ValueError):
+        _plan_chunks([1], 0, 0)
