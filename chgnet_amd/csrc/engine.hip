@@ -96,11 +96,16 @@ struct chg_batch {
   float* Ql[MAX_CONV];          // AtomConv l: [Eu,128]
   float* Rl[2 * MAX_CONV];      // BondConv l (slot l) / AngleUpdate l (slot L+l): [Eb,256]
   float* Sl[2 * MAX_CONV];      // same slots: [N,128]
-  float *agg, *aggB;
+  // scatter targets, one per layer so that each direction of the sweep needs ONE memset (not one per layer)
+  float* agg_l[MAX_CONV];       // AtomConv l: [N,64]
+  float* aggB_l[MAX_CONV];      // BondConv l: [Eb,64]
+  float* GP_l[MAX_CONV];        // AtomConv l adjoint: [N,256]
+  float* GR_l[2 * MAX_CONV];    // BondConv / AngleUpdate adjoint (slots like Rl): [Eb,256]
+  float* GS_l[2 * MAX_CONV];    // same slots: [N,128]
   // outputs
   float *energy, *site_energy, *site_raw, *magmom, *crystal_fea, *force, *virial, *volume;
   // reverse sweep
-  float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GP, *GQ, *GR, *GS, *Gagg, *Grk, *Gu;
+  float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GQ, *Gagg, *Grk, *Gu;
   float* phase = nullptr;   // CHG_PHASE_TIMING builds: per-phase shader-clock totals of the angle kernels
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
@@ -308,13 +313,12 @@ AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   a.P = b->Pl[l]; a.Q = b->Ql[l]; a.wag = b->wag;
   a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_d2u = b->e_d2u; a.n_edges = b->Ed;
   a.gw = eng->w.ac[l].g;
-  a.agg = b->agg; a.GA = b->GA; a.GP = b->GP; a.GQ = b->GQ; a.Gwag = b->Gwag;
+  a.agg = b->agg_l[l]; a.GA = b->GA; a.GP = b->GP_l[l]; a.GQ = b->GQ; a.Gwag = b->Gwag;
   return a;
 }
 
 int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
-  TRY(zero(eng, b->agg, sizeof(float) * (size_t)b->N * D));
   if (b->Ed > 0) {
     TRY(atomconv_tables(eng, b, l));
     LaunchScope ls(eng, "atomconv_fwd");
@@ -326,14 +330,13 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
     HIP_TRY(eng, hipGetLastError());
   }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
-  return rows_gemm(eng, "gemm_out", 64, 64, b->agg, D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
+  return rows_gemm(eng, "gemm_out", 64, 64, b->agg_l[l], D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
 }
 
 int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
   if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
   TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
-  TRY(zero(eng, b->GP, sizeof(float) * (size_t)b->N * 4 * D));
   {  // pair-ordered edge list: GQ and Gwag rows are owned by one tile each (no zeroing, no atomics)
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;
@@ -343,8 +346,8 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
-    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP, 4 * D, nullptr, w.w_cn_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
-    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP + 2 * D, 4 * D, nullptr, w.w_cn_t + 2 * D * D, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
+    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP_l[l], 4 * D, nullptr, w.w_cn_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
+    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP_l[l] + 2 * D, 4 * D, nullptr, w.w_cn_t + 2 * D * D, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
   }
   return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, 1);
 }
@@ -363,7 +366,7 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.ang = ang; a.wbgc = b->wbgc;
   a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
   a.w_ang = w_ang; a.gw = g; a.out = out;
-  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR; a.GS = b->GS; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
+  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
   return a;
 }
 
@@ -379,10 +382,9 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
 int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   const BCW& w = eng->w.bc[l];
   TRY(angle_tables(eng, b, l, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
-  TRY(zero(eng, b->aggB, sizeof(float) * (size_t)b->Eb * D));
-  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, b->aggB))));
+  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, b->aggB_l[l]))));
   // hbc[l+1] = agg . Wout^T + b_out + hbc[l]          (layers.py:255-260)
-  return rows_gemm(eng, "gemm_out", 64, 64, b->aggB, D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
+  return rows_gemm(eng, "gemm_out", 64, 64, b->aggB_l[l], D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
 }
 
 int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
@@ -392,27 +394,23 @@ int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
 }
 
 // scatter of the table gradients back to atoms / bond nodes
-int angle_table_grads(chg_engine* eng, chg_batch* b, const float* w_bij_t, const float* w_ctr_t) {
-  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR, 4 * D, nullptr, w_bij_t, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
-  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR + 2 * D, 4 * D, nullptr, w_bij_t + 2 * D * D, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
-  return rows_gemm(eng, "gemm_GS", 128, 64, b->GS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
+int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t) {
+  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR_l[slot], 4 * D, nullptr, w_bij_t, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
+  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR_l[slot] + 2 * D, 4 * D, nullptr, w_bij_t + 2 * D * D, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
+  return rows_gemm(eng, "gemm_GS", 128, 64, b->GS_l[slot], 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
 }
 
 int bondconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   const BCW& w = eng->w.bc[l];
   TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, w.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, b->Eb, 0));
-  TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
-  TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
   TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, nullptr))));
-  return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
+  return angle_table_grads(eng, b, l, w.w_bij_t, w.w_ctr_t);
 }
 
 int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
   const AUW& w = eng->w.au[l];
-  TRY(zero(eng, b->GR, sizeof(float) * (size_t)b->Eb * 4 * D));
-  TRY(zero(eng, b->GS, sizeof(float) * (size_t)b->N * 2 * D));
   TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, nullptr))));
-  return angle_table_grads(eng, b, w.w_bij_t, w.w_ctr_t);
+  return angle_table_grads(eng, b, b->L + l, w.w_bij_t, w.w_ctr_t);
 }
 
 BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
@@ -468,6 +466,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   HIP_TRY(eng, hipGetLastError());
 
   // ---- message passing (model.py:442-496) ----
+  TRY(zero(eng, b->zero1, (size_t)((char*)b->zero1_end - (char*)b->zero1)));   // every forward scatter target + crystal_fea
   for (int l = 0; l < L - 1; ++l) {
     TRY(atomconv_fwd(eng, b, l));
     if (b->A > 0) {
@@ -482,7 +481,6 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   TRY(atomconv_fwd(eng, b, L - 1));
 
   // ---- readout (model.py:497-509) and its adjoint ----
-  TRY(zero(eng, b->zero1, (size_t)((char*)b->zero1_end - (char*)b->zero1)));
   {
     ReadoutArgs r{};
     r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = b->N;
@@ -566,20 +564,27 @@ void carve(chg_batch* b, char* base, size_t& total) {
   for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
   for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
   for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
-  b->agg = c.take<float>(N * D); b->aggB = c.take<float>(Eb * D);
   b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
   // zero group 1 (cleared with one memset before the readout)
   b->zero1 = c.take<float>(0);
   b->crystal_fea = c.take<float>(B * D);
+  for (int l = 0; l < L; ++l) b->agg_l[l] = c.take<float>(N * D);
+  for (int l = 0; l < L - 1; ++l) b->aggB_l[l] = c.take<float>(Eb * D);
   b->zero1_end = c.take<float>(0);
   // zero group 2 (cleared with one memset before the reverse sweep)
   b->zero2 = c.take<float>(0);
   b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D); b->Gwbgc = c.take<float>(Eb * D); b->Gang = c.take<float>(A * D);
   b->Gu = c.take<float>(4 * Ed); b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B);
+  for (int l = 0; l < L; ++l) b->GP_l[l] = c.take<float>(N * 4 * D);
+  for (int t = 0; t < 2 * L; ++t) {
+    const bool used = (t < L - 1) || (t >= L && t < 2 * L - 2);   // BondConv 0..L-2, AngleUpdate L..2L-3
+    b->GR_l[t] = used ? c.take<float>(Eb * 4 * D) : nullptr;
+    b->GS_l[t] = used ? c.take<float>(N * 2 * D) : nullptr;
+  }
   b->zero2_end = c.take<float>(0);
   b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D);
-  b->GP = c.take<float>(N * 4 * D); b->GQ = c.take<float>(Eu * 2 * D);
-  b->GR = c.take<float>(Eb * 4 * D); b->GS = c.take<float>(N * 2 * D); b->Gagg = c.take<float>(Eb * D);
+  b->GQ = c.take<float>(Eu * 2 * D);
+  b->Gagg = c.take<float>(Eb * D);
   b->Grk = c.take<float>(Eu);
   b->phase = c.take<float>(64);
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
@@ -598,10 +603,10 @@ void register_names(chg_batch* b) {
   for (int l = 0; l < b->L; ++l) m["hbc" + std::to_string(l)] = {b->hbc[l], Eb * D};
   for (int l = 0; l < b->L - 1; ++l) m["ang" + std::to_string(l)] = {b->ang[l], A * D};
   for (int l = 0; l < b->L; ++l) { m["P" + std::to_string(l)] = {b->Pl[l], N * 4 * D}; m["Q" + std::to_string(l)] = {b->Ql[l], Eu * 2 * D}; }
-  m["agg"] = {b->agg, N * D}; m["aggB"] = {b->aggB, Eb * D};
+  m["agg"] = {b->agg_l[b->L - 1], N * D}; m["aggB"] = {b->aggB_l[0], Eb * D};
   m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
-  m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP, N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
-  m["GR"] = {b->GR, Eb * 4 * D}; m["GS"] = {b->GS, N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
+  m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP_l[0], N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
+  m["GR"] = {b->GR_l[0], Eb * 4 * D}; m["GS"] = {b->GS_l[0], N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
   m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["phase"] = {b->phase, 64};
   m["frac"] = {b->frac, 3 * N}; m["lattice"] = {b->lattice, 9 * B}; m["e_image"] = {b->e_image, 3 * Ed};
   auto& mi = b->named_i32;
