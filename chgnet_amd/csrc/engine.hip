@@ -247,25 +247,38 @@ int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS) {
   return std::max(g, 1);
 }
 
-template <int K, int NOUT>
+template <int K, int NOUT, int PARTS = 1>
 int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
   if (p.rows <= 0) return CHG_OK;
   LaunchScope ls(eng, label);
-  const size_t lds = rows_gemm_lds<K, NOUT>();
-  hipLaunchKernelGGL((k_rows_gemm<K, NOUT>), dim3(grid_for(p.rows, 4 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, p);
+  const size_t lds = rows_gemm_lds<K, NOUT, PARTS>();
+  hipLaunchKernelGGL((k_rows_gemm<K, NOUT, PARTS>), dim3(grid_for(p.rows, 4 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, p);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
 
-// Y[out] (+)= X[in] . Wt^T, dispatch on (K, NOUT); K = 256 / NOUT = 256 are split by the callers
+// Y[out] (+)= X[in] . Wt^T, dispatch on (K, NOUT)
 int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt,
               const float* bias, const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int accumulate) {
-  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate};
+  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate, nullptr, 0, 0};
   if (K == 64 && NOUT == 64) return launch_rows_gemm<64, 64>(eng, label, p);
   if (K == 64 && NOUT == 128) return launch_rows_gemm<64, 128>(eng, label, p);
   if (K == 128 && NOUT == 64) return launch_rows_gemm<128, 64>(eng, label, p);
   eng->err = "rows_gemm: unsupported shape";
   return CHG_EINVAL;
+}
+
+// both halves of a 256-wide table in one launch:  Y[:, 0:128 | 128:256] = X . [Wt ; Wt2]^T  (64 -> 2 x 128)
+int rows_gemm_out2(chg_engine* eng, const char* label, const float* X, const int* in_idx, const float* Wt, const float* Wt2,
+                   const float* bias, float* Y, int ldy, int rows) {
+  RowsGemm p{X, D, in_idx, Wt, bias, nullptr, 0, Y, ldy, nullptr, rows, 0, Wt2, 0, 2 * D};
+  return launch_rows_gemm<64, 128, 2>(eng, label, p);
+}
+// ... and its adjoint:  Y (+)= X[:, 0:128] . Wt^T + X[:, 128:256] . Wt2^T   (2 x 128 -> 64)
+int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, const float* Wt, const float* Wt2, float* Y,
+                  const int* out_idx, int rows, int accumulate) {
+  RowsGemm p{X, ldx, nullptr, Wt, nullptr, nullptr, 0, Y, D, out_idx, rows, accumulate, Wt2, 2 * D, 0};
+  return launch_rows_gemm<128, 64, 2>(eng, label, p);
 }
 
 int zero(chg_engine* eng, void* p, size_t bytes) {
@@ -298,8 +311,7 @@ inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4
 int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
   float *P = b->Pl[l], *Q = b->Ql[l];
-  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, P, 4 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_P", 64, 128, b->atom[l], D, nullptr, w.w_cn + 2 * D * D, nullptr, nullptr, 0, P + 2 * D, 4 * D, nullptr, b->N, 0));
+  TRY(rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, P, 4 * D, b->N));
   // q_bias: constant shift of the bonds outside the bond graph when mlp_out has a bias (0.2.0 only; zero otherwise);
   // the reference runs BondConv only when the batch has angles (model.py:460)
   TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, b->A > 0 ? w.q_bias : nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
@@ -346,8 +358,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
-    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP_l[l], 4 * D, nullptr, w.w_cn_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
-    TRY(rows_gemm(eng, "gemm_GP", 128, 64, b->GP_l[l] + 2 * D, 4 * D, nullptr, w.w_cn_t + 2 * D * D, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1));
+    TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
   }
   return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, 1);
 }
@@ -357,8 +368,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
 int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
   float *S = b->Sl[slot], *R = b->Rl[slot];
   TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0));
-  TRY(rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0));
-  return rows_gemm(eng, "gemm_R", 64, 128, hbc, D, nullptr, w_bij + 2 * D * D, nullptr, nullptr, 0, R + 2 * D, 4 * D, nullptr, b->Eb, 0);
+  return rows_gemm_out2(eng, "gemm_R", hbc, nullptr, w_bij, w_bij + 2 * D * D, nullptr, R, 4 * D, b->Eb);
 }
 
 AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_ang, const GatedW& g, float* out) {
@@ -395,8 +405,7 @@ int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
 
 // scatter of the table gradients back to atoms / bond nodes
 int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t) {
-  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR_l[slot], 4 * D, nullptr, w_bij_t, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
-  TRY(rows_gemm(eng, "gemm_GR", 128, 64, b->GR_l[slot] + 2 * D, 4 * D, nullptr, w_bij_t + 2 * D * D, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1));
+  TRY(rows_gemm_in2(eng, "gemm_GR", b->GR_l[slot], 4 * D, w_bij_t, w_bij_t + 2 * D * D, b->Gb, b->bn_und, b->Eb, 1));
   return rows_gemm(eng, "gemm_GS", 128, 64, b->GS_l[slot], 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
 }
 
@@ -910,6 +919,8 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
+  if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
+  if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, atomconv_lds<FWD_WAVES>()))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds<WAVES>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;

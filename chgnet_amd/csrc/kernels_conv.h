@@ -141,24 +141,32 @@ struct RowsGemm {
   const int* out_idx;
   int rows;
   int accumulate;      // Y += result (rows unique -> plain read-modify-write)
+  // two-part form (PARTS = 2): a second weight block Wt2 and EITHER a second output column block
+  // (y2_off > 0: Y[:, y2_off:] = X . Wt2^T, same X, no bias) OR a second input column block
+  // (x2_off > 0: Y (+)= X . Wt^T + X[:, x2_off:] . Wt2^T).  One launch and one pass over the rows
+  // for the two halves of a 256-wide table.
+  const float* Wt2;
+  int x2_off, y2_off;
 };
 
-template <int K, int NOUT>
+template <int K, int NOUT, int PARTS = 1>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KS = K + PAD, KT = K / 16, NFT = NOUT / 16;
   constexpr int XS = (K > NOUT ? K : NOUT) + PAD;  // tile stride: holds X (K wide) then Y (NOUT wide)
-  float* W = smem;                          // [NOUT][KS]
-  float* bias = W + NOUT * KS;              // [NOUT]
+  float* W = smem;                          // [PARTS][NOUT][KS]
+  float* bias = W + PARTS * NOUT * KS;      // [NOUT]
   float* tiles = bias + NOUT;               // [WAVES][16][XS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_weights(W, p.Wt, NOUT, K, tid);
+  if (PARTS == 2) stage_weights(W + NOUT * KS, p.Wt2, NOUT, K, tid);
   for (int idx = tid; idx < NOUT; idx += BLOCK) bias[idx] = p.bias ? p.bias[idx] : 0.f;
   __syncthreads();
   float* T = tiles + wave * TILE_ROWS * XS;
   const int ntiles = (p.rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
+  const bool split_in = PARTS == 2 && p.x2_off > 0;   // else (PARTS == 2): split output
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.rows - row0);
@@ -166,52 +174,59 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
     const int rr_ = row0 + (j < nvalid ? j : 0);
     const int in_row = p.in_idx ? p.in_idx[rr_] : rr_;
     const int out_row = p.out_idx ? p.out_idx[rr_] : rr_;
-    // X tile -> LDS, K/4 lanes per row
-    constexpr int LPR = K / 4, RPS = 64 / LPR;
-    {
-      const int sub = lane / LPR, t = lane % LPR;
-      f32x4 v[TILE_ROWS / RPS];
-#pragma unroll
-      for (int it = 0; it < TILE_ROWS / RPS; ++it) {
-        const int r = __shfl(in_row, RPS * it + sub);
-        v[it] = *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + 4 * t);
-      }
-#pragma unroll
-      for (int it = 0; it < TILE_ROWS / RPS; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + sub) * XS + 4 * t) = v[it];
-    }
-    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = K / 4, RPS = 64 / LPR;   // X tile -> LDS, K/4 lanes per row
+    constexpr int LPO = NOUT / 4, RPO = 64 / LPO; // Y tile -> global, NOUT/4 lanes per row
     f32x4 x[KT];
-    read_dl<KT>(T + j * XS, g, x);
     f32x4 acc[NFT];
     read_dl<NFT>(bias, g, acc);
-    gemm_dl<KT, NFT>(acc, W, KS, x, j, g);
-    __builtin_amdgcn_wave_barrier();
-    write_dl<NFT>(T + j * XS, g, acc);
-    __builtin_amdgcn_wave_barrier();
-    // Y tile -> global, NOUT/4 lanes per row
-    constexpr int LPO = NOUT / 4, RPO = 64 / LPO;
-    {
-      const int sub = lane / LPO, t = lane % LPO;
 #pragma unroll
-      for (int it = 0; it < TILE_ROWS / RPO; ++it) {
-        const int rr = RPO * it + sub;
-        const int r = __shfl(out_row, rr);
-        if (rr < nvalid) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * t);
-          if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)r * p.ldr + 4 * t);
-          f32x4* dst = reinterpret_cast<f32x4*>(p.Y + (size_t)r * p.ldy + 4 * t);
-          if (p.accumulate) v += *dst;
-          *dst = v;
+    for (int part = 0; part < PARTS; ++part) {
+      if (part == 0 || split_in) {
+        const float* X = p.X + (part ? p.x2_off : 0);
+        const int sub = lane / LPR, t = lane % LPR;
+        f32x4 v[TILE_ROWS / RPS];
+#pragma unroll
+        for (int it = 0; it < TILE_ROWS / RPS; ++it) {
+          const int r = __shfl(in_row, RPS * it + sub);
+          v[it] = *reinterpret_cast<const f32x4*>(X + (size_t)r * p.ldx + 4 * t);
         }
+#pragma unroll
+        for (int it = 0; it < TILE_ROWS / RPS; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + sub) * XS + 4 * t) = v[it];
+        __builtin_amdgcn_wave_barrier();
+        read_dl<KT>(T + j * XS, g, x);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (part == 1 && !split_in) {
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) acc[ft] = zero4();
+      }
+      gemm_dl<KT, NFT>(acc, W + part * NOUT * KS, KS, x, j, g);
+      if (part == PARTS - 1 || !split_in) {
+        write_dl<NFT>(T + j * XS, g, acc);
+        __builtin_amdgcn_wave_barrier();
+        float* Y = p.Y + (part ? p.y2_off : 0);
+        const int sub = lane / LPO, t = lane % LPO;
+#pragma unroll
+        for (int it = 0; it < TILE_ROWS / RPO; ++it) {
+          const int rr = RPO * it + sub;
+          const int r = __shfl(out_row, rr);
+          if (rr < nvalid) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * t);
+            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)r * p.ldr + 4 * t);
+            f32x4* dst = reinterpret_cast<f32x4*>(Y + (size_t)r * p.ldy + 4 * t);
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <int K, int NOUT>
+template <int K, int NOUT, int PARTS = 1>
 constexpr size_t rows_gemm_lds() {
-  return sizeof(float) * (NOUT * (K + PAD) + NOUT + WAVES * TILE_ROWS * ((K > NOUT ? K : NOUT) + PAD));
+  return sizeof(float) * (PARTS * NOUT * (K + PAD) + NOUT + WAVES * TILE_ROWS * ((K > NOUT ? K : NOUT) + PAD));
 }
 
 // =============================================================================================
