@@ -280,7 +280,11 @@ __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, in
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr) {
     const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
+#ifdef CHG_EXP_HALF_ROW_ATOMICS   // timing experiment only (wrong results): every other row is dropped
+    if (kk >= 0 && (rr & 1) == 0) {
+#else
     if (kk >= 0) {
+#endif
 #pragma unroll
       for (int c = 0; c < W / 64; ++c) tile_atomic_add(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
     }
