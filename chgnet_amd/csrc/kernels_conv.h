@@ -302,7 +302,6 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
     }
     if (nvalid <= 0) continue;
-    const bool valid = j < nvalid;
     __builtin_amdgcn_wave_barrier();
     V64 zc, zg;
     read_dl<VT>(Trow, g, zc.t);
