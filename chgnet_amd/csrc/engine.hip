@@ -240,6 +240,12 @@ int collect_profile(chg_engine* eng) {
   return CHG_OK;
 }
 
+// workgroups per CU launched for the tile kernels (CHGNET_GRID_MULT, timing experiments; default 2)
+static int tile_grid_mult() {
+  static const int m = [] { const char* e = std::getenv("CHGNET_GRID_MULT"); const int v = e ? std::atoi(e) : 2; return v > 0 ? v : 2; }();
+  return m;
+}
+
 int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS) {
   int ntiles = (rows + block_rows - 1) / block_rows;
   int g = std::min(ntiles, max_blocks);
@@ -338,7 +344,7 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;   // bond-pair order
     a.e_nbr = b->p_nbr;
-    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(grid_for(b->Ed, 2 * eng->num_cus, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
+    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
@@ -354,7 +360,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, 2 * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
+    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -384,7 +390,7 @@ template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
   const size_t lds = angle_lds<HIDDEN, NW>();
-  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, 2 * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, a);
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, tile_grid_mult() * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, a);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
