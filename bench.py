@@ -4,17 +4,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], SURVEY 8d "C2"): a batch of 1024 LiMnO2 5x1x1 supercells
-(40 atoms, ~3.45k directed bonds, ~3.9k angles each), fractional coordinates perturbed with
+``--gpus N`` with N > 1 outside a launcher (no ``$LOCAL_RANK``) re-executes this file under
+``torch.distributed.run`` with N ranks (one per GPU, RCCL over xGMI); under a launcher the ranks are
+taken from RANK / LOCAL_RANK / WORLD_SIZE and ``--gpus`` must agree with WORLD_SIZE.
+
+Headline workload (BASELINE.json configs[1], SURVEY 8d "C2"): a batch of 1024 LiMnO2 5x1x1 supercells
+(40 atoms, ~3.45k directed bonds, ~4.0k angles each), fractional coordinates perturbed with
 N(0, 0.01^2), numpy default_rng(seed = global structure index); random-init weights of the 0.3.0
 architecture (tests/golden/weights_seed0.npz -- the pretrained blobs are not available offline).
 One step = one pass of the hot path (chg_predict, task "efs") over the rank's 1024 device-resident
 structures plus the download of E/F/S to the host.  Ranks hold disjoint structures (weak scaling,
 no data-path collective); with N > 1 the per-structure energies are all-gathered over RCCL each step.
 
-Prints ONE JSON line (rank 0).  ``roofline`` describes the kernel with the largest share of the
-step, timed with HIP events on the engine's own stream; ``cpu_baseline`` is the CPU oracle
-(oracle/chgnet_oracle.py, a torch port of the reference path) timed on this box's host cores.
+Prints ONE JSON line (rank 0):
+  roofline       the kernel with the largest share of the step (fp32-MFMA-bound), HIP events on the engine stream
+  roofline_hbm   the HBM-bound kernels of the path against a STREAM-like copy measured in this process
+  configs        the other BASELINE.json configs: C1 (single LiMnO2 cell + x1024), C3 (ragged 10-100-atom sweep
+                 through predict_structure, sharded over the ranks), C4 (NVT MD of 2x2x2 Li9Co7O16, steps/s)
+  cpu_baseline   the CPU oracle (oracle/chgnet_oracle.py, a torch port of the reference path) timed on this
+                 box's host cores; the same leg checks the configs' results against the oracle (parity flags)
 """
 
 from __future__ import annotations
@@ -22,6 +30,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,40 +55,154 @@ KERNEL_MODEL = {
     "angleupd_bwd": ("n_angles", 32768, 780),
 }
 
+# HBM-bound kernels: (unit, compulsory bytes per unit) -- every distinct input read once, every output written once
+# (DESIGN.md "Roofline accounting", HBM regime).  Eb/Eu-dependent terms are added in hbm_model().
+LIMNO2_FRAC = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
+               [0.5, 0, 0.3608245], [0, 0.5, 0.0985135], [0.5, 0, 0.9014865], [0, 0.5, 0.6391755]]
+LIMNO2_SPECIES = ["Li", "Li", "Mn", "Mn", "O", "O", "O", "O"]
 
-def workload_structures(n_struct: int, first_seed: int):
+
+def limno2(supercell=(1, 1, 1)):
+    """mp-18767 LiMnO2 (the reference's own fixture, examples/mp-18767-LiMnO2.cif), written out so the
+    bench does not need /root/reference at run time."""
     from chgnet_amd import Structure
     from chgnet_amd.graph.structure import Lattice
 
-    lat = Lattice.from_parameters(2.868779, 4.634475, 5.832507, 90, 90, 90)
-    species = ["Li", "Li", "Mn", "Mn", "O", "O", "O", "O"]
-    frac = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
-            [0.5, 0, 0.3608245], [0, 0.5, 0.0985135], [0.5, 0, 0.9014865], [0, 0.5, 0.6391755]]
-    base = Structure(lat, species, frac).make_supercell([5, 1, 1])
+    base = Structure(Lattice.from_parameters(2.868779, 4.634475, 5.832507, 90, 90, 90), LIMNO2_SPECIES, LIMNO2_FRAC)
+    return base if tuple(supercell) == (1, 1, 1) else base.make_supercell(list(supercell))
+
+
+def workload_structures(n_struct: int, first_seed: int, supercell=(5, 1, 1)):
+    base = limno2(supercell)
     return [base.perturb(0.01, np.random.default_rng(first_seed + i)) for i in range(n_struct)]
 
 
 def build_workload(n_struct: int, first_seed: int):
-    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd import CrystalGraphConverter
+
+    conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+    return [conv(s) for s in workload_structures(n_struct, first_seed)]
+
+
+def sweep_atom_count(i: int) -> int:
+    return int(np.random.default_rng([12345, i]).integers(10, 101))
+
+
+def sweep_structure(i: int):
+    """Structure i of the SURVEY 8d "C3" sweep: random orthorhombic cell of 10-100 atoms at LiMnO2's number
+    density (0.103 atoms/A^3), species from {Li, Mn, Co, O}, sites on a jittered grid (min distance ~1.6 A)."""
+    from chgnet_amd import Structure
     from chgnet_amd.graph.structure import Lattice
 
-    # mp-18767 LiMnO2 (the reference's own fixture, examples/mp-18767-LiMnO2.cif), written out so the
-    # bench does not need /root/reference at run time
-    lat = Lattice.from_parameters(2.868779, 4.634475, 5.832507, 90, 90, 90)
-    species = ["Li", "Li", "Mn", "Mn", "O", "O", "O", "O"]
-    frac = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
-            [0.5, 0, 0.3608245], [0, 0.5, 0.0985135], [0.5, 0, 0.9014865], [0, 0.5, 0.6391755]]
-    base = Structure(lat, species, frac).make_supercell([5, 1, 1])
-    conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
-    return [conv(base.perturb(0.01, np.random.default_rng(first_seed + i))) for i in range(n_struct)]
+    rng = np.random.default_rng([12345, i])
+    n = int(rng.integers(10, 101))
+    vol = n / 0.103
+    a = vol ** (1 / 3) * rng.uniform(0.85, 1.15)
+    b = vol ** (1 / 3) * rng.uniform(0.85, 1.15)
+    m = int(np.ceil(n ** (1 / 3)))
+    grid = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    pick = rng.choice(len(grid), size=n, replace=False)
+    frac = (grid[pick] + 0.5 + rng.uniform(-0.15, 0.15, (n, 3))) / m
+    return Structure(Lattice(np.diag([a, b, vol / (a * b)])), rng.choice([3, 25, 27, 8], size=n), frac)
 
 
-def cpu_baseline(weights: dict, graphs, seconds_budget: float = 24.0) -> dict:
-    """Time the CPU oracle (port of the reference path) on a bounded sample of the same workload.
+def li9co7o16_supercell():
+    """2x2x2 supercell (256 atoms) of mp-1175469 Li9Co7O16 (reference fixture examples/mp-1175469-Li9Co7O16.cif;
+    the cell is stored with the golden cases)."""
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
 
-    The GPU box exposes 256 logical CPUs; torch's intra-op pool stops scaling (and then collapses)
-    well before that on these small graph ops, so a few thread counts are tried and the best one is
-    reported together with the thread count actually used."""
+    d = np.load(os.path.join(REPO, "tests", "golden", "case_li9co7o16.npz"))
+    return Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell([2, 2, 2])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# multi-GPU plumbing
+# ---------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """Re-execute this file under torch.distributed.run with n ranks on this node; returns its exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL over xGMI needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+class Ranks:
+    """The process group of this run (None-safe helpers for the single-process case)."""
+
+    def __init__(self, args) -> None:
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.torch = None
+        self.backend = "gloo" if args.dry_run else "nccl"   # "nccl" IS RCCL on ROCm
+        if self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
+            import torch
+            import torch.distributed as dist
+
+            self.torch, self.dist = torch, dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            kw = {}
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                kw["device_id"] = torch.device("cuda", self.local_rank)
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        elif args.gpus != 1:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {self.world}")
+
+    @property
+    def device(self):
+        return self.torch.device("cuda", self.local_rank) if self.backend == "nccl" else self.torch.device("cpu")
+
+    def all_gather(self, values: np.ndarray) -> np.ndarray:
+        """Equal-length float32 vectors of every rank, concatenated in rank order (RCCL all-gather)."""
+        if self.dist is None:
+            return values
+        mine = self.torch.from_numpy(np.ascontiguousarray(values, np.float32)).to(self.device)
+        allv = self.torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        self.dist.all_gather_into_tensor(allv, mine)
+        return allv.cpu().numpy()
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU leg: baseline timing + parity of the configs (the only place that touches oracle/)
+# ---------------------------------------------------------------------------------------------------------
+def cpu_leg(weights: dict, graphs, checks: dict, seconds_budget: float = 24.0) -> tuple[dict, dict]:
+    """Time the CPU oracle on a bounded sample of the headline workload and use it as the checker for the
+    small per-config samples collected in ``checks`` (name -> (graphs, engine results)).
+
+    The GPU box exposes 256 logical CPUs; torch's intra-op pool stops scaling (and then collapses) well before
+    that on these small graph ops, so a few thread counts are tried and the best one is reported."""
     import torch
 
     from oracle.chgnet_oracle import OracleCHGNet
@@ -98,9 +222,150 @@ def cpu_baseline(weights: dict, graphs, seconds_budget: float = 24.0) -> dict:
         rate = n_done / (time.perf_counter() - t0)
         if best is None or rate > best[0]:
             best = (rate, bs, n_done, threads)
-    return {"value": round(best[0], 3), "unit": "structures/s", "cores": best[3], "kind": "port",
-            "sample": f"{best[2]} structures of the same workload, oracle/chgnet_oracle.py (torch fp32 CPU, autograd F/S "
-                      f"like the reference), batch_size={best[1]}, best of 8/16/32 torch threads on {ncpu} logical CPUs"}
+    baseline = {
+        "value": round(best[0], 3), "unit": "structures/s", "cores": best[3], "kind": "port",
+        "sample": f"{best[2]} structures of the headline workload through oracle/chgnet_oracle.py (torch fp32 CPU restatement of the "
+                  f"reference path, autograd F/S like the reference; NOT the reference's CHGNet.predict_graph: one batched forward "
+                  f"without the per-graph BatchedGraph.from_graphs loop and without the dead third AngleUpdate, so it flatters "
+                  f"the CPU), batch_size={best[1]}, best of 8/16/32 torch threads on {ncpu} logical CPUs"}
+    torch.set_num_threads(best[3])
+    parity = {}
+    for name, (gs, got) in checks.items():
+        err = {"e": 0.0, "f": 0.0, "s": 0.0}
+        for g, r in zip(gs, got):
+            ref = model.predict_graph(g, "efs")
+            for k in err:
+                err[k] = max(err[k], float(np.abs(np.asarray(r[k], np.float64) - np.asarray(ref[k], np.float64)).max()))
+        # north-star bars: E 1e-4 eV/atom, F 1e-3 eV/A; stress 1e-2 GPa
+        parity[name] = {"n_checked": len(gs), "max_abs_err": {k: float(f"{v:.3g}") for k, v in err.items()},
+                        "ok": bool(err["e"] < 1e-4 and err["f"] < 1e-3 and err["s"] < 1e-2)}
+    return baseline, parity
+
+
+# ---------------------------------------------------------------------------------------------------------
+def hbm_model(packed) -> dict:
+    """Compulsory HBM bytes per launch of the HBM-bound kernels (all fp32 / int32)."""
+    Ed, Eu, A, Eb, N = packed.n_directed, packed.n_undirected, packed.n_angles, packed.n_bnodes, packed.n_atoms
+    return {
+        "gemm_Q": Eu * (256 + 512),                 # read h_bond row (64), write Q row (128)
+        "gemm_GQ": Eu * (512 + 256 + 256),          # read GQ row (128), read-modify-write Gb row (64)
+        "bond_embed_fwd": Eu * (16 + 8 + 512) + Eb * 256,   # ev + 2 indices in; hb0, wag (and wbgc for bond-graph nodes) out
+        "angle_embed_fwd": A * (8 + 256) + Ed * 16,         # 2 indices in, unit vectors once, angle row out
+        "edge_force": Ed * (16 + 16 + 16 + 4 * 4) + Eu * 8 + N * 12,   # ev, eu, Gu, 4 index arrays, (Grk, u2d) per bond, forces out
+    }
+
+
+def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
+    """BASELINE.json configs other than the headline; returns (configs, checks for the CPU leg)."""
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.calculator import CHGNetCalculator
+    from chgnet_amd.md import BerendsenNVT
+    from chgnet_amd.model import CHGNet
+
+    conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+    configs, checks = {}, {}
+    model = CHGNet(state_dict=weights, use_device=ranks.local_rank)
+    model._engine = eng   # one engine per GPU: share the bench's
+    model.graph_converter.set_isolated_atom_response("ignore")
+
+    def timed(fn, reps):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts), out
+
+    if ranks.rank == 0:
+        # ---- C1: the reference's plumbing case, one pristine 8-atom LiMnO2 cell -------------------------------------
+        s8 = limno2()
+        dt, pred = timed(lambda: model.predict_structure(s8, task="efsm"), 20)
+        checks["C1_single"] = ([conv(s8)], [pred])
+        g8 = conv(s8)
+        configs["C1_single"] = {
+            "workload": f"1 x mp-18767 LiMnO2 (8 atoms, {len(g8.atom_graph)} directed bonds, {len(g8.bond_graph)} angles), "
+                        "CHGNet.predict_structure task efsm, host structure in -> host dict out (graph built on the device)",
+            "ms_per_call": round(1e3 * dt, 3), "structures_per_s": round(1 / dt, 1)}
+        structs = workload_structures(args.structures, 0, supercell=(1, 1, 1))
+        b8 = eng.build_batch(structs)
+
+        def step8():
+            eng.predict(b8, "efs")
+            return eng.download(b8, "efs")
+
+        dt, _ = timed(step8, 10)
+        configs["C1_x1024"] = {
+            "workload": f"{args.structures} x perturbed LiMnO2 cell (8 atoms; {b8.packed.n_directed} directed bonds, "
+                        f"{b8.packed.n_angles} angles in the batch), task efs, device-resident",
+            "ms_per_step": round(1e3 * dt, 3), "structures_per_s": round(args.structures / dt, 1)}
+        b8.free()
+
+    # ---- C3: ragged sweep, sharded over the ranks by atom count (LPT), energies all-gathered ---------------------
+    from chgnet_amd.distributed import shard_indices
+
+    n_total = args.sweep_structures * ranks.world
+    counts = [sweep_atom_count(i) for i in range(n_total)]
+    shards = shard_indices([float(c) for c in counts], ranks.world)
+    mine = shards[ranks.rank]
+    structs = [sweep_structure(i) for i in mine]
+    model.predict_structure(structs[:8], task="efs", batch_size=8)            # warm-up
+    width = max(len(s) for s in shards)
+    best, preds = None, None
+    for _ in range(2):
+        ranks.barrier()
+        t0 = time.perf_counter()
+        preds = model.predict_structure(structs, task="efs", batch_size=args.sweep_chunk)
+        e_local = np.zeros(width, np.float32)
+        e_local[:len(preds)] = [p["e"] for p in preds]
+        table = ranks.all_gather(e_local)
+        ranks.barrier()
+        dt = ranks.max_over_ranks(time.perf_counter() - t0)
+        best = dt if best is None else min(best, dt)
+    if ranks.rank == 0:
+        sample = list(range(0, len(structs), max(1, len(structs) // 6)))[:6]
+        checks["C3_sweep"] = ([conv(structs[i]) for i in sample], [preds[i] for i in sample])
+        gs = [conv(s) for s in structs[:200]]
+        per_atom = (sum(len(g.atom_graph) for g in gs) / sum(len(s) for s in structs[:200]),
+                    sum(len(g.bond_graph) for g in gs) / sum(len(s) for s in structs[:200]))
+        configs["C3_sweep"] = {
+            "workload": f"{n_total} random orthorhombic cells of 10-100 atoms (density 0.103 atoms/A^3, species Li/Mn/Co/O, "
+                        f"default_rng([12345, i])), {sum(counts)} atoms, ~{per_atom[0]:.0f} directed bonds and ~{per_atom[1]:.0f} angles "
+                        f"per atom; host structures -> CHGNet.predict_structure(task efs, batch_size={args.sweep_chunk}) -> host dicts, "
+                        f"graphs built on the device, LPT-sharded over {ranks.world} GPU(s), energies all-gathered",
+            "seconds": round(best, 4), "structures_per_s": round(n_total / best, 1), "atoms_per_s": round(sum(counts) / best, 1),
+            "energies_gathered": int(np.isfinite(table).sum()) if ranks.world > 1 else len(preds)}
+
+    # ---- C4: NVT MD, graph rebuilt on the device every step (replicas only: rank 0) ------------------------------
+    if ranks.rank == 0:
+        cell = li9co7o16_supercell()
+        calc = CHGNetCalculator(model)
+        md = BerendsenNVT(cell, calc, temperature_K=1000.0, timestep_fs=2.0, task="ef")
+        md.run(10)
+        out = md.run(args.md_steps)
+        g = conv(md.structure)
+        checks["C4_md"] = ([g], [model.predict_structure(md.structure, task="efs")])
+        configs["C4_md"] = {
+            "workload": f"NVT (Berendsen, 1000 K, 2 fs) MD of 2x2x2 Li9Co7O16 = {len(cell)} atoms ({len(g.atom_graph)} directed bonds, "
+                        f"{len(g.bond_graph)} angles), {args.md_steps} steps through CHGNetCalculator.calculate(task ef), neighbour list "
+                        "and graph rebuilt on the device every step (in-repo integrator: ASE is not installed)",
+            "steps_per_s": round(out["steps_per_s"], 1), "ms_per_step": round(1e3 / out["steps_per_s"], 3),
+            "calculator_ms_per_step": round(1e3 * out["calculator_s"] / args.md_steps, 3),
+            "temperature_K": round(out["temperature_K"], 1)}
+    model._engine = None   # the bench owns the engine
+    return configs, checks
+
+
+def dry_run(args, ranks: Ranks) -> None:
+    """No GPU: exercises argument handling, rank spawning, the process group and the all-gather (CPU tests)."""
+    e = np.full(4, float(ranks.rank), np.float32)
+    table = ranks.all_gather(e)
+    ranks.barrier()
+    line = {"metric": "dry-run", "n_gpus": ranks.world, "ranks_in_all_gather": sorted({int(v) for v in table}),
+            "backend": ranks.backend if ranks.dist is not None else None}
+    ranks.close()
+    if ranks.rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def main() -> None:
@@ -109,50 +374,43 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1024, help="structures per GPU per step")
+    ap.add_argument("--sweep-structures", type=int, default=4000, help="C3: structures per GPU")
+    ap.add_argument("--sweep-chunk", type=int, default=1000, help="C3: batch_size handed to predict_structure")
+    ap.add_argument("--md-steps", type=int, default=300, help="C4: timed MD steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline workload only")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: process-group plumbing only (gloo)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+    if args.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))   # not under a launcher: start the N ranks ourselves
+    ranks = Ranks(args)
+    if args.dry_run:
+        return dry_run(args, ranks)
+    rank, world = ranks.rank, ranks.world
 
     from chgnet_amd.engine import Engine
     from chgnet_amd.pack import pack_batch, pack_weights
 
     weights = dict(np.load(os.path.join(REPO, "tests", "golden", "weights_seed0.npz")))
     graphs = build_workload(args.structures, first_seed=rank * args.structures)
-    eng = Engine(pack_weights(weights), local_rank)
+    eng = Engine(pack_weights(weights), ranks.local_rank)
     packed = pack_batch(graphs)
     batch = eng.upload(packed)   # inputs resident in HBM before the timed region
 
+    gathered = None
+
     def step():
+        nonlocal gathered
         eng.predict(batch, "efs")
         res = eng.download(batch, "efs")
-        if dist is not None:
-            import torch
-
-            mine = torch.from_numpy(res["e"]).cuda()
-            allv = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(allv, mine)
-            torch.cuda.synchronize()
+        if ranks.dist is not None:
+            gathered = ranks.all_gather(res["e"])
         return res
 
     def barrier():
         eng.synchronize()
-        if dist is not None:
-            import torch
-
-            dist.barrier()
-            torch.cuda.synchronize()
+        ranks.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -161,16 +419,11 @@ def main() -> None:
     for _ in range(args.steps):
         res = step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     assert np.isfinite(res["e"]).all() and np.isfinite(res["f"]).all() and np.isfinite(res["s"]).all()
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.structures / (elapsed / args.steps)
+    energies_in_gather = int(np.isfinite(gathered).sum()) if gathered is not None else args.structures
 
     # device-only time of one step and the per-kernel split (HIP events on the engine stream)
     eng.timer_start()
@@ -185,6 +438,7 @@ def main() -> None:
         eng.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
+    stream_gbs = eng.stream_copy_gbs(1 << 30, 10) if rank == 0 else None
 
     # secondary, informative only: structures on the host -> graph built on the device -> E/F/S on the host
     structs = workload_structures(args.structures, first_seed=rank * args.structures)
@@ -197,6 +451,18 @@ def main() -> None:
         e2e.append(time.perf_counter() - t0)
         b2.free()
     e2e_ms = 1e3 * min(e2e)
+
+    configs, checks = ({}, {})
+    if not args.no_configs:
+        import contextlib
+
+        with contextlib.redirect_stdout(sys.stderr):   # CHGNet / CHGNetCalculator print their banners; stdout carries ONE line
+            configs, checks = run_configs(eng, weights, ranks, args)
+    if rank == 0:
+        sample = [0, args.structures // 2, args.structures - 1]
+        o = packed.atom_off
+        checks["C2_headline"] = ([graphs[i] for i in sample],
+                                 [{"e": res["e"][i], "f": res["f"][o[i]:o[i + 1]], "s": res["s"][i]} for i in sample])
 
     line = None
     if rank == 0:
@@ -220,6 +486,18 @@ def main() -> None:
                                 frac=round(gbs / PEAK_HBM_GBS, 4))
             roofline.update(units_per_launch=int(units), flop_per_unit=flop_u, bytes_per_unit=byte_u,
                             algorithmic_gbs=round(gbs, 1), algorithmic_tflops=round(tflops, 3))
+        # every MFMA-bound tile kernel, same accounting (factorised flops)
+        tile = {}
+        step_flop = 0.0
+        for k, (unit_attr, flop_u, _) in KERNEL_MODEL.items():
+            if k in prof and prof[k][0]:
+                n_l, t_ms = prof[k]
+                fl = getattr(packed, unit_attr) * flop_u
+                step_flop += fl * n_l / prof_steps
+                tile[k] = {"avg_launch_ms": round(t_ms / n_l, 4), "tflops": round(fl / (t_ms / n_l * 1e-3) / 1e12, 2),
+                           "frac": round(fl / (t_ms / n_l * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        roofline["tile_kernels"] = tile
+        roofline["whole_step_frac"] = round(step_flop / (dev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE runs, summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction)
         roofline["traffic"] = None
@@ -231,6 +509,15 @@ def main() -> None:
                 roofline["traffic_source"] = pmc[dom]["profile"]
         except (OSError, ValueError, KeyError):
             pass
+        hbm = {"bound": "hbm", "stream_copy_gbs": round(stream_gbs, 1), "spec_gbs": PEAK_HBM_GBS, "kernels": {},
+               "note": "achieved = compulsory bytes per launch / mean launch time (HIP events); stream_copy = 1 GiB read + 1 GiB write "
+                       "device copy kernel timed in this process"}
+        for k, nbytes in hbm_model(packed).items():
+            if k in prof and prof[k][0]:
+                t_ms = prof[k][1] / prof[k][0]
+                gbs = nbytes / (t_ms * 1e-3) / 1e9
+                hbm["kernels"][k] = {"bytes_per_launch": int(nbytes), "avg_launch_ms": round(t_ms, 4), "achieved_gbs": round(gbs, 1),
+                                     "frac_of_stream": round(gbs / stream_gbs, 4), "frac_of_spec": round(gbs / PEAK_HBM_GBS, 4)}
         line = {
             "metric": "structures/s (energy+force+stress) on batched ~50-atom crystals",
             "value": round(value, 2), "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,23 +527,26 @@ def main() -> None:
                        "structures_per_gpu": args.structures, "atoms": int(packed.n_atoms), "directed_bonds": int(packed.n_directed),
                        "angles": int(packed.n_angles), "bond_graph_nodes": int(packed.n_bnodes),
                        "weights": "random-init 0.3.0 architecture (tests/golden/weights_seed0.npz)",
-                       "parallelism": f"structures sharded over {world} GPU(s), RCCL all-gather of energies only"},
+                       "parallelism": f"structures sharded over {world} GPU(s), RCCL all-gather of energies only",
+                       "process_group_ranks": world, "energies_in_all_gather": energies_in_gather},
             "device_ms_per_step": round(dev_ms, 3),
             "end_to_end": {"what": "host structures -> device graph build (chg_batch_build) -> predict -> E/F/S on host, per GPU",
                            "ms": round(e2e_ms, 3), "structures_per_s": round(args.structures / (e2e_ms * 1e-3), 1)},
             "device_bytes": batch.device_bytes,
             "roofline": roofline,
+            "roofline_hbm": hbm,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in ranked},
+            "configs": configs,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(weights, graphs[:128])
+            line["cpu_baseline"], parity = cpu_leg(weights, graphs[:128], checks)
+            for name, p in parity.items():
+                line["configs"].setdefault(name, {})["parity_vs_oracle"] = p
         else:
             line["cpu_baseline"] = None
     batch.free()
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     if line is not None:
         print(json.dumps(line), flush=True)
 

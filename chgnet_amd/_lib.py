@@ -17,6 +17,8 @@ EXPORTED_SYMBOLS = (
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
     "chg_debug_fetch", "chg_test_rows_gemm",
+    "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
+    "chg_stream_copy",
 )
 
 
@@ -80,6 +82,10 @@ def load() -> ctypes.CDLL:
     lib.chg_engine_destroy.argtypes = [vp]
     lib.chg_last_error.argtypes = [vp]
     lib.chg_last_error.restype = ctypes.c_char_p
+    lib.chg_engine_set_memory_limit.argtypes = [vp, ctypes.c_int64]
+    lib.chg_engine_memory_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.chg_batch_bytes_required.argtypes = [ctypes.c_int32] * 6
+    lib.chg_batch_bytes_required.restype = ctypes.c_int64
     lib.chg_batch_upload.argtypes = [vp, ctypes.POINTER(BatchHost), ctypes.POINTER(vp)]
     lib.chg_batch_build.argtypes = [vp, ctypes.POINTER(StructsHost), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.POINTER(vp), c_int_p]
@@ -93,6 +99,7 @@ def load() -> ctypes.CDLL:
     lib.chg_batch_download.argtypes = [vp, vp, ctypes.POINTER(OutHost)]
     lib.chg_timer_start.argtypes = [vp]
     lib.chg_timer_stop_ms.argtypes = [vp, c_float_p]
+    lib.chg_stream_copy.argtypes = [vp, ctypes.c_int64, ctypes.c_int, c_float_p]
     lib.chg_profile_enable.argtypes = [vp, ctypes.c_int]
     lib.chg_profile_reset.argtypes = [vp]
     lib.chg_profile_count.argtypes = [vp]

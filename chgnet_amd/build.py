@@ -74,6 +74,8 @@ def build_variant(name: str, defines: list[str], extra_flags: list[str] | None =
     """Experiment build (timing studies only): libchgnet_hip_<name>.so with extra -D / compiler flags."""
     out = os.path.join(LIB_DIR, f"libchgnet_hip_{name}.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    if any(d.startswith(("CHG_EXP_", "CHG_PHASE_TIMING")) for d in defines) and "CHG_EXPERIMENTS" not in defines:
+        defines = [*defines, "CHG_EXPERIMENTS"]   # mfma_tile.h refuses experiment switches without it
     _run([hipcc_path(), *HIP_FLAGS, *(extra_flags or []), *[f"-D{d}" for d in defines], f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", out])
     return out
 

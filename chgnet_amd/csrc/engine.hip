@@ -75,6 +75,7 @@ struct chg_engine {
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
   int num_cus = 256;
+  size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
 };
 
 struct chg_batch {
@@ -703,6 +704,10 @@ int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n
 }
 
 int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
+  if (eng->memory_limit && total > eng->memory_limit) {
+    eng->err = "batch needs " + std::to_string(total) + " bytes of device memory, the engine's limit is " + std::to_string(eng->memory_limit);
+    return CHG_ENOMEM;
+  }
   int best = -1;
   for (int i = 0; i < (int)eng->arena_pool.size(); ++i)
     if (eng->arena_pool[i].second >= total && (best < 0 || eng->arena_pool[i].second < eng->arena_pool[best].second)) best = i;
@@ -959,6 +964,32 @@ int chg_engine_destroy(chg_engine* eng) {
 
 const char* chg_last_error(const chg_engine* eng) { return eng ? eng->err.c_str() : "null engine"; }
 
+int chg_engine_set_memory_limit(chg_engine* eng, int64_t bytes) {
+  if (!eng || bytes < 0) return CHG_EINVAL;
+  eng->memory_limit = (size_t)bytes;
+  return CHG_OK;
+}
+
+int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!eng) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  size_t f = 0, t = 0;
+  HIP_TRY(eng, hipMemGetInfo(&f, &t));
+  for (auto& a : eng->arena_pool) f += a.second;   // pooled arenas are reusable
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return CHG_OK;
+}
+
+int64_t chg_batch_bytes_required(int32_t n_conv, int32_t n_struct, int32_t n_atoms, int32_t n_directed, int32_t n_angles, int32_t n_bnodes) {
+  if (n_conv < 2 || n_conv > MAX_CONV || n_struct < 0 || n_atoms < 0 || n_directed < 0 || (n_directed & 1) || n_angles < 0 || n_bnodes < 0) return -1;
+  chg_batch probe{};
+  probe.B = n_struct; probe.N = n_atoms; probe.Ed = n_directed; probe.Eu = n_directed / 2; probe.A = n_angles; probe.Eb = n_bnodes; probe.L = n_conv;
+  size_t total = 0;
+  carve(&probe, nullptr, total);
+  return (int64_t)total;
+}
+
 int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) {
   if (!eng || !h || !out) return CHG_EINVAL;
   if (h->n_struct <= 0 || h->n_atoms <= 0 || h->n_directed < 0 || h->n_directed != 2 * h->n_undirected || h->n_angles < 0 ||
@@ -1135,6 +1166,36 @@ int chg_debug_fetch(chg_engine* eng, chg_batch* b, const char* name, float* dst,
   if (n) HIP_TRY(eng, hipMemcpy(dst, it->second.first, n * sizeof(float), hipMemcpyDeviceToHost));
   if (n_written) *n_written = (int64_t)n;
   return CHG_OK;
+}
+
+// STREAM-like copy (read + write of `bytes` each) on the engine's stream: the measured HBM ceiling that the
+// HBM-bound kernels of the path are reported against (bench.py roofline_hbm).
+__global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+int chg_stream_copy(chg_engine* eng, int64_t bytes, int iters, float* ms_per_iter) {
+  if (!eng || bytes < 4096 || iters <= 0 || !ms_per_iter) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  char *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, (size_t)bytes) != hipSuccess) { eng->err = "chg_stream_copy: allocation failed"; return CHG_ENOMEM; }
+  if (hipMalloc(&b, (size_t)bytes) != hipSuccess) { hipFree(a); eng->err = "chg_stream_copy: allocation failed"; return CHG_ENOMEM; }
+  const size_t n = (size_t)bytes / sizeof(f32x4);
+  const dim3 grid((unsigned)(16 * eng->num_cus)), block(256);
+  hipMemsetAsync(a, 1, (size_t)bytes, eng->stream);
+  hipLaunchKernelGGL(k_stream_copy, grid, block, 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);   // warm-up (page faults, clocks)
+  hipEvent_t e0 = get_event(eng), e1 = get_event(eng);
+  hipEventRecord(e0, eng->stream);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_stream_copy, grid, block, 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
+  hipEventRecord(e1, eng->stream);
+  int s = CHG_OK;
+  float ms = 0.f;
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { eng->err = "chg_stream_copy: timing failed"; s = CHG_EHIP; }
+  eng->event_pool.push_back(e0); eng->event_pool.push_back(e1);
+  hipFree(a); hipFree(b);
+  *ms_per_iter = ms / iters;
+  return s;
 }
 
 int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const float* bias, float* y, int rows, int k, int nout) {

@@ -147,7 +147,9 @@ __device__ __forceinline__ void edge_gv(const ForceArgs& p, int e, float (&gv)[3
 // F_i = -sum_{c_e = i} gv_e + sum_{n_e = i} gv_e, and every edge with n_e = i is the reverse of an edge
 // with c_e = i, so each thread forms gv_rev(e) - gv_e for its own edge and the force is a segmented sum
 // over runs of equal centre (edges are centre-major): a wave-level segmented scan and one atomic per
-// run end replace 6 same-address atomics per edge.  Any edge order stays correct (shorter runs).
+// run end replace 6 same-address atomics per edge.  Runs are delimited by head flags (lane 0 or a key
+// change), not by key equality alone, so hand-built graphs whose edges are not centre-major ([A,B,A])
+// stay correct: they only make the runs shorter.
 __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -167,12 +169,14 @@ __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
     owner = p.e_owner[e];
     key = p.e_center[e];
   }
-  // segmented inclusive scan over runs of equal key
+  // segmented inclusive scan over runs of equal key: `start` = first lane of this lane's run
+  const int kprev = __shfl_up(key, 1);
+  const unsigned long long heads = __ballot(lane == 0 || kprev != key);
+  const int start = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const int k2 = __shfl_up(key, off);
     const float t0 = __shfl_up(d[0], off), t1 = __shfl_up(d[1], off), t2 = __shfl_up(d[2], off);
-    if (lane >= off && k2 == key) {
+    if (lane - off >= start) {
       d[0] += t0;
       d[1] += t1;
       d[2] += t2;

@@ -24,6 +24,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-experiment switches (several of them compute WRONG results on purpose: dropped atomics, stores
+// instead of adds).  None may be set in a product build: every one requires -DCHG_EXPERIMENTS next to
+// it (chgnet_amd/build.py:build_variant adds it; tests/test_abi.py checks that HIP_FLAGS define none).
+#if !defined(CHG_EXPERIMENTS) &&                                                                                  \
+    (defined(CHG_EXP_ATOMIC_AS_STORE) || defined(CHG_EXP_GEMM_T_PLAIN) || defined(CHG_EXP_HALF_ROW_ATOMICS) ||     \
+     defined(CHG_EXP_NO_GATHER) || defined(CHG_EXP_NO_ROW_ATOMICS) || defined(CHG_EXP_NO_SEG_ATOMICS) ||           \
+     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_PHASE_TIMING))
+#error "CHG_EXP_* / CHG_PHASE_TIMING are timing experiments: define CHG_EXPERIMENTS as well (never in a product build)"
+#endif
+
 namespace chg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -16,7 +16,11 @@ import numpy as np
 
 
 def structure_cost(graph) -> float:
-    """Cost proxy of one structure = GEMM flops of the reference formulation."""
+    """Cost proxy of one structure = GEMM flops of the reference formulation.  A structure
+    without a graph yet (``CHGNet.predict_structure`` builds it on the device) is charged by its atom count:
+    bonds and angles per atom are set by the density, which varies little inside one dataset."""
+    if not hasattr(graph, "atom_graph"):
+        return float(len(graph))
     n_dir = len(graph.atom_graph)
     n_ang = len(graph.bond_graph)
     return 262144.0 * n_dir + 380800.0 * n_ang + 57472.0 * len(graph.atomic_number)
@@ -57,8 +61,10 @@ def all_gather_energies(local_e: np.ndarray, shards: list[list[int]], n_total: i
 
 
 def predict_sharded(predict_fn: Callable, graphs: Sequence, *, task: str = "efs", gather_energies: bool = True, **kwargs):
-    """Each rank predicts its own shard with ``predict_fn(list_of_graphs, task=..., **kwargs)``
-    (e.g. ``CHGNet.predict_graph`` bound to the rank's GPU).
+    """Each rank predicts its own shard with ``predict_fn(list_of_graphs, task=..., **kwargs)``:
+    ``CHGNet.predict_graph`` for CrystalGraphs, or ``CHGNet.predict_structure`` for structures -- the
+    graph of every structure is then built on the owning rank's GPU (chg_batch_build), nothing is
+    converted on the host.
 
     Returns ``(local, energies)``: ``local`` maps original structure index -> prediction dict for the
     structures this rank owns; ``energies`` is the all-gathered float32 table of every structure (or

@@ -8,7 +8,7 @@ import numpy as np
 
 from chgnet_amd import _lib
 from chgnet_amd.graph.structure import atomic_numbers_of
-from chgnet_amd.pack import D, PackedBatch, PackedWeights, pack_batch
+from chgnet_amd.pack import D, PackedBatch, PackedWeights, _check_z, pack_batch
 
 
 def _fp(a: np.ndarray):
@@ -17,6 +17,11 @@ def _fp(a: np.ndarray):
 
 def _ip(a: np.ndarray):
     return a.ctypes.data_as(_lib.c_int_p)
+
+
+class EngineOutOfMemory(RuntimeError):
+    """CHG_ENOMEM: the batch arena could not be allocated (or exceeds ``Engine.set_memory_limit``).
+    The engine stays usable; ``CHGNet.predict_*`` answer by splitting the chunk."""
 
 
 class DeviceBatch:
@@ -87,7 +92,22 @@ class Engine:
 
     def _check(self, status: int) -> None:
         if status != 0:
-            raise RuntimeError(f"chgnet_hip error {status}: {self.lib.chg_last_error(self.handle).decode()}")
+            msg = f"chgnet_hip error {status}: {self.lib.chg_last_error(self.handle).decode()}"
+            raise EngineOutOfMemory(msg) if status == -3 else RuntimeError(msg)
+
+    def set_memory_limit(self, n_bytes: int) -> None:
+        """Refuse batch arenas above ``n_bytes`` with ``EngineOutOfMemory`` (0 = no limit)."""
+        self._check(self.lib.chg_engine_set_memory_limit(self.handle, int(n_bytes)))
+
+    def memory_info(self) -> tuple[int, int]:
+        """(free, total) device bytes; arenas pooled for reuse count as free."""
+        free, total = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.chg_engine_memory_info(self.handle, ctypes.byref(free), ctypes.byref(total)))
+        return int(free.value), int(total.value)
+
+    def bytes_required(self, n_struct: int, n_atoms: int, n_directed: int, n_angles: int, n_bnodes: int) -> int:
+        """Exact arena size of a batch with these counts (chg_batch_bytes_required)."""
+        return int(self.lib.chg_batch_bytes_required(self.weights.n_conv, n_struct, n_atoms, n_directed, n_angles, n_bnodes))
 
     def close(self) -> None:
         if self.handle:
@@ -114,6 +134,7 @@ class Engine:
         n_at = np.array([len(s) for s in structures], dtype=np.int64)
         a_off = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int32)
         z = np.ascontiguousarray(np.concatenate([atomic_numbers_of(s) for s in structures]), dtype=np.int32)
+        _check_z(z)
         frac = np.ascontiguousarray(np.concatenate([np.asarray(s.frac_coords, dtype=np.float64).reshape(-1, 3) for s in structures]))
         lattice = np.ascontiguousarray(np.stack([np.asarray(s.lattice.matrix, dtype=np.float64) for s in structures]))
         host = _lib.StructsHost(len(structures), int(a_off[-1]), _ip(z), frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
@@ -178,6 +199,12 @@ class Engine:
         ms = ctypes.c_float()
         self._check(self.lib.chg_timer_stop_ms(self.handle, ctypes.byref(ms)))
         return float(ms.value)
+
+    def stream_copy_gbs(self, n_bytes: int = 1 << 30, iters: int = 10) -> float:
+        """Measured HBM copy rate in GB/s (read + write counted), chg_stream_copy."""
+        ms = ctypes.c_float()
+        self._check(self.lib.chg_stream_copy(self.handle, int(n_bytes), int(iters), ctypes.byref(ms)))
+        return 2.0 * n_bytes / (ms.value * 1e-3) / 1e9
 
     def profile(self, on: bool) -> None:
         self._check(self.lib.chg_profile_enable(self.handle, int(on)))

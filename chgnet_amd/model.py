@@ -164,10 +164,60 @@ class CHGNet:
     def eval(self) -> "CHGNet":
         return self
 
+    # ---- batched forward (model.py:330-387) -----------------------------------------------------------
+    def forward(self, graphs: Sequence, *, task: str = "e", return_site_energies: bool = False,
+                return_atom_feas: bool = False, return_crystal_feas: bool = False) -> dict:
+        """One device batch from ``graphs`` -> the reference's batch dictionary (model.py:330-387, 427-542):
+        ``atoms_per_graph`` int64 [B], ``e`` float32 [B] (eV/atom when ``is_intensive``), and -- by task --
+        ``f`` list of [n,3] (eV/A), ``s`` list of [3,3] (GPa), ``m`` list of [n] (mu_B); optional
+        ``site_energies`` list of [n], ``atom_fea`` list of [n,64] (features before the last AtomConv),
+        ``crystal_fea`` [B,64].  Values are host numpy arrays (the reference returns torch tensors that
+        carry an autograd graph; here parameter gradients come from ``backward``, which consumes the
+        device-resident state this call leaves behind)."""
+        if task not in VALID_TASKS:
+            raise ValueError(f"Invalid {task=}. Must be one of {VALID_TASKS}.")
+        graphs = [graphs] if _is_graph(graphs) else list(graphs)
+        eng = self.engine
+        packed = pack_batch(graphs)
+        self.release_forward_state()
+        batch = eng.upload(packed)
+        self._fwd_batch, self._fwd_task = batch, task
+        eng.predict(batch, task)
+        res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,
+                           crystal_feas=return_crystal_feas)
+        off = packed.atom_off
+        split = lambda a: [a[off[i]:off[i + 1]] for i in range(len(graphs))]  # noqa: E731
+        out: dict = {"atoms_per_graph": np.diff(off).astype(np.int64), "e": res["e"]}
+        for key in ("f", "m", "site_energies", "atom_fea"):
+            if key in res:
+                out[key] = split(res[key])
+        if "s" in res:
+            out["s"] = [res["s"][i] for i in range(len(graphs))]
+        if "crystal_fea" in res:
+            out["crystal_fea"] = res["crystal_fea"]
+        return out
+
+    __call__ = forward
+
+    def release_forward_state(self) -> None:
+        """Free the device batch kept by the last ``forward`` call."""
+        batch = getattr(self, "_fwd_batch", None)
+        if batch is not None:
+            batch.free()
+        self._fwd_batch = None
+
     # ---- prediction (model.py:544-665) ---------------------------------------------------------------
     def predict_structure(self, structure, *, task: str = "efsm", return_site_energies: bool = False,
-                          return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16):
-        """Predict from structure(s) (pymatgen ``Structure`` or ``chgnet_amd.Structure``)."""
+                          return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16,
+                          min_atoms_per_batch: int | None = None):
+        """Predict from structure(s) (pymatgen ``Structure`` or ``chgnet_amd.Structure``).
+
+        ``batch_size`` is the reference's memory knob (model.py:639-650).  Here it is the MINIMUM number of
+        structures per device batch: a chunk keeps growing until it holds ``min_atoms_per_batch`` atoms
+        (default ``self.min_atoms_per_batch`` = 40,960), because per-structure results do not depend on the
+        chunking and 16 small cells leave most of an MI355X idle.  Pass ``min_atoms_per_batch=0`` to make
+        ``batch_size`` the hard cap it is in the reference.  A chunk whose arena does not fit in device
+        memory is split in two and retried (``EngineOutOfMemory`` only for a single structure)."""
         if self.graph_converter is None:
             raise ValueError("graph_converter cannot be None!")
         single = _is_structure(structure)
@@ -179,29 +229,36 @@ class CHGNet:
         # tests/test_gpu_parity.py::test_device_graph_build_is_bit_exact); the host converter is only
         # consulted to phrase the reference's isolated-atom error / warning for the offending structure.
         conv, eng = self.graph_converter, self.engine
-        predictions: list[dict] = []
-        for start, stop in _plan_chunks([len(s) for s in structures], batch_size, self.min_atoms_per_batch):
-            chunk = structures[start:stop]
+        flags = dict(site_energies=return_site_energies, atom_feas=return_atom_feas, crystal_feas=return_crystal_feas)
+
+        def run(chunk):
             batch = eng.build_batch(chunk, conv.atom_graph_cutoff, conv.bond_graph_cutoff)
             try:
                 if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
                     for struct in chunk:          # raises ValueError / prints the warning like converter.py:161-174
                         conv(struct)
                 eng.predict(batch, task)
-                res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,
-                                   crystal_feas=return_crystal_feas)
+                res = eng.download(batch, task, **flags)
             finally:
                 batch.free()
-            predictions.extend(_split_results(res, batch.packed.atom_off, len(chunk)))
-        return predictions[0] if single else predictions
+            return _split_results(res, batch.packed.atom_off, len(chunk))
+
+        predictions: list[dict] = []
+        floor = self.min_atoms_per_batch if min_atoms_per_batch is None else int(min_atoms_per_batch)
+        for start, stop in _plan_chunks([len(s) for s in structures], batch_size, floor):
+            predictions.extend(_run_splitting(run, structures[start:stop]))
+        # like the reference, which hands the list to predict_graph: a one-element list gives a bare dict (model.py:665)
+        return predictions[0] if len(structures) == 1 else predictions
 
     def predict_graph(self, graph, *, task: str = "efsm", return_site_energies: bool = False,
-                      return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16):
+                      return_atom_feas: bool = False, return_crystal_feas: bool = False, batch_size: int = 16,
+                      min_atoms_per_batch: int | None = None):
         """Predict from CrystalGraph(s).
 
         Returns a dict (single graph) or list of dicts with float32 numpy arrays:
         e () eV/atom, f (n,3) eV/A, s (3,3) GPa, m (n,) mu_B, and optionally
         site_energies (n,), atom_fea (n,64), crystal_fea (64,).
+        ``batch_size`` / ``min_atoms_per_batch``: see ``predict_structure``.
         """
         if not (_is_graph(graph) or isinstance(graph, Sequence)):
             raise TypeError(f"{type(graph)=} must be CrystalGraph or list of CrystalGraphs")
@@ -209,20 +266,23 @@ class CHGNet:
         if task not in valid_tasks:
             raise ValueError(f"Invalid {task=}. Must be one of {valid_tasks}.")
         graphs = [graph] if _is_graph(graph) else list(graph)
-        predictions: list[dict] = [{} for _ in range(len(graphs))]
         eng = self.engine
-        for start, stop in _plan_chunks([len(g.atomic_number) for g in graphs], batch_size, self.min_atoms_per_batch):
-            chunk = graphs[start:stop]
+        flags = dict(site_energies=return_site_energies, atom_feas=return_atom_feas, crystal_feas=return_crystal_feas)
+
+        def run(chunk):
             packed = pack_batch(chunk)
             batch = eng.upload(packed)
             try:
                 eng.predict(batch, task)
-                res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,
-                                   crystal_feas=return_crystal_feas)
+                res = eng.download(batch, task, **flags)
             finally:
                 batch.free()
-            for i, pred in enumerate(_split_results(res, packed.atom_off, len(chunk))):
-                predictions[start + i] = pred
+            return _split_results(res, packed.atom_off, len(chunk))
+
+        predictions: list[dict] = []
+        floor = self.min_atoms_per_batch if min_atoms_per_batch is None else int(min_atoms_per_batch)
+        for start, stop in _plan_chunks([len(g.atomic_number) for g in graphs], batch_size, floor):
+            predictions.extend(_run_splitting(run, graphs[start:stop]))
         return predictions[0] if len(graphs) == 1 else predictions
 
     # ---- (de)serialisation (model.py:667-745) ----------------------------------------------------------
@@ -265,6 +325,20 @@ class CHGNet:
         if verbose:
             print(f"CHGNet will run on {model.device}")
         return model
+
+
+def _run_splitting(run, chunk: list) -> list[dict]:
+    """``run(chunk)``; when the device cannot hold the chunk's arena (EngineOutOfMemory) the chunk is halved
+    and both halves are run the same way.  A single structure that does not fit raises."""
+    from chgnet_amd.engine import EngineOutOfMemory  # noqa: PLC0415
+
+    try:
+        return run(chunk)
+    except EngineOutOfMemory:
+        if len(chunk) <= 1:
+            raise
+    mid = len(chunk) // 2
+    return _run_splitting(run, chunk[:mid]) + _run_splitting(run, chunk[mid:])
 
 
 def _plan_chunks(n_atoms: list[int], batch_size: int, min_atoms: int) -> list[tuple[int, int]]:

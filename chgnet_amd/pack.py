@@ -86,6 +86,27 @@ def pack_batch(graphs) -> PackedBatch:
     arr["a_b2"] = cat([g.bond_graph[:, 3] + u_off[i] for i, g in enumerate(graphs)], np.int32)
     arr["a_d2"] = cat([g.bond_graph[:, 4] + e_off[i] for i, g in enumerate(graphs)], np.int32)
 
+    # Range checks before anything reaches the device: graphs may come from user code or from .pt cache
+    # files (CrystalGraph.from_file), and an out-of-range index would be an out-of-bounds device read or
+    # atomic write.  The reference fails the same inputs with IndexError (nn.Embedding(94), index_select).
+    a_owner = np.repeat(np.arange(B, dtype=np.int64), n_an)
+    e_owner64 = arr["e_owner"].astype(np.int64)
+    u_owner = np.repeat(np.arange(B, dtype=np.int64), n_un)
+    _check_z(arr["z"])
+    _check_index(arr["e_center"], a_off, e_owner64, "atom_graph[:, 0]")
+    _check_index(arr["e_nbr"], a_off, e_owner64, "atom_graph[:, 1]")
+    _check_index(arr["e_d2u"], u_off, e_owner64, "directed2undirected")
+    _check_index(arr["u_u2d"], e_off, u_owner, "undirected2directed")
+    _check_index(arr["a_ctr"], a_off, a_owner, "bond_graph[:, 0]")
+    _check_index(arr["a_b1"], u_off, a_owner, "bond_graph[:, 1]")
+    _check_index(arr["a_d1"], e_off, a_owner, "bond_graph[:, 2]")
+    _check_index(arr["a_b2"], u_off, a_owner, "bond_graph[:, 3]")
+    _check_index(arr["a_d2"], e_off, a_owner, "bond_graph[:, 4]")
+    if Eu and not (np.bincount(arr["e_d2u"], minlength=Eu) == 2).all():
+        raise ValueError("directed2undirected must map exactly two directed edges onto every undirected edge")
+    if Eu and not (arr["e_d2u"][arr["u_u2d"]] == np.arange(Eu)).all():
+        raise ValueError("undirected2directed[k] must be a directed edge of undirected edge k")
+
     # compact numbering of bond-graph nodes (monotone in the undirected index, so the
     # angle rows stay sorted by their owning bond: graph.py:283-327 emits them that way)
     is_node = np.zeros(Eu, dtype=bool)
@@ -120,6 +141,23 @@ def pack_batch(graphs) -> PackedBatch:
     return PackedBatch(B, N, Ed, Eu, A, int(len(bn_und)), arr)
 
 
+def _check_z(z) -> None:
+    """1 <= Z <= 94 (rows of the atom embedding / AtomRef tables, model.py:432-434)."""
+    z = np.asarray(z)
+    if z.size and (int(z.min()) < 1 or int(z.max()) > N_ELEM):
+        bad = z[(z < 1) | (z > N_ELEM)][0]
+        raise IndexError(f"atomic number {int(bad)} is out of range: the atom embedding has {N_ELEM} rows (Z = 1..{N_ELEM})")
+
+
+def _check_index(idx, offsets, owner, what: str) -> None:
+    """Every global index must lie inside its own structure's [offsets[b], offsets[b+1])."""
+    if len(idx) == 0:
+        return
+    lo, hi = offsets[owner], offsets[owner + 1]
+    if not ((idx >= lo) & (idx < hi)).all():
+        raise IndexError(f"{what} holds an index outside its structure")
+
+
 # ---------------------------------------------------------------------------------------
 # weights
 # ---------------------------------------------------------------------------------------
@@ -151,6 +189,11 @@ def check_model_args(model_args: dict) -> None:
         raise NotImplementedError("gated final_mlp is not implemented")
     if int(model_args.get("n_conv", 4)) < 2:
         raise NotImplementedError("n_conv must be >= 2")
+    p = model_args.get("cutoff_coeff", 8)
+    if float(p) != int(p) or int(p) < 1:
+        # basis.py:170-206: p = 0 means "no envelope" and any positive float is allowed there; the kernels
+        # evaluate s^(p-1) by repeated squaring, so only integer p >= 1 (every released checkpoint: 5 or 8)
+        raise NotImplementedError(f"cutoff_coeff={p!r} is not implemented (supports integers >= 1)")
 
 
 def _f32(x):

@@ -103,6 +103,16 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
 int chg_engine_destroy(chg_engine* eng);
 const char* chg_last_error(const chg_engine* eng);
 
+/* Device-memory contract.  A batch lives in ONE arena (inputs + every activation / gradient buffer of the
+ * forward and reverse sweeps); chg_batch_bytes_required gives its exact size from the counts alone, so a
+ * caller can size chunks before uploading (the reference's only memory knob is batch_size,
+ * chgnet/model/model.py:639-650).  chg_batch_upload / chg_batch_build return CHG_ENOMEM -- and leave the
+ * engine usable -- when the arena cannot be allocated or exceeds the limit set here (0 = no limit); the
+ * host side then splits the chunk and retries (chgnet_amd/model.py). */
+int chg_engine_set_memory_limit(chg_engine* eng, int64_t bytes);
+int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_bytes);
+int64_t chg_batch_bytes_required(int32_t n_conv, int32_t n_struct, int32_t n_atoms, int32_t n_directed, int32_t n_angles, int32_t n_bnodes);
+
 int chg_batch_upload(chg_engine* eng, const chg_batch_host* host, chg_batch** out);
 
 /* Structures only (no graph): the periodic neighbour list, bond numbering and bond graph are built on
@@ -133,6 +143,10 @@ int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* ou
 /* Wall time of the stream between two marks, from HIP events recorded on the engine's stream. */
 int chg_timer_start(chg_engine* eng);
 int chg_timer_stop_ms(chg_engine* eng, float* elapsed_ms);
+
+/* STREAM-like device copy of `bytes` (read + write) repeated `iters` times on the engine's stream; the average
+ * time of one copy.  2 * bytes / time is the measured HBM ceiling quoted next to the HBM-bound kernels. */
+int chg_stream_copy(chg_engine* eng, int64_t bytes, int iters, float* ms_per_iter);
 
 /* Per-kernel profile: when enabled every launch is bracketed by HIP events on the engine's
  * stream.  chg_profile_read returns, for entry i, the kernel label, launch count and total ms. */

@@ -112,3 +112,18 @@ def test_unsupported_architectures_are_rejected(golden_weights):
         pack_weights(golden_weights, {"mlp_first": False})
     with pytest.raises(NotImplementedError, match="gMLP_norm"):
         pack_weights(golden_weights, {"gMLP_norm": "batch"})
+
+
+def test_product_build_defines_no_experiment_switch():
+    """CHG_EXP_* / CHG_PHASE_TIMING select timing experiments that compute wrong results; the product
+    build must define none of them, and the headers refuse them without CHG_EXPERIMENTS."""
+    from chgnet_amd import build
+
+    assert not any("CHG_EXP" in f or "CHG_PHASE_TIMING" in f for f in build.HIP_FLAGS)
+    hdr = open(os.path.join(REPO, "chgnet_amd", "csrc", "mfma_tile.h")).read()
+    used = set()
+    for root, _, files in os.walk(os.path.join(REPO, "chgnet_amd", "csrc")):
+        for f in files:
+            used |= set(re.findall(r"\b(CHG_EXP_[A-Z0-9_]+|CHG_PHASE_TIMING)\b", open(os.path.join(root, f)).read()))
+    guard = hdr[hdr.index("#if !defined(CHG_EXPERIMENTS)"):hdr.index("#error")]
+    assert used and all(f"defined({name})" in guard for name in used), used

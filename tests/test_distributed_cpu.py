@@ -69,3 +69,35 @@ def test_two_rank_gloo_shard_and_allgather(tmp_path):
     for r in (r0, r1):
         for i in r["owned"]:
             assert np.abs(r[f"f{i}"] - load_case(NAMES[i])[1]["out_f"]).max() < 3e-6
+
+
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` outside a launcher starts 2 ranks itself (torch.distributed.run), builds the
+    process group and all-gathers across them; --dry-run swaps RCCL for gloo and skips the GPU work."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE json line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_in_all_gather"] == [0, 1] and line["backend"] == "gloo"
+    # under a launcher --gpus must agree with the world size
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE is 1" in bad.stderr
+
+
+def test_sharding_accepts_structures_without_graphs():
+    from bench import sweep_structure
+
+    structs = [sweep_structure(i) for i in range(12)]
+    costs = [structure_cost(s) for s in structs]
+    assert costs == [float(len(s)) for s in structs]
+    shards = shard_indices(costs, 2)
+    loads = [sum(costs[i] for i in sh) for sh in shards]
+    assert abs(loads[0] - loads[1]) <= max(costs)

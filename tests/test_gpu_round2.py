@@ -1,0 +1,194 @@
+"""GPU tests added in round 2: edge-order independence, memory contract, ``CHGNet.forward``, the full-size
+batch against the oracle fixture, and the device graph builder against the reference's compiled C builder."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_case
+from test_gpu_parity import TOL, _oracle, _predict, _split, _structures_for_graph_tests
+
+pytestmark = pytest.mark.gpu
+
+
+def _permute_directed_edges(g, perm):
+    """The same graph with its directed edges listed in another order (new position i holds old edge perm[i])."""
+    from chgnet_amd.graph.crystalgraph import CrystalGraph
+
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    bg = g.bond_graph.copy()
+    if len(bg):
+        bg[:, 2] = inv[bg[:, 2]]
+        bg[:, 4] = inv[bg[:, 4]]
+    return CrystalGraph(atomic_number=g.atomic_number, atom_frac_coord=g.atom_frac_coord, atom_graph=g.atom_graph[perm],
+                        atom_graph_cutoff=6, neighbor_image=g.neighbor_image[perm], directed2undirected=g.directed2undirected[perm],
+                        undirected2directed=inv[g.undirected2directed].astype(np.int32), bond_graph=bg, bond_graph_cutoff=3,
+                        lattice=g.lattice)
+
+
+@pytest.mark.parametrize("name", ["limno2", "s16tri", "s40"])
+def test_edge_order_does_not_matter(hip_engine, name):
+    """predict_graph takes hand-built graphs in ANY edge order (the reference's index_add_ does); the force
+    kernel's segmented scan must not merge two separate runs of one centre atom ([A, B, A])."""
+    g, d = load_case(name)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(g.atom_graph))
+    # interleaved: centre-major blocks dealt round-robin, so equal centres recur inside one wave
+    order = np.argsort(np.arange(len(g.atom_graph)) % 7, kind="stable")
+    for p in (perm, order):
+        batch, res = _predict(hip_engine, [_permute_directed_edges(g, p), g])
+        a, b = _split(res, batch.packed)
+        batch.free()
+        for key in ("e", "f", "s", "m"):
+            assert np.abs(a[key] - d["out_" + key]).max() < TOL[key], (name, key)
+            assert np.abs(a[key] - b[key]).max() < TOL[key], (name, key)
+
+
+def test_memory_limit_splits_chunks_and_keeps_results(hip_engine, golden_weights):
+    """batch_size / device-memory contract: an arena above the engine's limit is refused with CHG_ENOMEM, the
+    host halves the chunk and retries; results are those of the unrestricted run."""
+    import bench
+    from chgnet_amd.engine import EngineOutOfMemory
+    from chgnet_amd.model import CHGNet
+
+    structs = bench.workload_structures(48, 100)
+    model = CHGNet(state_dict=golden_weights)
+    model._engine = hip_engine
+    free, total = hip_engine.memory_info()
+    assert 0 < free <= total
+    want = model.predict_structure(structs, task="efs", batch_size=48)
+    full = hip_engine.build_batch(structs)
+    need = full.device_bytes
+    assert need == hip_engine.bytes_required(48, full.packed.n_atoms, full.packed.n_directed, full.packed.n_angles, full.packed.n_bnodes)
+    full.free()
+    builds = []
+    orig = hip_engine.build_batch
+    hip_engine.build_batch = lambda chunk, *a, **k: (builds.append(len(chunk)), orig(chunk, *a, **k))[1]
+    try:
+        hip_engine.set_memory_limit(need // 3)
+        got = model.predict_structure(structs, task="efs", batch_size=48)
+        assert builds[0] == 48 and len(builds) > 3 and max(builds[1:]) <= 24
+        for a, b in zip(got, want):
+            for key in ("e", "f", "s"):
+                assert np.abs(a[key] - b[key]).max() < 2e-6, key
+        # batch_size is a hard cap when the atom floor is switched off (the reference's meaning)
+        builds.clear()
+        hip_engine.set_memory_limit(0)
+        model.predict_structure(structs, task="e", batch_size=5, min_atoms_per_batch=0)
+        assert builds == [5] * 9 + [3]
+        # a single structure that does not fit raises, and the engine stays usable
+        hip_engine.set_memory_limit(1 << 20)
+        with pytest.raises(EngineOutOfMemory, match="limit"):
+            model.predict_structure(structs[0], task="e")
+        with pytest.raises(EngineOutOfMemory):
+            model.predict_graph(load_case("limno2")[0], task="e")
+    finally:
+        hip_engine.set_memory_limit(0)
+        hip_engine.build_batch = orig
+        model._engine = None
+    hip_engine.build_batch(structs[:2]).free()                         # still usable after the refusals
+
+
+def test_forward_returns_the_reference_batch_dictionary(hip_engine, golden_weights):
+    """CHGNet.forward (model.py:330-387): key set, container types, shapes and values of the batch dict."""
+    from chgnet_amd.model import CHGNet
+
+    d = np.load(os.path.join(GOLDEN, "batch_mixed.npz"))
+    order = [str(x) for x in d["order"]]
+    graphs = [load_case(n)[0] for n in order]
+    model = CHGNet(state_dict=golden_weights)
+    model._engine = hip_engine
+    try:
+        out = model.forward(graphs)                                   # default task "e"
+        assert set(out) == {"atoms_per_graph", "e"} and out["e"].shape == (len(graphs),) and out["e"].dtype == np.float32
+        assert out["atoms_per_graph"].tolist() == [len(g.atomic_number) for g in graphs] and out["atoms_per_graph"].dtype == np.int64
+        out = model(graphs, task="efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+        assert set(out) == {"atoms_per_graph", "e", "f", "s", "m", "site_energies", "atom_fea", "crystal_fea"}
+        for key in ("f", "s", "m", "site_energies", "atom_fea"):
+            assert isinstance(out[key], list) and len(out[key]) == len(graphs), key
+        assert out["crystal_fea"].shape == (len(graphs), 64)
+        for i, n in enumerate(order):
+            na = len(graphs[i].atomic_number)
+            assert out["f"][i].shape == (na, 3) and out["s"][i].shape == (3, 3) and out["m"][i].shape == (na,)
+            assert out["site_energies"][i].shape == (na,) and out["atom_fea"][i].shape == (na, 64)
+            assert abs(out["e"][i] - d[f"{n}_e"]) < TOL["e"]
+            for key in ("f", "s", "m", "site_energies", "atom_fea"):
+                ref = d[f"{n}_{key}"]
+                assert (np.abs(out[key][i] - ref).max() if ref.size else 0.0) < TOL[key], (n, key)
+            assert np.abs(out["crystal_fea"][i] - d[f"{n}_crystal_fea"]).max() < TOL["crystal_fea"]
+        single = model.predict_structure([_structures_for_graph_tests()[0]], task="e")
+        assert isinstance(single, dict)                               # one-element list -> bare dict, like the reference
+    finally:
+        model.release_forward_state()
+        model._engine = None
+
+
+def test_full_size_batch_every_structure_against_the_oracle(hip_engine, golden_weights):
+    """BASELINE configs[1] at full size: ALL 1024 structures against the oracle's fixture
+    (tests/golden/make_bench_fixture.py: E, |F|, tr S, force on atom 0) and 64 of them against the live oracle."""
+    import bench
+
+    fx = np.load(os.path.join(GOLDEN, "bench_c2_oracle.npz"))
+    graphs = bench.build_workload(1024, 0)
+    assert np.array_equal(fx["n_directed"], [len(g.atom_graph) for g in graphs])      # same workload as the fixture
+    assert np.array_equal(fx["n_angles"], [len(g.bond_graph) for g in graphs])
+    batch, res = _predict(hip_engine, graphs, task="efs")
+    outs = _split(res, batch.packed)
+    batch.free()
+    e = np.array([o["e"] for o in outs])
+    assert np.abs(e - fx["e"]).max() < TOL["e"]
+    fn = np.array([np.sqrt((o["f"].astype(np.float64) ** 2).sum()) for o in outs])
+    assert np.abs(fn - fx["f_norm"]).max() < 40 ** 0.5 * 3 ** 0.5 * TOL["f"]
+    st = np.array([np.trace(o["s"].astype(np.float64)) for o in outs])
+    assert np.abs(st - fx["s_trace"]).max() < 3 * TOL["s"]
+    f0 = np.array([o["f"][0] for o in outs])
+    assert np.abs(f0 - fx["f_atom0"]).max() < TOL["f"]
+    sample = list(range(0, 1024, 16))
+    refs = _oracle(golden_weights, [graphs[i] for i in sample], task="efs")
+    for i, r in zip(sample, refs):
+        assert abs(outs[i]["e"] - r["e"]) < TOL["e"]
+        assert np.abs(outs[i]["f"] - r["f"]).max() < TOL["f"]
+        assert np.abs(outs[i]["s"] - r["s"]).max() < TOL["s"]
+
+
+def test_device_graph_build_against_the_compiled_reference(hip_engine):
+    """The device builder vs the reference's own C builder (oracle/_ref/libref_graph.so = create_graph.c compiled
+    in place) DIRECTLY: the neighbour list found on the device goes into the reference's create_graph +
+    line-graph code and every index array must come out identical."""
+    from chgnet_amd.graph.converter import build_graph_arrays
+    from oracle import ref_graph
+
+    if not ref_graph.available():
+        pytest.fail("oracle/_ref/libref_graph.so is missing: build() compiles it and it travels with the snapshot")
+    structs = _structures_for_graph_tests()
+    for r_atom, r_bond in ((6.0, 3.0), (5.0, 3.0), (4.0, 4.0)):
+        batch = hip_engine.build_batch(structs, r_atom, r_bond)
+        pb = batch.packed
+        f = lambda name, n: hip_engine.debug_fetch_i32(batch, name, n)  # noqa: E731
+        ec, en, d2u, eo = (f(k, pb.n_directed) for k in ("e_center", "e_nbr", "e_d2u", "e_owner"))
+        img = hip_engine.debug_fetch(batch, "e_image", (pb.n_directed, 3)).astype(np.int64)
+        u2d = f("u_u2d", pb.n_undirected)
+        bn = f("bn_und", pb.n_bnodes)
+        a_ctr, a_b1c, a_b2c, a_d1, a_d2 = (f(k, pb.n_angles) for k in ("a_ctr", "a_b1c", "a_b2c", "a_d1", "a_d2"))
+        batch.free()
+        a_off = pb.atom_off
+        e_off = np.searchsorted(eo, np.arange(len(structs) + 1))
+        a_owner = np.searchsorted(a_off, a_ctr, side="right") - 1 if pb.n_angles else np.zeros(0, np.int64)
+        u_off = e_off // 2
+        for b, s in enumerate(structs):
+            sl = slice(e_off[b], e_off[b + 1])
+            if e_off[b] == e_off[b + 1]:
+                continue                                               # isolated atoms only: nothing to index
+            host = build_graph_arrays(np.asarray(s.frac_coords, np.float64), np.asarray(s.lattice.matrix, np.float64), r_atom, r_bond)
+            assert np.array_equal(host["atom_graph"], np.stack([ec[sl] - a_off[b], en[sl] - a_off[b]], 1)) and np.array_equal(host["image"], img[sl])
+            ref = ref_graph.reference_graph(len(s), ec[sl] - a_off[b], en[sl] - a_off[b], img[sl], host["distance"], r_bond)
+            assert np.array_equal(ref["directed2undirected"], d2u[sl] - u_off[b]), (b, "d2u")
+            assert np.array_equal(ref["undirected2directed"], u2d[u_off[b]:u_off[b + 1]] - e_off[b]), (b, "u2d")
+            rows = np.flatnonzero(a_owner == b)
+            got_bg = np.stack([a_ctr[rows] - a_off[b], bn[a_b1c[rows]] - u_off[b], a_d1[rows] - e_off[b], bn[a_b2c[rows]] - u_off[b],
+                               a_d2[rows] - e_off[b]], 1) if len(rows) else np.zeros((0, 5), np.int32)
+            assert np.array_equal(ref["bond_graph"].reshape(-1, 5), got_bg), (b, "bond_graph")

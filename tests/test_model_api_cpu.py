@@ -80,3 +80,73 @@ def test_chunk_planner():
     import pytest
     with pytest.raises(ValueError):
         _plan_chunks([1], 0, 0)
+
+
+def test_split_and_retry_on_device_out_of_memory():
+    """A chunk whose arena does not fit is halved and retried; a single structure that does not fit raises."""
+    from chgnet_amd.engine import EngineOutOfMemory
+    from chgnet_amd.model import _run_splitting
+
+    calls = []
+
+    def run(chunk):
+        calls.append(len(chunk))
+        if len(chunk) > 3:
+            raise EngineOutOfMemory("too large")
+        return [{"i": i} for i in chunk]
+
+    out = _run_splitting(run, list(range(10)))
+    assert [o["i"] for o in out] == list(range(10))          # order preserved
+    assert calls[0] == 10 and max(calls[1:]) <= 5 and all(c <= 3 for c in calls if c not in (10, 5))
+
+    def never(chunk):
+        raise EngineOutOfMemory("single structure too large")
+
+    with pytest.raises(EngineOutOfMemory):
+        _run_splitting(never, [0])
+
+
+def test_pack_batch_rejects_out_of_range_input():
+    """Indices and atomic numbers are checked on the host: nothing out of range reaches the device
+    (the reference raises IndexError from nn.Embedding(94) / index_select for the same inputs)."""
+    import copy
+
+    from chgnet_amd.pack import pack_batch
+    from conftest import load_case
+
+    g, _ = load_case("limno2")
+    pack_batch([g, g])                      # sane input passes
+    bad = copy.deepcopy(g)
+    bad.atomic_number = bad.atomic_number.copy()
+    bad.atomic_number[0] = 95               # Am: beyond the 94 embedding rows
+    with pytest.raises(IndexError, match="atomic number 95"):
+        pack_batch([bad])
+    bad.atomic_number[0] = 0
+    with pytest.raises(IndexError, match="atomic number 0"):
+        pack_batch([bad])
+    for field, col, val, what in (("atom_graph", 1, 8, r"atom_graph\[:, 1\]"), ("atom_graph", 0, -1, r"atom_graph\[:, 0\]"),
+                                  ("bond_graph", 1, 10**6, r"bond_graph\[:, 1\]"), ("bond_graph", 4, -3, r"bond_graph\[:, 4\]")):
+        bad = copy.deepcopy(g)
+        arr = getattr(bad, field).copy()
+        arr[5, col] = val
+        setattr(bad, field, arr)
+        with pytest.raises(IndexError, match=what):
+            pack_batch([g, bad])            # second structure: checked against ITS OWN index range
+    bad = copy.deepcopy(g)
+    bad.directed2undirected = bad.directed2undirected.copy()
+    bad.directed2undirected[0] = bad.directed2undirected[1] = bad.directed2undirected[2]
+    with pytest.raises(ValueError, match="exactly two directed edges"):
+        pack_batch([bad])
+
+
+def test_cutoff_coeff_must_be_a_positive_integer(golden_weights):
+    for p in (0, 2.5, -1):
+        with pytest.raises(NotImplementedError, match="cutoff_coeff"):
+            CHGNet(state_dict=golden_weights, cutoff_coeff=p)
+    assert CHGNet(state_dict=golden_weights, cutoff_coeff=5.0).model_args["cutoff_coeff"] == 5.0
+
+
+def test_forward_rejects_unknown_task(golden_weights):
+    model = CHGNet(state_dict=golden_weights)
+    with pytest.raises(ValueError, match="Invalid task='x'"):
+        model.forward([], task="x")

@@ -4,6 +4,6 @@
 for round in 1 2; do
   for lib in "$@"; do
     echo "== $lib (round $round)"
-    CHGNET_HIP_LIB=$lib timeout 150 python tests/gpu_scale_probe.py 1024 2>&1 | grep -E "conv_|angleupd_|steady" | awk '{printf "%s %s | ", $1, $(NF-1)} END {print ""}'
+    CHGNET_HIP_LIB=$lib timeout 150 python tools/gpu_scale_probe.py 1024 2>&1 | grep -E "conv_|angleupd_|steady" | awk '{printf "%s %s | ", $1, $(NF-1)} END {print ""}'
   done
 done

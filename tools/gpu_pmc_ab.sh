@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   tag=$(basename $lib .so)
   for c in FETCH_SIZE WRITE_SIZE; do
-    CHGNET_HIP_LIB=$R/$lib timeout 150 rocprofv3 --pmc $c --output-format csv -d $O -o ${tag}_$c -- python $R/tests/gpu_scale_probe.py 1024 > $O/${tag}_$c.log 2>&1
+    CHGNET_HIP_LIB=$R/$lib timeout 150 rocprofv3 --pmc $c --output-format csv -d $O -o ${tag}_$c -- python $R/tools/gpu_scale_probe.py 1024 > $O/${tag}_$c.log 2>&1
   done
   python - "$O" "$tag" <<'PY'
 import csv, sys, collections
