@@ -375,3 +375,68 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
         is_intensive=bool(model_args.get("is_intensive", True)),
         has_composition=has_comp,
     )
+
+
+def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
+    """Inverse of ``pack_weights`` for gradients: a blob in the weight-blob layout (what
+    ``chg_backward`` returns; derived entries such as transposed copies and ``q_bias`` carry no
+    gradient of their own and are ignored) -> ``{state_dict key: gradient}`` with the reference's
+    tensor shapes, i.e. what ``loss.backward()`` leaves in ``param.grad`` (trainer.py:399-411).
+    The frozen AtomRef (model.py:179-182) gets zeros."""
+    def G(name):
+        off, shape = pw.offsets[name]
+        return np.asarray(grad_blob[off:off + int(np.prod(shape))]).reshape(shape)
+
+    out: dict[str, np.ndarray] = {}
+    if pw.has_composition:
+        out["composition_model.fc.weight"] = np.zeros((1, N_ELEM), grad_blob.dtype)
+    out["atom_embedding.embedding.weight"] = G("emb")
+    out["bond_basis_expansion.rbf_expansion_ag.frequencies"] = G("freq_ag")
+    out["bond_basis_expansion.rbf_expansion_bg.frequencies"] = G("freq_bg")
+    out["angle_basis_expansion.fourier_expansion.frequencies"] = G("freq_ang")
+    out["bond_embedding.weight"] = G("w_bond_emb")
+    out["bond_weights_ag.weight"] = G("w_wag")
+    out["bond_weights_bg.weight"] = G("w_wbg")
+    out["angle_embedding.weight"] = G("w_ang_emb")
+
+    def split_cg(pre, name, full):            # rows 0..63 = core, 64..127 = gate
+        out[f"{pre}.mlp_core.{name}"], out[f"{pre}.mlp_gate.{name}"] = full[:D], full[D:]
+
+    def gated_tail(p, pre):
+        out[f"{pre}.mlp_core.layers.3.weight"], out[f"{pre}.mlp_core.layers.3.bias"] = G(p + "w2c"), G(p + "b2c")
+        out[f"{pre}.mlp_gate.layers.3.weight"], out[f"{pre}.mlp_gate.layers.3.bias"] = G(p + "w2g"), G(p + "b2g")
+
+    def ln(p, pre):
+        out[f"{pre}.bn1.weight"], out[f"{pre}.bn1.bias"] = G(p + "ln1_g"), G(p + "ln1_b")
+        out[f"{pre}.bn2.weight"], out[f"{pre}.bn2.bias"] = G(p + "ln2_g"), G(p + "ln2_b")
+
+    L = pw.n_conv
+    for l in range(L):
+        p, pre = f"ac{l}.", f"atom_conv_layers.{l}.twoBody_atom"
+        w_cn, w_bond = G(p + "w_cn"), G(p + "w_bond")       # [centre(core|gate) ; nbr(core|gate)], [bond(core|gate)]
+        split_cg(pre, "layers.0.weight", np.concatenate([w_cn[:2 * D], w_bond, w_cn[2 * D:]], axis=1))   # columns [centre | bond | nbr]
+        split_cg(pre, "layers.0.bias", G(p + "b1"))
+        gated_tail(p, pre)
+        ln(p, pre)
+        out[f"atom_conv_layers.{l}.mlp_out.layers.1.weight"] = G(p + "w_out")
+    for l in range(L - 1):
+        p, pre = f"bc{l}.", f"bond_conv_layers.{l}.twoBody_bond"
+        w_bij = G(p + "w_bij")
+        split_cg(pre, "layers.0.weight", np.concatenate([w_bij[:2 * D], w_bij[2 * D:], G(p + "w_ang"), G(p + "w_ctr")], axis=1))
+        split_cg(pre, "layers.0.bias", G(p + "b1"))
+        gated_tail(p, pre)
+        ln(p, pre)
+        out[f"bond_conv_layers.{l}.mlp_out.layers.1.weight"] = G(p + "w_out")
+    for l in range(L - 1):
+        p, pre = f"au{l}.", f"angle_layers.{l}.twoBody_bond"
+        w_bij = G(p + "w_bij")
+        split_cg(pre, "layers.1.weight", np.concatenate([w_bij[:2 * D], w_bij[2 * D:], G(p + "w_ang"), G(p + "w_ctr")], axis=1))
+        split_cg(pre, "layers.1.bias", G(p + "b1"))
+        ln(p, pre)
+    out["site_wise.weight"], out["site_wise.bias"] = G("site_w").reshape(1, D), G("site_b")
+    out["readout_norm.weight"], out["readout_norm.bias"] = G("ro_ln_g"), G("ro_ln_b")
+    for i, k in enumerate((0, 2, 4)):
+        out[f"mlp.layers.{k}.weight"], out[f"mlp.layers.{k}.bias"] = G(f"mlp_w{i}"), G(f"mlp_b{i}")
+    out["mlp.layers.7.weight"], out["mlp.layers.7.bias"] = G("mlp_w3").reshape(1, D), G("mlp_b3")
+    return out
+

@@ -109,9 +109,13 @@ class OracleCHGNet:
 
     # ---- the path ---------------------------------------------------------------------
     def forward(self, graphs, task: str = "efsm", *, return_site_energies=False, return_atom_feas=False,
-                return_crystal_feas=False, return_intermediates=False) -> dict:
+                return_crystal_feas=False, return_intermediates=False, as_tensors=False, create_graph=False):
         """graphs: sequence of objects with the CrystalGraph attributes.  Returns per-structure
-        numpy arrays exactly like ``CHGNet.predict_graph`` (model.py:651-663), batched once."""
+        numpy arrays exactly like ``CHGNet.predict_graph`` (model.py:651-663), batched once.
+
+        ``as_tensors=True`` returns the batch-wide torch tensors instead (``e`` [B], ``f`` [N,3], ``s`` [B,3,3],
+        ``m`` [N]) still attached to the autograd graph; with ``create_graph=True`` forces and stress are
+        differentiable like in the reference's training path (model.py:521-530)."""
         w, dt = self.w, self.dtype
         B = len(graphs)
         n_at = [len(_np(g.atomic_number, np.int64)) for g in graphs]
@@ -206,10 +210,10 @@ class OracleCHGNet:
 
         out = {}
         if "f" in task:                                                         # :517-524
-            (gpos,) = torch.autograd.grad(energy.sum(), cart, retain_graph=True)
+            (gpos,) = torch.autograd.grad(energy.sum(), cart, retain_graph=True, create_graph=create_graph)
             out["f"] = -gpos
         if "s" in task:                                                         # :527-535
-            (gstrain,) = torch.autograd.grad(energy.sum(), strain, retain_graph=True)
+            (gstrain,) = torch.autograd.grad(energy.sum(), strain, retain_graph=True, create_graph=create_graph)
             scale = 1 / volumes * 160.21766208
             out["s"] = gstrain * scale[:, None, None]
         apg = torch.tensor(n_at, dtype=dt)
@@ -223,6 +227,10 @@ class OracleCHGNet:
             e = e + F.linear(comp, w["composition_model.fc.weight"]).view(-1)
             site = site + wref[Z - 1]                                           # model.py:379-386
         out["e"] = e
+        if as_tensors:
+            out["m"] = magmom
+            out["atoms_per_graph"] = apg
+            return out
 
         def split(t, offs):
             return [t[offs[i]:offs[i + 1]].detach().cpu().numpy() for i in range(B)]
@@ -257,3 +265,24 @@ class OracleCHGNet:
             for i in range(len(chunk)):
                 preds.append({k: np.asarray(v[i]) for k, v in r.items()})
         return preds[0] if single else preds
+
+    def parameter_gradients(self, graphs, loss_fn, task: str = "e") -> dict:
+        """d loss / d parameter for every tensor of the state_dict, by autograd through this restatement
+        (what ``loss.backward()`` gives the reference's Trainer, trainer.py:399-411).  ``loss_fn`` maps the
+        tensor dictionary of ``forward(as_tensors=True)`` to a scalar.  The frozen AtomRef
+        (model.py:179-182) gets a zero gradient."""
+        names = [k for k in self.w if k != "composition_model.fc.weight"]
+        for k in names:
+            self.w[k].requires_grad_(True)
+        try:
+            out = self.forward(graphs, task, as_tensors=True, create_graph=True)
+            loss = loss_fn(out)
+            grads = torch.autograd.grad(loss, [self.w[k] for k in names], allow_unused=True)
+        finally:
+            for k in names:
+                self.w[k].requires_grad_(False)
+        res = {k: (g.detach().cpu().numpy() if g is not None else np.zeros(tuple(self.w[k].shape))) for k, g in zip(names, grads)}
+        if self.has_comp:
+            res["composition_model.fc.weight"] = np.zeros(tuple(self.w["composition_model.fc.weight"].shape))
+        return res
+

@@ -104,20 +104,34 @@ class StagedModel:
         cache = (z, H, n1, xh1, rs1, n2, xh2, rs2, a1, a2)
         return a1 * a2, cache
 
-    def gated_bwd(self, gy, cache, p, hidden):
+    def gated_bwd(self, gy, cache, p, hidden, wg=None):
+        """dE/dy -> dE/dz.  ``wg`` (dict) additionally receives the gradients of the gated MLP's own
+        parameters: LayerNorm affine (column sums of the pre-LayerNorm-backward adjoints), and for the
+        hidden form the second Linear (outer products of its output adjoint with the hidden activation)."""
         W = self.W
+        D = 64
         z, H, n1, xh1, rs1, n2, xh2, rs2, a1, a2 = cache
         gn1 = gy * a2 * dsilu(n1)
         gn2 = gy * a1 * a2 * (1 - a2)
         gc = ln_bwd(gn1, W(p + "ln1_g"), xh1, rs1)
         gg = ln_bwd(gn2, W(p + "ln2_g"), xh2, rs2)
+        if wg is not None:
+            wg[p + "ln1_g"], wg[p + "ln1_b"] = (gn1 * xh1).sum(0), gn1.sum(0)
+            wg[p + "ln2_g"], wg[p + "ln2_b"] = (gn2 * xh2).sum(0), gn2.sum(0)
+            if hidden:
+                wg[p + "w2c"], wg[p + "b2c"] = gc.T @ H[:, :D], gc.sum(0)
+                wg[p + "w2g"], wg[p + "b2g"] = gg.T @ H[:, D:], gg.sum(0)
         if hidden:
             gH = np.concatenate([gc @ W(p + "w2c"), gg @ W(p + "w2g")], axis=1)
             return gH * dsilu(z)
         return np.concatenate([gc, gg], axis=1)
 
     # ------------------------------------------------------------------------------
-    def run(self, pb, want_bwd=True) -> dict:
+    def run(self, pb, want_bwd=True, e_cot=None) -> dict:
+        """``e_cot`` [B] (optional): cotangent of the per-structure energies ``e``.  The reverse sweep then
+        starts from ``d(sum_b e_cot[b] e[b])/d(site energy)`` instead of 1 and ``out["wgrad"]`` holds the
+        gradient of that scalar with respect to every packed weight tensor (stage A: the
+        energy part of the fine-tuning loss, trainer.py:779-869)."""
         W, dt, pw = self.W, self.dt, self.pw
         D = 64
         L = pw.n_conv
@@ -241,11 +255,23 @@ class StagedModel:
             return out
 
         # ------------------------------ reverse sweep -----------------------------------
-        g3 = W("mlp_w3")[None, :] * dsilu(l3)
+        wg = {}                                             # weight gradients (packed names), filled when e_cot is given
+        train = e_cot is not None
+        cot = np.ones(N, dt)
+        if train:
+            cot = (np.asarray(e_cot, dt) / (n_at if pw.is_intensive else 1.0))[pb.atom_owner]
+            wg["mlp_w3"] = (cot[:, None] * silu(l3)).sum(0)
+            wg["mlp_b3"] = np.array([cot.sum()])
+        g3 = cot[:, None] * W("mlp_w3")[None, :] * dsilu(l3)
         g2 = (g3 @ W("mlp_w2")) * dsilu(l2)
         g1 = (g2 @ W("mlp_w1")) * dsilu(l1)
         gx0 = g1 @ W("mlp_w0")
         Ga = ln_bwd(gx0, W("ro_ln_g"), xh0, rs0)          # dE/d atom[L]
+        if train:
+            wg["mlp_w2"], wg["mlp_b2"] = g3.T @ silu(l2), g3.sum(0)
+            wg["mlp_w1"], wg["mlp_b1"] = g2.T @ silu(l1), g2.sum(0)
+            wg["mlp_w0"], wg["mlp_b0"] = g1.T @ x0, g1.sum(0)
+            wg["ro_ln_g"], wg["ro_ln_b"] = (gx0 * xh0).sum(0), gx0.sum(0)
         buf["Ga_readout"] = Ga.copy()
         Gb = np.zeros((Eu, D), dt)                          # dE/d bond features (node rows double as hbc grads)
         Gwag = np.zeros((Eu, D), dt)
@@ -255,27 +281,39 @@ class StagedModel:
         def atom_conv_bwd(l):
             nonlocal Ga
             p = f"ac{l}."
-            cache, y, _ = ac_cache[l]
+            cache, y, bl = ac_cache[l]
+            if train:
+                wg[p + "w_out"], wg[p + "b_out"] = Ga.T @ buf[f"ac{l}.agg"], Ga.sum(0)
             GA = Ga @ W(p + "w_out")
             Gm = GA[c]
             np.add.at(Gwag, k, Gm * y)
-            Gz = self.gated_bwd(Gm * wag[k], cache, p, True)
+            Gz = self.gated_bwd(Gm * wag[k], cache, p, True, wg if train else None)
             GP = np.zeros((N, 4 * D), dt)
             np.add.at(GP[:, :2 * D], c, Gz)
             np.add.at(GP[:, 2 * D:], n, Gz)
             GQ = np.zeros((Eu, 2 * D), dt)
             np.add.at(GQ, k, Gz)
+            if train:   # first layer, factorised: the table gradients contract with the rows the tables were made from
+                wg[p + "w_cn"] = GP.T @ atom[l]
+                wg[p + "b1"] = GP[:, :2 * D].sum(0)
+                wg[p + "w_bond"] = GQ.T @ hb_full(bl)
             Ga = Ga + GP @ W(p + "w_cn")
             Gb[:] += GQ @ W(p + "w_bond")
             buf[f"ac{l}.Gz"] = Gz
+            buf[f"ac{l}.GP"] = GP
+            buf[f"ac{l}.GQ"] = GQ
 
-        def angle_scatter(Gz, p):
+        def angle_scatter(Gz, p, hb_rows, atom_rows, ang_rows):
             nonlocal Ga
             GR = np.zeros((Eb, 4 * D), dt)
             np.add.at(GR[:, :2 * D], b1c, Gz)
             np.add.at(GR[:, 2 * D:], b2c, Gz)
             GS = np.zeros((N, 2 * D), dt)
             np.add.at(GS, ctr, Gz)
+            if train:
+                wg[p + "w_bij"] = GR.T @ hb_rows
+                wg[p + "w_ctr"], wg[p + "b1"] = GS.T @ atom_rows, GS.sum(0)
+                wg[p + "w_ang"] = Gz.T @ ang_rows
             Gb[bn] += GR @ W(p + "w_bij")
             Ga = Ga + GS @ W(p + "w_ctr")
             Gang[:] += Gz @ W(p + "w_ang")
@@ -285,17 +323,19 @@ class StagedModel:
             if A:
                 if l < L - 2:
                     p = f"au{l}."
-                    Gz = self.gated_bwd(Gang.copy(), au_cache[l], p, False)
-                    angle_scatter(Gz, p)
+                    Gz = self.gated_bwd(Gang.copy(), au_cache[l], p, False, wg if train else None)
+                    angle_scatter(Gz, p, hbc[l + 1], atom[l + 1], ang[l])
                 p = f"bc{l}."
                 cache, y = bc_cache[l]
+                if train:
+                    wg[p + "w_out"], wg[p + "b_out"] = Gb[bn].T @ buf[f"bc{l}.agg"], Gb[bn].sum(0)
                 Gagg = Gb[bn] @ W(p + "w_out")
                 Gu = Gagg[b1c]
                 w1, w2 = wbgc[b1c], wbgc[b2c]
                 np.add.at(Gwbgc, b1c, Gu * y * w2)
                 np.add.at(Gwbgc, b2c, Gu * y * w1)
-                Gz = self.gated_bwd(Gu * w1 * w2, cache, p, True)
-                angle_scatter(Gz, p)
+                Gz = self.gated_bwd(Gu * w1 * w2, cache, p, True, wg if train else None)
+                angle_scatter(Gz, p, hbc[l], atom[l + 1], ang[l])
             atom_conv_bwd(l)
         buf.update(Gb=Gb.copy(), Gwag=Gwag, Gwbgc=Gwbgc, Gang=Gang.copy())
 
@@ -304,6 +344,24 @@ class StagedModel:
         Gwbg_full = np.zeros((Eu, D), dt)
         Gwbg_full[bn] = Gwbgc
         Grbf3 = Gwbg_full @ W("w_wbg")
+        if train:
+            wg["emb"] = np.zeros((94, D), dt)
+            np.add.at(wg["emb"], pb.z - 1, Ga)              # Ga is dE/d atom[0] now
+            wg["w_bond_emb"], wg["w_wag"], wg["w_wbg"] = Gb.T @ rbf6, Gwag.T @ rbf6, Gwbg_full.T @ rbf3
+
+            def dfreq(Grbf, rc, freq):                      # d rbf_j / d f_j = env * sqrt(2/rc) * cos(f_j r/rc) / rc
+                env, _ = envelope(rk[:, None], rc, pw.cutoff_coeff)
+                return (Grbf * env * np.sqrt(2 / rc) * np.cos(freq[None, :] * rk[:, None] / rc) / rc).sum(0)
+
+            wg["freq_ag"] = dfreq(Grbf6, pw.atom_graph_cutoff, W("freq_ag"))
+            wg["freq_bg"] = dfreq(Grbf3, pw.bond_graph_cutoff, W("freq_bg"))
+            if A:
+                Gfour = Gang @ W("w_ang_emb")
+                wg["w_ang_emb"] = Gang.T @ four
+                t = np.outer(theta, W("freq_ang"))
+                nf = len(W("freq_ang"))
+                wg["freq_ang"] = ((Gfour[:, 1:1 + nf] * np.cos(t) - Gfour[:, 1 + nf:] * np.sin(t)) * theta[:, None]).sum(0) / np.sqrt(np.pi)
+            out["wgrad"] = wg
         Grk = (Grbf6 * drbf6).sum(1) + (Grbf3 * drbf3).sum(1)
         Gr = np.zeros(Ed, dt)
         Gr[pb.u_u2d] = Grk

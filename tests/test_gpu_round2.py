@@ -62,8 +62,8 @@ def test_memory_limit_splits_chunks_and_keeps_results(hip_engine, golden_weights
     assert 0 < free <= total
     want = model.predict_structure(structs, task="efs", batch_size=48)
     full = hip_engine.build_batch(structs)
-    need = full.device_bytes
-    assert need == hip_engine.bytes_required(48, full.packed.n_atoms, full.packed.n_directed, full.packed.n_angles, full.packed.n_bnodes)
+    need = hip_engine.bytes_required(48, full.packed.n_atoms, full.packed.n_directed, full.packed.n_angles, full.packed.n_bnodes)
+    assert 0 < need <= full.device_bytes            # the arena may be a (larger) pooled one
     full.free()
     builds = []
     orig = hip_engine.build_batch

@@ -38,3 +38,35 @@ def test_staged_pipeline_zero_angle_batch(golden_weights, packed_weights):
     assert abs(out["e"][0] - ref["e"][0]) < 1e-12
     assert np.abs(out["f"] - ref["f"][0]).max() < 1e-12
     assert np.abs(out["s"][0] - ref["s"][0]).max() < 1e-11
+
+
+def _blob_from(wg: dict, pw) -> np.ndarray:
+    blob = np.zeros(pw.blob.size, np.float64)
+    for name, g in wg.items():
+        off, shape = pw.offsets[name]
+        assert tuple(np.shape(g)) == tuple(shape), (name, np.shape(g), shape)
+        blob[off:off + int(np.prod(shape))] = np.asarray(g, np.float64).reshape(-1)
+    return blob
+
+
+def test_staged_weight_gradients_equal_autograd_fp64(golden_weights, packed_weights):
+    """Stage A of the fine-tuning backward: d(sum_b c_b e_b)/d(every parameter) from the
+    hand-derived reverse sweep of the factorised pipeline == torch.autograd through the oracle (fp64)."""
+    from chgnet_amd.pack import unpack_weight_grads
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    cot = np.array([0.3, -1.2, 0.7])
+    oracle = OracleCHGNet(golden_weights, dtype=torch.float64)
+    want = oracle.parameter_gradients(graphs, lambda o: (o["e"] * torch.tensor(cot)).sum())
+    out = StagedModel(packed_weights).run(pack_batch(graphs), e_cot=cot)
+    got = unpack_weight_grads(_blob_from(out["wgrad"], packed_weights), packed_weights)
+    assert set(got) == set(want) == set(golden_weights)
+    dead = [k for k in want if k.startswith("angle_layers.2.") or k.startswith("site_wise") or k.startswith("composition_model")]
+    for k, ref in want.items():
+        assert got[k].shape == ref.shape, k
+        if k in dead:                        # unused by the energy (model.py:442-496, 484-487, 179-182)
+            assert not np.any(ref) and not np.any(got[k]), k
+            continue
+        scale = np.abs(ref).max()
+        assert scale > 0, k
+        assert np.abs(got[k] - ref).max() < 1e-10 * scale, (k, np.abs(got[k] - ref).max(), scale)
