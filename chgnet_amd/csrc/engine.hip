@@ -27,6 +27,7 @@
 #include "kernels_embed.h"
 #include "kernels_geom.h"
 #include "kernels_graph.h"
+#include "kernels_train.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -117,6 +118,12 @@ struct chg_batch {
   int eager_calls = 0;        // the first call of a (batch, task) runs eagerly: one-shot batches never pay a capture
   std::map<std::string, std::pair<const float*, size_t>> named;
   std::map<std::string, std::pair<const int*, size_t>> named_i32;
+  // fine-tuning backward (chg_backward): allocated on first use, freed with the batch
+  char* train_arena = nullptr;
+  size_t train_bytes = 0;
+  std::vector<int> h_atom_off;   // host copy (chg_backward: atoms per structure)
+  float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
+        *t_ro = nullptr;
 };
 
 namespace {
@@ -361,7 +368,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
+    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -506,7 +513,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
     r.Ga = want_grad ? b->Ga : nullptr;
     LaunchScope ls(eng, "readout");
-    hipLaunchKernelGGL(k_readout, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
+    hipLaunchKernelGGL(k_readout<false>, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
     HIP_TRY(eng, hipGetLastError());
   }
 
@@ -645,6 +652,218 @@ template <class T>
 int d2h(chg_engine* eng, T* dst, const T* src, size_t n) {
   if (n == 0 || !dst) return CHG_OK;
   HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, eng->stream));
+  return CHG_OK;
+}
+
+// =====================================================================================================
+// Fine-tuning backward, stage A: gradient of  sum_b cot[b] * E_b  w.r.t. every weight.
+// The reverse sweep is the one of run_predict started from the cotangent; the TRAIN instantiations of the
+// adjoint kernels additionally leave what the weight-gradient reductions need (kernels_train.h).
+// =====================================================================================================
+template <int MT, int NT>
+int xty(chg_engine* eng, const char* label, const float* A, int lda, const int* a_idx, const float* B, int ldb, const int* b_idx, int rows,
+        float alpha, float* out, int ldo, int n_cols) {
+  if (rows <= 0) return CHG_OK;
+  LaunchScope ls(eng, label);
+  XtyArgs p{A, lda, a_idx, B, ldb, b_idx, rows, alpha, out, ldo, n_cols};
+  hipLaunchKernelGGL((k_xty<MT, NT>), dim3(grid_for(rows, 2 * eng->num_cus)), dim3(BLOCK), (xty_lds<MT, NT>()), eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, int rows, int width, float* out) {
+  if (rows <= 0) return CHG_OK;
+  LaunchScope ls(eng, "wgrad_colsum");
+  ColsumArgs p{A, lda, Bm, ldb, rows, width, 1.0f, out};
+  const int ngrp = 256 / width;
+  const int grid = std::max(1, std::min((rows + ngrp * 64 - 1) / (ngrp * 64), 4 * eng->num_cus));
+  hipLaunchKernelGGL(k_colsum, dim3(grid), dim3(256), 0, eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
+  if (b->train_arena) return CHG_OK;
+  const size_t N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, rows = std::max(Ed, A);
+  Carver c{nullptr};
+  auto lay = [&](Carver& cv) {
+    b->t_grad = cv.take<float>((size_t)eng->desc.n_weights);
+    b->t_cot = cv.take<float>(b->B);
+    b->t_dumpG = cv.take<float>(rows * 2 * D);
+    b->t_dumpH = cv.take<float>(rows * 2 * D);
+    b->t_dumpZ = cv.take<float>(A * 2 * D);
+    b->t_Xb = cv.take<float>(Eu * D);
+    b->t_Xa = cv.take<float>(A * KB);
+    b->t_ro = cv.take<float>((size_t)RO_NDUMP * N * D);
+  };
+  lay(c);
+  const size_t total = (c.pos + 255) & ~size_t(255);
+  if (eng->memory_limit && total + b->arena_bytes > eng->memory_limit) {
+    eng->err = "chg_backward: training workspace of " + std::to_string(total) + " bytes exceeds the engine's memory limit";
+    return CHG_ENOMEM;
+  }
+  char* base = nullptr;
+  if (hipMalloc(&base, total) != hipSuccess) {
+    eng->err = "hipMalloc of " + std::to_string(total) + " bytes (training workspace) failed";
+    return CHG_ENOMEM;
+  }
+  Carver c2{base};
+  lay(c2);
+  b->train_arena = base;
+  b->train_bytes = total;
+  return CHG_OK;
+}
+
+float* grad_of(chg_engine* eng, chg_batch* b, const float* w) { return b->t_grad + (w - eng->d_weights); }
+
+// gated-MLP internals of one layer: dW2c, dW2g, db2c, db2g from the (adjoint, hidden activation) dumps
+int gated_tail_grads(chg_engine* eng, chg_batch* b, const GatedW& g, int rows, float* (*G)(chg_engine*, chg_batch*, const float*)) {
+  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG, 2 * D, nullptr, b->t_dumpH, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2c), D, D)));
+  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG + D, 2 * D, nullptr, b->t_dumpH + D, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2g), D, D)));
+  TRY(colsum(eng, b->t_dumpG, 2 * D, nullptr, 0, rows, D, G(eng, b, g.b2c)));
+  return colsum(eng, b->t_dumpG + D, 2 * D, nullptr, 0, rows, D, G(eng, b, g.b2g));
+}
+
+int run_backward(chg_engine* eng, chg_batch* b) {
+  const Weights& w = eng->w;
+  const int L = b->L;
+  hipStream_t st = eng->stream;
+  auto G = [&](const float* wp) { return grad_of(eng, b, wp); };
+  const int N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+  TRY(zero(eng, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights));
+  TRY(zero(eng, b->zero2, (size_t)((char*)b->zero2_end - (char*)b->zero2)));
+
+  // ---- readout: dE/d atom[L] from the cotangent; per-atom operands of the MLP / LayerNorm gradients ----
+  {
+    ReadoutArgs r{};
+    r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = N;
+    r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
+    r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
+    r.has_composition = eng->desc.has_composition;
+    r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
+    r.Ga = b->Ga; r.cot = b->t_cot; r.dump = b->t_ro;
+    LaunchScope ls(eng, "readout_train");
+    hipLaunchKernelGGL(k_readout<true>, dim3(grid_for(N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
+    HIP_TRY(eng, hipGetLastError());
+  }
+  {
+    const size_t pl = (size_t)N * D;
+    const float* ro = b->t_ro;
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G1 * pl, D, nullptr, ro + RO_X0 * pl, D, nullptr, N, 1.0f, G(w.mlp_w0), D, D)));
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G2 * pl, D, nullptr, ro + RO_S1 * pl, D, nullptr, N, 1.0f, G(w.mlp_w1), D, D)));
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G3 * pl, D, nullptr, ro + RO_S2 * pl, D, nullptr, N, 1.0f, G(w.mlp_w2), D, D)));
+    TRY(colsum(eng, ro + RO_G1 * pl, D, nullptr, 0, N, D, G(w.mlp_b0)));
+    TRY(colsum(eng, ro + RO_G2 * pl, D, nullptr, 0, N, D, G(w.mlp_b1)));
+    TRY(colsum(eng, ro + RO_G3 * pl, D, nullptr, 0, N, D, G(w.mlp_b2)));
+    TRY(colsum(eng, ro + RO_S3C * pl, D, nullptr, 0, N, D, G(w.mlp_w3)));
+    TRY(colsum(eng, ro + RO_GXX * pl, D, nullptr, 0, N, D, G(w.ro_ln_g)));
+    TRY(colsum(eng, ro + RO_GX * pl, D, nullptr, 0, N, D, G(w.ro_ln_b)));
+    // d mlp_b3 = sum_b cot[b] * n_atoms[b] is formed on the host (chg_backward)
+  }
+
+  auto atomconv_train = [&](int l) -> int {
+    const ACW& aw = w.ac[l];
+    // atom[l+1] = agg . Wout^T + b_out + atom[l]
+    TRY((xty<4, 4>(eng, "wgrad_out", b->Ga, D, nullptr, b->agg_l[l], D, nullptr, N, 1.0f, G(aw.w_out), D, D)));
+    TRY(colsum(eng, b->Ga, D, nullptr, 0, N, D, G(aw.b_out)));
+    if (Ed == 0) return CHG_OK;
+    TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, N, 0));
+    {
+      AtomConvArgs a = atomconv_args(eng, b, l);
+      a.e_center = b->p_center; a.e_nbr = b->p_nbr;
+      a.dumpG = b->t_dumpG; a.dumpH = b->t_dumpH; a.g_ln = G(aw.g.ln1_g);
+      LaunchScope ls(eng, "atomconv_bwd_train");
+      hipLaunchKernelGGL(k_atomconv_bwd<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), st, a);
+      HIP_TRY(eng, hipGetLastError());
+    }
+    TRY(gated_tail_grads(eng, b, aw.g, Ed, grad_of));
+    // first layer, factorised: table gradients contract with the rows the tables were made from
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GP_l[l], 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn), D, D)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GP_l[l] + 2 * D, 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn) + 2 * D * D, D, D)));
+    TRY(colsum(eng, b->GP_l[l], 4 * D, nullptr, 0, N, 2 * D, G(aw.b1)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, nullptr, b->hb0, D, nullptr, Eu, 1.0f, G(aw.w_bond), D, D)));
+    if (Eb > 0 && b->hbc[l] != b->hbc[0]) {   // bond-graph nodes carry layer-l features instead of the embedding
+      TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hbc[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
+      TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hb0, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
+    }
+    TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, b->Ga, nullptr, N, 1));   // l == 0 too: d emb needs dE/d atom[0]
+    return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, Eu, 1);
+  };
+
+  // shared tail of BondConv / AngleUpdate: table gradients of slot -> weights, then back to atoms / bonds
+  auto angle_tables_train = [&](int slot, const float* hbc_rows, const float* atom_rows, const float* ang_rows, const float* gz_dump,
+                                const float* w_bij, const float* w_ctr, const float* b1, const float* w_ang, const float* w_bij_t,
+                                const float* w_ctr_t) -> int {
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GR_l[slot], 4 * D, nullptr, hbc_rows, D, nullptr, Eb, 1.0f, G(w_bij), D, D)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GR_l[slot] + 2 * D, 4 * D, nullptr, hbc_rows, D, nullptr, Eb, 1.0f, G(w_bij) + 2 * D * D, D, D)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GS_l[slot], 2 * D, nullptr, atom_rows, D, nullptr, N, 1.0f, G(w_ctr), D, D)));
+    TRY(colsum(eng, b->GS_l[slot], 2 * D, nullptr, 0, N, 2 * D, G(b1)));
+    TRY((xty<8, 4>(eng, "wgrad_ang", gz_dump, 2 * D, nullptr, ang_rows, D, nullptr, A, 1.0f, G(w_ang), D, D)));
+    return angle_table_grads(eng, b, slot, w_bij_t, w_ctr_t);
+  };
+
+  TRY(atomconv_train(L - 1));
+  for (int l = L - 2; l >= 0; --l) {
+    if (A > 0) {
+      if (l < L - 2) {
+        const AUW& uw = w.au[l];
+        AngleArgs a = angle_args(b, L + l, b->ang[l], uw.w_ang, uw.g, nullptr);
+        a.dumpG = b->t_dumpG; a.dumpH = nullptr; a.dumpZ = nullptr; a.g_ln = G(uw.g.ln1_g);
+        {
+          LaunchScope ls(eng, "angleupd_bwd_train");
+          hipLaunchKernelGGL((k_angle<false, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
+                             angle_lds<false>(), st, a);
+          HIP_TRY(eng, hipGetLastError());
+        }
+        TRY(angle_tables_train(L + l, b->hbc[l + 1], b->atom[l + 1], b->ang[l], b->t_dumpG, uw.w_bij, uw.w_ctr, uw.b1, uw.w_ang, uw.w_bij_t,
+                               uw.w_ctr_t));
+      }
+      const BCW& bw = w.bc[l];
+      // hbc[l+1] = aggB . Wout^T + b_out + hbc[l]; dE/d hbc[l+1] lives in the node rows of Gb
+      TRY((xty<4, 4>(eng, "wgrad_out", b->Gb, D, b->bn_und, b->aggB_l[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
+      TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, Eb, 0));
+      AngleArgs a = angle_args(b, l, b->ang[l], bw.w_ang, bw.g, nullptr);
+      a.dumpG = b->t_dumpG; a.dumpH = b->t_dumpH; a.dumpZ = b->t_dumpZ; a.g_ln = G(bw.g.ln1_g);
+      {
+        LaunchScope ls(eng, "bondconv_bwd_train");
+        hipLaunchKernelGGL((k_angle<true, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
+                           angle_lds<true>(), st, a);
+        HIP_TRY(eng, hipGetLastError());
+      }
+      TRY(gated_tail_grads(eng, b, bw.g, A, grad_of));
+      TRY(angle_tables_train(l, b->hbc[l], b->atom[l + 1], b->ang[l], b->t_dumpZ, bw.w_bij, bw.w_ctr, bw.b1, bw.w_ang, bw.w_bij_t, bw.w_ctr_t));
+    }
+    TRY(atomconv_train(l));
+  }
+
+  // ---- embeddings: 31 -> 64 linears, learnable frequencies, atom embedding table ----
+  if (Ed > 0) {
+    {
+      BondEmbedTArgs a = bond_embed_args(eng, b);
+      a.Xb = b->t_Xb; a.g_freq_ag = G(w.freq_ag); a.g_freq_bg = G(w.freq_bg);
+      LaunchScope ls(eng, "bond_embed_bwd_train");
+      hipLaunchKernelGGL((k_bond_embed_t<true, true>), dim3(grid_for(Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, a);
+      HIP_TRY(eng, hipGetLastError());
+    }
+    TRY((xty<4, 2>(eng, "wgrad_embed", b->Gb, D, nullptr, b->t_Xb, D, nullptr, Eu, 1.0f, G(w.w_bond_emb), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "wgrad_embed", b->Gwag, D, nullptr, b->t_Xb, D, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "wgrad_embed", b->Gwbgc, D, nullptr, b->t_Xb + KB, D, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
+    if (A > 0) {
+      AngleEmbedTArgs a = angle_embed_args(eng, b);
+      a.Xa = b->t_Xa; a.g_freq = G(w.freq_ang);
+      {
+        LaunchScope ls(eng, "angle_embed_bwd_train");
+        hipLaunchKernelGGL((k_angle_embed_t<true, true>), dim3(grid_for(A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, a);
+        HIP_TRY(eng, hipGetLastError());
+      }
+      TRY((xty<4, 2>(eng, "wgrad_embed", b->Gang, D, nullptr, b->t_Xa, KB, nullptr, A, 1.0f, G(w.w_ang_emb), NANG, NANG)));
+    }
+  }
+  {
+    LaunchScope ls(eng, "wgrad_atom_embed");
+    hipLaunchKernelGGL(k_embed_grad, g1((int64_t)N * D), dim3(256), 0, st, b->Ga, b->z, G(w.emb), N);
+    HIP_TRY(eng, hipGetLastError());
+  }
   return CHG_OK;
 }
 
@@ -854,6 +1073,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
   if (s != CHG_OK) { delete b; return s; }
   carve(b, b->arena, total);
   register_names(b);
+  b->h_atom_off.assign(h->atom_off, h->atom_off + B + 1);
   s = h2d(eng, b->z, h->z, (size_t)N);
   if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
   if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
@@ -933,12 +1153,21 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, atomconv_lds<FWD_WAVES>()))) return s;
-  if ((s = set_lds(eng, k_atomconv_bwd, atomconv_lds<WAVES>()))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd<false>, atomconv_lds<WAVES>()))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd<true>, atomconv_lds<WAVES>()))) return s;
+  if ((s = set_lds(eng, (k_angle<true, true, WAVES, true>), angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, (k_angle<false, true, WAVES, true>), angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_readout<true>, readout_lds()))) return s;
+  if ((s = set_lds(eng, (k_bond_embed_t<true, true>), bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_angle_embed_t<true, true>), angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_xty<8, 4>), (xty_lds<8, 4>())))) return s;
+  if ((s = set_lds(eng, (k_xty<4, 4>), (xty_lds<4, 4>())))) return s;
+  if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
-  if ((s = set_lds(eng, k_readout, readout_lds()))) return s;
+  if ((s = set_lds(eng, k_readout<false>, readout_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
@@ -1010,6 +1239,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   }
   carve(b, b->arena, total);
   register_names(b);
+  if (h->atom_off) b->h_atom_off.assign(h->atom_off, h->atom_off + h->n_struct + 1);
   int s = CHG_OK;
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
 #define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
@@ -1057,6 +1287,7 @@ int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (!b) return CHG_OK;
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
   if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
+  if (b->train_arena) hipFree(b->train_arena);
   if (b->arena) {
     if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
     else hipFree(b->arena);
@@ -1093,6 +1324,30 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   }
   HIP_TRY(eng, hipGraphLaunch(b->graph_exec, eng->stream));
   b->last_task = task;
+  return CHG_OK;
+}
+
+int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, float* grad_blob) {
+  if (!eng || !b || !grad_blob) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
+  if ((int)b->h_atom_off.size() != b->B + 1) { eng->err = "chg_backward: batch has no host atom offsets"; return CHG_EINVAL; }
+  TRY(ensure_train_buffers(eng, b));
+  // cotangent of the per-structure energy SUMS: e_b = E_b / n_b for an intensive model (model.py:538-540); AtomRef is frozen
+  std::vector<float> cot(b->B);
+  double g_b3 = 0.0;
+  for (int i = 0; i < b->B; ++i) {
+    const double n = b->h_atom_off[i + 1] - b->h_atom_off[i];
+    const double ce = energy_cotangent ? energy_cotangent[i] : 1.0;
+    cot[i] = (float)(eng->desc.is_intensive ? ce / n : ce);
+    g_b3 += (double)cot[i] * n;
+  }
+  HIP_TRY(eng, hipMemcpyAsync(b->t_cot, cot.data(), sizeof(float) * b->B, hipMemcpyHostToDevice, eng->stream));
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
+  TRY(run_backward(eng, b));
+  HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyDeviceToHost, eng->stream));
+  TRY(chg_synchronize(eng));
+  grad_blob[eng->w.mlp_b3 - eng->d_weights] = (float)g_b3;
   return CHG_OK;
 }
 

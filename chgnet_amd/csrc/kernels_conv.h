@@ -57,9 +57,20 @@ struct GatedState {
 //   HIDDEN: c = W2c silu(zc) + b2c, g = W2g silu(zg) + b2g ; else c = zc, g = zg
 //   HIDDEN: zc, zg are replaced by silu'(zc), silu'(zg), which is all the backward needs of them.
 //   SLIM: sigmoid(n1) is not kept either (the adjoint recomputes it: 32 transcendentals for 16 registers).
-template <bool HIDDEN, bool SLIM = false>
+// Training context of one tile (TRAIN instantiations of the adjoint kernels only):
+// where the per-row quantities that the weight-gradient reductions (kernels_train.h) contract are dumped,
+// and the LDS tile used for the in-tile column sums of the LayerNorm-affine gradients.
+struct TrainTile {
+  float* T;        // the wave's LDS tile (free while the gated MLP runs in registers)
+  int nvalid, lane;
+  float* hrow;     // this lane's row of the hidden-activation dump [rows][128] (null: row past the end)
+  float* grow;     // this lane's row of the second-layer adjoint dump [rows][128]
+  float ln[4];     // running column sums (column = lane): d ln1_g, d ln1_b, d ln2_g, d ln2_b
+};
+
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false>
 __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c, const float* W2g, const float* vecs,
-                                              int j, int g, GatedState& s, V64& y) {
+                                              int j, int g, GatedState& s, V64& y, TrainTile* tt = nullptr) {
   if (HIDDEN) {
     V64 hc, hg;
     CHG_EW(ft, r) {
@@ -68,6 +79,10 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
       hg.t[ft][r] = zg.t[ft][r] * sg;
       zc.t[ft][r] = sc * (1.0f + zc.t[ft][r] * (1.0f - sc));
       zg.t[ft][r] = sg * (1.0f + zg.t[ft][r] * (1.0f - sg));
+    }
+    if (TRAIN && tt->hrow) {   // hidden activations: the B operand of dW2 = gn'^T . h
+      write_dl<VT>(tt->hrow, g, hc.t);
+      write_dl<VT>(tt->hrow + D, g, hg.t);
     }
     s.xh1 = param64(vecs + 0 * D, g);
     s.xh2 = param64(vecs + 1 * D, g);
@@ -95,9 +110,26 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
 }
 
 // gy = dE/dy  ->  gzc, gzg = dE/dz (128 wide);  dzc, dzg: silu'(z) as left by gated_forward<true>
-template <bool HIDDEN, bool SLIM = false>
+// column sums of two 64-wide per-row vectors over the valid rows of the tile (column = lane)
+__device__ __forceinline__ void tile_colsum2(TrainTile* tt, int j, int g, const V64& a, const V64& b, float& sa, float& sb) {
+  float* Trow = tt->T + j * TS;
+  __builtin_amdgcn_wave_barrier();   // earlier reads of the tile stay above these writes
+  write_dl<VT>(Trow, g, a.t);
+  write_dl<VT>(Trow + D, g, b.t);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int rr = 0; rr < TILE_ROWS; ++rr)
+    if (rr < tt->nvalid) {
+      sa += tt->T[rr * TS + tt->lane];
+      sb += tt->T[rr * TS + D + tt->lane];
+    }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false>
 __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, const V64& dzg, const float* W2c, const float* W2g,
-                                               const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg) {
+                                               const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg,
+                                               TrainTile* tt = nullptr) {
   V64 gn1, gn2;
   const V64 gam1 = param64(vecs + 2 * D, g);
   {
@@ -109,8 +141,19 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
       gn2.t[ft][r] = gy.t[ft][r] * n1 * sg * a2 * (1.0f - a2);
     }
   }
+  if (TRAIN) {   // LayerNorm affine: d gamma = sum_rows gn * xhat, d beta = sum_rows gn  (gn = adjoint of the LayerNorm output)
+    V64 t;
+    CHG_EW(ft, r) t.t[ft][r] = gn1.t[ft][r] * s.xh1.t[ft][r];
+    tile_colsum2(tt, j, g, t, gn1, tt->ln[0], tt->ln[1]);
+    CHG_EW(ft, r) t.t[ft][r] = gn2.t[ft][r] * s.xh2.t[ft][r];
+    tile_colsum2(tt, j, g, t, gn2, tt->ln[2], tt->ln[3]);
+  }
   ln_backward(gn1, gam1, s.xh1, s.rstd1);
   ln_backward(gn2, param64(vecs + 4 * D, g), s.xh2, s.rstd2);
+  if (TRAIN && tt->grow) {   // adjoint of the second-layer pre-activations (core | gate): A operand of dW2, column sums = d b2
+    write_dl<VT>(tt->grow, g, gn1.t);
+    write_dl<VT>(tt->grow + D, g, gn2.t);
+  }
   if (HIDDEN) {
     gzc = zero64();
     gzg = zero64();
@@ -247,6 +290,10 @@ struct AtomConvArgs {
   float* GP;           // [N,256] zeroed: grads of the two partials
   float* GQ;           // [Eu,128] zeroed
   float* Gwag;         // [Eu,64] accumulated over layers
+  // training (k_atomconv_bwd<true>) only
+  float* dumpG;        // [Ed,128] pair order: adjoint of the second-layer pre-activations (core | gate)
+  float* dumpH;        // [Ed,128] pair order: hidden activations (core | gate)
+  float* g_ln;         // [4][64] gradient of ln1_g, ln1_b, ln2_g, ln2_b (accumulated with atomics)
 };
 
 template <int NW = WAVES>
@@ -389,6 +436,7 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
   tile_atomic_add(d2, a2[0]); tile_atomic_add(d2 + 64, a2[1]); tile_atomic_add(d2 + 128, a2[2]); tile_atomic_add(d2 + 192, a2[3]);
 }
 
+template <bool TRAIN>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2c = smem;
@@ -416,10 +464,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
     gather_commit128(gr, T, TS, lane);
   }
+  TrainTile tt{};
+  tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
     if (nvalid <= 0) break;                                 // waves past the end of the last tile
+    if (TRAIN) {
+      tt.nvalid = nvalid;
+      tt.hrow = j < nvalid ? p.dumpH + (size_t)(row0 + j) * 2 * D : nullptr;
+      tt.grow = j < nvalid ? p.dumpG + (size_t)(row0 + j) * 2 * D : nullptr;
+    }
     int cn, nn, kn;                                         // the next tile's rows (clamped: harmless reads at the range end)
     {
       const int row = min(row0 + BLOCK_ROWS + j, last_row);
@@ -439,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
     V64 y;
-    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    gated_forward<true, false, TRAIN>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
     CHG_EW(ft, r) {
@@ -462,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
           if (b < nb) dst[(size_t)b * D] = prev[b];
       }
     }
-    gated_backward<true>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+    gated_backward<true, false, TRAIN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg, &tt);
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
@@ -475,6 +530,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
       gather_commit128(gr, T, TS, lane);
     }
     c = cn; n = nn; k = kn;
+  }
+  if (TRAIN) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, tt.ln[q]);
   }
 }
 
@@ -498,6 +557,11 @@ struct AngleArgs {
   float* GS;           // [N,128] zeroed
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
+  // training (k_angle<.., true, .., true>) only
+  float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
+  float* dumpH;        // [A,128] hidden activations (BondConv)
+  float* dumpZ;        // [A,128] dE/dz of BondConv (A operand of dW_ang = gz^T . angle features)
+  float* g_ln;         // [4][64] gradient of ln1_g, ln1_b, ln2_g, ln2_b
 };
 
 template <bool HIDDEN, int NW = WAVES>
@@ -520,8 +584,9 @@ constexpr size_t angle_lds() {
 
 // HIDDEN = true: BondConv (gated MLP with one hidden layer, weighted, aggregated over the owning bond)
 // HIDDEN = false: AngleUpdate (single gated layer, residual on the angle itself)
-template <bool HIDDEN, bool BWD, int NW = WAVES>
+template <bool HIDDEN, bool BWD, int NW = WAVES, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
+  static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wang = smem;                                  // [128][WS]
   float* W2c = Wang + 2 * D * WS;
@@ -566,10 +631,17 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     }
   }
   PH_DECL
+  TrainTile tt{};
+  tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     const int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
+    if (TRAIN) {
+      tt.nvalid = nvalid;
+      tt.hrow = (HIDDEN && j < nvalid) ? p.dumpH + (size_t)(row0 + j) * 2 * D : nullptr;
+      tt.grow = j < nvalid ? p.dumpG + (size_t)(row0 + j) * 2 * D : nullptr;
+    }
     if (!PIPE && tile + 1 < te) {
       const int a1 = row_of(tile + 1);
       ctr_nx = p.a_ctr[a1]; b1_nx = p.a_b1c[a1]; b2_nx = p.a_b2c[a1];
@@ -619,7 +691,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     GatedState s;
     V64 y;
     constexpr bool SLIM = HIDDEN && BWD;   // the BondConv adjoint is the one kernel that spills otherwise (3.41 -> 3.36 ms)
-    gated_forward<HIDDEN, SLIM>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    gated_forward<HIDDEN, SLIM, TRAIN>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     __builtin_amdgcn_wave_barrier();
     PH(3)   // gated forward
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
@@ -659,10 +731,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
       PH(4)   // weight rows / Gang rows, dE/dy, (BondConv) Gwbgc scatter
-      gated_backward<HIDDEN, SLIM>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+      gated_backward<HIDDEN, SLIM, TRAIN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg, &tt);
       PH(5)   // gated backward
       // dE/d(angle in) += W_ang^T gz   (the residual identity is already in Gang)
       f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
+      if (TRAIN && HIDDEN && valid) write_dl<2 * VT>(p.dumpZ + (size_t)a * 2 * D, g, gz);
       V64 ga = zero64();
       if (HIDDEN) {
         // BondConv: this tile owns rows a of Gang; their read is issued above the contraction that produces
@@ -696,6 +769,10 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     __builtin_amdgcn_wave_barrier();
   }
   PH_FLUSH((HIDDEN ? 0 : 20) + (BWD ? 10 : 0))
+  if (TRAIN) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, tt.ln[q]);
+  }
 }
 
 // =============================================================================================
@@ -713,10 +790,16 @@ struct ReadoutArgs {
   float* site_raw;         // [N]  model part only; summed per structure (in order, fp64) by k_finalize
   float* crystal_fea;      // [B,64] zeroed
   float* Ga;               // [N,64] out: dE/d atom (null -> forward only)
+  // training (k_readout<true>) only: the reverse sweep starts from d(sum_b cot[b] E_b)/d(site energy)
+  const float* cot;        // [B] cotangent of the per-structure energy sums
+  float* dump;             // [9][N,64]: x0, silu(l1), silu(l2), cot*silu(l3), g1, g2, g3, gx0, gx0*xhat  (kernels_train.h contracts them)
 };
+
+enum { RO_X0 = 0, RO_S1, RO_S2, RO_S3C, RO_G1, RO_G2, RO_G3, RO_GX, RO_GXX, RO_NDUMP };
 
 constexpr size_t readout_lds() { return sizeof(float) * (3 * D * WS + 6 * D + WAVES * TILE_FLOATS); }
 
+template <bool TRAIN>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W0 = smem;
@@ -758,30 +841,50 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) 
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, x0.t);
     __builtin_amdgcn_wave_barrier();
-    seg_colsum_atomic<D>(T, TS, valid ? owner : -1, nvalid, p.crystal_fea, D, lane);
+    if (!TRAIN) seg_colsum_atomic<D>(T, TS, valid ? owner : -1, nvalid, p.crystal_fea, D, lane);
     V64 l1 = param64(vecs + 2 * D, g), l2 = param64(vecs + 3 * D, g), l3 = param64(vecs + 4 * D, g), sv;
+    const size_t plane = (size_t)p.n_atoms * D;                       // TRAIN: one dump plane
+    float* drow = TRAIN ? p.dump + (size_t)i * D : nullptr;           // this lane's row inside a plane
+    const bool dump = TRAIN && valid;
+    const float cot = TRAIN ? p.cot[owner] : 1.0f;
+    if (dump) write_dl<VT>(drow + RO_X0 * plane, g, x0.t);
     gemm_dl<VT, VT>(l1.t, W0, WS, x0.t, j, g);
     CHG_EW(ft, r) sv.t[ft][r] = siluf_(l1.t[ft][r]);
+    if (dump) write_dl<VT>(drow + RO_S1 * plane, g, sv.t);
     gemm_dl<VT, VT>(l2.t, W1, WS, sv.t, j, g);
     CHG_EW(ft, r) sv.t[ft][r] = siluf_(l2.t[ft][r]);
+    if (dump) write_dl<VT>(drow + RO_S2 * plane, g, sv.t);
     gemm_dl<VT, VT>(l3.t, W2, WS, sv.t, j, g);
     const V64 w3 = param64(vecs + 5 * D, g);
     float site = 0.f;
     CHG_EW(ft, r) site += w3.t[ft][r] * siluf_(l3.t[ft][r]);
     site = quad_sum(site) + b3;
-    if (valid && g == 0) {
+    if (!TRAIN && valid && g == 0) {
       const float ref = p.has_composition ? p.atomref[p.z[i] - 1] : 0.f;
       p.site_energy[i] = site + ref;
       p.site_raw[i] = site;
     }
+    if (dump) {
+      CHG_EW(ft, r) sv.t[ft][r] = cot * siluf_(l3.t[ft][r]);
+      write_dl<VT>(drow + RO_S3C * plane, g, sv.t);
+    }
     if (p.Ga) {
       V64 g3, g2 = zero64(), g1 = zero64(), gx = zero64();
-      CHG_EW(ft, r) g3.t[ft][r] = w3.t[ft][r] * dsiluf_(l3.t[ft][r]);
+      CHG_EW(ft, r) g3.t[ft][r] = cot * w3.t[ft][r] * dsiluf_(l3.t[ft][r]);
       gemm_dl_t<VT, VT>(g2.t, W2, WS, g3.t, j, g);
       CHG_EW(ft, r) g2.t[ft][r] *= dsiluf_(l2.t[ft][r]);
       gemm_dl_t<VT, VT>(g1.t, W1, WS, g2.t, j, g);
       CHG_EW(ft, r) g1.t[ft][r] *= dsiluf_(l1.t[ft][r]);
       gemm_dl_t<VT, VT>(gx.t, W0, WS, g1.t, j, g);
+      if (dump) {
+        write_dl<VT>(drow + RO_G1 * plane, g, g1.t);
+        write_dl<VT>(drow + RO_G2 * plane, g, g2.t);
+        write_dl<VT>(drow + RO_G3 * plane, g, g3.t);
+        write_dl<VT>(drow + RO_GX * plane, g, gx.t);
+        V64 t;
+        CHG_EW(ft, r) t.t[ft][r] = gx.t[ft][r] * xh.t[ft][r];
+        write_dl<VT>(drow + RO_GXX * plane, g, t.t);
+      }
       ln_backward(gx, gam, xh, rstd);
       __builtin_amdgcn_wave_barrier();
       write_dl<VT>(Trow, g, gx.t);

@@ -42,12 +42,16 @@ struct BondEmbedTArgs {
   float *hb0, *wag, *wbgc;    // fwd out: [Eu,64], [Eu,64], [Eb,64]
   const float *Gb, *Gwag, *Gwbgc;   // bwd in
   float* Grk;                 // bwd out [Eu] dE/d r_k
+  // training (k_bond_embed_t<true, true>) only
+  float* Xb;                  // [Eu,64] out: radial bases of every bond, cols 0..31 cutoff r_atom (col 31 = 0), 32..63 cutoff r_bond
+  float *g_freq_ag, *g_freq_bg;     // [31] gradients of the learnable frequencies (atomics)
 };
 
 constexpr size_t bond_embed_lds() { return sizeof(float) * (3 * D * WSB + WAVES * TILE_ROWS * ETS); }
 
-template <bool BWD>
+template <bool BWD, bool TRAIN = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedTArgs p) {
+  static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
   float* Wa = We + D * WSB;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   const int ntiles = (p.n_und + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
+  float fa6[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, fa3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // TRAIN: d freq, this lane's rows
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_und - row0);
@@ -81,20 +86,26 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
     const int k = row0 + (valid ? j : 0);
     const float rlen = p.ev[p.u_u2d[k]][3];
     const int node = p.u_bnode[k];
-    f32x4 x6[2], x3[2], d6[2], d3[2];
+    f32x4 x6[2], x3[2], d6[2], d3[2], q6[2], q3[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool pad = 16 * kt + 4 * g + r >= NRAD;
-        float v, dv;
-        rbf_eval(rlen, p.rc_ag, f6[kt][r], p.env, v, dv);
+        float v, dv, df;
+        rbf_eval(rlen, p.rc_ag, f6[kt][r], p.env, v, dv, df);
         x6[kt][r] = pad ? 0.f : v;
         d6[kt][r] = pad ? 0.f : dv;
-        rbf_eval(rlen, p.rc_bg, f3[kt][r], p.env, v, dv);
+        q6[kt][r] = pad ? 0.f : df;
+        rbf_eval(rlen, p.rc_bg, f3[kt][r], p.env, v, dv, df);
         x3[kt][r] = pad ? 0.f : v;
         d3[kt][r] = pad ? 0.f : dv;
+        q3[kt][r] = pad ? 0.f : df;
       }
+    if (TRAIN && valid) {   // bases of this bond: B operand of the embedding-weight gradients (kernels_train.h)
+      write_dl<2>(p.Xb + (size_t)k * D, g, x6);
+      write_dl<2>(p.Xb + (size_t)k * D + KB, g, x3);
+    }
     if (!BWD) {
       V64 h = zero64();
       gemm_dl<2, VT>(h.t, We, WSB, x6, j, g);
@@ -150,7 +161,34 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
         for (int r = 0; r < 4; ++r) acc += t6[kt][r] * d6[kt][r] + t3[kt][r] * d3[kt][r];
       acc = quad_sum(acc);
       if (valid && g == 0) p.Grk[k] = acc;
+      if (TRAIN && valid) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            fa6[kt][r] += t6[kt][r] * q6[kt][r];
+            fa3[kt][r] += t3[kt][r] * q3[kt][r];
+          }
+      }
     }
+  }
+  if (TRAIN) {   // sum over the 16 rows held by the lanes that share g, then one atomic per frequency and wave
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = fa6[kt][r], b = fa3[kt][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          a += __shfl_xor(a, off);
+          b += __shfl_xor(b, off);
+        }
+        const int kf = 16 * kt + 4 * g + r;
+        if (j == 0 && kf < NRAD) {
+          atomicAdd(p.g_freq_ag + kf, a);
+          atomicAdd(p.g_freq_bg + kf, b);
+        }
+      }
   }
 }
 
@@ -163,12 +201,16 @@ struct AngleEmbedTArgs {
   float* ang0;                // fwd out [A,64]
   const float* Gang;          // bwd in  [A,64]
   float* Gu;                  // bwd out [Ed,4] zeroed, dE/d unit vectors
+  // training (k_angle_embed_t<true, true>) only
+  float* Xa;                  // [A,32] out: Fourier basis of every angle (col 31 = 0)
+  float* g_freq;              // [15] gradient of the learnable frequencies (atomics)
 };
 
 constexpr size_t angle_embed_lds() { return sizeof(float) * (D * WSB + WAVES * TILE_ROWS * ETS); }
 
-template <bool BWD>
+template <bool BWD, bool TRAIN = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
+  static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
   float* tiles = We + D * WSB;
@@ -188,6 +230,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
   const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
+  float fas[4] = {0.f, 0.f, 0.f, 0.f}, fac[4] = {0.f, 0.f, 0.f, 0.f};   // TRAIN: d freq through the sin / cos columns of this lane
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
@@ -225,6 +268,15 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
       read_dl<VT>(Trow, g, gin.t);
       gemm_dl_t<VT, 2>(t, We, WSB, gin.t, j, g);
       __builtin_amdgcn_wave_barrier();
+      if (TRAIN && valid) {
+        write_dl<2>(p.Xa + (size_t)a * KB, g, x);
+        // d/df sin(f t) = t cos(f t) = t * dx_sin / f,  d/df cos(f t) = -t sin(f t) = t * dx_cos / f: reuse dx (zero where padded)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          fas[r] += fs[r] != 0.f ? t[0][r] * dx[0][r] * theta / fs[r] : 0.f;
+          fac[r] += fc[r] != 0.f ? t[1][r] * dx[1][r] * theta / fc[r] : 0.f;
+        }
+      }
       float gtheta = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -235,6 +287,22 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
       if (valid && g < 3) {   // lane g handles cartesian component g of this row
         atomicAdd(p.Gu + 4 * (size_t)d1 + g, gcos * u2[g]);
         atomicAdd(p.Gu + 4 * (size_t)d2 + g, gcos * u1[g]);
+      }
+    }
+  }
+  if (TRAIN) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sa = fas[r], ca = fac[r];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        sa += __shfl_xor(sa, off);
+        ca += __shfl_xor(ca, off);
+      }
+      const int ks = 4 * g + r;                 // sin column ks uses freq[ks - 1], cos column uses freq[ks]
+      if (j == 0) {
+        if (ks >= 1) atomicAdd(p.g_freq + ks - 1, sa);
+        if (ks < NFREQ) atomicAdd(p.g_freq + ks, ca);
       }
     }
   }

@@ -79,7 +79,8 @@ __device__ __forceinline__ float ipow(float x, int n) {
   return r;
 }
 // basis value and d/dr for one frequency (basis.py:108-116, 197-206)
-__device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope env, float& val, float& dval) {
+// (dfreq: d val / d freq, needed by the weight-gradient path only)
+__device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope env, float& val, float& dval, float& dfreq) {
   const float inv_rc = 1.0f / rc;
   const float ds = r * inv_rc;
   const float arg = freq * ds;
@@ -97,6 +98,11 @@ __device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope
   const float dbase = norm * (freq * inv_rc * cs / r - sn / (r * r));
   val = e * base;
   dval = de * base + e * dbase;
+  dfreq = e * norm * cs * inv_rc;      // d/df [sin(f r / rc) / r] = cos(f r / rc) / rc
+}
+__device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope env, float& val, float& dval) {
+  float unused;
+  rbf_eval(r, rc, freq, env, val, dval, unused);
 }
 
 // ---- atom embedding ------------------------------------------------------------------------------

@@ -1,0 +1,159 @@
+// kernels_train.h -- reductions that turn the adjoints of the reverse sweep into WEIGHT gradients
+// (fine-tuning backward; reference: loss.backward() in chgnet/trainer/trainer.py:399-411
+// through CHGNet._compute, model/model.py:427-542).
+//
+// With the first gated-MLP layer factorised into per-atom / per-bond tables (kernels_conv.h), the
+// gradient of a first-layer weight block is a contraction over the TABLE rows, not over edges / angles:
+//     dW_centre = GP[:, 0:128]^T . h_atom      dW_bond = GQ^T . h_bond      dW_ctr = GS^T . h_atom  ...
+// and the only per-edge / per-angle contractions left are the second Linear of the gated MLP
+// (dW2 = gn'^T . hidden) and the angle block (dW_ang = gz^T . angle features).  All of them are the same
+// operation, out[m][n] += alpha * sum_rows A[row][m] * B[row][n], done here on MFMA tiles with the
+// accumulator kept in registers over a workgroup's whole row range (k_xty).  Bias / LayerNorm-affine
+// gradients are column sums (k_colsum, or in-tile sums inside the adjoint kernels).
+#pragma once
+
+#include "mfma_tile.h"
+
+namespace chg {
+
+struct XtyArgs {
+  const float* A;      // [rows or gathered][>= 16*MT] row stride lda
+  int lda;
+  const int* a_idx;    // optional row map (null = identity)
+  const float* B;      // [rows or gathered][>= 16*NT] row stride ldb
+  int ldb;
+  const int* b_idx;
+  int rows;
+  float alpha;
+  float* out;          // [16*MT][ldo], accumulated with fp32 atomics (zeroed by the caller)
+  int ldo;
+  int n_cols;          // columns of the result that exist (<= 16*NT): the 31-wide embedding weights are padded to 32
+};
+
+template <int MT, int NT>
+constexpr size_t xty_lds() {
+  return sizeof(float) * (16 * MT * 16 * NT + WAVES * TILE_ROWS * ((16 * MT + PAD) + (16 * NT + PAD)));
+}
+
+// v_mfma_f32_16x16x4_f32 with the ROW index as the contraction index: lane (i, kk) supplies
+// A_op[i][kk] = A[row 4s+kk][16mt + i] and B_op[kk][i] = B[row 4s+kk][16nt + i] (both read from the LDS copy of
+// the tile, ds_read_b32, consecutive lanes = consecutive addresses); the accumulator element (lane (i, kk), r)
+// is out[16mt + 4kk + r][16nt + i].
+template <int MT, int NT>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int M = 16 * MT, N = 16 * NT, SA = M + PAD, SB = N + PAD;
+  float* red = smem;                         // [M][N] workgroup partial
+  float* tiles = red + M * N;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+  for (int idx = tid; idx < M * N; idx += BLOCK) red[idx] = 0.f;
+  __syncthreads();
+  float* TA = tiles + wave * TILE_ROWS * (SA + SB);
+  float* TB = TA + TILE_ROWS * SA;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero4();
+  const int ntiles = (p.rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  constexpr int LA = M / 4, RA = 64 / LA;    // lanes per A row (float4 each), rows per load step
+  constexpr int LB = N / 4, RB = 64 / LB;
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.rows - row0);
+    if (nvalid <= 0) continue;
+    const int row = row0 + (i < nvalid ? i : 0);
+    const int ra = p.a_idx ? p.a_idx[row] : row;
+    const int rb = p.b_idx ? p.b_idx[row] : row;
+    {
+      const int sub = lane / LA, t = lane % LA;
+      f32x4 v[TILE_ROWS / RA];
+#pragma unroll
+      for (int it = 0; it < TILE_ROWS / RA; ++it) {
+        const int rr = RA * it + sub;
+        const int r = __shfl(ra, rr);
+        v[it] = rr < nvalid ? *reinterpret_cast<const f32x4*>(p.A + (size_t)r * p.lda + 4 * t) : zero4();   // rows past the end add nothing
+      }
+#pragma unroll
+      for (int it = 0; it < TILE_ROWS / RA; ++it) *reinterpret_cast<f32x4*>(TA + (RA * it + sub) * SA + 4 * t) = v[it];
+    }
+    {
+      const int sub = lane / LB, t = lane % LB;
+      f32x4 v[TILE_ROWS / RB];
+#pragma unroll
+      for (int it = 0; it < TILE_ROWS / RB; ++it) {
+        const int rr = RB * it + sub;
+        const int r = __shfl(rb, rr);
+        v[it] = rr < nvalid ? *reinterpret_cast<const f32x4*>(p.B + (size_t)r * p.ldb + 4 * t) : zero4();
+      }
+#pragma unroll
+      for (int it = 0; it < TILE_ROWS / RB; ++it) *reinterpret_cast<f32x4*>(TB + (RB * it + sub) * SB + 4 * t) = v[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < TILE_ROWS / 4; ++s) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = TA[(4 * s + kk) * SA + 16 * mt + i];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = TB[(4 * s + kk) * SB + 16 * nt + i];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the workgroup's waves meet in LDS (ds_add_f32), then one global atomic per element and workgroup
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mt + 4 * kk + r) * N + 16 * nt + i], acc[mt][nt][r]);
+  __syncthreads();
+  for (int idx = tid; idx < M * N; idx += BLOCK) {
+    const int m = idx / N, n = idx - m * N;
+    if (n < p.n_cols) atomicAdd(p.out + (size_t)m * p.ldo + n, p.alpha * red[idx]);
+  }
+}
+
+// out[c] += alpha * sum_rows A[row][c] (* Bm[row][c]),  width in {64, 128, 256}
+struct ColsumArgs {
+  const float* A;
+  int lda;
+  const float* Bm;     // optional elementwise factor (null = 1)
+  int ldb;
+  int rows, width;
+  float alpha;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void k_colsum(ColsumArgs p) {
+  __shared__ float part[256];
+  const int tid = threadIdx.x;
+  const int c = tid % p.width, grp = tid / p.width, ngrp = 256 / p.width;
+  float acc = 0.f;
+  for (int r = blockIdx.x * ngrp + grp; r < p.rows; r += gridDim.x * ngrp) {
+    const float a = p.A[(size_t)r * p.lda + c];
+    acc += p.Bm ? a * p.Bm[(size_t)r * p.ldb + c] : a;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    for (int g2 = 1; g2 < ngrp; ++g2) acc += part[g2 * p.width + c];
+    atomicAdd(p.out + c, p.alpha * acc);
+  }
+}
+
+// d emb[z-1] += dE/d atom[0]   (embedding lookup, model.py:432-434)
+__global__ void k_embed_grad(const float* __restrict__ Ga, const int* __restrict__ z, float* __restrict__ gemb, int n_atoms) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_atoms * D) return;
+  const int i = idx / D, c = idx - i * D;
+  atomicAdd(gemb + (size_t)(z[i] - 1) * D + c, Ga[idx]);
+}
+
+}  // namespace chg

@@ -160,6 +160,16 @@ class Engine:
         """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""
         self._check(self.lib.chg_predict(self.handle, batch.handle, _lib.task_mask(task)))
 
+    def backward(self, batch: DeviceBatch, e_grad=None) -> np.ndarray:
+        """Gradient blob (weight-blob layout) of ``sum_b e_grad[b] * e[b]`` after ``predict`` on ``batch``
+        (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names."""
+        grad = np.zeros(self.weights.blob.size, np.float32)
+        cot = None if e_grad is None else np.ascontiguousarray(e_grad, np.float32).reshape(-1)
+        if cot is not None and cot.size != batch.packed.n_struct:
+            raise ValueError(f"e_grad has {cot.size} entries, the batch holds {batch.packed.n_struct} structures")
+        self._check(self.lib.chg_backward(self.handle, batch.handle, _fp(cot) if cot is not None else None, _fp(grad)))
+        return grad
+
     def synchronize(self) -> None:
         self._check(self.lib.chg_synchronize(self.handle))
 

@@ -199,6 +199,21 @@ class CHGNet:
 
     __call__ = forward
 
+    def backward(self, e_grad=None) -> dict:
+        """Parameter gradients of ``sum_b e_grad[b] * e[b]`` for the batch of the last ``forward`` call
+        (``e_grad`` = d loss / d e, default ones): ``{state_dict key: float32 array}``, i.e. what
+        ``loss.backward()`` leaves in ``param.grad`` in the reference's train step (trainer.py:399-411) for the
+        energy term of ``CombinedLoss`` (trainer.py:779-869).  AtomRef is frozen (model.py:179-182): zeros.
+        Force / stress / magmom terms are not differentiated yet (SURVEY 8f-3 stages B, C)."""
+        from chgnet_amd.pack import unpack_weight_grads  # noqa: PLC0415
+
+        batch = getattr(self, "_fwd_batch", None)
+        if batch is None:
+            raise RuntimeError("backward() needs the device state of a preceding forward() call")
+        if any(k.endswith("mlp_out.layers.1.bias") for k in self._state_dict):
+            raise NotImplementedError("parameter gradients are not implemented for models with mlp_out bias (0.2.0)")
+        return unpack_weight_grads(self.engine.backward(batch, e_grad), self._weights)
+
     def release_forward_state(self) -> None:
         """Free the device batch kept by the last ``forward`` call."""
         batch = getattr(self, "_fwd_batch", None)
