@@ -70,13 +70,46 @@ def install_stubs() -> None:
     calc.all_properties = []
 
 
-def load_reference():
-    """Return the reference ``chgnet`` package (model + graph sub-modules imported)."""
+def build_cygraph(scratch: str | None = None) -> str:
+    """make the reference's own Cython/C graph builder (``chgnet.graph.cygraph`` =
+    cygraph.pyx + fast_converter_libraries/create_graph.c) importable, so that
+    ``CrystalGraphConverter(algorithm="fast")`` really is the fast path.  /root/reference is read-only, hence a
+    verbatim copy of the package goes to a scratch directory OUTSIDE the repository (default
+    /tmp/chgnet_reference_build), where ``cythonize`` + ``build_ext --inplace`` run exactly like the reference's
+    setup.py:6-10.  Returns the directory to put first on ``sys.path``."""
+    import shutil  # noqa: PLC0415
+    import subprocess  # noqa: PLC0415
+
+    scratch = scratch or os.environ.get("CHGNET_REFERENCE_BUILD", "/tmp/chgnet_reference_build")
+    pkg = os.path.join(scratch, "chgnet")
+    have = [f for f in (os.listdir(os.path.join(pkg, "graph")) if os.path.isdir(os.path.join(pkg, "graph")) else [])
+            if f.startswith("cygraph") and f.endswith(".so")]
+    if not have:
+        if os.path.isdir(scratch):
+            shutil.rmtree(scratch)
+        os.makedirs(scratch)
+        shutil.copytree(os.path.join(REFERENCE_ROOT, "chgnet"), pkg, ignore=shutil.ignore_patterns("__pycache__", "pretrained"))
+        setup_py = os.path.join(scratch, "setup_cygraph.py")
+        with open(setup_py, "w") as fh:   # the reference's setup.py:1-10, minus the package metadata
+            fh.write("import numpy as np\nfrom Cython.Build import cythonize\nfrom setuptools import Extension, setup\n"
+                     "setup(name='cygraph_build', ext_modules=cythonize([Extension('chgnet.graph.cygraph', ['chgnet/graph/cygraph.pyx'],"
+                     " include_dirs=[np.get_include()])], language_level=3), script_args=['build_ext', '--inplace'])\n")
+        subprocess.run([sys.executable, setup_py], cwd=scratch, check=True, capture_output=True)
+    return scratch
+
+
+def load_reference(fast_graph: bool = False):
+    """Return the reference ``chgnet`` package (model + graph sub-modules imported).  ``fast_graph=True``
+    imports it from the scratch copy that carries the compiled ``cygraph`` (see ``build_cygraph``): the
+    Python sources are byte-identical to /root/reference, only the extension module is added."""
     if not reference_available():
         raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
     install_stubs()
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    root = build_cygraph() if fast_graph else REFERENCE_ROOT
+    if "chgnet" in sys.modules and not getattr(sys.modules["chgnet"], "__file__", "").startswith(root):
+        raise RuntimeError("the reference package is already imported from another location")
+    if root not in sys.path:
+        sys.path.insert(0, root)
     import chgnet  # noqa: PLC0415
     import chgnet.graph.converter  # noqa: F401, PLC0415
     import chgnet.graph.crystalgraph  # noqa: F401, PLC0415

@@ -35,6 +35,12 @@ def golden_weights():
 
 
 @pytest.fixture(scope="session")
+def trained_like_weights():
+    """Second golden weight set at trained-checkpoint magnitudes (tests/golden/make_golden.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "weights_trained_like.npz")))
+
+
+@pytest.fixture(scope="session")
 def packed_weights(golden_weights):
     from chgnet_amd.pack import pack_weights
 

@@ -8,12 +8,19 @@ Writes (all small, committed):
                          and every basis ``frequencies`` tensor perturbed by 0.1*randn so
                          that non-default affine / learned frequencies are exercised
                          (the pretrained checkpoints are absent: .MISSING_LARGE_BLOBS)
-  case_<name>.npz        CrystalGraph arrays (from our native builder) + the reference's
-                         ``predict_graph(task="efsm", return_site_energies=True,
-                         return_atom_feas=True, return_crystal_feas=True)`` outputs
-  graph_<name>.npz       neighbour list fed to the reference converter (legacy Graph.add_edge
-                         + line_graph_adjacency_list) and the graph it produced, for the
-                         bit-exact indexing tests
+  weights_trained_like.npz   the same state_dict pushed to the magnitudes of a TRAINED model: every Linear
+                         weight x1.5 (gates and LayerNorm inputs leave the linear regime), LayerNorm affine
+                         +0.3*randn, biases +0.2*randn, the energy head's last layer x10: |E_model| ~ 1 eV/atom
+                         on top of the MPtrj AtomRef (-6 eV/atom total), |F| up to 3 eV/A, |stress| 10-17 GPa
+                         -- the scale at which the north star's 1e-4 eV / 1e-3 eV/A bars are meant
+  case_<name>.npz        CrystalGraph arrays as produced by the reference's OWN converter
+                         ``CrystalGraphConverter(algorithm="fast")`` (its Cython/C builder compiled here,
+                         oracle/_refimport.py:build_cygraph; the neighbour list comes from our builder because
+                         pymatgen is not installed) + the reference's ``predict_graph(task="efsm",
+                         return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)``
+                         outputs for both weight sets (``out_*`` seed0, ``tl_out_*`` trained-like)
+  graph_<name>.npz       (shuffled) neighbour list fed to the reference converter and the graph it
+                         produced ("fast" == "legacy" is asserted), for the bit-exact indexing tests
 The reference model runs on CPU in fp32 (``CHGNet.predict_graph``, model.py:593-665).
 """
 
@@ -28,16 +35,18 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
 
 from oracle._refimport import REFERENCE_ROOT, load_reference  # noqa: E402
 
-load_reference()
+load_reference(fast_graph=True)   # the reference with its compiled cygraph: algorithm="fast" is real
 from chgnet.graph.converter import CrystalGraphConverter as RefConverter  # noqa: E402
 from chgnet.graph.crystalgraph import CrystalGraph as RefGraph  # noqa: E402
 from chgnet.model.model import CHGNet as RefCHGNet  # noqa: E402
 
 from chgnet_amd.graph.converter import build_graph_arrays  # noqa: E402
 from chgnet_amd.graph.structure import Lattice, Structure  # noqa: E402
+from make_golden_helpers import DuckStructure as _DuckStructure  # noqa: E402
 
 
 def make_reference_model() -> RefCHGNet:
@@ -52,6 +61,24 @@ def make_reference_model() -> RefCHGNet:
     return model
 
 
+def make_trained_like(model: RefCHGNet) -> RefCHGNet:
+    """In place: the seed-0 model moved to trained-like magnitudes (see the module docstring)."""
+    rng = np.random.default_rng(3)
+    with torch.no_grad():
+        for name, p in model.state_dict().items():
+            if name.endswith("frequencies") or name.startswith("composition_model"):
+                continue
+            if ".bn" in name or name.startswith("readout_norm"):
+                p.add_(torch.tensor(0.3 * rng.normal(size=tuple(p.shape)), dtype=p.dtype))
+            elif name.startswith("mlp.layers.7"):
+                p.mul_(10.0)
+            elif name.endswith(".weight") and p.ndim == 2 and "embedding.embedding" not in name:
+                p.mul_(1.5)
+            elif name.endswith(".bias"):
+                p.add_(torch.tensor(0.2 * rng.normal(size=tuple(p.shape)), dtype=p.dtype))
+    return model
+
+
 def structures() -> dict[str, Structure]:
     limno2 = Structure.from_file(f"{REFERENCE_ROOT}/examples/mp-18767-LiMnO2.cif")
     licoo = Structure.from_file(f"{REFERENCE_ROOT}/examples/mp-1175469-Li9Co7O16.cif")
@@ -61,27 +88,6 @@ def structures() -> dict[str, Structure]:
     noangle = Structure(Lattice(np.diag([4.2, 4.2, 4.2])), ["Cs", "Cl"], [[0, 0, 0], [0.5, 0.5, 0.5]])
     return {"limno2": limno2, "s40": s40, "s16tri": s16, "noangle": noangle,
             "li9co7o16": licoo.perturb(0.005, np.random.default_rng(3))}
-
-
-class _DuckStructure:
-    """What converter.py:120-134,187 touches on a pymatgen Structure."""
-
-    def __init__(self, s: Structure, nl: dict) -> None:
-        self._s, self._nl = s, nl
-        self.frac_coords = s.frac_coords
-        self.lattice = s.lattice
-        self.sites = s.sites
-        self.composition = s.composition
-
-    def __len__(self):
-        return len(self._s)
-
-    def __iter__(self):
-        return iter(self._s)
-
-    def get_neighbor_list(self, r, sites=None, numerical_tol=1e-8):  # noqa: ARG002
-        nl = self._nl
-        return nl["center"], nl["neighbor"], nl["image"], nl["distance"]
 
 
 def ref_graph_from(s: Structure, arrays: dict, r_atom=6.0, r_bond=3.0) -> RefGraph:
@@ -98,58 +104,79 @@ def ref_graph_from(s: Structure, arrays: dict, r_atom=6.0, r_bond=3.0) -> RefGra
     )
 
 
+def neighbour_list(s: Structure, r_atom=6.0, r_bond=3.0) -> tuple[dict, dict]:
+    arrays = build_graph_arrays(s.frac_coords, s.lattice.matrix, r_atom, r_bond)
+    nl = {"center": arrays["atom_graph"][:, 0].astype(np.int64), "neighbor": arrays["atom_graph"][:, 1].astype(np.int64),
+          "image": arrays["image"].astype(np.int64), "distance": arrays["distance"]}
+    return nl, arrays
+
+
 def main() -> None:
     torch.set_num_threads(1)  # deterministic summation order for the fixtures
     model = make_reference_model()
     sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
     np.savez_compressed(os.path.join(HERE, "weights_seed0.npz"), **sd)
     print("weights:", len(sd), "tensors,", sum(v.size for v in sd.values()), "values")
+    model_tl = make_trained_like(make_reference_model())
+    np.savez_compressed(os.path.join(HERE, "weights_trained_like.npz"),
+                        **{k: v.detach().numpy().copy() for k, v in model_tl.state_dict().items()})
 
+    conv = RefConverter(atom_graph_cutoff=6, bond_graph_cutoff=3, algorithm="fast", on_isolated_atoms="ignore")
+    assert conv.algorithm == "fast", "the reference fell back to its legacy converter: cygraph is not importable"
     structs = structures()
     ref_graphs = {}
+    kw = dict(task="efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
     for name, s in structs.items():
-        arrays = build_graph_arrays(s.frac_coords, s.lattice.matrix, 6.0, 3.0)
-        rg = ref_graph_from(s, arrays)
+        nl, arrays = neighbour_list(s)
+        rg = conv(_DuckStructure(s, nl))            # the reference's own converter, end to end
         ref_graphs[name] = rg
-        out = model.predict_graph(rg, task="efsm", return_site_energies=True,
-                                  return_atom_feas=True, return_crystal_feas=True)
+        # ... and it is, element for element, the graph of the product's native builder
+        assert np.array_equal(rg.atom_graph.numpy(), arrays["atom_graph"]) and np.array_equal(rg.bond_graph.numpy().reshape(-1, 5), arrays["bond_graph"].reshape(-1, 5))
+        assert np.array_equal(rg.directed2undirected.numpy(), arrays["directed2undirected"])
+        assert np.array_equal(rg.undirected2directed.numpy(), arrays["undirected2directed"])
         save = {
-            "atomic_number": s.atomic_numbers, "atom_frac_coord": s.frac_coords.astype(np.float32),
+            "atomic_number": s.atomic_numbers, "atom_frac_coord": rg.atom_frac_coord.detach().numpy(),
             "frac_coord_f64": s.frac_coords, "lattice_f64": s.lattice.matrix,
-            "lattice": s.lattice.matrix.astype(np.float32),
-            "atom_graph": arrays["atom_graph"], "neighbor_image": arrays["image"].astype(np.float32),
-            "directed2undirected": arrays["directed2undirected"],
-            "undirected2directed": arrays["undirected2directed"],
-            "bond_graph": arrays["bond_graph"].reshape(-1, 5),
+            "lattice": rg.lattice.detach().numpy(),
+            "atom_graph": rg.atom_graph.numpy(), "neighbor_image": rg.neighbor_image.numpy(),
+            "directed2undirected": rg.directed2undirected.numpy(),
+            "undirected2directed": rg.undirected2directed.numpy(),
+            "bond_graph": rg.bond_graph.numpy().reshape(-1, 5),
         }
+        out = model.predict_graph(rg, **kw)
+        out_tl = model_tl.predict_graph(rg, **kw)
         for k, v in out.items():
             save["out_" + k] = np.asarray(v)
+        for k, v in out_tl.items():
+            save["tl_out_" + k] = np.asarray(v)
         np.savez_compressed(os.path.join(HERE, f"case_{name}.npz"), **save)
         print(name, "N", len(s), "Ed", len(arrays["atom_graph"]), "A", len(arrays["bond_graph"]),
-              "e", float(out["e"]), "|f|max", float(np.abs(out["f"]).max()))
+              "e", float(out["e"]), "|f|max", float(np.abs(out["f"]).max()),
+              "| trained-like: e", float(out_tl["e"]), "|f|max", float(np.abs(out_tl["f"]).max()), "|s|max", float(np.abs(out_tl["s"]).max()))
 
     # one batched call (mixed sizes, a zero-angle structure in the middle): batch == singles
     order = ["limno2", "noangle", "s16tri"]
-    outs = model.predict_graph([ref_graphs[n] for n in order], task="efsm", return_site_energies=True,
-                               return_atom_feas=True, return_crystal_feas=True, batch_size=16)
     save = {"order": np.array(order)}
-    for n, o in zip(order, outs):
-        for k, v in o.items():
-            save[f"{n}_{k}"] = np.asarray(v)
+    for prefix, mdl in (("", model), ("tl_", model_tl)):
+        outs = mdl.predict_graph([ref_graphs[n] for n in order], batch_size=16, **kw)
+        for n, o in zip(order, outs):
+            for k, v in o.items():
+                save[f"{prefix}{n}_{k}"] = np.asarray(v)
     np.savez_compressed(os.path.join(HERE, "batch_mixed.npz"), **save)
 
-    # graph-indexing goldens: reference converter (legacy python algorithm) on our neighbour list
-    conv = RefConverter(atom_graph_cutoff=6, bond_graph_cutoff=3, algorithm="legacy")
+    # graph-indexing goldens: the reference converter ("fast" = cygraph/create_graph.c, checked against its
+    # "legacy" Python algorithm) on a neighbour list whose rows are shuffled inside every centre block
+    legacy = RefConverter(atom_graph_cutoff=6, bond_graph_cutoff=3, algorithm="legacy")
     for name in ("limno2", "s16tri", "noangle"):
         s = structs[name]
-        arrays = build_graph_arrays(s.frac_coords, s.lattice.matrix, 6.0, 3.0)
-        nl = {"center": arrays["atom_graph"][:, 0].astype(np.int64), "neighbor": arrays["atom_graph"][:, 1].astype(np.int64),
-              "image": arrays["image"].astype(np.int64), "distance": arrays["distance"]}
-        # shuffle rows inside each centre block so the numbering rules are really exercised
+        nl, _ = neighbour_list(s)
         rng = np.random.default_rng(11)
         perm = np.concatenate([rng.permutation(np.flatnonzero(nl["center"] == c)) for c in range(len(s))])
         nl = {k: v[perm] for k, v in nl.items()}
         g = conv(_DuckStructure(s, nl))
+        g2 = legacy(_DuckStructure(s, nl))
+        for attr in ("atom_graph", "directed2undirected", "undirected2directed", "bond_graph", "neighbor_image"):
+            assert np.array_equal(getattr(g, attr).numpy(), getattr(g2, attr).numpy()), (name, attr)
         np.savez_compressed(
             os.path.join(HERE, f"graph_{name}.npz"), n_atoms=len(s), **{"nl_" + k: v for k, v in nl.items()},
             atom_graph=g.atom_graph.numpy(), directed2undirected=g.directed2undirected.numpy(),

@@ -192,3 +192,68 @@ def test_device_graph_build_against_the_compiled_reference(hip_engine):
             got_bg = np.stack([a_ctr[rows] - a_off[b], bn[a_b1c[rows]] - u_off[b], a_d1[rows] - e_off[b], bn[a_b2c[rows]] - u_off[b],
                                a_d2[rows] - e_off[b]], 1) if len(rows) else np.zeros((0, 5), np.int32)
             assert np.array_equal(ref["bond_graph"].reshape(-1, 5), got_bg), (b, "bond_graph")
+
+
+# ---------------------------------------------------------------------------------------------------
+# second weight set: the magnitudes of a trained checkpoint (tests/golden/weights_trained_like.npz)
+# ---------------------------------------------------------------------------------------------------
+# |E| 5-6 eV/atom, |F| up to 4.6 eV/A, |stress| up to 29 GPa, gates driven into saturation.  The reference's own
+# fp32-vs-fp64 error at this scale is E 4e-7, F 1.2e-5, S 1e-4; the north star asks 1e-4 eV and 1e-3 eV/A.
+TOL_TL = {"e": 5e-6, "f": 5e-5, "s": 5e-4, "m": 2e-5, "site_energies": 3e-5, "atom_fea": 1e-4, "crystal_fea": 6e-4}
+
+
+@pytest.fixture(scope="module")
+def engine_tl(trained_like_weights):
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.pack import pack_weights
+
+    eng = Engine(pack_weights(trained_like_weights), 0)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["limno2", "s40", "s16tri", "noangle", "li9co7o16"])
+def test_trained_like_weights_match_reference_golden(engine_tl, name):
+    g, d = load_case(name)
+    batch, res = _predict(engine_tl, [g])
+    out = _split(res, batch.packed)[0]
+    batch.free()
+    for key, tol in TOL_TL.items():
+        ref = d["tl_out_" + key]
+        err = float(np.abs(out[key] - ref).max()) if ref.size else 0.0
+        assert np.isfinite(out[key]).all() and err < tol, f"{name}:{key} max|d|={err:.3e} tol={tol:.1e}"
+
+
+def test_trained_like_weights_batched_and_ragged(engine_tl, trained_like_weights):
+    """The mixed batch of the reference (batch_mixed.npz, tl_ keys) and a ragged 10-100-atom batch against the oracle
+    (fp64 as truth, the reference-equivalent fp32 oracle as the yardstick)."""
+    import bench
+    import torch
+    from chgnet_amd import CrystalGraphConverter
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    d = np.load(os.path.join(GOLDEN, "batch_mixed.npz"))
+    order = [str(x) for x in d["order"]]
+    batch, res = _predict(engine_tl, [load_case(n)[0] for n in order])
+    for n, o in zip(order, _split(res, batch.packed)):
+        for key, tol in TOL_TL.items():
+            ref = d[f"tl_{n}_{key}"]
+            assert (float(np.abs(o[key] - ref).max()) if ref.size else 0.0) < tol, (n, key)
+    batch.free()
+    conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+    graphs = [conv(bench.sweep_structure(i)) for i in range(10)]
+    batch, res = _predict(engine_tl, graphs)
+    outs = _split(res, batch.packed)
+    batch.free()
+    torch.set_num_threads(8)
+    kw = dict(return_site_energies=True, return_atom_feas=True, return_crystal_feas=True, batch_size=64)
+    o64 = OracleCHGNet(trained_like_weights, dtype=torch.float64).predict_graph(graphs, "efsm", **kw)
+    o32 = OracleCHGNet(trained_like_weights).predict_graph(graphs, "efsm", **kw)
+    worst = {}
+    for got, r64, r32 in zip(outs, o64, o32):
+        for key in ("e", "f", "s", "m"):
+            ref_err = float(np.abs(np.asarray(r32[key], np.float64) - r64[key]).max())
+            err = float(np.abs(got[key] - r64[key]).max())
+            worst[key] = max(worst.get(key, 0.0), err)
+            assert err < max(2 * TOL_TL[key], 20 * ref_err), f"{key}: engine {err:.3e} vs reference-fp32 {ref_err:.3e}"
+    assert worst["e"] < 1e-4 and worst["f"] < 1e-3        # the north star's bars, at realistic magnitudes

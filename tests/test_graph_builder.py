@@ -195,3 +195,36 @@ def test_builder_matches_the_references_compiled_c_algorithm():
                 got = graph_arrays_from_neighbors(len(s), nl["center"], nl["neighbor"], nl["image"], nl["distance"], r_bond)
                 for key in ("atom_graph", "directed2undirected", "undirected2directed", "bond_graph"):
                     assert np.array_equal(got[key].reshape(ref[key].shape), ref[key]), (key, r_atom, r_bond, shuffle)
+
+
+def test_cutoff_boundary_rules_known_answer():
+    """Bond-graph cutoff boundary, hand-made (reference graph.py:283-327 / create_graph.c via cygraph): an
+    undirected bond whose length EQUALS the cutoff still owns angles (it is skipped only when dist > cutoff), but
+    is never the second bond of an angle (a neighbour qualifies only when dist < cutoff).  Atom-graph boundary:
+    the neighbour list keeps d < r_atom strictly (host_graph.cpp: d2 < r2); pymatgen's own inequality at
+    exactly d == r cannot be pinned offline (pymatgen is not installed) and cannot change E/F/S because the
+    envelope and its derivative vanish at the cutoff (basis.py:197-205)."""
+    # triangle A(0) B(1) C(2): |AB| = 3.0 (== cutoff), |AC| = 2.0, |BC| = 2.5
+    center = [0, 0, 1, 1, 2, 2]
+    nbr = [1, 2, 0, 2, 0, 1]
+    dist = [3.0, 2.0, 3.0, 2.5, 2.0, 2.5]
+    g = graph_arrays_from_neighbors(3, center, nbr, [[0, 0, 0]] * 6, dist, r_bond=3.0)
+    d2u, bg = g["directed2undirected"], g["bond_graph"]
+    ab, ac, bc = d2u[0], d2u[1], d2u[3]
+    assert (ab, ac, bc) == (0, 1, 2)
+    assert sorted(bg[:, 1].tolist()) == [0, 0, 1, 2]          # AB owns an angle at A and one at B; AC, BC one each (at C)
+    assert ab not in bg[:, 3].tolist()                         # ... but never appears as the SECOND bond
+    assert bg.tolist() == [[0, 0, 0, 1, 1], [1, 0, 2, 2, 3], [2, 1, 4, 2, 5], [2, 2, 5, 1, 4]]
+    from oracle import ref_graph
+
+    if ref_graph.available() or ref_graph.build() is not None:  # the reference's compiled C says the same
+        ref = ref_graph.reference_graph(3, center, nbr, [[0, 0, 0]] * 6, dist, 3.0)
+        assert np.array_equal(ref["bond_graph"].reshape(-1, 5), bg)
+    # one ulp above the cutoff: the bond drops out of the bond graph entirely
+    dist2 = [np.nextafter(3.0, 4.0) if x == 3.0 else x for x in dist]
+    g2 = graph_arrays_from_neighbors(3, center, nbr, [[0, 0, 0]] * 6, dist2, r_bond=3.0)
+    assert g2["bond_graph"].tolist() == [[2, 1, 4, 2, 5], [2, 2, 5, 1, 4]]
+    # atom-graph boundary of our own neighbour list: strict d < r
+    s = Structure(Lattice(np.eye(3) * 3.0), ["Fe"], [[0, 0, 0]])     # images at exactly 3.0
+    assert len(build_graph_arrays(s.frac_coords, s.lattice.matrix, 3.0, 3.0)["atom_graph"]) == 0
+    assert len(build_graph_arrays(s.frac_coords, s.lattice.matrix, np.nextafter(3.0, 4.0), 3.0)["atom_graph"]) == 6

@@ -17,10 +17,33 @@ CASES = ["limno2", "s40", "s16tri", "noangle", "li9co7o16"]
 TOL = {"e": 2e-6, "f": 2e-6, "s": 5e-6, "m": 3e-6, "site_energies": 3e-6, "atom_fea": 1e-5, "crystal_fea": 5e-5}
 
 
+# trained-like weight set (weights_trained_like.npz: |F| up to 4.6 eV/A, |stress| up to 29 GPa): absolute noise of
+# the reference's own fp32 arithmetic grows with the magnitudes
+TOL_TL = {"e": 4e-6, "f": 4e-5, "s": 4e-4, "m": 2e-5, "site_energies": 3e-5, "atom_fea": 1e-4, "crystal_fea": 5e-4}
+
+
 @pytest.fixture(scope="module")
 def oracle(golden_weights):
     torch.set_num_threads(1)
     return OracleCHGNet(golden_weights)
+
+
+@pytest.fixture(scope="module")
+def oracle_tl(trained_like_weights):
+    torch.set_num_threads(1)
+    return OracleCHGNet(trained_like_weights)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference_outputs_trained_like_weights(oracle_tl, name):
+    """Second weight set at the magnitudes of a trained checkpoint (saturating gates, eV-scale forces)."""
+    g, d = load_case(name)
+    out = oracle_tl.predict_graph(g, "efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+    for key, tol in TOL_TL.items():
+        ref = d["tl_out_" + key]
+        err = float(np.abs(out[key] - ref).max()) if ref.size else 0.0
+        assert err <= tol, f"{name}:{key} {err:.2e}"
+    assert float(np.abs(d["tl_out_f"]).max()) > 1.0 or name == "noangle"      # eV/A-scale forces: the point of this set
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -67,12 +90,14 @@ def test_oracle_matches_live_reference_on_fresh_input(golden_weights):
     """Fresh random structure, reference imported from /root/reference (never on the GPU box)."""
     from oracle._refimport import load_reference
 
-    load_reference()
-    from chgnet.graph.crystalgraph import CrystalGraph as RefGraph
+    load_reference(fast_graph=True)            # with the reference's compiled cygraph: its "fast" converter is real
+    from chgnet.graph.converter import CrystalGraphConverter as RefConverter
     from chgnet.model.model import CHGNet as RefCHGNet
 
     from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.converter import build_graph_arrays
     from chgnet_amd.graph.structure import Lattice
+    from golden.make_golden_helpers import DuckStructure
 
     torch.set_num_threads(1)
     model = RefCHGNet()
@@ -80,10 +105,15 @@ def test_oracle_matches_live_reference_on_fresh_input(golden_weights):
     rng = np.random.default_rng(99)
     s = Structure(Lattice(np.diag([4.1, 4.4, 5.0]) + rng.normal(0, 0.2, (3, 3))), [3, 8, 25, 8, 27], rng.random((5, 3)))
     g = CrystalGraphConverter()(s)
-    rg = RefGraph(atomic_number=torch.tensor(g.atomic_number), atom_frac_coord=torch.tensor(g.atom_frac_coord),
-                  atom_graph=torch.tensor(g.atom_graph), neighbor_image=torch.tensor(g.neighbor_image),
-                  directed2undirected=torch.tensor(g.directed2undirected), undirected2directed=torch.tensor(g.undirected2directed),
-                  bond_graph=torch.tensor(g.bond_graph), lattice=torch.tensor(g.lattice), atom_graph_cutoff=6, bond_graph_cutoff=3)
+    # the reference's own converter, end to end (structure -> neighbour list -> cygraph -> CrystalGraph)
+    a = build_graph_arrays(s.frac_coords, s.lattice.matrix, 6.0, 3.0)
+    nl = {"center": a["atom_graph"][:, 0].astype(np.int64), "neighbor": a["atom_graph"][:, 1].astype(np.int64),
+          "image": a["image"].astype(np.int64), "distance": a["distance"]}
+    conv = RefConverter(atom_graph_cutoff=6, bond_graph_cutoff=3, algorithm="fast")
+    assert conv.algorithm == "fast"
+    rg = conv(DuckStructure(s, nl))
+    for attr in ("atom_graph", "directed2undirected", "undirected2directed", "bond_graph", "neighbor_image"):
+        assert np.array_equal(getattr(rg, attr).numpy().reshape(getattr(g, attr).shape), getattr(g, attr)), attr
     ref = model.predict_graph(rg, task="efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
     out = OracleCHGNet(golden_weights).predict_graph(g, "efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
     for key in ref:
