@@ -70,3 +70,45 @@ def test_staged_weight_gradients_equal_autograd_fp64(golden_weights, packed_weig
         scale = np.abs(ref).max()
         assert scale > 0, k
         assert np.abs(got[k] - ref).max() < 1e-10 * scale, (k, np.abs(got[k] - ref).max(), scale)
+
+
+def test_stage_b_force_and_stress_loss_gradients_equal_double_backward_fp64(golden_weights, packed_weights):
+    """Stage B of the fine-tuning backward: d L / d(every parameter) for a loss with energy, force AND
+    stress terms -- one tangent sweep + a two-adjoint reverse sweep (oracle/staged_train.py) -- against
+    torch double-backward through the oracle (the reference's create_graph=True path, model.py:517-535)."""
+    from chgnet_amd.pack import unpack_weight_grads
+    from oracle.staged_train import StagedTrainer
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    pb = pack_batch(graphs)
+    rng = np.random.default_rng(17)
+    gE, gF, gS = rng.normal(size=pb.n_struct), rng.normal(size=(pb.n_atoms, 3)), rng.normal(size=(pb.n_struct, 3, 3))
+    oracle = OracleCHGNet(golden_weights, dtype=torch.float64)
+    tE, tF, tS = torch.tensor(gE), torch.tensor(gF), torch.tensor(gS)
+    for terms in ("efs", "f", "s", "e"):
+        cE = gE if "e" in terms else None
+        cF = gF if "f" in terms else None
+        cS = gS if "s" in terms else None
+
+        def loss(o, terms=terms):
+            val = 0.0
+            if "e" in terms:
+                val = val + (o["e"] * tE).sum()
+            if "f" in terms:
+                val = val + (o["f"] * tF).sum()
+            if "s" in terms:
+                val = val + (o["s"] * tS).sum()
+            return val
+
+        want = oracle.parameter_gradients(graphs, loss, task="efs")
+        out = StagedTrainer(packed_weights).run(pb, gE=cE, gF=cF, gS=cS)
+        got = unpack_weight_grads(_blob_from(out["wgrad"], packed_weights), packed_weights)
+        for k, ref in want.items():
+            if k.startswith(("angle_layers.2.", "site_wise", "composition_model")):
+                assert not np.any(got[k]), k
+                continue
+            scale = np.abs(ref).max()
+            if scale == 0:                      # e.g. the last bias does not move forces or stress
+                assert np.abs(got[k]).max() < 1e-12, (terms, k)
+                continue
+            assert np.abs(got[k] - ref).max() < 2e-9 * scale, (terms, k, np.abs(got[k] - ref).max(), scale)
