@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
     "chg_debug_fetch", "chg_test_rows_gemm",
     "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
-    "chg_stream_copy", "chg_backward",
+    "chg_stream_copy", "chg_backward", "chg_engine_build_stats",
 )
 
 
@@ -82,6 +82,7 @@ def load() -> ctypes.CDLL:
     lib.chg_engine_destroy.argtypes = [vp]
     lib.chg_last_error.argtypes = [vp]
     lib.chg_last_error.restype = ctypes.c_char_p
+    lib.chg_engine_build_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_engine_set_memory_limit.argtypes = [vp, ctypes.c_int64]
     lib.chg_engine_memory_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_batch_bytes_required.argtypes = [ctypes.c_int32] * 6

@@ -76,6 +76,11 @@ struct chg_engine {
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
   int num_cus = 256;
+  // single-pass graph builds (chg_batch_build): counts of the previous build size the next one's scratch speculatively
+  bool spec_builds = true;    // CHGNET_SPEC_BUILD=0 forces the exact three-round-trip pass
+  int last_N = 0, last_Ed = 0, last_A = 0, last_Eb = 0;
+  double last_r_atom = 0.0, last_r_bond = 0.0;
+  long n_spec_builds = 0, n_spec_overflows = 0;
   size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
 };
 
@@ -953,6 +958,126 @@ int d2d(chg_engine* eng, T* dst, const T* src, size_t n) {
   return CHG_OK;
 }
 
+// Two ways through the same kernels:
+//  * exact (first build of a shape): count pass -> host reads Ed -> fill -> host reads A -> fill -> host reads Eb:
+//    three blocking round trips;
+//  * single pass (every later build: MD rebuilds the graph of the same cell every step, a sweep builds chunk after
+//    chunk of similar structures): the scratch arrays are sized from the PREVIOUS build's per-atom counts plus
+//    headroom, every kernel takes its counts from device memory, and the host reads {Ed, A, Eb, flags} once at the
+//    end.  A capacity that turns out too small raises a device-side flag and the build is repeated exactly.
+struct GraphCounts { int Ed = 0, A = 0, Eb = 0, unpaired = 0, isolated = 0; };
+
+int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const double* d_cart, const double* d_frac, const double* d_lat,
+               const double* d_reach, const int* d_owner, const int* d_aoff, double r_atom, double r_bond, double tol, bool speculative,
+               int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
+               int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
+               int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2) {
+  const int N = h->n_atoms;
+  hipStream_t st = eng->stream;
+  overflowed = false;
+  int* d_ccnt = tmp.get<int>(N + 1);
+  int* d_coff = tmp.get<int>(N + 1);
+  int* d_flags = tmp.get<int>(4);   // [0] unpaired directed edge, [1] isolated atoms, [2] speculative capacity exceeded
+  int* d_counts = tmp.get<int>(8);
+  if (!d_ccnt || !d_coff || !d_flags || !d_counts) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  HIP_TRY(eng, hipMemsetAsync(d_ccnt, 0, sizeof(int) * (N + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
+  NlArgs nl{};
+  nl.cart = d_cart; nl.frac = d_frac; nl.lattice = d_lat; nl.reach = d_reach; nl.atom_owner = d_owner; nl.atom_off = d_aoff;
+  nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt; nl.overflow = d_flags + 2;
+  const dim3 wave_per_atom((unsigned)((N + 3) / 4));
+  hipLaunchKernelGGL((k_neighbors<false>), wave_per_atom, dim3(256), 0, st, nl);
+  TRY(exclusive_scan(eng, tmp, d_ccnt, d_coff, N + 1));
+  int Ed = 0;
+  if (!speculative) {
+    HIP_TRY(eng, hipMemcpyAsync(&Ed, d_coff + N, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipStreamSynchronize(st));
+    if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
+    capE = Ed;
+  }
+  const int capU = capE / 2;
+  const DevCount nE{Ed, speculative ? d_coff + N : nullptr, 1}, nU{Ed / 2, speculative ? d_coff + N : nullptr, 2};
+  e_center = tmp.get<int>(capE); e_nbr = tmp.get<int>(capE);
+  int* e_img = tmp.get<int>(3 * (size_t)capE);
+  e_image = tmp.get<float>(3 * (size_t)capE);
+  double* e_dist = tmp.get<double>(capE);
+  e_owner = tmp.get<int>(capE); e_rev = tmp.get<int>(capE); e_d2u = tmp.get<int>(capE);
+  int* is_first = tmp.get<int>(capE + 1); int* first_scan = tmp.get<int>(capE + 1);
+  p_center = tmp.get<int>(capE); p_nbr = tmp.get<int>(capE);
+  u_u2d = tmp.get<int>(capU);
+  int* short_cnt = tmp.get<int>(N); int* ang_cnt = tmp.get<int>(capU + 1); int* ang_off = tmp.get<int>(capU + 1);
+  int* is_node = tmp.get<int>(capU + 1); int* node_scan = tmp.get<int>(capU + 1);
+  u_bnode = tmp.get<int>(capU);
+  if (!e_center || !e_nbr || !e_img || !e_image || !e_dist || !e_owner || !e_rev || !e_d2u || !is_first || !first_scan || !p_center ||
+      !p_nbr || !u_u2d || !short_cnt || !ang_cnt || !ang_off || !is_node || !node_scan || !u_bnode) {
+    eng->err = "graph build: scratch allocation failed";
+    return CHG_ENOMEM;
+  }
+  HIP_TRY(eng, hipMemsetAsync(ang_cnt, 0, sizeof(int) * (capU + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(is_node, 0, sizeof(int) * (capU + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(is_first, 0, sizeof(int) * (capE + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(short_cnt, 0, sizeof(int) * std::max(N, 1), st));
+  if (capE > 0) {
+    nl.center_off = d_coff; nl.e_center = e_center; nl.e_nbr = e_nbr; nl.e_img = e_img; nl.e_image = e_image; nl.e_dist = e_dist;
+    nl.e_owner = e_owner; nl.cap_edges = capE;
+    hipLaunchKernelGGL((k_neighbors<true>), wave_per_atom, dim3(256), 0, st, nl);
+    hipLaunchKernelGGL(k_reverse, g1(capE), dim3(256), 0, st, e_center, e_nbr, e_img, d_coff, nE, e_rev, is_first, d_flags);
+    TRY(exclusive_scan(eng, tmp, is_first, first_scan, capE + 1));
+    hipLaunchKernelGGL(k_undirected, g1(capE), dim3(256), 0, st, e_center, e_nbr, e_rev, is_first, first_scan, nE, e_d2u, u_u2d, p_center, p_nbr,
+                       d_flags + 2);
+  }
+  hipLaunchKernelGGL(k_short_count, g1(N), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1,
+                     d_flags + 2);
+  int A = 0, Eb = 0;
+  if (capU > 0) {
+    hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2);
+    TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1));   // entries past Eu are zero: the total sits at ang_off[capU]
+  } else {
+    HIP_TRY(eng, hipMemsetAsync(ang_off, 0, sizeof(int) * (capU + 1), st));
+  }
+  int flags[4] = {0, 0, 0, 0};
+  if (!speculative) {
+    HIP_TRY(eng, hipMemcpyAsync(&A, ang_off + capU, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipStreamSynchronize(st));
+    if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
+    capA = A;
+  }
+  a_ctr = tmp.get<int>(capA); a_b1 = tmp.get<int>(capA); a_d1 = tmp.get<int>(capA); a_b2 = tmp.get<int>(capA); a_d2 = tmp.get<int>(capA);
+  if (!a_ctr || !a_b1 || !a_d1 || !a_b2 || !a_d2) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  if (capA > 0 && capU > 0) {
+    hipLaunchKernelGGL(k_angle_fill, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
+                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2);
+    TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1));
+  } else {
+    HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (capU + 1), st));
+  }
+  if (!speculative) {
+    if (A > 0) {
+      HIP_TRY(eng, hipMemcpyAsync(&Eb, node_scan + capU, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(eng, hipStreamSynchronize(st));
+    }
+    capEb = Eb;
+  }
+  bn_und = tmp.get<int>(capEb);
+  if (!bn_und) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  if (capU > 0) hipLaunchKernelGGL(k_bond_nodes, g1(capU), dim3(256), 0, st, is_node, node_scan, nU, u_bnode, bn_und, capEb, d_flags + 2);
+  HIP_TRY(eng, hipGetLastError());
+  if (speculative) {   // the one round trip of this path
+    int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, (const int*)(d_coff + N), (const int*)(ang_off + capU),
+                       (const int*)(node_scan + capU), (const int*)d_flags, d_counts);
+    HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipStreamSynchronize(st));
+    Ed = hc[0]; A = hc[1]; Eb = hc[2]; flags[0] = hc[3]; flags[1] = hc[4]; flags[2] = hc[5];
+    if (flags[2] || Ed > capE || A > capA || Eb > capEb) { overflowed = true; return CHG_OK; }
+    if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
+    if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
+  }
+  gc.Ed = Ed; gc.A = A; gc.Eb = Eb; gc.unpaired = flags[0]; gc.isolated = flags[1];
+  return CHG_OK;
+}
+
 int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double tol, chg_batch** out,
                           int32_t* counts_out) {
   const int B = h->n_struct, N = h->n_atoms;
@@ -978,123 +1103,81 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
         cart[3 * i + k] = h->frac[3 * i] * a[k] + h->frac[3 * i + 1] * bb[k] + h->frac[3 * i + 2] * c[k];
     }
   }
-  TmpPool tmp(eng);
-  double* d_cart = tmp.get<double>(3 * (size_t)N);
-  double* d_frac = tmp.get<double>(3 * (size_t)N);
-  double* d_lat = tmp.get<double>(9 * (size_t)B);
-  double* d_reach = tmp.get<double>(3 * (size_t)B);
-  int* d_owner = tmp.get<int>(N);
-  int* d_aoff = tmp.get<int>(B + 1);
-  int* d_ccnt = tmp.get<int>(N + 1);
-  int* d_coff = tmp.get<int>(N + 1);
-  int* d_flags = tmp.get<int>(4);   // [0] unpaired-edge error, [1] isolated atoms
-  if (!d_cart || !d_frac || !d_lat || !d_reach || !d_owner || !d_aoff || !d_ccnt || !d_coff || !d_flags) {
-    eng->err = "graph build: scratch allocation failed";
-    return CHG_ENOMEM;
-  }
-  HIP_TRY(eng, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemcpyAsync(d_frac, h->frac, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemcpyAsync(d_lat, h->lattice, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemcpyAsync(d_reach, reach.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemcpyAsync(d_owner, owner.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemcpyAsync(d_aoff, h->atom_off, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
-  HIP_TRY(eng, hipMemsetAsync(d_ccnt, 0, sizeof(int) * (N + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
+  // speculative capacities from the previous build (same cutoffs): per-atom counts + 25 % + a constant
+  const bool speculate = eng->spec_builds && eng->last_N > 0 && eng->last_r_atom == r_atom && eng->last_r_bond == r_bond;
+  GraphCounts gc;
+  int *e_center = nullptr, *e_nbr = nullptr, *e_owner = nullptr, *e_rev = nullptr, *e_d2u = nullptr, *p_center = nullptr, *p_nbr = nullptr,
+      *u_u2d = nullptr, *u_bnode = nullptr, *bn_und = nullptr, *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr;
+  float* e_image = nullptr;
+  double *d_cart = nullptr, *d_frac = nullptr, *d_lat = nullptr;
+  int *d_owner = nullptr, *d_aoff = nullptr;
+  for (int attempt = speculate ? 0 : 1; attempt < 2; ++attempt) {
+    TmpPool tmp(eng);
+    d_cart = tmp.get<double>(3 * (size_t)N);
+    d_frac = tmp.get<double>(3 * (size_t)N);
+    d_lat = tmp.get<double>(9 * (size_t)B);
+    double* d_reach = tmp.get<double>(3 * (size_t)B);
+    d_owner = tmp.get<int>(N);
+    d_aoff = tmp.get<int>(B + 1);
+    int* d_z = tmp.get<int>(N);     // every host buffer is consumed before the pass's round trip: nothing of the caller's is read after it
+    if (!d_cart || !d_frac || !d_lat || !d_reach || !d_owner || !d_aoff || !d_z) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+    HIP_TRY(eng, hipMemcpyAsync(d_z, h->z, sizeof(int) * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_frac, h->frac, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_lat, h->lattice, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_reach, reach.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_owner, owner.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(eng, hipMemcpyAsync(d_aoff, h->atom_off, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+    const bool spec = attempt == 0;
+    auto cap = [&](double per_atom) { return (int)std::min<double>(2.0e9, per_atom * N * 1.25 + 4096.0); };
+    int capE = spec ? (cap(eng->last_Ed / (double)eng->last_N) & ~1) : 0, capA = spec ? cap(eng->last_A / (double)eng->last_N) : 0,
+        capEb = spec ? cap(eng->last_Eb / (double)eng->last_N) : 0;
+    bool overflowed = false;
+    TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, r_atom, r_bond, tol, spec, capE, capA, capEb, gc, overflowed,
+                   e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr, a_b1, a_d1, a_b2, a_d2));
+    if (overflowed) { eng->n_spec_overflows++; continue; }   // capacities too small: repeat with the exact, three-round-trip pass
+    if (spec) eng->n_spec_builds++;
+    const int Ed = gc.Ed, Eu = gc.Ed / 2, A = gc.A, Eb = gc.Eb;
+    eng->last_N = N; eng->last_Ed = Ed; eng->last_A = A; eng->last_Eb = Eb; eng->last_r_atom = r_atom; eng->last_r_bond = r_bond;
 
-  NlArgs nl{};
-  nl.cart = d_cart; nl.frac = d_frac; nl.lattice = d_lat; nl.reach = d_reach; nl.atom_owner = d_owner; nl.atom_off = d_aoff;
-  nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt;
-  const dim3 wave_per_atom((unsigned)((N + 3) / 4));
-  hipLaunchKernelGGL((k_neighbors<false>), wave_per_atom, dim3(256), 0, st, nl);
-  TRY(exclusive_scan(eng, tmp, d_ccnt, d_coff, N + 1));
-  int Ed = 0;
-  HIP_TRY(eng, hipMemcpyAsync(&Ed, d_coff + N, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(eng, hipStreamSynchronize(st));
-  if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
-  const int Eu = Ed / 2;
-
-  int* e_center = tmp.get<int>(Ed); int* e_nbr = tmp.get<int>(Ed); int* e_img = tmp.get<int>(3 * (size_t)Ed);
-  float* e_image = tmp.get<float>(3 * (size_t)Ed); double* e_dist = tmp.get<double>(Ed); int* e_owner = tmp.get<int>(Ed);
-  int* e_rev = tmp.get<int>(Ed); int* e_d2u = tmp.get<int>(Ed); int* is_first = tmp.get<int>(Ed + 1); int* first_scan = tmp.get<int>(Ed + 1);
-  int* p_center = tmp.get<int>(Ed); int* p_nbr = tmp.get<int>(Ed);
-  int* u_u2d = tmp.get<int>(Eu); int* short_cnt = tmp.get<int>(N); int* ang_cnt = tmp.get<int>(Eu + 1); int* ang_off = tmp.get<int>(Eu + 1);
-  int* is_node = tmp.get<int>(Eu + 1); int* node_scan = tmp.get<int>(Eu + 1); int* u_bnode = tmp.get<int>(Eu);
-  if (!e_center || !e_nbr || !e_img || !e_image || !e_dist || !e_owner || !e_rev || !e_d2u || !is_first || !first_scan || !p_center ||
-      !p_nbr || !u_u2d || !short_cnt || !ang_cnt || !ang_off || !is_node || !node_scan || !u_bnode) {
-    eng->err = "graph build: scratch allocation failed";
-    return CHG_ENOMEM;
-  }
-  int A = 0, Eb = 0, flags[4] = {0, 0, 0, 0};
-  int *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr, *bn_und = nullptr;
-  HIP_TRY(eng, hipMemsetAsync(ang_cnt, 0, sizeof(int) * (Eu + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(is_node, 0, sizeof(int) * (Eu + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(is_first, 0, sizeof(int) * (Ed + 1), st));
-  if (Ed > 0) {
-    nl.center_off = d_coff; nl.e_center = e_center; nl.e_nbr = e_nbr; nl.e_img = e_img; nl.e_image = e_image; nl.e_dist = e_dist;
-    nl.e_owner = e_owner;
-    hipLaunchKernelGGL((k_neighbors<true>), wave_per_atom, dim3(256), 0, st, nl);
-    hipLaunchKernelGGL(k_reverse, g1(Ed), dim3(256), 0, st, e_center, e_nbr, e_img, d_coff, Ed, e_rev, is_first, d_flags);
-    TRY(exclusive_scan(eng, tmp, is_first, first_scan, Ed + 1));
-    hipLaunchKernelGGL(k_undirected, g1(Ed), dim3(256), 0, st, e_center, e_nbr, e_rev, is_first, first_scan, Ed, e_d2u, u_u2d, p_center, p_nbr);
-  }
-  hipLaunchKernelGGL(k_short_count, g1(N), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1);
-  if (Eu > 0) {
-    hipLaunchKernelGGL(k_angle_count, g1(Eu), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, Eu, r_bond, ang_cnt);
-    TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, Eu + 1));
-    HIP_TRY(eng, hipMemcpyAsync(&A, ang_off + Eu, sizeof(int), hipMemcpyDeviceToHost, st));
-  }
-  HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(eng, hipStreamSynchronize(st));
-  if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
-  a_ctr = tmp.get<int>(A); a_b1 = tmp.get<int>(A); a_d1 = tmp.get<int>(A); a_b2 = tmp.get<int>(A); a_d2 = tmp.get<int>(A);
-  if (!a_ctr || !a_b1 || !a_d1 || !a_b2 || !a_d2) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-  if (A > 0) {
-    hipLaunchKernelGGL(k_angle_fill, g1(Eu), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, Eu, r_bond, a_ctr, a_b1,
-                       a_d1, a_b2, a_d2, is_node);
-    TRY(exclusive_scan(eng, tmp, is_node, node_scan, Eu + 1));
-    HIP_TRY(eng, hipMemcpyAsync(&Eb, node_scan + Eu, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(eng, hipStreamSynchronize(st));
-  }
-  bn_und = tmp.get<int>(Eb);
-  if (!bn_und) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-  if (Eu > 0) {
-    if (A == 0) HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (Eu + 1), st));
-    hipLaunchKernelGGL(k_bond_nodes, g1(Eu), dim3(256), 0, st, is_node, node_scan, Eu, u_bnode, bn_und);
-  }
-  HIP_TRY(eng, hipGetLastError());
-
-  // the batch itself: same arena layout as an uploaded batch, filled by device-to-device copies
-  chg_batch* b = new (std::nothrow) chg_batch();
-  if (!b) return CHG_ENOMEM;
-  b->B = B; b->N = N; b->Ed = Ed; b->Eu = Eu; b->A = A; b->Eb = Eb; b->L = eng->desc.n_conv;
-  size_t total = 0;
-  carve(b, nullptr, total);
-  int s = acquire_arena(eng, b, total);
-  if (s != CHG_OK) { delete b; return s; }
-  carve(b, b->arena, total);
-  register_names(b);
-  b->h_atom_off.assign(h->atom_off, h->atom_off + B + 1);
-  s = h2d(eng, b->z, h->z, (size_t)N);
-  if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
-  if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
-  if (s == CHG_OK) {
-    hipLaunchKernelGGL(k_f64_to_f32, g1(3 * (int64_t)N), dim3(256), 0, st, d_frac, b->frac, 3 * N);
-    hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
-  }
+    // the batch itself: same arena layout as an uploaded batch, filled by device-to-device copies (stream order: no sync)
+    chg_batch* b = new (std::nothrow) chg_batch();
+    if (!b) return CHG_ENOMEM;
+    b->B = B; b->N = N; b->Ed = Ed; b->Eu = Eu; b->A = A; b->Eb = Eb; b->L = eng->desc.n_conv;
+    size_t total = 0;
+    carve(b, nullptr, total);
+    int s = acquire_arena(eng, b, total);
+    if (s != CHG_OK) { delete b; return s; }
+    carve(b, b->arena, total);
+    register_names(b);
+    b->h_atom_off.assign(h->atom_off, h->atom_off + B + 1);
+    s = d2d(eng, b->z, (const int*)d_z, (size_t)N);
+    if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
+    if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
+    if (s == CHG_OK) {
+      hipLaunchKernelGGL(k_f64_to_f32, g1(3 * (int64_t)N), dim3(256), 0, st, d_frac, b->frac, 3 * N);
+      hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
+    }
 #define CP(dst, src, n) if (s == CHG_OK) s = d2d(eng, b->dst, src, (size_t)(n))
-  CP(e_center, e_center, Ed); CP(e_nbr, e_nbr, Ed); CP(e_d2u, e_d2u, Ed); CP(e_owner, e_owner, Ed); CP(e_rev, e_rev, Ed);
-  CP(p_center, p_center, Ed); CP(p_nbr, p_nbr, Ed); CP(e_image, e_image, 3 * (size_t)Ed);
-  CP(u_u2d, u_u2d, Eu); CP(u_bnode, u_bnode, Eu); CP(bn_und, bn_und, Eb);
-  CP(a_ctr, a_ctr, A); CP(a_d1, a_d1, A); CP(a_d2, a_d2, A);
+    CP(e_center, e_center, Ed); CP(e_nbr, e_nbr, Ed); CP(e_d2u, e_d2u, Ed); CP(e_owner, e_owner, Ed); CP(e_rev, e_rev, Ed);
+    CP(p_center, p_center, Ed); CP(p_nbr, p_nbr, Ed); CP(e_image, e_image, 3 * (size_t)Ed);
+    CP(u_u2d, u_u2d, Eu); CP(u_bnode, u_bnode, Eu); CP(bn_und, bn_und, Eb);
+    CP(a_ctr, a_ctr, A); CP(a_d1, a_d1, A); CP(a_d2, a_d2, A);
 #undef CP
-  if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
-  if (s == CHG_OK && hipStreamSynchronize(st) != hipSuccess) { eng->err = "graph build: synchronisation failed"; s = CHG_EHIP; }
-  if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
-  if (counts_out) {
-    counts_out[0] = Ed; counts_out[1] = Eu; counts_out[2] = A; counts_out[3] = Eb; counts_out[4] = flags[1]; counts_out[5] = 0;
+    if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
+    // the scratch (TmpPool) is reused by the next build on this same stream, so stream order protects it; overflow
+    // allocations of the pool are freed by its destructor and need the copies to have finished
+    if (s == CHG_OK && !tmp.extra.empty() && hipStreamSynchronize(st) != hipSuccess) { eng->err = "graph build: synchronisation failed"; s = CHG_EHIP; }
+    if (s == CHG_OK && hipGetLastError() != hipSuccess) { eng->err = "graph build: launch failed"; s = CHG_EHIP; }
+    if (s != CHG_OK) { hipStreamSynchronize(st); hipFree(b->arena); delete b; return s; }
+    if (counts_out) {
+      counts_out[0] = Ed; counts_out[1] = Eu; counts_out[2] = A; counts_out[3] = Eb; counts_out[4] = gc.isolated; counts_out[5] = spec ? 1 : 0;
+    }
+    *out = b;
+    return CHG_OK;
   }
-  *out = b;
-  return CHG_OK;
+  eng->err = "graph build: internal error";
+  return CHG_EINVAL;
 }
 
 // =====================================================================================================
@@ -1125,6 +1208,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   eng->device = device;
   eng->desc = *desc;
   if (const char* g = std::getenv("CHGNET_HIP_GRAPHS")) eng->use_graphs = std::string(g) != "0";
+  if (const char* g = std::getenv("CHGNET_SPEC_BUILD")) eng->spec_builds = std::string(g) != "0";
   HIP_TRY(eng, hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(eng, hipGetDeviceProperties(&prop, device));
@@ -1192,6 +1276,13 @@ int chg_engine_destroy(chg_engine* eng) {
 }
 
 const char* chg_last_error(const chg_engine* eng) { return eng ? eng->err.c_str() : "null engine"; }
+
+int chg_engine_build_stats(chg_engine* eng, int64_t* single_pass_builds, int64_t* capacity_overflows) {
+  if (!eng) return CHG_EINVAL;
+  if (single_pass_builds) *single_pass_builds = eng->n_spec_builds;
+  if (capacity_overflows) *capacity_overflows = eng->n_spec_overflows;
+  return CHG_OK;
+}
 
 int chg_engine_set_memory_limit(chg_engine* eng, int64_t bytes) {
   if (!eng || bytes < 0) return CHG_EINVAL;

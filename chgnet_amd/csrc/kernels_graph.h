@@ -39,6 +39,17 @@ struct NlArgs {
   float* e_image;            // [Ed,3] float (engine input)
   double* e_dist;            // [Ed]
   int* e_owner;
+  int cap_edges;             // fill pass: capacity of the e_* arrays (speculative sizing: rows beyond it are dropped and flagged)
+  int* overflow;             // set to 1 when a capacity was exceeded
+};
+
+// A count that is either known on the host (exact, two-pass build) or still on the device (single-pass build with
+// speculative capacities: the host reads all counts once, at the end).
+struct DevCount {
+  int host;
+  const int* dev;            // null: use host
+  int div;                   // the count is *dev / div (undirected = directed / 2)
+  __device__ __forceinline__ int get() const { return dev ? *dev / div : host; }
 };
 
 __device__ __forceinline__ double sq_dist(const double* __restrict__ cart, const double* __restrict__ L, int i, int j, int ia, int ib,
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256) void k_neighbors(NlArgs p) {
             if (d2 < p.r2) {
               const double d = sqrt(d2);
               if (d > p.tol) {
+                if (w >= p.cap_edges) { *p.overflow = 1; ++w; continue; }
                 p.e_center[w] = i;
                 p.e_nbr[w] = j;
                 p.e_img[3 * w] = ia; p.e_img[3 * w + 1] = ib; p.e_img[3 * w + 2] = ic;
@@ -131,10 +143,10 @@ __global__ __launch_bounds__(256) void k_neighbors(NlArgs p) {
 
 // reverse edge of every directed edge by binary search in the neighbour's (nbr, image)-sorted range
 __global__ void k_reverse(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_img,
-                          const int* __restrict__ center_off, int n_edges, int* __restrict__ e_rev, int* __restrict__ is_first,
+                          const int* __restrict__ center_off, DevCount n_edges, int* __restrict__ e_rev, int* __restrict__ is_first,
                           int* __restrict__ err) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_edges) return;
+  if (e >= n_edges.get() || err[2]) return;     // err[2]: a speculative capacity was exceeded, the edge list is truncated
   const int i = e_center[e], j = e_nbr[e];
   const int t0 = -e_img[3 * e], t1 = -e_img[3 * e + 1], t2 = -e_img[3 * e + 2];
   int lo = center_off[j], hi = center_off[j + 1] - 1, found = -1;
@@ -154,10 +166,10 @@ __global__ void k_reverse(const int* __restrict__ e_center, const int* __restric
 }
 
 __global__ void k_undirected(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_rev,
-                             const int* __restrict__ is_first, const int* __restrict__ first_scan, int n_edges, int* __restrict__ e_d2u,
-                             int* __restrict__ u_u2d, int* __restrict__ p_center, int* __restrict__ p_nbr) {
+                             const int* __restrict__ is_first, const int* __restrict__ first_scan, DevCount n_edges, int* __restrict__ e_d2u,
+                             int* __restrict__ u_u2d, int* __restrict__ p_center, int* __restrict__ p_nbr, const int* __restrict__ overflow) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_edges || !is_first[e]) return;
+  if (e >= n_edges.get() || *overflow || !is_first[e]) return;
   const int k = first_scan[e], s = e_rev[e];
   u_u2d[k] = e;
   e_d2u[e] = k;
@@ -168,9 +180,9 @@ __global__ void k_undirected(const int* __restrict__ e_center, const int* __rest
 
 // per centre: number of edges strictly shorter than the bond-graph cutoff (graph.py:313 uses '<')
 __global__ void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
-                              int* __restrict__ short_cnt, int* __restrict__ n_isolated) {
+                              int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_atoms) return;
+  if (i >= n_atoms || *overflow) return;
   int c = 0;
   for (int e = center_off[i]; e < center_off[i + 1]; ++e) c += e_dist[e] < r_bond ? 1 : 0;
   short_cnt[i] = c;
@@ -179,10 +191,10 @@ __global__ void k_short_count(const double* __restrict__ e_dist, const int* __re
 
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
 __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
-                              const double* __restrict__ e_dist, const int* __restrict__ short_cnt, int n_und, double r_bond,
-                              int* __restrict__ ang_cnt) {
+                              const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
+                              int* __restrict__ ang_cnt, const int* __restrict__ overflow) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_und) return;
+  if (k >= n_und.get() || *overflow) return;
   const int f = u_u2d[k], s = e_rev[f];
   int c = 0;
   if (!(e_dist[f] > r_bond)) {   // note '>' on the first directed edge's distance (graph.py:289)
@@ -194,11 +206,13 @@ __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restri
 
 __global__ void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                              const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
-                             const int* __restrict__ ang_off, int n_und, double r_bond, int* __restrict__ a_ctr, int* __restrict__ a_b1,
-                             int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2, int* __restrict__ is_node) {
+                             const int* __restrict__ ang_off, DevCount n_und, double r_bond, int* __restrict__ a_ctr, int* __restrict__ a_b1,
+                             int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2, int* __restrict__ is_node,
+                             int cap_angles, int* __restrict__ overflow) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_und) return;
+  if (k >= n_und.get() || *overflow) return;
   if (ang_off[k + 1] == ang_off[k]) return;
+  if (ang_off[k + 1] > cap_angles) { *overflow = 1; return; }   // speculative capacity exceeded: the build is repeated exactly
   const int f = u_u2d[k];
   const int des[2] = {f, e_rev[f]};
   int w = ang_off[k];
@@ -217,12 +231,13 @@ __global__ void k_angle_fill(const int* __restrict__ u_u2d, const int* __restric
   is_node[k] = 1;
 }
 
-__global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, int n_und, int* __restrict__ u_bnode,
-                             int* __restrict__ bn_und) {
+__global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und, int* __restrict__ u_bnode,
+                             int* __restrict__ bn_und, int cap_nodes, int* __restrict__ overflow) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_und) return;
+  if (k >= n_und.get() || *overflow) return;
   if (is_node[k]) {
     u_bnode[k] = node_scan[k];
+    if (node_scan[k] >= cap_nodes) { *overflow = 1; return; }
     bn_und[node_scan[k]] = k;
   } else {
     u_bnode[k] = -1;
@@ -235,6 +250,13 @@ __global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restr
   if (a >= n_ang) return;
   a_b1c[a] = u_bnode[a_b1[a]];
   a_b2c[a] = u_bnode[a_b2[a]];
+}
+
+// counts of a single-pass build, gathered for one device-to-host copy: {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow}
+__global__ void k_collect_counts(const int* ed, const int* a, const int* eb, const int* flags, int* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2];
+  }
 }
 
 __global__ void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int n) {

@@ -95,6 +95,12 @@ class Engine:
             msg = f"chgnet_hip error {status}: {self.lib.chg_last_error(self.handle).decode()}"
             raise EngineOutOfMemory(msg) if status == -3 else RuntimeError(msg)
 
+    def build_stats(self) -> tuple[int, int]:
+        """(single-pass graph builds, capacity overflows that fell back to the exact pass) of ``build_batch``."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.chg_engine_build_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
     def set_memory_limit(self, n_bytes: int) -> None:
         """Refuse batch arenas above ``n_bytes`` with ``EngineOutOfMemory`` (0 = no limit)."""
         self._check(self.lib.chg_engine_set_memory_limit(self.handle, int(n_bytes)))

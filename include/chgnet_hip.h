@@ -109,6 +109,7 @@ const char* chg_last_error(const chg_engine* eng);
  * chgnet/model/model.py:639-650).  chg_batch_upload / chg_batch_build return CHG_ENOMEM -- and leave the
  * engine usable -- when the arena cannot be allocated or exceeds the limit set here (0 = no limit); the
  * host side then splits the chunk and retries (chgnet_amd/model.py). */
+int chg_engine_build_stats(chg_engine* eng, int64_t* single_pass_builds, int64_t* capacity_overflows);
 int chg_engine_set_memory_limit(chg_engine* eng, int64_t bytes);
 int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_bytes);
 int64_t chg_batch_bytes_required(int32_t n_conv, int32_t n_struct, int32_t n_atoms, int32_t n_directed, int32_t n_angles, int32_t n_bnodes);
@@ -125,7 +126,11 @@ typedef struct chg_structs_host {
   const double* lattice;      /* [B,3,3] float64, rows a,b,c          */
   const int32_t* atom_off;    /* [B+1]                                */
 } chg_structs_host;
-/* counts_out[6] = { n_directed, n_undirected, n_angles, n_bnodes, n_isolated_atoms, 0 } */
+/* counts_out[6] = { n_directed, n_undirected, n_angles, n_bnodes, n_isolated_atoms, single_pass }.
+ * The first build on an engine takes three blocking count round trips; later builds size their scratch from the previous
+ * build's per-atom counts (+25 %), take every count from device memory and read them once at the end (single_pass = 1);
+ * a capacity that proves too small is caught by a device-side flag and the build repeats on the exact path.
+ * chg_engine_build_stats reports how many builds went each way. */
 int chg_batch_build(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
                     chg_batch** out, int32_t* counts_out);
 /* int32 index array of a batch by pack.py name (e_center, e_nbr, e_d2u, u_u2d, a_ctr, ...) -- tests only */

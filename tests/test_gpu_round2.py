@@ -257,3 +257,45 @@ def test_trained_like_weights_batched_and_ragged(engine_tl, trained_like_weights
             worst[key] = max(worst.get(key, 0.0), err)
             assert err < max(2 * TOL_TL[key], 20 * ref_err), f"{key}: engine {err:.3e} vs reference-fp32 {ref_err:.3e}"
     assert worst["e"] < 1e-4 and worst["f"] < 1e-3        # the north star's bars, at realistic magnitudes
+
+
+def test_single_pass_graph_build_is_bit_exact_and_falls_back_on_overflow(hip_engine):
+    """Later builds size their scratch from the previous build and read the counts once (one round trip instead of
+    three): same arrays bit for bit; a denser structure than predicted trips the device-side overflow flag and
+    the exact pass takes over."""
+    import bench
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.pack import pack_batch
+    from test_gpu_parity import INT_ARRAYS
+
+    structs = bench.workload_structures(24, 7)
+    conv = CrystalGraphConverter()
+    want = pack_batch([conv(s) for s in structs])
+    hip_engine.build_batch(structs).free()                     # primes the per-atom counts for these cutoffs
+    s0, o0 = hip_engine.build_stats()
+    batch = hip_engine.build_batch(structs)
+    s1, o1 = hip_engine.build_stats()
+    assert (s1, o1) == (s0 + 1, o0)                            # went through the single-pass path
+    for attr in ("n_directed", "n_undirected", "n_angles", "n_bnodes"):
+        assert getattr(batch.packed, attr) == getattr(want, attr), attr
+    for name, count in INT_ARRAYS.items():
+        assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+    hip_engine.predict(batch, "efs")
+    r1 = hip_engine.download(batch, "efs")
+    batch.free()
+    up = hip_engine.upload(want)
+    hip_engine.predict(up, "efs")
+    r2 = hip_engine.download(up, "efs")
+    up.free()
+    for key in ("e", "f", "s"):
+        assert np.abs(r1[key] - r2[key]).max() < 2e-6, key
+    # a sparse gas primes tiny capacities; the dense cells that follow overflow them and are rebuilt exactly
+    sparse = [Structure(Lattice(np.eye(3) * 9.0), ["H", "O"], [[0, 0, 0], [0.3, 0.3, 0.3]]) for _ in range(24 * 20)]
+    hip_engine.build_batch(sparse).free()
+    batch = hip_engine.build_batch(structs)
+    s2, o2 = hip_engine.build_stats()
+    assert o2 == o1 + 1 and s2 == s1                           # overflow detected, exact pass used
+    for name, count in INT_ARRAYS.items():
+        assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+    batch.free()
