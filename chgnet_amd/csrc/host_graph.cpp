@@ -89,6 +89,109 @@ int neighbor_list(int32_t n, const double* frac, const double* L, double r, doub
   return CHG_GRAPH_OK;
 }
 
+// Cell-list neighbour search for large cells: O(n) instead of O(n^2), and THE SAME rows in THE SAME order as
+// neighbor_list above (centre-major, inside a centre sorted by (neighbour, ia, ib, ic)) with bit-identical
+// distances: candidates are found by binning the wrapped fractional coordinates into slabs no thinner than r
+// along every lattice-plane direction, then every candidate goes through the identical distance expression
+// (unwrapped coordinates, image relative to the coordinates as given) and the identical tests, and each
+// centre's rows are sorted.  pymatgen's find_points_in_spheres (the reference's neighbour list,
+// chgnet/graph/converter.py:132-134) is a cell list as well.
+int neighbor_list_cells(int32_t n, const double* frac, const double* L, double r, double tol, NeighborRows& rows) {
+  const double *a = L, *b = L + 3, *c = L + 6;
+  double bc[3], ca[3], ab[3];
+  cross3(b, c, bc);
+  cross3(c, a, ca);
+  cross3(a, b, ab);
+  const double vol = a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2];
+  if (!(std::fabs(vol) > 1e-12)) return CHG_GRAPH_EINVAL;
+  const double h[3] = {
+      std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
+      std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
+      std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
+  const double r2 = r * r;
+  int nb[3], reach_bins[3];
+  for (int k = 0; k < 3; ++k) {
+    nb[k] = std::max(1, std::min(1024, static_cast<int>(std::floor(h[k] / r))));
+    // |x_j + I nb - x_i| <= r nb / h in bin units, so the bin offset is at most floor(r nb / h) + 1
+    reach_bins[k] = static_cast<int>(std::floor(r * nb[k] / h[k] + 1e-9)) + 1;
+  }
+  std::vector<double> cart(3 * static_cast<size_t>(n));
+  std::vector<int32_t> shift(3 * static_cast<size_t>(n)), bin3(3 * static_cast<size_t>(n)), bin_of(n);
+  const size_t n_bins = static_cast<size_t>(nb[0]) * nb[1] * nb[2];
+  std::vector<int32_t> bin_start(n_bins + 1, 0), bin_atoms(n);
+  for (int32_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      cart[3 * i + k] = frac[3 * i] * a[k] + frac[3 * i + 1] * b[k] + frac[3 * i + 2] * c[k];
+      double fl = std::floor(frac[3 * i + k]);
+      double w = frac[3 * i + k] - fl;
+      if (w >= 1.0) { w -= 1.0; fl += 1.0; }          // -1e-17 - floor(-1e-17) rounds to 1.0
+      shift[3 * i + k] = static_cast<int32_t>(fl);
+      bin3[3 * i + k] = std::min(nb[k] - 1, static_cast<int>(w * nb[k]));
+    }
+    bin_of[i] = (bin3[3 * i] * nb[1] + bin3[3 * i + 1]) * nb[2] + bin3[3 * i + 2];
+    ++bin_start[bin_of[i] + 1];
+  }
+  for (size_t q = 0; q < n_bins; ++q) bin_start[q + 1] += bin_start[q];
+  {
+    std::vector<int32_t> fill(bin_start.begin(), bin_start.end() - 1);
+    for (int32_t i = 0; i < n; ++i) bin_atoms[fill[bin_of[i]]++] = i;
+  }
+  struct Row { int32_t j, ia, ib, ic; double d; };
+  std::vector<Row> found;
+  for (int32_t i = 0; i < n; ++i) {
+    found.clear();
+    for (int oa = -reach_bins[0]; oa <= reach_bins[0]; ++oa)
+      for (int ob = -reach_bins[1]; ob <= reach_bins[1]; ++ob)
+        for (int oc = -reach_bins[2]; oc <= reach_bins[2]; ++oc) {
+          const int o[3] = {oa, ob, oc};
+          int t[3], wrap[3];        // target bin and the image (relative to WRAPPED coordinates) it is reached through
+          for (int k = 0; k < 3; ++k) {
+            const int x = bin3[3 * i + k] + o[k];
+            wrap[k] = x >= 0 ? x / nb[k] : -((-x + nb[k] - 1) / nb[k]);
+            t[k] = x - wrap[k] * nb[k];
+          }
+          const int32_t q = (t[0] * nb[1] + t[1]) * nb[2] + t[2];
+          for (int32_t s = bin_start[q]; s < bin_start[q + 1]; ++s) {
+            const int32_t j = bin_atoms[s];
+            // image relative to the coordinates as given:  (f_j + I) - f_i = (w_j + wrap) - w_i  with w = f - shift
+            const int ia = wrap[0] - shift[3 * j] + shift[3 * i], ib = wrap[1] - shift[3 * j + 1] + shift[3 * i + 1],
+                      ic = wrap[2] - shift[3 * j + 2] + shift[3 * i + 2];
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {   // the expression of neighbor_list, term for term
+              const double dx = cart[3 * j + k] + ia * a[k] + ib * b[k] + ic * c[k] - cart[3 * i + k];
+              d2 += dx * dx;
+            }
+            if (d2 < r2) {
+              const double d = std::sqrt(d2);
+              if (d > tol) found.push_back(Row{j, ia, ib, ic, d});
+            }
+          }
+        }
+    std::sort(found.begin(), found.end(), [](const Row& x, const Row& y) {
+      if (x.j != y.j) return x.j < y.j;
+      if (x.ia != y.ia) return x.ia < y.ia;
+      if (x.ib != y.ib) return x.ib < y.ib;
+      return x.ic < y.ic;
+    });
+    for (const Row& w : found) {
+      rows.center.push_back(i);
+      rows.neighbor.push_back(w.j);
+      rows.image.push_back(w.ia);
+      rows.image.push_back(w.ib);
+      rows.image.push_back(w.ic);
+      rows.dist.push_back(w.d);
+    }
+  }
+  return CHG_GRAPH_OK;
+}
+
+// all-pairs below this size (the window loop is cheaper than binning + sorting for small cells); the choice never
+// changes the result.  method: 0 = by size, 1 = all pairs, 2 = cell list (chg_graph_build_with, tests).
+int neighbor_search(int32_t n, const double* frac, const double* L, double r, double tol, int method, NeighborRows& rows) {
+  const bool cells = method == CHG_GRAPH_SEARCH_CELLS || (method == CHG_GRAPH_SEARCH_AUTO && n >= 96);
+  return cells ? neighbor_list_cells(n, frac, L, r, tol, rows) : neighbor_list(n, frac, L, r, tol, rows);
+}
+
 template <class T>
 T* dup_array(const std::vector<T>& v) {
   T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
@@ -223,10 +326,15 @@ extern "C" {
 
 int chg_graph_build(int32_t n_atoms, const double* frac, const double* lattice, double r_atom,
                     double r_bond, double numerical_tol, chg_graph** out) {
-  if (n_atoms < 0 || !frac || !lattice || !out || !(r_atom > 0)) return CHG_GRAPH_EINVAL;
+  return chg_graph_build_with(n_atoms, frac, lattice, r_atom, r_bond, numerical_tol, CHG_GRAPH_SEARCH_AUTO, out);
+}
+
+int chg_graph_build_with(int32_t n_atoms, const double* frac, const double* lattice, double r_atom,
+                         double r_bond, double numerical_tol, int search, chg_graph** out) {
+  if (n_atoms < 0 || !frac || !lattice || !out || !(r_atom > 0) || search < 0 || search > 2) return CHG_GRAPH_EINVAL;
   try {
     NeighborRows rows;
-    const int st = neighbor_list(n_atoms, frac, lattice, r_atom, numerical_tol, rows);
+    const int st = neighbor_search(n_atoms, frac, lattice, r_atom, numerical_tol, search, rows);
     if (st != CHG_GRAPH_OK) return st;
     return build_from_rows(n_atoms, static_cast<int64_t>(rows.center.size()), rows.center.data(),
                            rows.neighbor.data(), rows.image.data(), rows.dist.data(), r_bond, out);

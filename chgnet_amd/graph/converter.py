@@ -46,6 +46,8 @@ def graph_lib() -> ctypes.CDLL:
         ip = ctypes.POINTER(ctypes.c_int64)
         lib.chg_graph_build.argtypes = [ctypes.c_int32, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, pp]
         lib.chg_graph_build.restype = ctypes.c_int
+        lib.chg_graph_build_with.argtypes = [ctypes.c_int32, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, pp]
+        lib.chg_graph_build_with.restype = ctypes.c_int
         lib.chg_graph_from_neighbors.argtypes = [ctypes.c_int32, ctypes.c_int64, ip, ip, ip, dp, ctypes.c_double, pp]
         lib.chg_graph_from_neighbors.restype = ctypes.c_int
         lib.chg_graph_free.argtypes = [ctypes.POINTER(_CGraph)]
@@ -82,16 +84,20 @@ def _check(lib, status: int) -> None:
         raise (ValueError if status in (-1, -3) else MemoryError)(f"graph builder: {msg}")
 
 
+_SEARCH = {"auto": 0, "pairs": 1, "cells": 2}
+
+
 def build_graph_arrays(frac: np.ndarray, lattice: np.ndarray, r_atom: float, r_bond: float,
-                       numerical_tol: float = 1e-8) -> dict:
-    """Neighbour list + graph for one structure -> dict of flat arrays."""
+                       numerical_tol: float = 1e-8, search: str = "auto") -> dict:
+    """Neighbour list + graph for one structure -> dict of flat arrays.  ``search``: "auto" (all pairs below 96
+    atoms, cell list above), "pairs" or "cells" -- the result is the same, bit for bit."""
     lib = graph_lib()
     frac = np.ascontiguousarray(frac, dtype=np.float64)
     lattice = np.ascontiguousarray(lattice, dtype=np.float64)
     out = ctypes.POINTER(_CGraph)()
     dp = ctypes.POINTER(ctypes.c_double)
-    st = lib.chg_graph_build(len(frac), frac.ctypes.data_as(dp), lattice.ctypes.data_as(dp),
-                             float(r_atom), float(r_bond), float(numerical_tol), ctypes.byref(out))
+    st = lib.chg_graph_build_with(len(frac), frac.ctypes.data_as(dp), lattice.ctypes.data_as(dp),
+                                  float(r_atom), float(r_bond), float(numerical_tol), _SEARCH[search], ctypes.byref(out))
     _check(lib, st)
     try:
         return _unpack(out)

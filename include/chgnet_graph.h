@@ -54,6 +54,14 @@ typedef struct chg_graph {
 int chg_graph_build(int32_t n_atoms, const double* frac, const double* lattice,
                     double r_atom, double r_bond, double numerical_tol, chg_graph** out);
 
+/* The neighbour search behind chg_graph_build: all pairs with an exact image window (small cells) or a cell list
+ * (slabs no thinner than r_atom along every lattice-plane direction; what pymatgen's find_points_in_spheres, the
+ * reference's neighbour list, does too).  Both give the same rows in the same order with bit-identical distances;
+ * AUTO switches at 96 atoms.  chg_graph_build_with exists so that tests can force either. */
+enum { CHG_GRAPH_SEARCH_AUTO = 0, CHG_GRAPH_SEARCH_PAIRS = 1, CHG_GRAPH_SEARCH_CELLS = 2 };
+int chg_graph_build_with(int32_t n_atoms, const double* frac, const double* lattice, double r_atom, double r_bond,
+                         double numerical_tol, int search, chg_graph** out);
+
 /* Same graph construction from a caller-supplied neighbour list (the arrays pymatgen's
  * get_neighbor_list returns); rows are taken in the given order, which fixes the
  * directed / undirected numbering exactly as create_graph.c:135-203 does. */

@@ -299,3 +299,25 @@ def test_single_pass_graph_build_is_bit_exact_and_falls_back_on_overflow(hip_eng
     for name, count in INT_ARRAYS.items():
         assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
     batch.free()
+
+
+def test_device_graph_build_2048_atom_cell(hip_engine):
+    """A 2,048-atom cell: the device builder (one wave per centre over all atoms of the structure) against the host's
+    cell-list builder, every index array bit for bit."""
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.pack import pack_batch
+    from test_gpu_parity import INT_ARRAYS
+
+    big = bench.limno2((4, 4, 2)).perturb(0.03, np.random.default_rng(9)).make_supercell([2, 2, 2])
+    assert len(big) == 2048
+    want = pack_batch([CrystalGraphConverter()(big)])
+    batch = hip_engine.build_batch([big])
+    for attr in ("n_directed", "n_undirected", "n_angles", "n_bnodes"):
+        assert getattr(batch.packed, attr) == getattr(want, attr), attr
+    for name, count in INT_ARRAYS.items():
+        assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+    hip_engine.predict(batch, "ef")
+    res = hip_engine.download(batch, "ef")
+    batch.free()
+    assert np.isfinite(res["e"]).all() and np.abs(res["f"].sum(0)).max() < 5e-3

@@ -228,3 +228,46 @@ def test_cutoff_boundary_rules_known_answer():
     s = Structure(Lattice(np.eye(3) * 3.0), ["Fe"], [[0, 0, 0]])     # images at exactly 3.0
     assert len(build_graph_arrays(s.frac_coords, s.lattice.matrix, 3.0, 3.0)["atom_graph"]) == 0
     assert len(build_graph_arrays(s.frac_coords, s.lattice.matrix, np.nextafter(3.0, 4.0), 3.0)["atom_graph"]) == 6
+
+
+def _random_cells():
+    rng = np.random.default_rng(21)
+    out = [s for s in _cases_for_native_reference()]
+    out.append(limno2().make_supercell([4, 3, 2]).perturb(0.05, rng))                       # 192 atoms, orthorhombic
+    out.append(Structure(Lattice([[7.1, 0.3, -0.4], [2.2, 6.5, 0.6], [-1.7, 2.4, 8.3]]), rng.choice([3, 8, 25], 40),
+                         rng.random((40, 3)) * 3 - 1))                                     # skewed, unwrapped coordinates
+    out.append(Structure(Lattice(np.diag([30.0, 3.2, 3.4])), rng.choice([3, 8], 24), rng.random((24, 3))))   # needle: 1 bin on two axes
+    out.append(Structure(Lattice(np.diag([12.0, 12.0, 12.0])), ["O"] * 8,
+                         [[0, 0, 0], [0.5, 0, 0], [1.0 - 1e-17, 0.5, 0.5], [-1e-17, 0.25, 0.75], [0.999999999999, 0.1, 0.1],
+                          [0.5, 0.5, 1.0], [2.5, -1.5, 0.5], [0.25, 0.25, 0.25]]))          # coordinates on / across the cell faces
+    return out
+
+
+def test_cell_list_equals_all_pairs_bit_for_bit():
+    """The O(n) cell-list search returns the rows of the all-pairs search in the same order with bit-identical
+    distances and images (any cell shape, unwrapped / on-the-boundary coordinates, cells smaller than the cutoff)."""
+    for s in _random_cells():
+        for r_atom, r_bond in ((6.0, 3.0), (3.7, 3.7), (11.0, 2.0)):
+            a = build_graph_arrays(s.frac_coords, s.lattice.matrix, r_atom, r_bond, search="pairs")
+            b = build_graph_arrays(s.frac_coords, s.lattice.matrix, r_atom, r_bond, search="cells")
+            for key in ("atom_graph", "image", "distance", "directed2undirected", "undirected2directed", "bond_graph"):
+                assert np.array_equal(a[key], b[key]), (len(s), r_atom, key)
+
+
+def test_cell_list_scales_linearly_to_thousands_of_atoms():
+    """2,048-atom cell: the automatic choice is the cell list; build time grows ~linearly with the atom count
+    (the all-pairs search grows quadratically), and a sub-sampled comparison with all pairs still matches."""
+    import time
+
+    base = limno2().make_supercell([4, 4, 2]).perturb(0.03, np.random.default_rng(9))      # 256 atoms
+    big = base.make_supercell([2, 2, 2])                                                   # 2048 atoms
+    t0 = time.perf_counter()
+    small = build_graph_arrays(base.frac_coords, base.lattice.matrix, 6.0, 3.0)
+    t1 = time.perf_counter()
+    large = build_graph_arrays(big.frac_coords, big.lattice.matrix, 6.0, 3.0)
+    t2 = time.perf_counter()
+    assert len(large["atom_graph"]) == 8 * len(small["atom_graph"]) and len(large["bond_graph"]) == 8 * len(small["bond_graph"])
+    assert (t2 - t1) < 20 * max(t1 - t0, 1e-3)                                              # 8x the atoms: nowhere near 64x
+    pairs = build_graph_arrays(big.frac_coords, big.lattice.matrix, 6.0, 3.0, search="pairs")
+    for key in ("atom_graph", "image", "distance", "bond_graph"):
+        assert np.array_equal(pairs[key], large[key]), key
