@@ -89,7 +89,7 @@ int neighbor_list(int32_t n, const double* frac, const double* L, double r, doub
   return CHG_GRAPH_OK;
 }
 
-// Cell-list neighbour search for large cells: O(n) instead of O(n^2), and THE SAME rows in THE SAME order as
+// Cell-list neighbour search for large cells (1024+ atoms): O(n) instead of O(n^2), and THE SAME rows in THE SAME order as
 // neighbor_list above (centre-major, inside a centre sorted by (neighbour, ia, ib, ic)) with bit-identical
 // distances: candidates are found by binning the wrapped fractional coordinates into slabs no thinner than r
 // along every lattice-plane direction, then every candidate goes through the identical distance expression
@@ -188,7 +188,7 @@ int neighbor_list_cells(int32_t n, const double* frac, const double* L, double r
 // all-pairs below this size (the window loop is cheaper than binning + sorting for small cells); the choice never
 // changes the result.  method: 0 = by size, 1 = all pairs, 2 = cell list (chg_graph_build_with, tests).
 int neighbor_search(int32_t n, const double* frac, const double* L, double r, double tol, int method, NeighborRows& rows) {
-  const bool cells = method == CHG_GRAPH_SEARCH_CELLS || (method == CHG_GRAPH_SEARCH_AUTO && n >= 96);
+  const bool cells = method == CHG_GRAPH_SEARCH_CELLS || (method == CHG_GRAPH_SEARCH_AUTO && n >= 1024);
   return cells ? neighbor_list_cells(n, frac, L, r, tol, rows) : neighbor_list(n, frac, L, r, tol, rows);
 }
 

@@ -89,7 +89,7 @@ _SEARCH = {"auto": 0, "pairs": 1, "cells": 2}
 
 def build_graph_arrays(frac: np.ndarray, lattice: np.ndarray, r_atom: float, r_bond: float,
                        numerical_tol: float = 1e-8, search: str = "auto") -> dict:
-    """Neighbour list + graph for one structure -> dict of flat arrays.  ``search``: "auto" (all pairs below 96
+    """Neighbour list + graph for one structure -> dict of flat arrays.  ``search``: "auto" (all pairs below 1024
     atoms, cell list above), "pairs" or "cells" -- the result is the same, bit for bit."""
     lib = graph_lib()
     frac = np.ascontiguousarray(frac, dtype=np.float64)
