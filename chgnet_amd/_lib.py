@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
     "chg_debug_fetch", "chg_test_rows_gemm",
     "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
-    "chg_stream_copy", "chg_backward", "chg_engine_build_stats",
+    "chg_stream_copy", "chg_backward", "chg_engine_build_stats", "chg_engine_update_weights",
 )
 
 
@@ -97,7 +97,8 @@ def load() -> ctypes.CDLL:
     lib.chg_batch_device_bytes.restype = ctypes.c_int64
     lib.chg_predict.argtypes = [vp, vp, ctypes.c_uint32]
     lib.chg_synchronize.argtypes = [vp]
-    lib.chg_backward.argtypes = [vp, vp, c_float_p, c_float_p]
+    lib.chg_backward.argtypes = [vp, vp, c_float_p, c_float_p, c_float_p]
+    lib.chg_engine_update_weights.argtypes = [vp, c_float_p]
     lib.chg_batch_download.argtypes = [vp, vp, ctypes.POINTER(OutHost)]
     lib.chg_timer_start.argtypes = [vp]
     lib.chg_timer_stop_ms.argtypes = [vp, c_float_p]

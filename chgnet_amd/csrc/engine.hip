@@ -127,6 +127,8 @@ struct chg_batch {
   char* train_arena = nullptr;
   size_t train_bytes = 0;
   std::vector<int> h_atom_off;   // host copy (chg_backward: atoms per structure)
+  float* t_mcot = nullptr;   // [N] magmom cotangent
+  bool t_has_mcot = false;
   float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
         *t_ro = nullptr;
 };
@@ -694,6 +696,7 @@ int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
   auto lay = [&](Carver& cv) {
     b->t_grad = cv.take<float>((size_t)eng->desc.n_weights);
     b->t_cot = cv.take<float>(b->B);
+    b->t_mcot = cv.take<float>(N);
     b->t_dumpG = cv.take<float>(rows * 2 * D);
     b->t_dumpH = cv.take<float>(rows * 2 * D);
     b->t_dumpZ = cv.take<float>(A * 2 * D);
@@ -808,6 +811,12 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   };
 
   TRY(atomconv_train(L - 1));
+  if (b->t_has_mcot) {   // Ga is dE/d atom[L-1] now: the features the magmom head reads (model.py:477-487)
+    LaunchScope ls(eng, "magmom_bwd");
+    hipLaunchKernelGGL(k_magmom_bwd, dim3(wave_grid(eng, N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->t_mcot, b->Ga, G(w.site_w),
+                       G(w.site_b), N);
+    HIP_TRY(eng, hipGetLastError());
+  }
   for (int l = L - 2; l >= 0; --l) {
     if (A > 0) {
       if (l < L - 2) {
@@ -1418,7 +1427,15 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   return CHG_OK;
 }
 
-int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, float* grad_blob) {
+int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
+  if (!eng || !weights_blob) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  HIP_TRY(eng, hipMemcpyAsync(eng->d_weights, weights_blob, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyHostToDevice, eng->stream));
+  HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+  return CHG_OK;
+}
+
+int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent, float* grad_blob) {
   if (!eng || !b || !grad_blob) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
@@ -1434,6 +1451,8 @@ int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, f
     g_b3 += (double)cot[i] * n;
   }
   HIP_TRY(eng, hipMemcpyAsync(b->t_cot, cot.data(), sizeof(float) * b->B, hipMemcpyHostToDevice, eng->stream));
+  b->t_has_mcot = magmom_cotangent != nullptr;
+  if (magmom_cotangent) HIP_TRY(eng, hipMemcpyAsync(b->t_mcot, magmom_cotangent, sizeof(float) * b->N, hipMemcpyHostToDevice, eng->stream));
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
   TRY(run_backward(eng, b));
   HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyDeviceToHost, eng->stream));

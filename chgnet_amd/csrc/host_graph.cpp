@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <unordered_map>
@@ -354,6 +356,95 @@ int chg_graph_from_neighbors(int32_t n_atoms, int64_t n_edges, const int64_t* ce
   }
 }
 
+int chg_pack_batch(int32_t B, const chg_graph_view* v, const chg_packed_out* o, int32_t* n_bnodes, int32_t* bad_graph) {
+  if (B < 0 || (B > 0 && !v) || !o || !n_bnodes) return CHG_GRAPH_EINVAL;
+  auto fail = [&](int32_t g, int code) { if (bad_graph) *bad_graph = g; return code; };
+  int64_t a0 = 0, e0 = 0, u0 = 0, g0 = 0;
+  o->atom_off[0] = o->edge_off[0] = o->und_off[0] = o->ang_off[0] = 0;
+  for (int32_t b = 0; b < B; ++b) {
+    const chg_graph_view& g = v[b];
+    const int32_t n = g.n_atoms, ed = g.n_directed, eu = g.n_undirected, na = g.n_angles;
+    if (n < 0 || ed < 0 || eu < 0 || na < 0 || ed != 2 * eu) return fail(b, CHG_GRAPH_EPAIRING);
+    if (a0 + n >= INT32_MAX || e0 + ed >= INT32_MAX || g0 + na >= INT32_MAX) return fail(b, CHG_GRAPH_EINVAL);
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t z = g.atomic_number[i];
+      if (z < 1 || z > 94) return fail(b, CHG_GRAPH_ERANGE);
+      o->z[a0 + i] = z;
+      o->atom_owner[a0 + i] = b;
+    }
+    std::memcpy(o->frac + 3 * a0, g.frac, sizeof(float) * 3 * static_cast<size_t>(n));
+    std::memcpy(o->lattice + 9 * static_cast<size_t>(b), g.lattice, sizeof(float) * 9);
+    std::memcpy(o->e_image + 3 * e0, g.image, sizeof(float) * 3 * static_cast<size_t>(ed));
+    for (int32_t k = 0; k < eu; ++k) {
+      const int32_t f = g.undirected2directed[k];
+      if (f < 0 || f >= ed) return fail(b, CHG_GRAPH_ERANGE);
+      o->u_u2d[u0 + k] = static_cast<int32_t>(e0 + f);
+      o->e_rev[e0 + f] = -1;           // marks "first edge of bond k seen", the second one is filled below
+    }
+    // bond-pair order and reverse edges: bond k = (first = u2d[k], second = its other directed edge)
+    for (int32_t e = 0; e < ed; ++e) o->p_center[e0 + e] = -1;   // scratch: second edge of bond (e0 + k), indexed by k
+    for (int32_t e = 0; e < ed; ++e) {
+      const int32_t c = g.atom_graph[2 * e], nb = g.atom_graph[2 * e + 1], k = g.directed2undirected[e];
+      if (c < 0 || c >= n || nb < 0 || nb >= n || k < 0 || k >= eu) return fail(b, CHG_GRAPH_ERANGE);
+      o->e_center[e0 + e] = static_cast<int32_t>(a0 + c);
+      o->e_nbr[e0 + e] = static_cast<int32_t>(a0 + nb);
+      o->e_d2u[e0 + e] = static_cast<int32_t>(u0 + k);
+      o->e_owner[e0 + e] = b;
+      if (g.undirected2directed[k] != e) {
+        if (o->p_center[e0 + k] != -1) return fail(b, CHG_GRAPH_EPAIRING);   // a third edge on bond k
+        o->p_center[e0 + k] = e;
+      }
+    }
+    for (int32_t k = 0; k < eu; ++k) {
+      const int32_t f = g.undirected2directed[k], s2 = o->p_center[e0 + k];
+      if (s2 < 0 || g.directed2undirected[f] != k) return fail(b, CHG_GRAPH_EPAIRING);
+      o->e_rev[e0 + f] = static_cast<int32_t>(e0 + s2);
+      o->e_rev[e0 + s2] = static_cast<int32_t>(e0 + f);
+    }
+    for (int32_t k = eu - 1; k >= 0; --k) {   // descending: slot 2k / 2k+1 >= k, the scratch entries still to be read sit below
+      const int32_t f = g.undirected2directed[k], s2 = o->p_center[e0 + k];
+      o->p_nbr[e0 + 2 * k] = static_cast<int32_t>(a0 + g.atom_graph[2 * f + 1]);
+      o->p_nbr[e0 + 2 * k + 1] = static_cast<int32_t>(a0 + g.atom_graph[2 * s2 + 1]);
+      const int32_t c1 = static_cast<int32_t>(a0 + g.atom_graph[2 * f]), c2 = static_cast<int32_t>(a0 + g.atom_graph[2 * s2]);
+      o->p_center[e0 + 2 * k] = c1;
+      o->p_center[e0 + 2 * k + 1] = c2;
+    }
+    for (int32_t a = 0; a < na; ++a) {
+      const int32_t* r = g.bond_graph + 5 * static_cast<size_t>(a);
+      if (r[0] < 0 || r[0] >= n || r[1] < 0 || r[1] >= eu || r[2] < 0 || r[2] >= ed || r[3] < 0 || r[3] >= eu || r[4] < 0 || r[4] >= ed)
+        return fail(b, CHG_GRAPH_ERANGE);
+      o->a_ctr[g0 + a] = static_cast<int32_t>(a0 + r[0]);
+      o->a_b1[g0 + a] = static_cast<int32_t>(u0 + r[1]);
+      o->a_d1[g0 + a] = static_cast<int32_t>(e0 + r[2]);
+      o->a_b2[g0 + a] = static_cast<int32_t>(u0 + r[3]);
+      o->a_d2[g0 + a] = static_cast<int32_t>(e0 + r[4]);
+    }
+    a0 += n; e0 += ed; u0 += eu; g0 += na;
+    o->atom_off[b + 1] = static_cast<int32_t>(a0);
+    o->edge_off[b + 1] = static_cast<int32_t>(e0);
+    o->und_off[b + 1] = static_cast<int32_t>(u0);
+    o->ang_off[b + 1] = static_cast<int32_t>(g0);
+  }
+  // compact numbering of the bond-graph nodes (monotone in the undirected index)
+  for (int64_t k = 0; k < u0; ++k) o->u_bnode[k] = -1;
+  for (int64_t a = 0; a < g0; ++a) {
+    o->u_bnode[o->a_b1[a]] = 0;
+    o->u_bnode[o->a_b2[a]] = 0;
+  }
+  int32_t nn = 0;
+  for (int64_t k = 0; k < u0; ++k)
+    if (o->u_bnode[k] == 0) {
+      o->u_bnode[k] = nn;
+      o->bn_und[nn++] = static_cast<int32_t>(k);
+    }
+  for (int64_t a = 0; a < g0; ++a) {
+    o->a_b1c[a] = o->u_bnode[o->a_b1[a]];
+    o->a_b2c[a] = o->u_bnode[o->a_b2[a]];
+  }
+  *n_bnodes = nn;
+  return CHG_GRAPH_OK;
+}
+
 void chg_graph_free(chg_graph* g) {
   if (!g) return;
   std::free(g->atom_graph);
@@ -371,6 +462,8 @@ const char* chg_graph_strerror(int status) {
     case CHG_GRAPH_EINVAL: return "invalid argument (null pointer, negative size, index out of range or singular lattice)";
     case CHG_GRAPH_ENOMEM: return "out of host memory";
     case CHG_GRAPH_EUNPAIRED: return "number of directed edges != 2 * number of undirected edges (directed edges are not complete)";
+    case CHG_GRAPH_ERANGE: return "an index (or an atomic number outside 1..94) lies outside its structure";
+    case CHG_GRAPH_EPAIRING: return "directed2undirected must map exactly two directed edges onto every undirected edge, one of them undirected2directed[k]";
     default: return "unknown status";
   }
 }

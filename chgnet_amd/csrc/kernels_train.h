@@ -156,4 +156,30 @@ __global__ void k_embed_grad(const float* __restrict__ Ga, const int* __restrict
   atomicAdd(gemb + (size_t)(z[i] - 1) * D + c, Ga[idx]);
 }
 
+// magmom head m_i = |h_i . w + b| (model.py:484-487): given gm_i = d loss / d m_i,
+//   dE/d h_i += gm_i sign(h_i . w + b) w,   d w += sum_i gm_i sign h_i,   d b += sum_i gm_i sign
+// one wave per atom (grid-stride), lane = feature; the weight sums stay in registers until the end.
+__global__ __launch_bounds__(256) void k_magmom_bwd(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
+                                                    const float* __restrict__ gm, float* __restrict__ Ga, float* __restrict__ g_w,
+                                                    float* __restrict__ g_b, int n_atoms) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float wl = w[lane], bb = b[0];
+  float acc_w = 0.f, acc_b = 0.f;
+  for (int i = wave; i < n_atoms; i += nwaves) {
+    const float h = atom[(size_t)i * D + lane];
+    float s = h * wl;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    s += bb;
+    const float coef = gm[i] * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));   // torch.abs: subgradient 0 at 0
+    Ga[(size_t)i * D + lane] += coef * wl;
+    acc_w += coef * h;
+    acc_b += coef;
+  }
+  atomicAdd(g_w + lane, acc_w);
+  if (lane == 0) atomicAdd(g_b, acc_b);
+}
+
 }  // namespace chg

@@ -166,15 +166,27 @@ class Engine:
         """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""
         self._check(self.lib.chg_predict(self.handle, batch.handle, _lib.task_mask(task)))
 
-    def backward(self, batch: DeviceBatch, e_grad=None) -> np.ndarray:
-        """Gradient blob (weight-blob layout) of ``sum_b e_grad[b] * e[b]`` after ``predict`` on ``batch``
-        (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names."""
+    def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None) -> np.ndarray:
+        """Gradient blob (weight-blob layout) of ``sum_b e_grad[b] * e[b] + sum_i m_grad[i] * m[i]`` after
+        ``predict`` on ``batch`` (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names."""
         grad = np.zeros(self.weights.blob.size, np.float32)
         cot = None if e_grad is None else np.ascontiguousarray(e_grad, np.float32).reshape(-1)
         if cot is not None and cot.size != batch.packed.n_struct:
             raise ValueError(f"e_grad has {cot.size} entries, the batch holds {batch.packed.n_struct} structures")
-        self._check(self.lib.chg_backward(self.handle, batch.handle, _fp(cot) if cot is not None else None, _fp(grad)))
+        mcot = None if m_grad is None else np.ascontiguousarray(m_grad, np.float32).reshape(-1)
+        if mcot is not None and mcot.size != batch.packed.n_atoms:
+            raise ValueError(f"m_grad has {mcot.size} entries, the batch holds {batch.packed.n_atoms} atoms")
+        self._check(self.lib.chg_backward(self.handle, batch.handle, _fp(cot) if cot is not None else None,
+                                          _fp(mcot) if mcot is not None else None, _fp(grad)))
         return grad
+
+    def update_weights(self, weights: PackedWeights) -> None:
+        """Replace the parameter values (optimizer step); same architecture / blob layout."""
+        if weights.blob.size != self.weights.blob.size:
+            raise ValueError("update_weights: blob length differs from the engine's")
+        blob = np.ascontiguousarray(weights.blob, dtype=np.float32)
+        self._check(self.lib.chg_engine_update_weights(self.handle, _fp(blob)))
+        self.weights = weights
 
     def synchronize(self) -> None:
         self._check(self.lib.chg_synchronize(self.handle))

@@ -50,6 +50,8 @@ def graph_lib() -> ctypes.CDLL:
         lib.chg_graph_build_with.restype = ctypes.c_int
         lib.chg_graph_from_neighbors.argtypes = [ctypes.c_int32, ctypes.c_int64, ip, ip, ip, dp, ctypes.c_double, pp]
         lib.chg_graph_from_neighbors.restype = ctypes.c_int
+        lib.chg_pack_batch.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        lib.chg_pack_batch.restype = ctypes.c_int
         lib.chg_graph_free.argtypes = [ctypes.POINTER(_CGraph)]
         lib.chg_graph_free.restype = None
         lib.chg_graph_strerror.argtypes = [ctypes.c_int]

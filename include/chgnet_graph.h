@@ -69,6 +69,38 @@ int chg_graph_from_neighbors(int32_t n_atoms, int64_t n_edges, const int64_t* ce
                              const int64_t* neighbor, const int64_t* image /*[E,3]*/,
                              const double* distance, double r_bond, chg_graph** out);
 
+/* ---- batching: list of CrystalGraphs -> one packed batch in global numbering (what chg_batch_upload takes) ----
+ * Replaces the per-graph Python loop of BatchedGraph.from_graphs (chgnet/model/model.py:820-899: index offsetting
+ * 856-857, 873-877, atom_owners 879) plus the extra index arrays of chgnet_amd/pack.py (compact bond-graph nodes,
+ * bond-pair order, reverse edges).  Every index is range-checked against its own structure first
+ * (CHG_GRAPH_ERANGE; the reference raises IndexError from index_select / nn.Embedding for the same inputs).
+ * All output arrays are caller-allocated with the sizes given by the counts (sum over the views); bn_und needs
+ * room for n_undirected entries, the number actually used is returned in *n_bnodes. */
+typedef struct chg_graph_view {
+  int32_t n_atoms, n_directed, n_undirected, n_angles;
+  const int32_t* atomic_number;        /* [n]     */
+  const float* frac;                   /* [n,3]   */
+  const float* lattice;                /* [3,3]   */
+  const int32_t* atom_graph;           /* [ed,2]  */
+  const float* image;                  /* [ed,3]  */
+  const int32_t* directed2undirected;  /* [ed]    */
+  const int32_t* undirected2directed;  /* [eu]    */
+  const int32_t* bond_graph;           /* [a,5]   */
+} chg_graph_view;
+
+typedef struct chg_packed_out {
+  int32_t *z, *atom_owner, *atom_off, *edge_off, *und_off, *ang_off;       /* [N] [N] [B+1] x4 */
+  float *frac, *lattice, *e_image;                                          /* [N,3] [B,9] [Ed,3] */
+  int32_t *e_center, *e_nbr, *e_d2u, *e_owner, *e_rev, *p_center, *p_nbr;   /* [Ed] */
+  int32_t *u_u2d, *u_bnode, *bn_und;                                        /* [Eu] [Eu] [<=Eu] */
+  int32_t *a_ctr, *a_b1, *a_d1, *a_b2, *a_d2, *a_b1c, *a_b2c;               /* [A] */
+} chg_packed_out;
+
+#define CHG_GRAPH_ERANGE (-4)   /* an index (or an atomic number outside 1..94) does not belong to its structure */
+#define CHG_GRAPH_EPAIRING (-5) /* directed2undirected / undirected2directed do not pair every bond with two directed edges */
+int chg_pack_batch(int32_t n_graphs, const chg_graph_view* views, const chg_packed_out* out, int32_t* n_bnodes,
+                   int32_t* bad_graph /* index of the offending graph on error, may be null */);
+
 void chg_graph_free(chg_graph* g);
 const char* chg_graph_strerror(int status);
 

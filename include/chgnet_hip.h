@@ -144,13 +144,18 @@ int64_t chg_batch_device_bytes(const chg_batch* batch);
 int chg_predict(chg_engine* eng, chg_batch* batch, uint32_t task_mask);
 int chg_synchronize(chg_engine* eng);
 
-/* Fine-tuning backward, energy part (reference: loss.backward() through CHGNet.forward, chgnet/trainer/trainer.py:399-411,
- * model.py:427-542).  After chg_predict on `batch`: grad_blob[i] = d( sum_b energy_cotangent[b] * energy[b] ) / d weights_blob[i],
+/* Fine-tuning backward, first-order part (reference: loss.backward() through CHGNet.forward, chgnet/trainer/trainer.py:399-411,
+ * model.py:427-542).  After chg_predict on `batch`:
+ *   grad_blob[i] = d( sum_b energy_cotangent[b] * energy[b] + sum_i magmom_cotangent[i] * magmom[i] ) / d weights_blob[i],
  * in the layout of the weight blob (chgnet_amd/pack.py:weight_layout; derived entries -- transposed copies, q_bias -- and the
  * frozen AtomRef stay 0; pack.py:unpack_weight_grads maps it back to state_dict names).  energy_cotangent: host [B] = d loss /
- * d energy[b] with energy as chg_batch_download returns it (null = all ones); grad_blob: host [n_weights].  Synchronous.
- * Overwrites the batch's gradient workspace: download forces / stress before calling. */
-int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, float* grad_blob);
+ * d energy[b] with energy as chg_batch_download returns it (null = all ones); magmom_cotangent: host [N] or null (no magmom term);
+ * grad_blob: host [n_weights].  Synchronous.  Overwrites the batch's gradient workspace: download forces / stress before calling.
+ * Force / stress terms of the loss need second derivatives (model.py:521-530); their sweep is derived and checked in
+ * oracle/staged_train.py and not yet in this library. */
+int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent, float* grad_blob);
+/* New parameter values for an existing engine (optimizer step): same blob layout and length as at creation. */
+int chg_engine_update_weights(chg_engine* eng, const float* weights_blob);
 int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* out);
 
 /* Wall time of the stream between two marks, from HIP events recorded on the engine's stream. */

@@ -1,0 +1,117 @@
+"""Host side of the fine-tuning path: CombinedLoss against the reference's own class, Adam against torch.optim.Adam,
+gradient all-reduce over a 2-rank gloo group."""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from chgnet_amd.trainer import Adam, CombinedLoss, TrainStep, allreduce_gradients
+from conftest import REPO
+
+
+def _batch(rng, missing: bool):
+    n_at = [3, 5, 2]
+    pred = {"e": rng.normal(size=3), "f": [rng.normal(size=(n, 3)) for n in n_at], "s": [rng.normal(size=(3, 3)) for _ in n_at],
+            "m": [np.abs(rng.normal(size=n)) for n in n_at]}
+    targ = {"e": rng.normal(size=3), "f": [rng.normal(size=(n, 3)) for n in n_at], "s": [rng.normal(size=(3, 3)) for _ in n_at],
+            "m": [np.abs(rng.normal(size=n)) for n in n_at]}
+    if missing:
+        targ["e"][1] = np.nan
+        targ["f"][0][1] = np.nan
+        targ["s"][2][:] = np.nan
+        targ["m"][1] = None
+        targ["m"][2][0] = np.nan            # a NaN anywhere drops the whole structure's magmoms (trainer.py:846)
+    return targ, pred
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/chgnet"), reason="live reference only in the build container")
+@pytest.mark.parametrize("criterion", ["MSE", "MAE", "Huber"])
+@pytest.mark.parametrize("missing", [False, True])
+def test_combined_loss_equals_the_references(criterion, missing):
+    """Loss value, MAEs, MAE sizes and d loss / d prediction against chgnet.trainer.trainer.CombinedLoss + autograd."""
+    from oracle._refimport import load_reference
+
+    load_reference(fast_graph=True)
+    from chgnet.trainer.trainer import CombinedLoss as RefLoss
+
+    rng = np.random.default_rng(3)
+    targ, pred = _batch(rng, missing)
+    kw = dict(target_str="efsm", criterion=criterion, energy_loss_ratio=1.3, force_loss_ratio=0.7, stress_loss_ratio=0.2,
+              mag_loss_ratio=0.4, delta=0.3)
+    ours, grads = CombinedLoss(**kw).gradients(targ, pred)
+    tp = {"e": torch.tensor(pred["e"], requires_grad=True), "f": [torch.tensor(x, requires_grad=True) for x in pred["f"]],
+          "s": [torch.tensor(x, requires_grad=True) for x in pred["s"]], "m": [torch.tensor(x, requires_grad=True) for x in pred["m"]]}
+    tt = {"e": torch.tensor(targ["e"]), "f": [torch.tensor(x) for x in targ["f"]], "s": [torch.tensor(x) for x in targ["s"]],
+          "m": [None if x is None else torch.tensor(x) for x in targ["m"]]}
+    ref = RefLoss(**kw)(tt, tp)
+    assert abs(ours["loss"] - float(ref["loss"])) < 1e-12
+    for k in "efsm":
+        assert abs(ours[f"{k}_MAE"] - float(ref[f"{k}_MAE"])) < 1e-12, k
+        assert ours[f"{k}_MAE_size"] == int(ref[f"{k}_MAE_size"]), k
+    ref["loss"].backward()
+    assert np.allclose(grads["e"], tp["e"].grad.numpy(), atol=1e-14)
+    assert np.allclose(grads["f"], np.concatenate([x.grad.numpy() for x in tp["f"]]), atol=1e-14)
+    assert np.allclose(grads["s"].reshape(-1, 3), np.concatenate([x.grad.numpy() for x in tp["s"]]), atol=1e-14)
+    gm = np.concatenate([np.zeros(len(x)) if x.grad is None else x.grad.numpy() for x in tp["m"]])
+    assert np.allclose(grads["m"], gm, atol=1e-14)
+
+
+def test_adam_equals_torch_adam():
+    rng = np.random.default_rng(0)
+    params = {"a": rng.normal(size=(4, 3)).astype(np.float32), "b": rng.normal(size=5).astype(np.float32),
+              "frozen": np.ones(2, np.float32)}
+    tparams = {k: torch.tensor(v.copy(), requires_grad=True) for k, v in params.items() if k != "frozen"}
+    topt = torch.optim.Adam(list(tparams.values()), lr=3e-3)
+    opt = Adam(params, lr=3e-3, frozen=("frozen",))
+    for _ in range(5):
+        grads = {k: rng.normal(size=v.shape).astype(np.float32) for k, v in params.items()}
+        for k, t in tparams.items():
+            t.grad = torch.tensor(grads[k])
+        topt.step()
+        params = opt.step(params, grads)
+    for k, t in tparams.items():
+        assert np.allclose(params[k], t.detach().numpy(), atol=2e-6), k
+    assert np.array_equal(params["frozen"], np.ones(2, np.float32))
+
+
+def _allreduce_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grads = {"w": np.full((3, 2), float(rank + 1), np.float32), "b": np.arange(4, dtype=np.float32) * (rank + 1)}
+    out = allreduce_gradients(grads)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_allreduce_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in ("w", "b"):
+        assert np.array_equal(r0[k], r1[k])
+    assert np.allclose(r0["w"], 1.5) and np.allclose(r0["b"], np.arange(4) * 1.5)      # mean over the two ranks
+    same = {"w": np.ones(2, np.float32)}
+    assert allreduce_gradients(same) is same                                             # no process group: unchanged
+
+
+def test_train_step_refuses_terms_the_device_cannot_differentiate(golden_weights):
+    from chgnet_amd.model import CHGNet
+
+    model = CHGNet(state_dict=golden_weights)
+    with pytest.raises(NotImplementedError, match="second-order sweep"):
+        TrainStep(model, targets="ef")
+    TrainStep(model, targets="em")          # first-order terms are fine (no GPU touched until the first call)
