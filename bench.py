@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0):
   roofline       the kernel with the largest share of the step (fp32-MFMA-bound), HIP events on the engine stream
   roofline_hbm   the HBM-bound kernels of the path against a STREAM-like copy measured in this process
   configs        the other BASELINE.json configs: C1 (single LiMnO2 cell + x1024), C3 (ragged 10-100-atom sweep
-                 through predict_structure, sharded over the ranks), C4 (NVT MD of 2x2x2 Li9Co7O16, steps/s)
+                 through predict_structure, sharded over the ranks), C4 (NVT MD of 2x2x2 Li9Co7O16, steps/s),
+                 C5 (one data-parallel fine-tuning epoch, energy + magmom terms, gradient all-reduce)
   cpu_baseline   the CPU oracle (oracle/chgnet_oracle.py, a torch port of the reference path) timed on this
                  box's host cores; the same leg checks the configs' results against the oracle (parity flags)
 """
@@ -352,6 +353,39 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             "steps_per_s": round(out["steps_per_s"], 1), "ms_per_step": round(1e3 / out["steps_per_s"], 3),
             "calculator_ms_per_step": round(1e3 * out["calculator_s"] / args.md_steps, 3),
             "temperature_K": round(out["temperature_K"], 1)}
+    # ---- C5: one fine-tuning epoch, data-parallel (energy + magmom terms: what the device differentiates today) ----
+    if args.train_structures > 0:
+        from chgnet_amd.trainer import TrainStep
+
+        per_rank = max(1, args.train_structures // ranks.world)
+        bs = min(args.structures, per_rank)
+        n_steps = (per_rank + bs - 1) // bs
+        conv6 = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+        first = 10_000_000 + ranks.rank * per_rank                       # structures no other config uses
+        batches = [[conv6(s) for s in workload_structures(min(bs, per_rank - i * bs), first + i * bs)] for i in range(n_steps)]
+        rng = np.random.default_rng(ranks.rank)
+        p0 = model.predict_graph(batches[0][:8], task="em")
+        labels = [{"e": np.float32(p0[0]["e"]) + rng.normal(0, 0.05, len(b_)).astype(np.float32),
+                   "m": [np.abs(rng.normal(0.5, 0.2, len(g_.atomic_number))).astype(np.float32) for g_ in b_]} for b_ in batches]
+        step = TrainStep(model, targets="em", learning_rate=1e-4)
+        step(batches[0], labels[0])                                      # warm-up: allocations, first-touch
+        ranks.barrier()
+        t0 = time.perf_counter()
+        losses = [step(b_, l_)["loss"] for b_, l_ in zip(batches, labels)]
+        eng.synchronize()
+        ranks.barrier()
+        dt = ranks.max_over_ranks(time.perf_counter() - t0)
+        model.release_forward_state()
+        if ranks.rank == 0:
+            n_done = sum(len(b_) for b_ in batches) * ranks.world
+            configs["C5_train_epoch"] = {
+                "workload": f"one epoch over {n_done} perturbed LiMnO2 5x1x1 cells (40 atoms) with synthetic energy + magmom labels, "
+                            f"{ranks.world} rank(s) x {n_steps} step(s) of {bs} structures: host graphs -> pack -> upload -> forward(em) -> "
+                            "CombinedLoss(MSE) -> chg_backward (all 136 parameter tensors) -> all-reduce of the 1.65 MB gradient -> Adam -> "
+                            "weights back on the engine",
+                "terms": "energy + magmom (first-order); force / stress terms need the stage-B sweep, not on the device yet",
+                "seconds": round(dt, 3), "structures_per_s": round(n_done / dt, 1), "ms_per_step": round(1e3 * dt / n_steps, 2),
+                "loss_first_last": [float(f"{losses[0]:.4g}"), float(f"{losses[-1]:.4g}")]}
     model._engine = None   # the bench owns the engine
     return configs, checks
 
@@ -377,6 +411,7 @@ def main() -> None:
     ap.add_argument("--sweep-structures", type=int, default=4000, help="C3: structures per GPU")
     ap.add_argument("--sweep-chunk", type=int, default=1000, help="C3: batch_size handed to predict_structure")
     ap.add_argument("--md-steps", type=int, default=300, help="C4: timed MD steps")
+    ap.add_argument("--train-structures", type=int, default=10240, help="C5: structures in the fine-tuning epoch (all ranks together); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: process-group plumbing only (gloo)")

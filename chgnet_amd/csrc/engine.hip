@@ -669,11 +669,16 @@ int d2h(chg_engine* eng, T* dst, const T* src, size_t n) {
 // =====================================================================================================
 template <int MT, int NT>
 int xty(chg_engine* eng, const char* label, const float* A, int lda, const int* a_idx, const float* B, int ldb, const int* b_idx, int rows,
-        float alpha, float* out, int ldo, int n_cols) {
+        float alpha, float* out, int ldo, int n_cols, float* a_colsum = nullptr) {
   if (rows <= 0) return CHG_OK;
   LaunchScope ls(eng, label);
-  XtyArgs p{A, lda, a_idx, B, ldb, b_idx, rows, alpha, out, ldo, n_cols};
-  hipLaunchKernelGGL((k_xty<MT, NT>), dim3(grid_for(rows, 2 * eng->num_cus)), dim3(BLOCK), (xty_lds<MT, NT>()), eng->stream, p);
+  XtyArgs p{A, lda, a_idx, B, ldb, b_idx, rows, alpha, out, ldo, n_cols, a_colsum};
+  // one workgroup per CU is resident (LDS), and every workgroup ends with one global atomic per output element:
+  // no more workgroups than CUs, and at least four row tiles each
+  const int ntiles = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int grid = std::max(1, std::min((ntiles + 3) / 4, eng->num_cus));
+  if (grid >= 8) grid &= ~7;
+  hipLaunchKernelGGL((k_xty<MT, NT>), dim3(grid), dim3(BLOCK), (xty_lds<MT, NT>()), eng->stream, p);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
@@ -726,10 +731,9 @@ float* grad_of(chg_engine* eng, chg_batch* b, const float* w) { return b->t_grad
 
 // gated-MLP internals of one layer: dW2c, dW2g, db2c, db2g from the (adjoint, hidden activation) dumps
 int gated_tail_grads(chg_engine* eng, chg_batch* b, const GatedW& g, int rows, float* (*G)(chg_engine*, chg_batch*, const float*)) {
-  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG, 2 * D, nullptr, b->t_dumpH, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2c), D, D)));
-  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG + D, 2 * D, nullptr, b->t_dumpH + D, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2g), D, D)));
-  TRY(colsum(eng, b->t_dumpG, 2 * D, nullptr, 0, rows, D, G(eng, b, g.b2c)));
-  return colsum(eng, b->t_dumpG + D, 2 * D, nullptr, 0, rows, D, G(eng, b, g.b2g));
+  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG, 2 * D, nullptr, b->t_dumpH, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2c), D, D, G(eng, b, g.b2c))));
+  return xty<4, 4>(eng, "wgrad_w2", b->t_dumpG + D, 2 * D, nullptr, b->t_dumpH + D, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2g), D, D,
+                   G(eng, b, g.b2g));
 }
 
 int run_backward(chg_engine* eng, chg_batch* b) {
@@ -757,12 +761,9 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   {
     const size_t pl = (size_t)N * D;
     const float* ro = b->t_ro;
-    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G1 * pl, D, nullptr, ro + RO_X0 * pl, D, nullptr, N, 1.0f, G(w.mlp_w0), D, D)));
-    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G2 * pl, D, nullptr, ro + RO_S1 * pl, D, nullptr, N, 1.0f, G(w.mlp_w1), D, D)));
-    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G3 * pl, D, nullptr, ro + RO_S2 * pl, D, nullptr, N, 1.0f, G(w.mlp_w2), D, D)));
-    TRY(colsum(eng, ro + RO_G1 * pl, D, nullptr, 0, N, D, G(w.mlp_b0)));
-    TRY(colsum(eng, ro + RO_G2 * pl, D, nullptr, 0, N, D, G(w.mlp_b1)));
-    TRY(colsum(eng, ro + RO_G3 * pl, D, nullptr, 0, N, D, G(w.mlp_b2)));
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G1 * pl, D, nullptr, ro + RO_X0 * pl, D, nullptr, N, 1.0f, G(w.mlp_w0), D, D, G(w.mlp_b0))));
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G2 * pl, D, nullptr, ro + RO_S1 * pl, D, nullptr, N, 1.0f, G(w.mlp_w1), D, D, G(w.mlp_b1))));
+    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G3 * pl, D, nullptr, ro + RO_S2 * pl, D, nullptr, N, 1.0f, G(w.mlp_w2), D, D, G(w.mlp_b2))));
     TRY(colsum(eng, ro + RO_S3C * pl, D, nullptr, 0, N, D, G(w.mlp_w3)));
     TRY(colsum(eng, ro + RO_GXX * pl, D, nullptr, 0, N, D, G(w.ro_ln_g)));
     TRY(colsum(eng, ro + RO_GX * pl, D, nullptr, 0, N, D, G(w.ro_ln_b)));
@@ -772,8 +773,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   auto atomconv_train = [&](int l) -> int {
     const ACW& aw = w.ac[l];
     // atom[l+1] = agg . Wout^T + b_out + atom[l]
-    TRY((xty<4, 4>(eng, "wgrad_out", b->Ga, D, nullptr, b->agg_l[l], D, nullptr, N, 1.0f, G(aw.w_out), D, D)));
-    TRY(colsum(eng, b->Ga, D, nullptr, 0, N, D, G(aw.b_out)));
+    TRY((xty<4, 4>(eng, "wgrad_out", b->Ga, D, nullptr, b->agg_l[l], D, nullptr, N, 1.0f, G(aw.w_out), D, D, G(aw.b_out))));
     if (Ed == 0) return CHG_OK;
     TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, N, 0));
     {
@@ -786,9 +786,8 @@ int run_backward(chg_engine* eng, chg_batch* b) {
     }
     TRY(gated_tail_grads(eng, b, aw.g, Ed, grad_of));
     // first layer, factorised: table gradients contract with the rows the tables were made from
-    TRY((xty<8, 4>(eng, "wgrad_tab", b->GP_l[l], 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn), D, D)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GP_l[l], 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn), D, D, G(aw.b1))));   // b1 sits in the centre half
     TRY((xty<8, 4>(eng, "wgrad_tab", b->GP_l[l] + 2 * D, 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn) + 2 * D * D, D, D)));
-    TRY(colsum(eng, b->GP_l[l], 4 * D, nullptr, 0, N, 2 * D, G(aw.b1)));
     TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, nullptr, b->hb0, D, nullptr, Eu, 1.0f, G(aw.w_bond), D, D)));
     if (Eb > 0 && b->hbc[l] != b->hbc[0]) {   // bond-graph nodes carry layer-l features instead of the embedding
       TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hbc[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
@@ -804,8 +803,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
                                 const float* w_ctr_t) -> int {
     TRY((xty<8, 4>(eng, "wgrad_tab", b->GR_l[slot], 4 * D, nullptr, hbc_rows, D, nullptr, Eb, 1.0f, G(w_bij), D, D)));
     TRY((xty<8, 4>(eng, "wgrad_tab", b->GR_l[slot] + 2 * D, 4 * D, nullptr, hbc_rows, D, nullptr, Eb, 1.0f, G(w_bij) + 2 * D * D, D, D)));
-    TRY((xty<8, 4>(eng, "wgrad_tab", b->GS_l[slot], 2 * D, nullptr, atom_rows, D, nullptr, N, 1.0f, G(w_ctr), D, D)));
-    TRY(colsum(eng, b->GS_l[slot], 2 * D, nullptr, 0, N, 2 * D, G(b1)));
+    TRY((xty<8, 4>(eng, "wgrad_tab", b->GS_l[slot], 2 * D, nullptr, atom_rows, D, nullptr, N, 1.0f, G(w_ctr), D, D, G(b1))));
     TRY((xty<8, 4>(eng, "wgrad_ang", gz_dump, 2 * D, nullptr, ang_rows, D, nullptr, A, 1.0f, G(w_ang), D, D)));
     return angle_table_grads(eng, b, slot, w_bij_t, w_ctr_t);
   };

@@ -28,6 +28,7 @@ struct XtyArgs {
   float* out;          // [16*MT][ldo], accumulated with fp32 atomics (zeroed by the caller)
   int ldo;
   int n_cols;          // columns of the result that exist (<= 16*NT): the 31-wide embedding weights are padded to 32
+  float* a_colsum;     // optional [16*MT]: += alpha * column sums of A (bias gradients ride along with the weight gradient)
 };
 
 template <int MT, int NT>
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
   const int ntiles = (p.rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
+  float asum[(M + 63) / 64];
+#pragma unroll
+  for (int c = 0; c < (M + 63) / 64; ++c) asum[c] = 0.f;
   constexpr int LA = M / 4, RA = 64 / LA;    // lanes per A row (float4 each), rows per load step
   constexpr int LB = N / 4, RB = 64 / LB;
   for (int tile = tb; tile < te; ++tile) {
@@ -92,6 +96,14 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
       for (int it = 0; it < TILE_ROWS / RB; ++it) *reinterpret_cast<f32x4*>(TB + (RB * it + sub) * SB + 4 * t) = v[it];
     }
     __builtin_amdgcn_wave_barrier();
+    if (p.a_colsum) {   // rows past the end were zero-filled: all 16 rows may be summed
+#pragma unroll
+      for (int c = 0; c < (M + 63) / 64; ++c)
+        if (64 * c + lane < M) {
+#pragma unroll
+          for (int rr = 0; rr < TILE_ROWS; ++rr) asum[c] += TA[rr * SA + 64 * c + lane];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < TILE_ROWS / 4; ++s) {
       float a[MT], b[NT];
@@ -117,6 +129,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
   for (int idx = tid; idx < M * N; idx += BLOCK) {
     const int m = idx / N, n = idx - m * N;
     if (n < p.n_cols) atomicAdd(p.out + (size_t)m * p.ldo + n, p.alpha * red[idx]);
+  }
+  if (p.a_colsum) {
+#pragma unroll
+    for (int c = 0; c < (M + 63) / 64; ++c)
+      if (64 * c + lane < M) atomicAdd(p.a_colsum + 64 * c + lane, p.alpha * asum[c]);
   }
 }
 
