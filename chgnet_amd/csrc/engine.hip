@@ -347,6 +347,7 @@ AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_d2u = b->e_d2u; a.n_edges = b->Ed;
   a.gw = eng->w.ac[l].g;
   a.agg = b->agg_l[l]; a.GA = b->GA; a.GP = b->GP_l[l]; a.GQ = b->GQ; a.Gwag = b->Gwag;
+  a.first_wag = l == b->L - 1;   // the reverse sweep starts with the last AtomConv
   return a;
 }
 
@@ -381,7 +382,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
     TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
   }
-  return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, 1);
+  return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, l == b->L - 1 ? 0 : 1);
 }
 
 // ---- BondConv / AngleUpdate ----------------------------------------------------------------------------
@@ -398,6 +399,7 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
   a.w_ang = w_ang; a.gw = g; a.out = out;
   a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
+  a.first_gang = slot == b->L - 2;   // slot l < L is BondConv l; the sweep's first angle kernel is BondConv L-2
   return a;
 }
 
@@ -603,7 +605,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->zero1_end = c.take<float>(0);
   // zero group 2 (cleared with one memset before the reverse sweep)
   b->zero2 = c.take<float>(0);
-  b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D); b->Gwbgc = c.take<float>(Eb * D); b->Gang = c.take<float>(A * D);
+  b->Gwbgc = c.take<float>(Eb * D);
   b->Gu = c.take<float>(4 * Ed); b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B);
   for (int l = 0; l < L; ++l) b->GP_l[l] = c.take<float>(N * 4 * D);
   for (int t = 0; t < 2 * L; ++t) {
@@ -612,6 +614,8 @@ void carve(chg_batch* b, char* base, size_t& total) {
     b->GS_l[t] = used ? c.take<float>(N * 2 * D) : nullptr;
   }
   b->zero2_end = c.take<float>(0);
+  // first written by a plain store in every sweep (AtomConv L-1: Gwag, its gemm_GQ: Gb; BondConv L-2: Gang): never zeroed
+  b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D); b->Gang = c.take<float>(A * D);
   b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D);
   b->GQ = c.take<float>(Eu * 2 * D);
   b->Gagg = c.take<float>(Eb * D);
@@ -794,7 +798,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hb0, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
     }
     TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, b->Ga, nullptr, N, 1));   // l == 0 too: d emb needs dE/d atom[0]
-    return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, Eu, 1);
+    return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, Eu, l == L - 1 ? 0 : 1);
   };
 
   // shared tail of BondConv / AngleUpdate: table gradients of slot -> weights, then back to atoms / bonds

@@ -290,6 +290,7 @@ struct AtomConvArgs {
   float* GP;           // [N,256] zeroed: grads of the two partials
   float* GQ;           // [Eu,128] zeroed
   float* Gwag;         // [Eu,64] accumulated over layers
+  int first_wag;       // this launch is the first writer of Gwag in the sweep: store, do not read (the buffer is not zeroed)
   // training (k_atomconv_bwd<true>) only
   float* dumpG;        // [Ed,128] pair order: adjoint of the second-layer pre-activations (core | gate)
   float* dumpH;        // [Ed,128] pair order: hidden activations (core | gate)
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     float* gwag_rows = p.Gwag + (size_t)k0 * D + lane;     // this tile owns these rows of Gwag: old values read here,
     float prev[TILE_ROWS / 2];                             // under the forward recomputation
 #pragma unroll
-    for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] = gwag_rows[(size_t)min(b, nb - 1) * D];
+    for (int b = 0; b < TILE_ROWS / 2; ++b) prev[b] = p.first_wag ? 0.f : gwag_rows[(size_t)min(b, nb - 1) * D];
     __builtin_amdgcn_wave_barrier();
     V64 zc, zg;
     read_dl<VT>(Trow, g, zc.t);
@@ -556,6 +557,7 @@ struct AngleArgs {
   float* GR;           // [Eb,256] zeroed
   float* GS;           // [N,128] zeroed
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
+  int first_gang;      // BondConv adjoint of the last layer: first writer of Gang in the sweep (store, do not read: not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
   // training (k_angle<.., true, .., true>) only
   float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
@@ -742,7 +744,12 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         // the increment (the group barriers keep the 4 loads ahead of the 128 MFMAs): 3.49 -> 3.41 ms.
         // For AngleUpdate the same costs 8 % (measured), it keeps the plain read-modify-write.
         Rows64 gang_old;
-        rows64_issue(gang_old, p.Gang, a, lane);
+        if (p.first_gang) {
+#pragma unroll
+          for (int it = 0; it < TILE_ROWS / 4; ++it) gang_old.v[it] = zero4();
+        } else {
+          rows64_issue(gang_old, p.Gang, a, lane);
+        }
         gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);

@@ -203,15 +203,15 @@ def test_train_step_lowers_the_loss_and_updates_the_engine(golden_weights):
     graphs = [conv(s) for s in bench.workload_structures(24, 300)]
     model = CHGNet(state_dict=golden_weights)
     before = model.predict_graph(graphs, task="em")
-    rng = np.random.default_rng(1)
-    targets = {"e": np.array([p["e"] for p in before]) + rng.normal(0, 0.05, len(graphs)),
-               "m": [p["m"] + 0.1 for p in before]}
-    step = TrainStep(model, targets="em", learning_rate=2e-3)
+    # labels a small, coherent shift away from the current predictions (with torch.optim.Adam at this learning rate the
+    # CPU oracle brings the same loss from 3.5e-3 to 1.8e-4 in 10 steps)
+    targets = {"e": np.array([p["e"] for p in before]) + 0.05, "m": [p["m"] + 0.1 for p in before]}
+    step = TrainStep(model, targets="em", learning_rate=2e-4)
     try:
-        losses = [step(graphs, targets)["loss"] for _ in range(8)]
+        losses = [step(graphs, targets)["loss"] for _ in range(10)]
     finally:
         model.release_forward_state()
-    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    assert np.isfinite(losses).all() and abs(losses[0] - 3.5e-3) < 2e-4 and losses[-1] < 0.3 * losses[0], losses
     after = model.predict_graph(graphs, task="em")
     assert max(abs(a["e"] - b["e"]) for a, b in zip(after, before)) > 1e-4            # the engine sees the new weights
     fresh = CHGNet(state_dict=model.state_dict()).predict_graph(graphs[:3], task="em")  # ... and they are the state_dict's
