@@ -371,7 +371,7 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
         step(batches[0], labels[0])                                      # warm-up: allocations, first-touch
         ranks.barrier()
         t0 = time.perf_counter()
-        losses = [step(b_, l_)["loss"] for b_, l_ in zip(batches, labels)]
+        losses = [info["loss"] for info in step.run_epoch(batches, labels)]
         eng.synchronize()
         ranks.barrier()
         dt = ranks.max_over_ranks(time.perf_counter() - t0)
@@ -380,7 +380,7 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             n_done = sum(len(b_) for b_ in batches) * ranks.world
             configs["C5_train_epoch"] = {
                 "workload": f"one epoch over {n_done} perturbed LiMnO2 5x1x1 cells (40 atoms) with synthetic energy + magmom labels, "
-                            f"{ranks.world} rank(s) x {n_steps} step(s) of {bs} structures: host graphs -> pack -> upload -> forward(em) -> "
+                            f"{ranks.world} rank(s) x {n_steps} step(s) of {bs} structures: host graphs -> pack (next batch on a helper thread) -> upload -> forward(em) -> "
                             "CombinedLoss(MSE) -> chg_backward (all 136 parameter tensors) -> all-reduce of the 1.65 MB gradient -> Adam -> "
                             "weights back on the engine",
                 "terms": "energy + magmom (first-order); force / stress terms need the stage-B sweep, not on the device yet",

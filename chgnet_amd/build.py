@@ -49,7 +49,7 @@ def build_graph(force: bool = False) -> str:
     src = os.path.join(CSRC, "host_graph.cpp")
     deps = [src, os.path.join(INCLUDE, "chgnet_graph.h")]
     if force or not _newer(GRAPH_LIB, deps):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", f"-I{INCLUDE}", src, "-o", GRAPH_LIB])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", f"-I{INCLUDE}", src, "-o", GRAPH_LIB])
     return GRAPH_LIB
 
 

@@ -9,6 +9,8 @@
 #include "chgnet_graph.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <climits>
@@ -358,17 +360,32 @@ int chg_graph_from_neighbors(int32_t n_atoms, int64_t n_edges, const int64_t* ce
 
 int chg_pack_batch(int32_t B, const chg_graph_view* v, const chg_packed_out* o, int32_t* n_bnodes, int32_t* bad_graph) {
   if (B < 0 || (B > 0 && !v) || !o || !n_bnodes) return CHG_GRAPH_EINVAL;
-  auto fail = [&](int32_t g, int code) { if (bad_graph) *bad_graph = g; return code; };
+  // offsets first (serial, trivial), then every graph writes its own disjoint output ranges: graphs are spread over threads
   int64_t a0 = 0, e0 = 0, u0 = 0, g0 = 0;
   o->atom_off[0] = o->edge_off[0] = o->und_off[0] = o->ang_off[0] = 0;
   for (int32_t b = 0; b < B; ++b) {
     const chg_graph_view& g = v[b];
+    if (g.n_atoms < 0 || g.n_directed < 0 || g.n_undirected < 0 || g.n_angles < 0 || g.n_directed != 2 * g.n_undirected) {
+      if (bad_graph) *bad_graph = b;
+      return CHG_GRAPH_EPAIRING;
+    }
+    a0 += g.n_atoms; e0 += g.n_directed; u0 += g.n_undirected; g0 += g.n_angles;
+    if (a0 >= INT32_MAX || e0 >= INT32_MAX || g0 >= INT32_MAX) {
+      if (bad_graph) *bad_graph = b;
+      return CHG_GRAPH_EINVAL;
+    }
+    o->atom_off[b + 1] = static_cast<int32_t>(a0);
+    o->edge_off[b + 1] = static_cast<int32_t>(e0);
+    o->und_off[b + 1] = static_cast<int32_t>(u0);
+    o->ang_off[b + 1] = static_cast<int32_t>(g0);
+  }
+  auto one_graph = [&](int32_t b) -> int {
+    const chg_graph_view& g = v[b];
     const int32_t n = g.n_atoms, ed = g.n_directed, eu = g.n_undirected, na = g.n_angles;
-    if (n < 0 || ed < 0 || eu < 0 || na < 0 || ed != 2 * eu) return fail(b, CHG_GRAPH_EPAIRING);
-    if (a0 + n >= INT32_MAX || e0 + ed >= INT32_MAX || g0 + na >= INT32_MAX) return fail(b, CHG_GRAPH_EINVAL);
+    const int64_t a0 = o->atom_off[b], e0 = o->edge_off[b], u0 = o->und_off[b], g0 = o->ang_off[b];
     for (int32_t i = 0; i < n; ++i) {
       const int32_t z = g.atomic_number[i];
-      if (z < 1 || z > 94) return fail(b, CHG_GRAPH_ERANGE);
+      if (z < 1 || z > 94) return CHG_GRAPH_ERANGE;
       o->z[a0 + i] = z;
       o->atom_owner[a0 + i] = b;
     }
@@ -377,31 +394,30 @@ int chg_pack_batch(int32_t B, const chg_graph_view* v, const chg_packed_out* o, 
     std::memcpy(o->e_image + 3 * e0, g.image, sizeof(float) * 3 * static_cast<size_t>(ed));
     for (int32_t k = 0; k < eu; ++k) {
       const int32_t f = g.undirected2directed[k];
-      if (f < 0 || f >= ed) return fail(b, CHG_GRAPH_ERANGE);
+      if (f < 0 || f >= ed) return CHG_GRAPH_ERANGE;
       o->u_u2d[u0 + k] = static_cast<int32_t>(e0 + f);
-      o->e_rev[e0 + f] = -1;           // marks "first edge of bond k seen", the second one is filled below
     }
     // bond-pair order and reverse edges: bond k = (first = u2d[k], second = its other directed edge)
-    for (int32_t e = 0; e < ed; ++e) o->p_center[e0 + e] = -1;   // scratch: second edge of bond (e0 + k), indexed by k
+    for (int32_t e = 0; e < ed; ++e) o->p_center[e0 + e] = -1;   // scratch: second edge of bond k, indexed by k
     for (int32_t e = 0; e < ed; ++e) {
       const int32_t c = g.atom_graph[2 * e], nb = g.atom_graph[2 * e + 1], k = g.directed2undirected[e];
-      if (c < 0 || c >= n || nb < 0 || nb >= n || k < 0 || k >= eu) return fail(b, CHG_GRAPH_ERANGE);
+      if (c < 0 || c >= n || nb < 0 || nb >= n || k < 0 || k >= eu) return CHG_GRAPH_ERANGE;
       o->e_center[e0 + e] = static_cast<int32_t>(a0 + c);
       o->e_nbr[e0 + e] = static_cast<int32_t>(a0 + nb);
       o->e_d2u[e0 + e] = static_cast<int32_t>(u0 + k);
       o->e_owner[e0 + e] = b;
       if (g.undirected2directed[k] != e) {
-        if (o->p_center[e0 + k] != -1) return fail(b, CHG_GRAPH_EPAIRING);   // a third edge on bond k
+        if (o->p_center[e0 + k] != -1) return CHG_GRAPH_EPAIRING;   // a third edge on bond k
         o->p_center[e0 + k] = e;
       }
     }
     for (int32_t k = 0; k < eu; ++k) {
       const int32_t f = g.undirected2directed[k], s2 = o->p_center[e0 + k];
-      if (s2 < 0 || g.directed2undirected[f] != k) return fail(b, CHG_GRAPH_EPAIRING);
+      if (s2 < 0 || g.directed2undirected[f] != k) return CHG_GRAPH_EPAIRING;
       o->e_rev[e0 + f] = static_cast<int32_t>(e0 + s2);
       o->e_rev[e0 + s2] = static_cast<int32_t>(e0 + f);
     }
-    for (int32_t k = eu - 1; k >= 0; --k) {   // descending: slot 2k / 2k+1 >= k, the scratch entries still to be read sit below
+    for (int32_t k = eu - 1; k >= 0; --k) {   // descending: slots 2k, 2k+1 >= k, the scratch entries still to be read sit below
       const int32_t f = g.undirected2directed[k], s2 = o->p_center[e0 + k];
       o->p_nbr[e0 + 2 * k] = static_cast<int32_t>(a0 + g.atom_graph[2 * f + 1]);
       o->p_nbr[e0 + 2 * k + 1] = static_cast<int32_t>(a0 + g.atom_graph[2 * s2 + 1]);
@@ -412,18 +428,38 @@ int chg_pack_batch(int32_t B, const chg_graph_view* v, const chg_packed_out* o, 
     for (int32_t a = 0; a < na; ++a) {
       const int32_t* r = g.bond_graph + 5 * static_cast<size_t>(a);
       if (r[0] < 0 || r[0] >= n || r[1] < 0 || r[1] >= eu || r[2] < 0 || r[2] >= ed || r[3] < 0 || r[3] >= eu || r[4] < 0 || r[4] >= ed)
-        return fail(b, CHG_GRAPH_ERANGE);
+        return CHG_GRAPH_ERANGE;
       o->a_ctr[g0 + a] = static_cast<int32_t>(a0 + r[0]);
       o->a_b1[g0 + a] = static_cast<int32_t>(u0 + r[1]);
       o->a_d1[g0 + a] = static_cast<int32_t>(e0 + r[2]);
       o->a_b2[g0 + a] = static_cast<int32_t>(u0 + r[3]);
       o->a_d2[g0 + a] = static_cast<int32_t>(e0 + r[4]);
     }
-    a0 += n; e0 += ed; u0 += eu; g0 += na;
-    o->atom_off[b + 1] = static_cast<int32_t>(a0);
-    o->edge_off[b + 1] = static_cast<int32_t>(e0);
-    o->und_off[b + 1] = static_cast<int32_t>(u0);
-    o->ang_off[b + 1] = static_cast<int32_t>(g0);
+    return CHG_GRAPH_OK;
+  };
+  const int n_threads = B >= 64 ? static_cast<int>(std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+  std::atomic<int> first_bad{INT32_MAX}, status{CHG_GRAPH_OK};
+  auto worker = [&](int t) {
+    for (int32_t b = t; b < B; b += n_threads) {
+      const int st = one_graph(b);
+      if (st != CHG_GRAPH_OK) {
+        int cur = first_bad.load();
+        while (b < cur && !first_bad.compare_exchange_weak(cur, b)) {}
+        if (first_bad.load() == b) status.store(st);
+        return;
+      }
+    }
+  };
+  if (n_threads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker, t);
+    for (auto& th : pool) th.join();
+  }
+  if (first_bad.load() != INT32_MAX) {
+    if (bad_graph) *bad_graph = first_bad.load();
+    return status.load();
   }
   // compact numbering of the bond-graph nodes (monotone in the undirected index)
   for (int64_t k = 0; k < u0; ++k) o->u_bnode[k] = -1;

@@ -176,9 +176,15 @@ class CHGNet:
         device-resident state this call leaves behind)."""
         if task not in VALID_TASKS:
             raise ValueError(f"Invalid {task=}. Must be one of {VALID_TASKS}.")
-        graphs = [graphs] if _is_graph(graphs) else list(graphs)
+        from chgnet_amd.pack import PackedBatch  # noqa: PLC0415
+
+        if isinstance(graphs, PackedBatch):           # already packed (a data loader packs the next batch while this one runs)
+            packed = graphs
+            graphs = range(packed.n_struct)
+        else:
+            graphs = [graphs] if _is_graph(graphs) else list(graphs)
+            packed = pack_batch(graphs)
         eng = self.engine
-        packed = pack_batch(graphs)
         self.release_forward_state()
         batch = eng.upload(packed)
         self._fwd_batch, self._fwd_task = batch, task

@@ -183,6 +183,23 @@ class TrainStep:
         self.optimizer = Adam(model.state_dict(), lr=learning_rate, frozen=("composition_model.fc.weight",))
         self.task = "em" if "m" in targets else "e"
 
+    def run_epoch(self, batches, targets) -> list[dict]:
+        """One pass over ``batches`` (lists of CrystalGraphs) with their label dictionaries.  The next batch is packed
+        on a helper thread (native code, GIL released) while the device works on the current one -- the role of the
+        reference's DataLoader workers (chgnet/data/dataset.py ``get_train_val_test_loader``)."""
+        from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
+
+        from chgnet_amd.pack import pack_batch  # noqa: PLC0415
+
+        infos = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(pack_batch, batches[0]) if len(batches) else None
+            for i in range(len(batches)):
+                packed = nxt.result()
+                nxt = pool.submit(pack_batch, batches[i + 1]) if i + 1 < len(batches) else None
+                infos.append(self(packed, targets[i]))
+        return infos
+
     def __call__(self, graphs, targets: dict) -> dict:
         model = self.model
         pred = model.forward(graphs, task=self.task)
