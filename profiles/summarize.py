@@ -12,7 +12,9 @@ import csv, json, os, shutil, sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "gpurun_out", "prof")
+SRC = os.path.join(REPO, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01", "prof")
+if not os.path.isdir(SRC):
+    SRC = os.path.join(REPO, "gpurun_out", "prof")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 LABELS = {  # kernel-name substring -> bench.py label
