@@ -97,7 +97,7 @@ def load() -> ctypes.CDLL:
     lib.chg_batch_device_bytes.restype = ctypes.c_int64
     lib.chg_predict.argtypes = [vp, vp, ctypes.c_uint32]
     lib.chg_synchronize.argtypes = [vp]
-    lib.chg_backward.argtypes = [vp, vp, c_float_p, c_float_p, c_float_p]
+    lib.chg_backward.argtypes = [vp, vp, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     lib.chg_engine_update_weights.argtypes = [vp, c_float_p]
     lib.chg_batch_download.argtypes = [vp, vp, ctypes.POINTER(OutHost)]
     lib.chg_timer_start.argtypes = [vp]

@@ -28,6 +28,7 @@
 #include "kernels_geom.h"
 #include "kernels_graph.h"
 #include "kernels_train.h"
+#include "kernels_train2.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -41,8 +42,8 @@ constexpr int MAX_CONV = 8;
 #endif
 constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
 
-struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
-struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
+struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
+struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
 struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };
 
 struct Weights {
@@ -51,6 +52,7 @@ struct Weights {
   BCW bc[MAX_CONV];
   AUW au[MAX_CONV];
   const float *site_w, *site_b, *ro_ln_g, *ro_ln_b, *mlp_w0, *mlp_b0, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2, *mlp_w3, *mlp_b3;
+  const float *mlp_w0_t, *mlp_w1_t, *mlp_w2_t;
 };
 
 struct ProfEntry { std::string label; int64_t launches = 0; double ms = 0.0; };
@@ -83,6 +85,8 @@ struct chg_engine {
   long n_spec_builds = 0, n_spec_overflows = 0;
   size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
 };
+
+struct Train2;   // stage-B buffers (defined with run_backward2)
 
 struct chg_batch {
   int B = 0, N = 0, Ed = 0, Eu = 0, A = 0, Eb = 0, L = 0;
@@ -127,6 +131,11 @@ struct chg_batch {
   char* train_arena = nullptr;
   size_t train_bytes = 0;
   std::vector<int> h_atom_off;   // host copy (chg_backward: atoms per structure)
+  std::vector<double> h_volume;  // host copy of the cell volumes (chg_backward: stress cotangent -> strain direction)
+  // stage B (second-order) workspace: one more arena, carved by layout_train2
+  char* t2_arena = nullptr;
+  size_t t2_bytes = 0;
+  struct Train2* t2 = nullptr;
   float* t_mcot = nullptr;   // [N] magmom cotangent
   bool t_has_mcot = false;
   float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
@@ -166,14 +175,13 @@ void take_ln(Cursor& c, GatedW& g) {
 
 size_t layout_weights(const float* base, int L, Weights& w) {
   Cursor c{base};
-  const float *dummy1, *dummy2;
   w.atomref = c.take(94); w.emb = c.take(94 * D);
   w.freq_ag = c.take(NRAD); w.freq_bg = c.take(NRAD); w.freq_ang = c.take(NFREQ);
   w.w_bond_emb = c.take(D * NRAD); w.w_wag = c.take(D * NRAD); w.w_wbg = c.take(D * NRAD); w.w_ang_emb = c.take(D * NANG);
   for (int l = 0; l < L; ++l) {
     ACW& a = w.ac[l];
     a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D); a.q_bias = c.take(2 * D);
-    take_gated_tail(c, a.g, dummy1, dummy2);
+    take_gated_tail(c, a.g, a.w2c_t, a.w2g_t);
     take_ln(c, a.g);
     a.w_out = c.take(D * D); a.b_out = c.take(D); a.w_out_t = c.take(D * D);
     a.w_cn_t = c.take(4 * D * D); a.w_bond_t = c.take(2 * D * D);
@@ -181,7 +189,7 @@ size_t layout_weights(const float* base, int L, Weights& w) {
   for (int l = 0; l < L - 1; ++l) {
     BCW& b = w.bc[l];
     b.w_bij = c.take(4 * D * D); b.w_ang = c.take(2 * D * D); b.w_ctr = c.take(2 * D * D); b.b1 = c.take(2 * D);
-    take_gated_tail(c, b.g, dummy1, dummy2);
+    take_gated_tail(c, b.g, b.w2c_t, b.w2g_t);
     take_ln(c, b.g);
     b.w_out = c.take(D * D); b.b_out = c.take(D); b.w_out_t = c.take(D * D);
     b.w_bij_t = c.take(4 * D * D); b.w_ang_t = c.take(2 * D * D); b.w_ctr_t = c.take(2 * D * D);
@@ -196,7 +204,7 @@ size_t layout_weights(const float* base, int L, Weights& w) {
   w.site_w = c.take(D); w.site_b = c.take(1); w.ro_ln_g = c.take(D); w.ro_ln_b = c.take(D);
   w.mlp_w0 = c.take(D * D); w.mlp_b0 = c.take(D); w.mlp_w1 = c.take(D * D); w.mlp_b1 = c.take(D);
   w.mlp_w2 = c.take(D * D); w.mlp_b2 = c.take(D); w.mlp_w3 = c.take(D); w.mlp_b3 = c.take(1);
-  c.take(D * D); c.take(D * D); c.take(D * D);  // mlp_w*_t (kept in the blob for the layout contract)
+  w.mlp_w0_t = c.take(D * D); w.mlp_w1_t = c.take(D * D); w.mlp_w2_t = c.take(D * D);
   return c.pos;
 }
 
@@ -883,6 +891,424 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   return CHG_OK;
 }
 
+// =====================================================================================================
+// Stage B: gradient of  sum_b ce_b e_b + sum_i gm_i m_i + sum_i gF_i . F_i + sum_b gS_b : sigma_b  w.r.t. every weight
+// (kernels_train2.h has the derivation).  Unfused first version: row GEMMs + row-local kernels + k_xty.
+// =====================================================================================================
+}  // namespace
+
+struct Train2 {
+  float *ux, *Wst;                                   // direction: [N,3], [B,9]
+  f32x4 *vd4, *ud4;                                  // [Ed]
+  float *X6, *X6d, *X3, *X3d, *X4, *X4d, *th2;       // bases + tangents [Eu,32] x4, [A,32] x2, [A,2]
+  float *hb0d, *wagd, *wbgcd;                        // tangent embeddings [Eu,64] x2, [Eb,64]
+  float *atomd[MAX_CONV + 1], *hbcd[MAX_CONV + 1], *angd[MAX_CONV], *aggd[MAX_CONV], *aggBd[MAX_CONV];
+  float *Pd, *Qd, *Rd, *Sd, *ZA, *ZAd;               // tangent tables [N,256] [Eu,128] [Eb,256] [N,128]; W_ang . ang [A,128] x2
+  float *Z, *Zd, *H, *Hd, *CG, *CGd, *BCG, *GCG, *BH, *GH, *BZ, *GZ;   // [R,128]
+  float *bar_a, *g_a, *bar_b, *g_b, *bar_wag, *g_wag, *bar_wbg, *g_wbg, *bar_ang, *g_ang, *bar_agg, *g_agg;
+  float *barP, *gP, *barQ, *gQ, *barR, *gR, *barS, *gS;
+  float* ro[26];                                     // readout planes [N,64]
+  float *zero_lo, *zero_hi;                          // range cleared at the start of every call
+};
+
+namespace {
+
+void free_train2(chg_batch* b) { delete b->t2; b->t2 = nullptr; }
+
+void layout_train2(chg_batch* b, Train2& t, Carver& c) {
+  const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb, R = std::max(Ed, A);
+  const int L = b->L;
+  t.ux = c.take<float>(3 * N); t.Wst = c.take<float>(9 * B);
+  t.vd4 = c.take<f32x4>(Ed); t.ud4 = c.take<f32x4>(Ed);
+  t.X6 = c.take<float>(Eu * KB2); t.X6d = c.take<float>(Eu * KB2); t.X3 = c.take<float>(Eu * KB2); t.X3d = c.take<float>(Eu * KB2);
+  t.X4 = c.take<float>(A * KB2); t.X4d = c.take<float>(A * KB2); t.th2 = c.take<float>(2 * A);
+  t.hb0d = c.take<float>(Eu * D); t.wagd = c.take<float>(Eu * D); t.wbgcd = c.take<float>(Eb * D);
+  for (int l = 0; l <= L; ++l) t.atomd[l] = c.take<float>(N * D);
+  for (int l = 0; l < L; ++l) t.hbcd[l] = c.take<float>(Eb * D);
+  for (int l = 0; l < L - 1; ++l) t.angd[l] = c.take<float>(A * D);
+  t.Pd = c.take<float>(N * 4 * D); t.Qd = c.take<float>(Eu * 2 * D); t.Rd = c.take<float>(Eb * 4 * D); t.Sd = c.take<float>(N * 2 * D);
+  t.ZA = c.take<float>(A * 2 * D); t.ZAd = c.take<float>(A * 2 * D);
+  float** rows[] = {&t.Z, &t.Zd, &t.H, &t.Hd, &t.CG, &t.CGd, &t.BCG, &t.GCG, &t.BH, &t.GH, &t.BZ, &t.GZ};
+  for (float** r : rows) *r = c.take<float>(R * 2 * D);
+  t.bar_agg = c.take<float>(std::max(N, Eb) * D); t.g_agg = c.take<float>(std::max(N, Eb) * D);
+  t.bar_a = c.take<float>(N * D); t.g_a = c.take<float>(N * D);
+  for (int i = 0; i < 26; ++i) t.ro[i] = c.take<float>(N * D);
+  // everything below is accumulated into (atomics / += GEMMs): cleared at the start of a call
+  t.zero_lo = c.take<float>(0);
+  for (int l = 0; l < L; ++l) t.aggd[l] = c.take<float>(N * D);
+  for (int l = 0; l < L - 1; ++l) t.aggBd[l] = c.take<float>(Eb * D);
+  t.bar_b = c.take<float>(Eu * D); t.g_b = c.take<float>(Eu * D); t.bar_wag = c.take<float>(Eu * D); t.g_wag = c.take<float>(Eu * D);
+  t.bar_wbg = c.take<float>(Eb * D); t.g_wbg = c.take<float>(Eb * D); t.bar_ang = c.take<float>(A * D); t.g_ang = c.take<float>(A * D);
+  t.zero_hi = c.take<float>(0);
+  // table gradients: cleared before every layer
+  t.barP = c.take<float>(N * 4 * D); t.gP = c.take<float>(N * 4 * D); t.barQ = c.take<float>(Eu * 2 * D); t.gQ = c.take<float>(Eu * 2 * D);
+  t.barR = c.take<float>(Eb * 4 * D); t.gR = c.take<float>(Eb * 4 * D); t.barS = c.take<float>(N * 2 * D); t.gS = c.take<float>(N * 2 * D);
+}
+
+int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
+  if (b->t2) return CHG_OK;
+  Train2* t = new (std::nothrow) Train2();
+  if (!t) return CHG_ENOMEM;
+  Carver c{nullptr};
+  layout_train2(b, *t, c);
+  const size_t total = (c.pos + 255) & ~size_t(255);
+  if (eng->memory_limit && total + b->arena_bytes + b->train_bytes > eng->memory_limit) {
+    delete t;
+    eng->err = "chg_backward: second-order training workspace of " + std::to_string(total) + " bytes exceeds the engine's memory limit";
+    return CHG_ENOMEM;
+  }
+  char* base = nullptr;
+  if (hipMalloc(&base, total) != hipSuccess) {
+    delete t;
+    eng->err = "hipMalloc of " + std::to_string(total) + " bytes (second-order training workspace) failed";
+    return CHG_ENOMEM;
+  }
+  Carver c2{base};
+  layout_train2(b, *t, c2);
+  b->t2 = t;
+  b->t2_arena = base;
+  b->t2_bytes = total;
+  return CHG_OK;
+}
+
+inline dim3 wave_rows_grid(chg_engine* eng, int64_t rows) { return dim3((unsigned)wave_grid(eng, rows)); }
+
+int run_backward2(chg_engine* eng, chg_batch* b) {
+  const Weights& w = eng->w;
+  Train2& t = *b->t2;
+  const int L = b->L;
+  hipStream_t st = eng->stream;
+  auto G = [&](const float* wp) { return grad_of(eng, b, wp); };
+  const int N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+  const bool angles = A > 0;
+  TRY(zero(eng, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights));
+  TRY(zero(eng, t.zero_lo, (size_t)((char*)t.zero_hi - (char*)t.zero_lo)));
+  auto gemm = [&](const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt, const float* bias,
+                  const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int acc) {
+    return rows_gemm(eng, label, K, NOUT, X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, acc);
+  };
+  // Y[:, 0:64 | 64:128] = X[:, 0:64 | 64:128] . [Wc ; Wg]^T   (the two 64 x 64 second-layer blocks of a gated MLP)
+  auto gemm_pair = [&](const float* X, const float* Wc, const float* Wg, const float* bc, const float* bg, float* Y, int rows) -> int {
+    TRY(gemm("t2_gemm_w2", 64, 64, X, 2 * D, nullptr, Wc, bc, nullptr, 0, Y, 2 * D, nullptr, rows, 0));
+    return gemm("t2_gemm_w2", 64, 64, X + D, 2 * D, nullptr, Wg, bg, nullptr, 0, Y + D, 2 * D, nullptr, rows, 0);
+  };
+  auto check = [&]() -> int { HIP_TRY(eng, hipGetLastError()); return CHG_OK; };
+
+  // ---- direction -> tangent of geometry, bases, embeddings ---------------------------------------------
+  if (Ed > 0) {
+    LaunchScope ls(eng, "t2_geom");
+    hipLaunchKernelGGL(k2_geom_t, g1(Ed), dim3(256), 0, st, b->ev, b->eu, b->e_center, b->e_nbr, b->e_owner, t.ux, t.Wst, t.vd4, t.ud4, Ed);
+  }
+  const double pc = eng->desc.cutoff_coeff;
+  const Envelope env{(float)(-(pc + 1) * (pc + 2) / 2), (float)(pc * (pc + 2)), (float)(-pc * (pc + 1) / 2), eng->desc.cutoff_coeff};
+  if (Eu > 0) {
+    BondBasisArgs a{Eu, b->ev, t.vd4, b->u_u2d, w.freq_ag, w.freq_bg, eng->desc.atom_graph_cutoff, eng->desc.bond_graph_cutoff, env,
+                    t.X6, t.X6d, t.X3, t.X3d};
+    { LaunchScope ls(eng, "t2_basis");
+      hipLaunchKernelGGL(k2_bond_basis, g1((int64_t)Eu * KB2), dim3(256), 0, st, a); }
+    LaunchScope ls(eng, "t2_embed_lin");
+    hipLaunchKernelGGL(k2_embed_lin, wave_rows_grid(eng, Eu), dim3(256), 0, st, t.X6d, w.w_bond_emb, t.hb0d, nullptr, Eu);
+    hipLaunchKernelGGL(k2_embed_lin, wave_rows_grid(eng, Eu), dim3(256), 0, st, t.X6d, w.w_wag, t.wagd, nullptr, Eu);
+    if (Eb > 0) hipLaunchKernelGGL(k2_embed_lin, wave_rows_grid(eng, Eb), dim3(256), 0, st, t.X3d, w.w_wbg, t.wbgcd, b->bn_und, Eb);
+  }
+  if (angles) {
+    { LaunchScope ls(eng, "t2_basis");
+      hipLaunchKernelGGL(k2_angle_basis, g1((int64_t)A * KB2), dim3(256), 0, st, b->eu, t.ud4, b->a_d1, b->a_d2, w.freq_ang, t.X4, t.X4d, t.th2, A); }
+    LaunchScope ls(eng, "t2_embed_lin");
+    hipLaunchKernelGGL(k2_embed_lin, wave_rows_grid(eng, A), dim3(256), 0, st, t.X4d, w.w_ang_emb, t.angd[0], nullptr, A);
+  }
+  TRY(zero(eng, t.atomd[0], sizeof(float) * (size_t)N * D));     // the atom embedding does not depend on the geometry
+  if (Eb > 0) {
+    LaunchScope ls(eng, "t2_gather");
+    hipLaunchKernelGGL(k_gather_rows, g1((int64_t)Eb * (D / 4)), dim3(256), 0, st, t.hb0d, b->bn_und, t.hbcd[0], Eb);
+  }
+  TRY(check());
+
+  // ---- per-layer pieces ------------------------------------------------------------------------------------
+  // tangent tables of AtomConv l:  Pd = atomd . [Wc;Wn]^T,  Qd = hbd . Wb^T  (node rows from hbcd[l])
+  auto atom_tables_t = [&](int l) -> int {
+    const ACW& aw = w.ac[l];
+    TRY(rows_gemm_out2(eng, "t2_gemm_tab", t.atomd[l], nullptr, aw.w_cn, aw.w_cn + 2 * D * D, nullptr, t.Pd, 4 * D, N));
+    TRY(gemm("t2_gemm_tab", 64, 128, t.hb0d, D, nullptr, aw.w_bond, nullptr, nullptr, 0, t.Qd, 2 * D, nullptr, Eu, 0));
+    if (Eb > 0 && b->hbc[l] != b->hbc[0])
+      TRY(gemm("t2_gemm_tab", 64, 128, t.hbcd[l], D, nullptr, aw.w_bond, nullptr, nullptr, 0, t.Qd, 2 * D, b->bn_und, Eb, 0));
+    return CHG_OK;
+  };
+  // z, zd (and the hidden activations) of AtomConv l for every directed edge (centre-major order), then c|g and tangents
+  auto atom_rows = [&](int l) -> int {
+    const ACW& aw = w.ac[l];
+    TRY(atom_tables_t(l));
+    GatherZArgs a{};
+    a.rows = Ed; a.t0 = b->Pl[l]; a.t1 = b->Pl[l]; a.t2 = b->Ql[l]; a.d0 = t.Pd; a.d1 = t.Pd; a.d2 = t.Qd;
+    a.ld0 = 4 * D; a.ld1 = 4 * D; a.ld2 = 2 * D; a.off0 = 0; a.off1 = 2 * D; a.off2 = 0;
+    a.i0 = b->e_center; a.i1 = b->e_nbr; a.i2 = b->e_d2u; a.hidden = 1; a.Z = t.Z; a.Zd = t.Zd; a.H = t.H; a.Hd = t.Hd;
+    { LaunchScope ls(eng, "t2_gather_z");
+      hipLaunchKernelGGL(k2_gather_z, wave_rows_grid(eng, Ed), dim3(256), 0, st, a); }
+    TRY(gemm_pair(t.H, aw.g.w2c, aw.g.w2g, aw.g.b2c, aw.g.b2g, t.CG, Ed));
+    return gemm_pair(t.Hd, aw.g.w2c, aw.g.w2g, nullptr, nullptr, t.CGd, Ed);
+  };
+  // the same for BondConv (hidden) / AngleUpdate (single layer) of slot; hrows / atoms / angs are the layer's inputs
+  auto angle_rows = [&](int slot, bool hidden, const float* w_bij, const float* w_ctr, const float* w_ang, const GatedW& g, const float* hrowsd,
+                        const float* atomsd, const float* angs, const float* angsd) -> int {
+    TRY(rows_gemm_out2(eng, "t2_gemm_tab", hrowsd, nullptr, w_bij, w_bij + 2 * D * D, nullptr, t.Rd, 4 * D, Eb));
+    TRY(gemm("t2_gemm_tab", 64, 128, atomsd, D, nullptr, w_ctr, nullptr, nullptr, 0, t.Sd, 2 * D, nullptr, N, 0));
+    TRY(gemm("t2_gemm_ang", 64, 128, angs, D, nullptr, w_ang, nullptr, nullptr, 0, t.ZA, 2 * D, nullptr, A, 0));
+    TRY(gemm("t2_gemm_ang", 64, 128, angsd, D, nullptr, w_ang, nullptr, nullptr, 0, t.ZAd, 2 * D, nullptr, A, 0));
+    GatherZArgs a{};
+    a.rows = A; a.t0 = b->Rl[slot]; a.t1 = b->Rl[slot]; a.t2 = b->Sl[slot]; a.d0 = t.Rd; a.d1 = t.Rd; a.d2 = t.Sd;
+    a.ld0 = 4 * D; a.ld1 = 4 * D; a.ld2 = 2 * D; a.off0 = 0; a.off1 = 2 * D; a.off2 = 0;
+    a.i0 = b->a_b1c; a.i1 = b->a_b2c; a.i2 = b->a_ctr; a.add = t.ZA; a.addd = t.ZAd; a.hidden = hidden ? 1 : 0;
+    a.Z = hidden ? t.Z : t.CG; a.Zd = hidden ? t.Zd : t.CGd; a.H = t.H; a.Hd = t.Hd;   // single layer: c|g IS z
+    { LaunchScope ls(eng, "t2_gather_z");
+      hipLaunchKernelGGL(k2_gather_z, wave_rows_grid(eng, A), dim3(256), 0, st, a); }
+    if (!hidden) return CHG_OK;
+    TRY(gemm_pair(t.H, g.w2c, g.w2g, g.b2c, g.b2g, t.CG, A));
+    return gemm_pair(t.Hd, g.w2c, g.w2g, nullptr, nullptr, t.CGd, A);
+  };
+
+  // ---- tangent forward ---------------------------------------------------------------------------------------
+  auto atomconv_t = [&](int l) -> int {
+    const ACW& aw = w.ac[l];
+    if (Ed > 0) {
+      TRY(atom_rows(l));
+      GatedTArgs a{};
+      a.rows = Ed; a.mode = T2_ATOM; a.CG = t.CG; a.CGd = t.CGd; a.ln = aw.g.ln1_g; a.i_dst = b->e_center; a.i_w1 = b->e_d2u;
+      a.w = b->wag; a.wd = t.wagd; a.aggd = t.aggd[l];
+      LaunchScope ls(eng, "t2_gated_t");
+      hipLaunchKernelGGL(k2_gated_t, wave_rows_grid(eng, Ed), dim3(256), 0, st, a);
+    }
+    return gemm("t2_gemm_out", 64, 64, t.aggd[l], D, nullptr, aw.w_out, nullptr, t.atomd[l], D, t.atomd[l + 1], D, nullptr, N, 0);
+  };
+  for (int l = 0; l < L - 1; ++l) {
+    TRY(atomconv_t(l));
+    if (angles) {
+      const BCW& bw = w.bc[l];
+      TRY(angle_rows(l, true, bw.w_bij, bw.w_ctr, bw.w_ang, bw.g, t.hbcd[l], t.atomd[l + 1], b->ang[l], t.angd[l]));
+      {
+        GatedTArgs a{};
+        a.rows = A; a.mode = T2_BOND; a.CG = t.CG; a.CGd = t.CGd; a.ln = bw.g.ln1_g; a.i_dst = b->a_b1c; a.i_w1 = b->a_b1c; a.i_w2 = b->a_b2c;
+        a.w = b->wbgc; a.wd = t.wbgcd; a.aggd = t.aggBd[l];
+        LaunchScope ls(eng, "t2_gated_t");
+        hipLaunchKernelGGL(k2_gated_t, wave_rows_grid(eng, A), dim3(256), 0, st, a);
+      }
+      TRY(gemm("t2_gemm_out", 64, 64, t.aggBd[l], D, nullptr, bw.w_out, nullptr, t.hbcd[l], D, t.hbcd[l + 1], D, nullptr, Eb, 0));
+      if (l < L - 2) {
+        const AUW& uw = w.au[l];
+        TRY(angle_rows(L + l, false, uw.w_bij, uw.w_ctr, uw.w_ang, uw.g, t.hbcd[l + 1], t.atomd[l + 1], b->ang[l], t.angd[l]));
+        GatedTArgs a{};
+        a.rows = A; a.mode = T2_ANGLE; a.CG = t.CG; a.CGd = t.CGd; a.ln = uw.g.ln1_g; a.angd_in = t.angd[l]; a.angd_out = t.angd[l + 1];
+        LaunchScope ls(eng, "t2_gated_t");
+        hipLaunchKernelGGL(k2_gated_t, wave_rows_grid(eng, A), dim3(256), 0, st, a);
+      }
+    } else if (Eb > 0) {
+      HIP_TRY(eng, hipMemcpyAsync(t.hbcd[l + 1], t.hbcd[l], sizeof(float) * (size_t)Eb * D, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  TRY(atomconv_t(L - 1));
+  TRY(check());
+
+  // ---- readout: tangent forward, seeds, two-adjoint backward --------------------------------------------------
+  enum { X0 = 0, X0D, XH, XHD, L0, L0D, L1, L1D, L2, L2D, S1, S1D, S2, S2D, S3, S3D, BS, GS, BL, GLr, DW3, DGAM, DBET, TMP0, TMP1, TMP2 };
+  const size_t nd = (size_t)N * D;
+  {
+    { LaunchScope ls(eng, "t2_readout");
+      hipLaunchKernelGGL(k2_ln_t, wave_rows_grid(eng, N), dim3(256), 0, st, b->atom[L], t.atomd[L], w.ro_ln_g, w.ro_ln_b, t.ro[X0], t.ro[X0D],
+                         t.ro[XH], t.ro[XHD], N); }
+    const float* Wm[3] = {w.mlp_w0, w.mlp_w1, w.mlp_w2};
+    const float* Wt[3] = {w.mlp_w0_t, w.mlp_w1_t, w.mlp_w2_t};
+    const float* bm[3] = {w.mlp_b0, w.mlp_b1, w.mlp_b2};
+    const int sidx[4] = {X0, S1, S2, S3}, sdidx[4] = {X0D, S1D, S2D, S3D}, lidx[3] = {L0, L1, L2}, ldidx[3] = {L0D, L1D, L2D};
+    for (int i = 0; i < 3; ++i) {
+      TRY(gemm("t2_readout", 64, 64, t.ro[sidx[i]], D, nullptr, Wm[i], bm[i], nullptr, 0, t.ro[lidx[i]], D, nullptr, N, 0));
+      TRY(gemm("t2_readout", 64, 64, t.ro[sdidx[i]], D, nullptr, Wm[i], nullptr, nullptr, 0, t.ro[ldidx[i]], D, nullptr, N, 0));
+      LaunchScope ls(eng, "t2_readout");
+      hipLaunchKernelGGL(k2_silu_t, g1((int64_t)nd), dim3(256), 0, st, t.ro[lidx[i]], t.ro[ldidx[i]], t.ro[sidx[i + 1]], t.ro[sdidx[i + 1]], nd);
+    }
+    { LaunchScope ls(eng, "t2_readout");
+      hipLaunchKernelGGL(k2_readout_seed, g1((int64_t)nd), dim3(256), 0, st, w.mlp_w3, b->t_cot, b->atom_owner, t.ro[S3], t.ro[S3D], t.ro[BS],
+                         t.ro[GS], t.ro[DW3], N); }
+    TRY(colsum(eng, t.ro[DW3], D, nullptr, 0, N, D, G(w.mlp_w3)));
+    const float* gW[3] = {G(w.mlp_w0), G(w.mlp_w1), G(w.mlp_w2)};
+    const float* gb[3] = {G(w.mlp_b0), G(w.mlp_b1), G(w.mlp_b2)};
+    for (int i = 2; i >= 0; --i) {
+      { LaunchScope ls(eng, "t2_readout");
+        hipLaunchKernelGGL(k2_hidden_b, g1((int64_t)nd), dim3(256), 0, st, t.ro[lidx[i]], t.ro[ldidx[i]], t.ro[BS], t.ro[GS], t.ro[BL], t.ro[GLr], nd); }
+      TRY((xty<4, 4>(eng, "t2_wgrad", t.ro[BL], D, nullptr, t.ro[sidx[i]], D, nullptr, N, 1.0f, (float*)gW[i], D, D, (float*)gb[i])));
+      TRY((xty<4, 4>(eng, "t2_wgrad", t.ro[GLr], D, nullptr, t.ro[sdidx[i]], D, nullptr, N, 1.0f, (float*)gW[i], D, D)));
+      TRY(gemm("t2_readout", 64, 64, t.ro[BL], D, nullptr, Wt[i], nullptr, nullptr, 0, t.ro[BS], D, nullptr, N, 0));
+      TRY(gemm("t2_readout", 64, 64, t.ro[GLr], D, nullptr, Wt[i], nullptr, nullptr, 0, t.ro[GS], D, nullptr, N, 0));
+    }
+    { LaunchScope ls(eng, "t2_readout");
+      hipLaunchKernelGGL(k2_ln_b, wave_rows_grid(eng, N), dim3(256), 0, st, b->atom[L], t.atomd[L], w.ro_ln_g, t.ro[BS], t.ro[GS], t.bar_a, t.g_a,
+                         t.ro[DGAM], t.ro[DBET], N); }
+    TRY(colsum(eng, t.ro[DGAM], D, nullptr, 0, N, D, G(w.ro_ln_g)));
+    TRY(colsum(eng, t.ro[DBET], D, nullptr, 0, N, D, G(w.ro_ln_b)));
+  }
+  TRY(check());
+
+  // ---- reverse sweep with two adjoints -----------------------------------------------------------------------
+  // gated-MLP internals common to the three layer kinds: BCG / GCG -> weight gradients of the second layer, BZ / GZ
+  auto hidden_back = [&](const GatedW& g, const float* w2c_t, const float* w2g_t, int rows) -> int {
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.BCG, 2 * D, nullptr, t.H, 2 * D, nullptr, rows, 1.0f, G(g.w2c), D, D, G(g.b2c))));
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.GCG, 2 * D, nullptr, t.Hd, 2 * D, nullptr, rows, 1.0f, G(g.w2c), D, D)));
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.BCG + D, 2 * D, nullptr, t.H + D, 2 * D, nullptr, rows, 1.0f, G(g.w2g), D, D, G(g.b2g))));
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.GCG + D, 2 * D, nullptr, t.Hd + D, 2 * D, nullptr, rows, 1.0f, G(g.w2g), D, D)));
+    TRY(gemm_pair(t.BCG, w2c_t, w2g_t, nullptr, nullptr, t.BH, rows));
+    TRY(gemm_pair(t.GCG, w2c_t, w2g_t, nullptr, nullptr, t.GH, rows));
+    LaunchScope ls(eng, "t2_hidden_b");
+    hipLaunchKernelGGL(k2_hidden_b, g1((int64_t)rows * 2 * D), dim3(256), 0, st, t.Z, t.Zd, t.BH, t.GH, t.BZ, t.GZ, (size_t)rows * 2 * D);
+    return check();
+  };
+
+  auto atomconv_b = [&](int l) -> int {
+    const ACW& aw = w.ac[l];
+    // atom[l+1] = agg . Wout^T + b_out + atom[l]
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.bar_a, D, nullptr, b->agg_l[l], D, nullptr, N, 1.0f, G(aw.w_out), D, D, G(aw.b_out))));
+    TRY((xty<4, 4>(eng, "t2_wgrad", t.g_a, D, nullptr, t.aggd[l], D, nullptr, N, 1.0f, G(aw.w_out), D, D)));
+    if (Ed == 0) return CHG_OK;
+    TRY(gemm("t2_gemm_out", 64, 64, t.bar_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, N, 0));
+    TRY(gemm("t2_gemm_out", 64, 64, t.g_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.g_agg, D, nullptr, N, 0));
+    TRY(atom_rows(l));
+    {
+      GatedBArgs a{};
+      a.rows = Ed; a.mode = T2_ATOM; a.CG = t.CG; a.CGd = t.CGd; a.ln = aw.g.ln1_g; a.i_dst = b->e_center; a.i_w1 = b->e_d2u;
+      a.w = b->wag; a.wd = t.wagd; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wag; a.g_w = t.g_wag;
+      a.BCG = t.BCG; a.GCG = t.GCG; a.g_ln = G(aw.g.ln1_g);
+      LaunchScope ls(eng, "t2_gated_b");
+      hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, Ed), dim3(256), 0, st, a);
+    }
+    TRY(hidden_back(aw.g, aw.w2c_t, aw.w2g_t, Ed));
+    TRY(zero(eng, t.barP, sizeof(float) * (size_t)N * 4 * D)); TRY(zero(eng, t.gP, sizeof(float) * (size_t)N * 4 * D));
+    TRY(zero(eng, t.barQ, sizeof(float) * (size_t)Eu * 2 * D)); TRY(zero(eng, t.gQ, sizeof(float) * (size_t)Eu * 2 * D));
+    {
+      ScatterZArgs a{Ed, t.BZ, t.GZ, t.barP, t.barP, t.barQ, t.gP, t.gP, t.gQ, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->e_center, b->e_nbr, b->e_d2u};
+      LaunchScope ls(eng, "t2_scatter_z");
+      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, Ed), dim3(256), 0, st, a);
+    }
+    // first layer (factorised): table gradients contract with the rows the tables were made from, bar with primal and G with tangent
+    for (int half = 0; half < 2; ++half) {
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.barP + half * 2 * D, 4 * D, nullptr, b->atom[l], D, nullptr, N, 1.0f, G(aw.w_cn) + half * 2 * D * D, D, D,
+                     half == 0 ? G(aw.b1) : nullptr)));
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.gP + half * 2 * D, 4 * D, nullptr, t.atomd[l], D, nullptr, N, 1.0f, G(aw.w_cn) + half * 2 * D * D, D, D)));
+    }
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.barQ, 2 * D, nullptr, b->hb0, D, nullptr, Eu, 1.0f, G(aw.w_bond), D, D)));
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.gQ, 2 * D, nullptr, t.hb0d, D, nullptr, Eu, 1.0f, G(aw.w_bond), D, D)));
+    if (Eb > 0 && b->hbc[l] != b->hbc[0]) {
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.barQ, 2 * D, b->bn_und, b->hbc[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.barQ, 2 * D, b->bn_und, b->hb0, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.gQ, 2 * D, b->bn_und, t.hbcd[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.gQ, 2 * D, b->bn_und, t.hb0d, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
+    }
+    TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.barP, 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, t.bar_a, nullptr, N, 1));
+    TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.gP, 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, t.g_a, nullptr, N, 1));
+    TRY(gemm("t2_gemm_tab", 128, 64, t.barQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, t.bar_b, D, nullptr, Eu, 1));
+    return gemm("t2_gemm_tab", 128, 64, t.gQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, t.g_b, D, nullptr, Eu, 1);
+  };
+
+  // tail shared by BondConv / AngleUpdate: BZ / GZ [A,128] -> table gradients, weight gradients, adjoints of the inputs
+  auto angle_back = [&](const float* w_bij, const float* w_ctr, const float* b1, const float* w_ang, const float* w_bij_t, const float* w_ctr_t,
+                        const float* w_ang_t, const float* hrows, const float* hrowsd, const float* atoms, const float* atomsd,
+                        const float* angs, const float* angsd) -> int {
+    TRY(zero(eng, t.barR, sizeof(float) * (size_t)Eb * 4 * D)); TRY(zero(eng, t.gR, sizeof(float) * (size_t)Eb * 4 * D));
+    TRY(zero(eng, t.barS, sizeof(float) * (size_t)N * 2 * D)); TRY(zero(eng, t.gS, sizeof(float) * (size_t)N * 2 * D));
+    {
+      ScatterZArgs a{A, t.BZ, t.GZ, t.barR, t.barR, t.barS, t.gR, t.gR, t.gS, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->a_b1c, b->a_b2c, b->a_ctr};
+      LaunchScope ls(eng, "t2_scatter_z");
+      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, A), dim3(256), 0, st, a);
+    }
+    for (int half = 0; half < 2; ++half) {
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.barR + half * 2 * D, 4 * D, nullptr, hrows, D, nullptr, Eb, 1.0f, G(w_bij) + half * 2 * D * D, D, D)));
+      TRY((xty<8, 4>(eng, "t2_wgrad", t.gR + half * 2 * D, 4 * D, nullptr, hrowsd, D, nullptr, Eb, 1.0f, G(w_bij) + half * 2 * D * D, D, D)));
+    }
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.barS, 2 * D, nullptr, atoms, D, nullptr, N, 1.0f, G(w_ctr), D, D, G(b1))));
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.gS, 2 * D, nullptr, atomsd, D, nullptr, N, 1.0f, G(w_ctr), D, D)));
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.BZ, 2 * D, nullptr, angs, D, nullptr, A, 1.0f, G(w_ang), D, D)));
+    TRY((xty<8, 4>(eng, "t2_wgrad", t.GZ, 2 * D, nullptr, angsd, D, nullptr, A, 1.0f, G(w_ang), D, D)));
+    TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.barR, 4 * D, w_bij_t, w_bij_t + 2 * D * D, t.bar_b, b->bn_und, Eb, 1));
+    TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.gR, 4 * D, w_bij_t, w_bij_t + 2 * D * D, t.g_b, b->bn_und, Eb, 1));
+    TRY(gemm("t2_gemm_tab", 128, 64, t.barS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, t.bar_a, D, nullptr, N, 1));
+    TRY(gemm("t2_gemm_tab", 128, 64, t.gS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, t.g_a, D, nullptr, N, 1));
+    TRY(gemm("t2_gemm_ang", 128, 64, t.BZ, 2 * D, nullptr, w_ang_t, nullptr, nullptr, 0, t.bar_ang, D, nullptr, A, 1));
+    return gemm("t2_gemm_ang", 128, 64, t.GZ, 2 * D, nullptr, w_ang_t, nullptr, nullptr, 0, t.g_ang, D, nullptr, A, 1);
+  };
+
+  TRY(atomconv_b(L - 1));
+  if (b->t_has_mcot) {   // magmom head reads atom[L-1]: first-order term, joins bar(atom[L-1])
+    LaunchScope ls(eng, "magmom_bwd");
+    hipLaunchKernelGGL(k_magmom_bwd, dim3(wave_grid(eng, N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->t_mcot, t.bar_a, G(w.site_w),
+                       G(w.site_b), N);
+  }
+  for (int l = L - 2; l >= 0; --l) {
+    if (angles) {
+      if (l < L - 2) {
+        const AUW& uw = w.au[l];
+        TRY(angle_rows(L + l, false, uw.w_bij, uw.w_ctr, uw.w_ang, uw.g, t.hbcd[l + 1], t.atomd[l + 1], b->ang[l], t.angd[l]));
+        GatedBArgs a{};
+        a.rows = A; a.mode = T2_ANGLE; a.CG = t.CG; a.CGd = t.CGd; a.ln = uw.g.ln1_g; a.bar_agg = t.bar_ang; a.g_agg = t.g_ang;
+        a.BCG = t.BZ; a.GCG = t.GZ; a.g_ln = G(uw.g.ln1_g);      // single layer: bar(c|g) IS bar(z)
+        { LaunchScope ls(eng, "t2_gated_b");
+          hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, A), dim3(256), 0, st, a); }
+        TRY(angle_back(uw.w_bij, uw.w_ctr, uw.b1, uw.w_ang, uw.w_bij_t, uw.w_ctr_t, uw.w_ang_t, b->hbc[l + 1], t.hbcd[l + 1], b->atom[l + 1],
+                       t.atomd[l + 1], b->ang[l], t.angd[l]));
+      }
+      const BCW& bw = w.bc[l];
+      // hbc[l+1] = aggB . Wout^T + hbc[l]; its adjoints live in the node rows of bar_b / g_b
+      TRY((xty<4, 4>(eng, "t2_wgrad", t.bar_b, D, b->bn_und, b->aggB_l[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
+      TRY((xty<4, 4>(eng, "t2_wgrad", t.g_b, D, b->bn_und, t.aggBd[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
+      TRY(gemm("t2_gemm_out", 64, 64, t.bar_b, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, Eb, 0));
+      TRY(gemm("t2_gemm_out", 64, 64, t.g_b, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, t.g_agg, D, nullptr, Eb, 0));
+      TRY(angle_rows(l, true, bw.w_bij, bw.w_ctr, bw.w_ang, bw.g, t.hbcd[l], t.atomd[l + 1], b->ang[l], t.angd[l]));
+      {
+        GatedBArgs a{};
+        a.rows = A; a.mode = T2_BOND; a.CG = t.CG; a.CGd = t.CGd; a.ln = bw.g.ln1_g; a.i_dst = b->a_b1c; a.i_w1 = b->a_b1c; a.i_w2 = b->a_b2c;
+        a.w = b->wbgc; a.wd = t.wbgcd; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wbg; a.g_w = t.g_wbg;
+        a.BCG = t.BCG; a.GCG = t.GCG; a.g_ln = G(bw.g.ln1_g);
+        LaunchScope ls(eng, "t2_gated_b");
+        hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, A), dim3(256), 0, st, a);
+      }
+      TRY(hidden_back(bw.g, bw.w2c_t, bw.w2g_t, A));
+      TRY(angle_back(bw.w_bij, bw.w_ctr, bw.b1, bw.w_ang, bw.w_bij_t, bw.w_ctr_t, bw.w_ang_t, b->hbc[l], t.hbcd[l], b->atom[l + 1], t.atomd[l + 1],
+                     b->ang[l], t.angd[l]));
+    }
+    TRY(atomconv_b(l));
+  }
+  TRY(check());
+
+  // ---- embeddings: 31 -> 64 linears (bar with basis, G with basis tangent), frequencies, atom embedding table ----
+  if (Eu > 0) {
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_b, D, nullptr, t.X6, KB2, nullptr, Eu, 1.0f, G(w.w_bond_emb), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_b, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_bond_emb), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_wag, D, nullptr, t.X6, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_wag, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_wbg, D, nullptr, t.X3, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_wbg, D, nullptr, t.X3d, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
+    {
+      FreqGradArgs a{Eu, nullptr, b->ev, t.vd4, b->u_u2d, w.freq_ag, eng->desc.atom_graph_cutoff, env, t.bar_b, t.g_b, w.w_bond_emb,
+                     t.bar_wag, t.g_wag, w.w_wag, G(w.freq_ag)};
+      LaunchScope ls(eng, "t2_freq");
+      hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eu), dim3(256), 0, st, a);
+    }
+    if (Eb > 0) {
+      FreqGradArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, t.g_wbg, w.w_wbg,
+                     nullptr, nullptr, nullptr, G(w.freq_bg)};
+      LaunchScope ls(eng, "t2_freq");
+      hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eb), dim3(256), 0, st, a);
+    }
+  }
+  if (angles) {
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_ang, D, nullptr, t.X4, KB2, nullptr, A, 1.0f, G(w.w_ang_emb), NANG, NANG)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_ang, D, nullptr, t.X4d, KB2, nullptr, A, 1.0f, G(w.w_ang_emb), NANG, NANG)));
+    LaunchScope ls(eng, "t2_freq");
+    hipLaunchKernelGGL(k2_angle_freq_grad, wave_rows_grid(eng, A), dim3(256), 0, st, t.bar_ang, t.g_ang, w.w_ang_emb, t.th2, w.freq_ang,
+                       G(w.freq_ang), A);
+  }
+  {
+    LaunchScope ls(eng, "wgrad_atom_embed");
+    hipLaunchKernelGGL(k_embed_grad, g1((int64_t)N * D), dim3(256), 0, st, t.bar_a, b->z, G(w.emb), N);
+  }
+  return check();
+}
+
 template <class K>
 int set_lds(chg_engine* eng, K kernel, size_t bytes) {
   HIP_TRY(eng, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1162,6 +1588,12 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     carve(b, b->arena, total);
     register_names(b);
     b->h_atom_off.assign(h->atom_off, h->atom_off + B + 1);
+    b->h_volume.resize(B);
+    for (int q = 0; q < B; ++q) {   // float32 lattice like k_finalize (model.py:834-836)
+      float Lf[9];
+      for (int k = 0; k < 9; ++k) Lf[k] = (float)h->lattice[9 * q + k];
+      b->h_volume[q] = Lf[0] * (Lf[4] * Lf[8] - Lf[5] * Lf[7]) + Lf[1] * (Lf[5] * Lf[6] - Lf[3] * Lf[8]) + Lf[2] * (Lf[3] * Lf[7] - Lf[4] * Lf[6]);
+    }
     s = d2d(eng, b->z, (const int*)d_z, (size_t)N);
     if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
     if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
@@ -1342,6 +1774,11 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   carve(b, b->arena, total);
   register_names(b);
   if (h->atom_off) b->h_atom_off.assign(h->atom_off, h->atom_off + h->n_struct + 1);
+  b->h_volume.resize(h->n_struct);
+  for (int q = 0; q < h->n_struct; ++q) {
+    const float* Lf = h->lattice + 9 * q;
+    b->h_volume[q] = Lf[0] * (Lf[4] * Lf[8] - Lf[5] * Lf[7]) + Lf[1] * (Lf[5] * Lf[6] - Lf[3] * Lf[8]) + Lf[2] * (Lf[3] * Lf[7] - Lf[4] * Lf[6]);
+  }
   int s = CHG_OK;
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
 #define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
@@ -1390,6 +1827,8 @@ int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
   if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
   if (b->train_arena) hipFree(b->train_arena);
+  if (b->t2_arena) hipFree(b->t2_arena);
+  free_train2(b);
   if (b->arena) {
     if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
     else hipFree(b->arena);
@@ -1437,7 +1876,8 @@ int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
   return CHG_OK;
 }
 
-int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent, float* grad_blob) {
+int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                 const float* force_cotangent, const float* stress_cotangent, float* grad_blob) {
   if (!eng || !b || !grad_blob) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
@@ -1455,8 +1895,25 @@ int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, c
   HIP_TRY(eng, hipMemcpyAsync(b->t_cot, cot.data(), sizeof(float) * b->B, hipMemcpyHostToDevice, eng->stream));
   b->t_has_mcot = magmom_cotangent != nullptr;
   if (magmom_cotangent) HIP_TRY(eng, hipMemcpyAsync(b->t_mcot, magmom_cotangent, sizeof(float) * b->N, hipMemcpyHostToDevice, eng->stream));
+  const bool second_order = force_cotangent || stress_cotangent;
+  std::vector<float> ux, wst;
+  if (second_order) {
+    // direction of the one tangent sweep: ux = -dL/dF,  W_b = (160.21766208 / V_b) dL/d sigma_b   (kernels_train2.h)
+    if (b->last_task == 0 || !(b->last_task & (CHG_TASK_F | CHG_TASK_S))) {
+      // any task leaves the activations the sweep needs; nothing to check beyond "a forward has run"
+    }
+    TRY(ensure_train2_buffers(eng, b));
+    ux.assign((size_t)3 * b->N, 0.f);
+    wst.assign((size_t)9 * b->B, 0.f);
+    if (force_cotangent) for (size_t q = 0; q < ux.size(); ++q) ux[q] = -force_cotangent[q];
+    if (stress_cotangent)
+      for (int q = 0; q < b->B; ++q)
+        for (int k = 0; k < 9; ++k) wst[9 * q + k] = (float)(EV_A3_TO_GPA / b->h_volume[q]) * stress_cotangent[9 * q + k];
+    HIP_TRY(eng, hipMemcpyAsync(b->t2->ux, ux.data(), sizeof(float) * ux.size(), hipMemcpyHostToDevice, eng->stream));
+    HIP_TRY(eng, hipMemcpyAsync(b->t2->Wst, wst.data(), sizeof(float) * wst.size(), hipMemcpyHostToDevice, eng->stream));
+  }
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
-  TRY(run_backward(eng, b));
+  TRY(second_order ? run_backward2(eng, b) : run_backward(eng, b));
   HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyDeviceToHost, eng->stream));
   TRY(chg_synchronize(eng));
   grad_blob[eng->w.mlp_b3 - eng->d_weights] = (float)g_b3;

@@ -166,18 +166,27 @@ class Engine:
         """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""
         self._check(self.lib.chg_predict(self.handle, batch.handle, _lib.task_mask(task)))
 
-    def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None) -> np.ndarray:
-        """Gradient blob (weight-blob layout) of ``sum_b e_grad[b] * e[b] + sum_i m_grad[i] * m[i]`` after
-        ``predict`` on ``batch`` (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names."""
+    def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None, f_grad=None, s_grad=None) -> np.ndarray:
+        """Gradient blob (weight-blob layout) of ``sum e_grad*e + sum m_grad*m + sum f_grad.f + sum s_grad:s`` after
+        ``predict`` on ``batch`` (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names.
+        ``f_grad`` [N,3] / ``s_grad`` [B,3,3] switch to the second-order sweep."""
+        pb = batch.packed
         grad = np.zeros(self.weights.blob.size, np.float32)
-        cot = None if e_grad is None else np.ascontiguousarray(e_grad, np.float32).reshape(-1)
-        if cot is not None and cot.size != batch.packed.n_struct:
-            raise ValueError(f"e_grad has {cot.size} entries, the batch holds {batch.packed.n_struct} structures")
-        mcot = None if m_grad is None else np.ascontiguousarray(m_grad, np.float32).reshape(-1)
-        if mcot is not None and mcot.size != batch.packed.n_atoms:
-            raise ValueError(f"m_grad has {mcot.size} entries, the batch holds {batch.packed.n_atoms} atoms")
-        self._check(self.lib.chg_backward(self.handle, batch.handle, _fp(cot) if cot is not None else None,
-                                          _fp(mcot) if mcot is not None else None, _fp(grad)))
+
+        def arg(x, n, what):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(x, np.float32).reshape(-1)
+            if a.size != n:
+                raise ValueError(f"{what} has {a.size} entries, the batch needs {n}")
+            return a
+
+        cot = arg(e_grad, pb.n_struct, "e_grad")
+        mcot = arg(m_grad, pb.n_atoms, "m_grad")
+        fcot = arg(f_grad, 3 * pb.n_atoms, "f_grad")
+        scot = arg(s_grad, 9 * pb.n_struct, "s_grad")
+        ptr = lambda a: _fp(a) if a is not None else None  # noqa: E731
+        self._check(self.lib.chg_backward(self.handle, batch.handle, ptr(cot), ptr(mcot), ptr(fcot), ptr(scot), _fp(grad)))
         return grad
 
     def update_weights(self, weights: PackedWeights) -> None:

@@ -144,16 +144,18 @@ int64_t chg_batch_device_bytes(const chg_batch* batch);
 int chg_predict(chg_engine* eng, chg_batch* batch, uint32_t task_mask);
 int chg_synchronize(chg_engine* eng);
 
-/* Fine-tuning backward, first-order part (reference: loss.backward() through CHGNet.forward, chgnet/trainer/trainer.py:399-411,
- * model.py:427-542).  After chg_predict on `batch`:
- *   grad_blob[i] = d( sum_b energy_cotangent[b] * energy[b] + sum_i magmom_cotangent[i] * magmom[i] ) / d weights_blob[i],
+/* Fine-tuning backward (reference: loss.backward() through CHGNet.forward, chgnet/trainer/trainer.py:399-411, model.py:427-542,
+ * and through the create_graph=True forces / stress of model.py:517-535).  After chg_predict on `batch`:
+ *   grad_blob[i] = d( sum_b ce[b] energy[b] + sum_i gm[i] magmom[i] + sum_i gF[i] . force[i] + sum_b gS[b] : stress[b] ) / d weights_blob[i]
  * in the layout of the weight blob (chgnet_amd/pack.py:weight_layout; derived entries -- transposed copies, q_bias -- and the
- * frozen AtomRef stay 0; pack.py:unpack_weight_grads maps it back to state_dict names).  energy_cotangent: host [B] = d loss /
- * d energy[b] with energy as chg_batch_download returns it (null = all ones); magmom_cotangent: host [N] or null (no magmom term);
- * grad_blob: host [n_weights].  Synchronous.  Overwrites the batch's gradient workspace: download forces / stress before calling.
- * Force / stress terms of the loss need second derivatives (model.py:521-530); their sweep is derived and checked in
- * oracle/staged_train.py and not yet in this library. */
-int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent, float* grad_blob);
+ * frozen AtomRef stay 0; pack.py:unpack_weight_grads maps it back to state_dict names).  All cotangents are host arrays in the
+ * units chg_batch_download returns the quantities in: energy_cotangent [B] (null = ones), magmom_cotangent [N] or null,
+ * force_cotangent [N,3] or null, stress_cotangent [B,9] or null; grad_blob: host [n_weights].  Synchronous.
+ * Without force / stress terms this is a first-order reverse sweep (fused kernels).  With them it is ONE tangent sweep along
+ * (ux = -gF, strain direction (160.2 / V) gS) followed by a reverse sweep with two adjoints per activation (kernels_train2.h),
+ * currently unfused.  Overwrites the batch's gradient workspace: download forces / stress before calling. */
+int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent,
+                 const float* force_cotangent, const float* stress_cotangent, float* grad_blob);
 /* New parameter values for an existing engine (optimizer step): same blob layout and length as at creation. */
 int chg_engine_update_weights(chg_engine* eng, const float* weights_blob);
 int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* out);

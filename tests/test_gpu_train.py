@@ -217,3 +217,76 @@ def test_train_step_lowers_the_loss_and_updates_the_engine(golden_weights):
     fresh = CHGNet(state_dict=model.state_dict()).predict_graph(graphs[:3], task="em")  # ... and they are the state_dict's
     for a, b in zip(after[:3], fresh):
         assert abs(a["e"] - b["e"]) < 2e-6 and np.abs(a["m"] - b["m"]).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage B: force / stress terms (second-order sweep)
+# ---------------------------------------------------------------------------------------------------------
+REL_TOL_B = 3e-4     # fp32, second derivatives: the fp32 torch double-backward of the oracle itself is ~1e-5..1e-4 off its fp64
+
+
+def _cots(rng, pb):
+    return (rng.normal(size=pb.n_struct).astype(np.float32), rng.normal(size=(pb.n_atoms, 3)).astype(np.float32),
+            rng.normal(size=(pb.n_struct, 3, 3)).astype(np.float32))
+
+
+@pytest.mark.parametrize("terms", ["efs", "f", "s"])
+def test_second_order_packed_gradients_vs_pipeline_model(hip_engine, packed_weights, terms):
+    """Localisation test for the force / stress terms: every packed entry of the gradient blob against the float64 model of
+    the tangent + two-adjoint sweep (oracle/staged_train.py, == torch double-backward to 2e-9 on the CPU)."""
+    from oracle.staged_train import StagedTrainer
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    batch = hip_engine.upload(graphs)
+    pb = batch.packed
+    gE, gF, gS = _cots(np.random.default_rng(17), pb)
+    cE, cF, cS = (gE if "e" in terms else None), (gF if "f" in terms else None), (gS if "s" in terms else None)
+    hip_engine.predict(batch, "efs")
+    blob = hip_engine.backward(batch, cE if cE is not None else np.zeros(pb.n_struct, np.float32), None, cF, cS)
+    want = StagedTrainer(packed_weights).run(pb, gE=cE, gF=cF, gS=cS)["wgrad"]
+    batch.free()
+    msgs = []
+    for name, ref in want.items():
+        if name.startswith("bc") and name.endswith("b_out"):
+            continue
+        off, shape = packed_weights.offsets[name]
+        got = blob[off:off + int(np.prod(shape))].reshape(shape)
+        scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
+        if not np.isfinite(got).all() or not err <= REL_TOL_B * scale + 1e-12:
+            msgs.append(f"{name}: max|d|={err:.3e} scale={scale:.3e}")
+    assert not msgs, f"[{terms}] " + "; ".join(msgs)
+
+
+def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_weights):
+    """d( sum ce e + sum gm m + sum gF.F + sum gS:S ) / d(all parameters) against torch double-backward through the fp64 oracle
+    (the reference's create_graph=True path) on the five golden structures."""
+    import torch
+    from chgnet_amd.model import CHGNet
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri", "s40", "li9co7o16")]
+    n_atoms = sum(len(g.atomic_number) for g in graphs)
+    rng = np.random.default_rng(23)
+    ce, gm = rng.normal(size=len(graphs)).astype(np.float32), rng.normal(size=n_atoms).astype(np.float32)
+    gf, gs = rng.normal(size=(n_atoms, 3)).astype(np.float32), rng.normal(size=(len(graphs), 3, 3)).astype(np.float32)
+    model = CHGNet(state_dict=golden_weights)
+    model._engine = hip_engine
+    try:
+        model.forward(graphs, task="efsm")
+        got = model.backward(ce, gm, gf, gs)
+    finally:
+        model.release_forward_state()
+        model._engine = None
+    torch.set_num_threads(8)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    want = OracleCHGNet(golden_weights, dtype=torch.float64).parameter_gradients(
+        graphs, lambda o: (o["e"] * t(ce)).sum() + (o["m"] * t(gm)).sum() + (o["f"] * t(gf)).sum() + (o["s"] * t(gs)).sum(), task="efsm")
+    msgs = []
+    for k, ref in want.items():
+        if k.startswith(("angle_layers.2.", "composition_model")):
+            assert not np.any(got[k]), k
+            continue
+        scale, err = float(np.abs(ref).max()), float(np.abs(got[k] - ref).max())
+        if not np.isfinite(got[k]).all() or not err <= REL_TOL_B * scale:
+            msgs.append(f"{k}: {err:.3e} / {scale:.3e} = {err / max(scale, 1e-300):.1e}")
+    assert not msgs, "; ".join(msgs)
