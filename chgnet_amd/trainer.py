@@ -7,10 +7,9 @@ missing labels, MAE bookkeeping), one optimisation step (``_train`` 386-411: for
 one-process-per-GPU data-parallel run (RCCL over xGMI through ``torch.distributed``; 412,525 float32 = 1.65 MB per
 step).  Datasets, schedulers, checkpoint bookkeeping and logging are out of scope.
 
-What the device differentiates today: the ENERGY and MAGMOM terms (first-order, ``chg_backward``).  Force and stress
-terms need the second-order sweep of SURVEY 8f-3 stage B, which is derived and checked on the CPU but not yet on the
-device: a ``target_str`` containing "f" or "s" still gets its loss value and MAEs, and ``TrainStep`` refuses to
-optimise it rather than silently dropping the term.
+The device differentiates all four terms: energy and magmom by a first-order reverse sweep (fused kernels), forces and
+stress -- first derivatives of the energy themselves -- by one tangent sweep plus a reverse sweep with two adjoints per
+activation (``chg_backward``; derivation and float64 check in the tests' pipeline model).
 """
 
 from __future__ import annotations
@@ -168,20 +167,18 @@ def allreduce_gradients(grads: dict, average: bool = True) -> dict:
 
 class TrainStep:
     """forward -> CombinedLoss -> backward -> (all-reduce) -> Adam -> new weights on the engine: one iteration of the
-    reference's ``Trainer._train`` loop (trainer.py:386-411) for the terms the device differentiates."""
+    reference's ``Trainer._train`` loop (trainer.py:386-411)."""
 
-    def __init__(self, model, *, targets: str = "e", criterion: str = "MSE", learning_rate: float = 1e-3, **loss_kwargs) -> None:
-        if set(targets) - set("efsm"):
-            raise ValueError(f"unknown training targets {targets!r}")
-        if "f" in targets or "s" in targets:
-            raise NotImplementedError(
-                "force / stress loss terms need the second-order sweep (SURVEY 8f-3 stage B), which is derived and checked on the "
-                "CPU but not yet implemented on the device; train with targets 'e' or 'em'")
+    def __init__(self, model, *, targets: str = "ef", criterion: str = "MSE", learning_rate: float = 1e-3, **loss_kwargs) -> None:
+        if set(targets) - set("efsm") or "e" not in targets:
+            raise ValueError(f"training targets {targets!r}: a combination of e, f, s, m that contains e (chgnet/__init__.py:15 TrainTask)")
         self.model = model
         self.targets = targets
         self.loss = CombinedLoss(target_str=targets, criterion=criterion, **loss_kwargs)
         self.optimizer = Adam(model.state_dict(), lr=learning_rate, frozen=("composition_model.fc.weight",))
-        self.task = "em" if "m" in targets else "e"
+        self.task = "".join(k for k in "efsm" if k in targets)
+        if self.task not in ("e", "ef", "em", "efs", "efsm"):       # the engine's task strings (chgnet/__init__.py:15 PredTask)
+            self.task = "efsm" if "m" in targets else "efs"
 
     def run_epoch(self, batches, targets) -> list[dict]:
         """One pass over ``batches`` (lists of CrystalGraphs) with their label dictionaries.  The next batch is packed
@@ -204,7 +201,7 @@ class TrainStep:
         model = self.model
         pred = model.forward(graphs, task=self.task)
         info, g = self.loss.gradients(targets, pred)
-        grads = model.backward(g.get("e"), g.get("m"))
+        grads = model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s"))
         grads = allreduce_gradients(grads)
         model.load_state_dict(self.optimizer.step(model.state_dict(), grads))
         return info

@@ -290,3 +290,25 @@ def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_w
         if not np.isfinite(got[k]).all() or not err <= REL_TOL_B * scale:
             msgs.append(f"{k}: {err:.3e} / {scale:.3e} = {err / max(scale, 1e-300):.1e}")
     assert not msgs, "; ".join(msgs)
+
+
+def test_train_step_with_force_and_stress_terms(golden_weights):
+    """All four terms of CombinedLoss through the device: energy, force, stress, magmom labels a small coherent shift away
+    from the current predictions; Adam steps bring the loss down and the engine runs on the updated weights."""
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.model import CHGNet
+    from chgnet_amd.trainer import TrainStep
+
+    conv = CrystalGraphConverter()
+    graphs = [conv(s) for s in bench.workload_structures(16, 500)]
+    model = CHGNet(state_dict=golden_weights)
+    before = model.predict_graph(graphs, task="efsm")
+    targets = {"e": np.array([p["e"] for p in before]) + 0.05, "f": [p["f"] * 1.5 for p in before],
+               "s": [p["s"] + 0.1 * np.eye(3, dtype=np.float32) for p in before], "m": [p["m"] + 0.1 for p in before]}
+    step = TrainStep(model, targets="efsm", learning_rate=2e-4)
+    try:
+        losses = [step(graphs, targets)["loss"] for _ in range(10)]
+    finally:
+        model.release_forward_state()
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses

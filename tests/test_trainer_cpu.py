@@ -108,10 +108,10 @@ def test_gradient_allreduce_two_ranks(tmp_path):
     assert allreduce_gradients(same) is same                                             # no process group: unchanged
 
 
-def test_train_step_refuses_terms_the_device_cannot_differentiate(golden_weights):
+def test_train_step_argument_checks(golden_weights):
     from chgnet_amd.model import CHGNet
 
     model = CHGNet(state_dict=golden_weights)
-    with pytest.raises(NotImplementedError, match="second-order sweep"):
-        TrainStep(model, targets="ef")
-    TrainStep(model, targets="em")          # first-order terms are fine (no GPU touched until the first call)
+    with pytest.raises(ValueError, match="training targets"):
+        TrainStep(model, targets="fs")          # the reference's TrainTask always contains the energy
+    assert TrainStep(model, targets="efsm").task == "efsm" and TrainStep(model, targets="ef").task == "ef"
