@@ -1183,7 +1183,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     {
       ScatterZArgs a{Ed, t.BZ, t.GZ, t.barP, t.barP, t.barQ, t.gP, t.gP, t.gQ, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->e_center, b->e_nbr, b->e_d2u};
       LaunchScope ls(eng, "t2_scatter_z");
-      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, Ed), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, (Ed + TILE_ROWS - 1) / TILE_ROWS), dim3(256), scatter_z_lds(), st, a);
     }
     // first layer (factorised): table gradients contract with the rows the tables were made from, bar with primal and G with tangent
     for (int half = 0; half < 2; ++half) {
@@ -1214,7 +1214,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     {
       ScatterZArgs a{A, t.BZ, t.GZ, t.barR, t.barR, t.barS, t.gR, t.gR, t.gS, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->a_b1c, b->a_b2c, b->a_ctr};
       LaunchScope ls(eng, "t2_scatter_z");
-      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, A), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, (A + TILE_ROWS - 1) / TILE_ROWS), dim3(256), scatter_z_lds(), st, a);
     }
     for (int half = 0; half < 2; ++half) {
       TRY((xty<8, 4>(eng, "t2_wgrad", t.barR + half * 2 * D, 4 * D, nullptr, hrows, D, nullptr, Eb, 1.0f, G(w_bij) + half * 2 * D * D, D, D)));
@@ -1690,6 +1690,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_xty<8, 4>), (xty_lds<8, 4>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 4>), (xty_lds<4, 4>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
+  if ((s = set_lds(eng, k2_scatter_z, scatter_z_lds()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;

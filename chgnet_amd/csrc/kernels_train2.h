@@ -251,19 +251,41 @@ struct ScatterZArgs {
   const int *i0, *i1, *i2;
 };
 
+// One wave = 16 consecutive rows staged in LDS; each destination leaves the tile as run sums over equal adjacent keys
+// (mfma_tile.h:seg_colsum_atomic): the rows are centre-major (edges) / sorted by owning bond (angles), so the first key is one
+// long run, and keys that are not sorted simply make 16 runs of one row -- one 256-B atomic row per run and 64 columns.
+constexpr int SZ_TS = 2 * D + PAD;
+constexpr size_t scatter_z_lds() { return sizeof(float) * 4 * 2 * TILE_ROWS * SZ_TS; }
+
 __global__ __launch_bounds__(256) void k2_scatter_z(ScatterZArgs p) {
-  const int lane = threadIdx.x & 63;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* TB = smem + wv * 2 * TILE_ROWS * SZ_TS;
+  float* TG = TB + TILE_ROWS * SZ_TS;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int r = wave; r < p.rows; r += nwaves) {
-    const size_t a0 = (size_t)p.i0[r] * p.ld0 + p.off0, a1 = (size_t)p.i1[r] * p.ld1 + p.off1, a2 = (size_t)p.i2[r] * p.ld2 + p.off2;
-    const size_t o = (size_t)r * 2 * D;
+  const int ntiles = (p.rows + TILE_ROWS - 1) / TILE_ROWS;
+  const int hw = lane >> 5, t4 = lane & 31;     // half-wave per row, 32 lanes x float4 = one 512-B row
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int row0 = tile * TILE_ROWS, nvalid = min(TILE_ROWS, p.rows - row0);
+    const int j = lane & 15;
+    const int r = row0 + (j < nvalid ? j : 0);
+    const int k0 = j < nvalid ? p.i0[r] : -1, k1 = j < nvalid ? p.i1[r] : -1, k2 = j < nvalid ? p.i2[r] : -1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int f = 64 * h + lane;
-      const float bz = p.BZ[o + f], gz = p.GZ[o + f];
-      atomicAdd(p.b0 + a0 + f, bz); atomicAdd(p.b1 + a1 + f, bz); atomicAdd(p.b2 + a2 + f, bz);
-      atomicAdd(p.g0 + a0 + f, gz); atomicAdd(p.g1 + a1 + f, gz); atomicAdd(p.g2 + a2 + f, gz);
+    for (int it = 0; it < TILE_ROWS / 2; ++it) {
+      const int rr = 2 * it + hw;
+      if (rr < nvalid) {
+        *reinterpret_cast<f32x4*>(TB + rr * SZ_TS + 4 * t4) = *reinterpret_cast<const f32x4*>(p.BZ + (size_t)(row0 + rr) * 2 * D + 4 * t4);
+        *reinterpret_cast<f32x4*>(TG + rr * SZ_TS + 4 * t4) = *reinterpret_cast<const f32x4*>(p.GZ + (size_t)(row0 + rr) * 2 * D + 4 * t4);
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    seg_colsum_atomic<2 * D>(TB, SZ_TS, k0, nvalid, p.b0 + p.off0, p.ld0, lane);
+    seg_colsum_atomic<2 * D>(TB, SZ_TS, k1, nvalid, p.b1 + p.off1, p.ld1, lane);
+    seg_colsum_atomic<2 * D>(TB, SZ_TS, k2, nvalid, p.b2 + p.off2, p.ld2, lane);
+    seg_colsum_atomic<2 * D>(TG, SZ_TS, k0, nvalid, p.g0 + p.off0, p.ld0, lane);
+    seg_colsum_atomic<2 * D>(TG, SZ_TS, k1, nvalid, p.g1 + p.off1, p.ld1, lane);
+    seg_colsum_atomic<2 * D>(TG, SZ_TS, k2, nvalid, p.g2 + p.off2, p.ld2, lane);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
