@@ -74,6 +74,7 @@ struct chg_engine {
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
+  std::vector<std::pair<char*, size_t>> work_pool;    // released training workspaces (tens of GB: a hipMalloc per step would dominate it)
   bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
@@ -706,6 +707,32 @@ int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, i
   return CHG_OK;
 }
 
+// training workspaces are taken from / returned to an engine-level pool (a train step makes a new batch every iteration)
+char* acquire_workspace(chg_engine* eng, size_t total, size_t& got) {
+  int best = -1;
+  for (int i = 0; i < (int)eng->work_pool.size(); ++i)
+    if (eng->work_pool[i].second >= total && (best < 0 || eng->work_pool[i].second < eng->work_pool[best].second)) best = i;
+  if (best >= 0) {
+    char* p = eng->work_pool[best].first;
+    got = eng->work_pool[best].second;
+    eng->work_pool.erase(eng->work_pool.begin() + best);
+    return p;
+  }
+  char* p = nullptr;
+  if (hipMalloc(&p, total) != hipSuccess) {
+    for (auto& a : eng->work_pool) hipFree(a.first);   // make room and try once more
+    eng->work_pool.clear();
+    if (hipMalloc(&p, total) != hipSuccess) return nullptr;
+  }
+  got = total;
+  return p;
+}
+void release_workspace(chg_engine* eng, char* p, size_t bytes) {
+  if (!p) return;
+  if (eng && eng->work_pool.size() < 4) eng->work_pool.emplace_back(p, bytes);
+  else hipFree(p);
+}
+
 int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
   if (b->train_arena) return CHG_OK;
   const size_t N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, rows = std::max(Ed, A);
@@ -727,15 +754,16 @@ int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
     eng->err = "chg_backward: training workspace of " + std::to_string(total) + " bytes exceeds the engine's memory limit";
     return CHG_ENOMEM;
   }
-  char* base = nullptr;
-  if (hipMalloc(&base, total) != hipSuccess) {
+  size_t got = 0;
+  char* base = acquire_workspace(eng, total, got);
+  if (!base) {
     eng->err = "hipMalloc of " + std::to_string(total) + " bytes (training workspace) failed";
     return CHG_ENOMEM;
   }
   Carver c2{base};
   lay(c2);
   b->train_arena = base;
-  b->train_bytes = total;
+  b->train_bytes = got;
   return CHG_OK;
 }
 
@@ -957,8 +985,9 @@ int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
     eng->err = "chg_backward: second-order training workspace of " + std::to_string(total) + " bytes exceeds the engine's memory limit";
     return CHG_ENOMEM;
   }
-  char* base = nullptr;
-  if (hipMalloc(&base, total) != hipSuccess) {
+  size_t got = 0;
+  char* base = acquire_workspace(eng, total, got);
+  if (!base) {
     delete t;
     eng->err = "hipMalloc of " + std::to_string(total) + " bytes (second-order training workspace) failed";
     return CHG_ENOMEM;
@@ -967,7 +996,7 @@ int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
   layout_train2(b, *t, c2);
   b->t2 = t;
   b->t2_arena = base;
-  b->t2_bytes = total;
+  b->t2_bytes = got;
   return CHG_OK;
 }
 
@@ -1712,6 +1741,7 @@ int chg_engine_destroy(chg_engine* eng) {
   if (eng->t0) hipEventDestroy(eng->t0);
   if (eng->t1) hipEventDestroy(eng->t1);
   for (auto& a : eng->arena_pool) hipFree(a.first);
+  for (auto& a : eng->work_pool) hipFree(a.first);
   if (eng->scratch) hipFree(eng->scratch);
   if (eng->d_weights) hipFree(eng->d_weights);
   if (eng->stream) hipStreamDestroy(eng->stream);
@@ -1740,6 +1770,7 @@ int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_
   size_t f = 0, t = 0;
   HIP_TRY(eng, hipMemGetInfo(&f, &t));
   for (auto& a : eng->arena_pool) f += a.second;   // pooled arenas are reusable
+  for (auto& a : eng->work_pool) f += a.second;
   if (free_bytes) *free_bytes = (int64_t)f;
   if (total_bytes) *total_bytes = (int64_t)t;
   return CHG_OK;
@@ -1827,8 +1858,8 @@ int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (!b) return CHG_OK;
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
   if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
-  if (b->train_arena) hipFree(b->train_arena);
-  if (b->t2_arena) hipFree(b->t2_arena);
+  release_workspace(eng, b->train_arena, b->train_bytes);
+  release_workspace(eng, b->t2_arena, b->t2_bytes);
   free_train2(b);
   if (b->arena) {
     if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
