@@ -212,6 +212,80 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
   int tb, te;
   tile_range(ntiles, tb, te);
   const bool split_in = PARTS == 2 && p.x2_off > 0;   // else (PARTS == 2): split output
+  if constexpr (PARTS == 1 && K == 128) {
+    // 128 -> 64 form (gemm_GQ: read-dominated, Eu rows, HBM-bound): software pipeline over tiles -- the X rows of tile t+1 and
+    // the old Y rows of tile t are in flight while tile t is contracted (0.46 -> 0.38 ms, 3.9 -> 4.8 TB/s).  The
+    // write-dominated 64 -> 128 form (gemm_Q) measured SLOWER with the same pipeline (0.37 -> 0.44 ms) and keeps the plain loop.
+    constexpr int LPR = K / 4, RPS = 64 / LPR, NV = TILE_ROWS / RPS;
+    constexpr int LPO = NOUT / 4, RPO = 64 / LPO, NO = TILE_ROWS / RPO;
+    const int subx = lane / LPR, tx = lane % LPR, suby = lane / LPO, ty = lane % LPO;
+    auto rows_of = [&](int tile, int& nvalid, int& in_row, int& out_row) {
+      const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+      nvalid = min(TILE_ROWS, p.rows - row0);
+      const int rr_ = nvalid > 0 ? row0 + (j < nvalid ? j : 0) : 0;
+      in_row = p.in_idx ? p.in_idx[rr_] : rr_;
+      out_row = p.out_idx ? p.out_idx[rr_] : rr_;
+    };
+    auto issue_x = [&](int in_row, f32x4 (&v)[NV]) {
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int r = __shfl(in_row, RPS * it + subx);
+        v[it] = *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + 4 * tx);
+      }
+    };
+    f32x4 vn[NV];
+    int nvalid_n = 0, in_n = 0, out_n = 0;
+    if (tb < te) {
+      rows_of(tb, nvalid_n, in_n, out_n);
+      if (nvalid_n > 0) issue_x(in_n, vn);
+    }
+    for (int tile = tb; tile < te; ++tile) {
+      const int nvalid = nvalid_n, out_row = out_n;
+      if (nvalid <= 0) break;                      // waves past the end of the last tile (tiles of a wave only grow)
+#pragma unroll
+      for (int it = 0; it < NV; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + subx) * XS + 4 * tx) = vn[it];
+      __builtin_amdgcn_wave_barrier();
+      f32x4 x[KT];
+      read_dl<KT>(T + j * XS, g, x);
+      __builtin_amdgcn_wave_barrier();
+      if (tile + 1 < te) {
+        rows_of(tile + 1, nvalid_n, in_n, out_n);
+        if (nvalid_n > 0) issue_x(in_n, vn);
+      } else {
+        nvalid_n = 0;
+      }
+      const bool rmw = p.accumulate || p.resid;    // uniform: the plain-store form keeps no old rows in registers
+      f32x4 old[NO];
+      if (rmw) {
+#pragma unroll
+        for (int it = 0; it < NO; ++it) {
+          const int r = __shfl(out_row, RPO * it + suby);
+          old[it] = zero4();
+          if (RPO * it + suby < nvalid) {
+            if (p.accumulate) old[it] = *reinterpret_cast<const f32x4*>(p.Y + (size_t)r * p.ldy + 4 * ty);
+            if (p.resid) old[it] += *reinterpret_cast<const f32x4*>(p.resid + (size_t)r * p.ldr + 4 * ty);
+          }
+        }
+      }
+      f32x4 acc[NFT];
+      read_dl<NFT>(bias, g, acc);
+      gemm_dl<KT, NFT>(acc, W, KS, x, j, g);
+      write_dl<NFT>(T + j * XS, g, acc);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NO; ++it) {
+        const int rr = RPO * it + suby;
+        const int r = __shfl(out_row, rr);
+        if (rr < nvalid) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * ty);
+          if (rmw) v += old[it];
+          *reinterpret_cast<f32x4*>(p.Y + (size_t)r * p.ldy + 4 * ty) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.rows - row0);
