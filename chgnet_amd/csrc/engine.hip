@@ -932,7 +932,12 @@ struct Train2 {
   float *hb0d, *wagd, *wbgcd;                        // tangent embeddings [Eu,64] x2, [Eb,64]
   float *atomd[MAX_CONV + 1], *hbcd[MAX_CONV + 1], *angd[MAX_CONV], *aggd[MAX_CONV], *aggBd[MAX_CONV];
   float *Pd, *Qd, *Rd, *Sd, *ZA, *ZAd;               // tangent tables [N,256] [Eu,128] [Eb,256] [N,128]; W_ang . ang [A,128] x2
-  float *Z, *Zd, *H, *Hd, *CG, *CGd, *BCG, *GCG, *BH, *GH, *BZ, *GZ;   // [R,128]
+  float *Z, *Zd, *H, *Hd, *CG, *CGd, *BCG, *GCG, *BH, *GH, *BZ, *GZ;   // [R,128]  (Z..CGd: the CURRENT layer's rows, see cache)
+  float* scratch6[6];                                // one shared set of Z, Zd, H, Hd, CG, CGd (recompute mode)
+  // per-layer rows kept from the tangent forward for the reverse sweep when device memory allows (layer ids: AtomConv l -> l,
+  // BondConv l -> L + l, AngleUpdate l -> 2L + l); otherwise the reverse sweep recomputes them into scratch6
+  float* cache[3 * MAX_CONV][6];
+  bool cached = false;
   float *bar_a, *g_a, *bar_b, *g_b, *bar_wag, *g_wag, *bar_wbg, *g_wbg, *bar_ang, *g_ang, *bar_agg, *g_agg;
   float *barP, *gP, *barQ, *gQ, *barR, *gR, *barS, *gS;
   float* ro[26];                                     // readout planes [N,64]
@@ -956,8 +961,21 @@ void layout_train2(chg_batch* b, Train2& t, Carver& c) {
   for (int l = 0; l < L - 1; ++l) t.angd[l] = c.take<float>(A * D);
   t.Pd = c.take<float>(N * 4 * D); t.Qd = c.take<float>(Eu * 2 * D); t.Rd = c.take<float>(Eb * 4 * D); t.Sd = c.take<float>(N * 2 * D);
   t.ZA = c.take<float>(A * 2 * D); t.ZAd = c.take<float>(A * 2 * D);
-  float** rows[] = {&t.Z, &t.Zd, &t.H, &t.Hd, &t.CG, &t.CGd, &t.BCG, &t.GCG, &t.BH, &t.GH, &t.BZ, &t.GZ};
+  for (int q = 0; q < 6; ++q) t.scratch6[q] = c.take<float>(R * 2 * D);
+  float** rows[] = {&t.BCG, &t.GCG, &t.BH, &t.GH, &t.BZ, &t.GZ};
   for (float** r : rows) *r = c.take<float>(R * 2 * D);
+  for (int id = 0; id < 3 * MAX_CONV; ++id)
+    for (int q = 0; q < 6; ++q) t.cache[id][q] = nullptr;
+  if (t.cached) {
+    for (int l = 0; l < L; ++l)
+      for (int q = 0; q < 6; ++q) t.cache[l][q] = c.take<float>(Ed * 2 * D);
+    if (A > 0) {
+      for (int l = 0; l < L - 1; ++l)
+        for (int q = 0; q < 6; ++q) t.cache[L + l][q] = c.take<float>(A * 2 * D);
+      for (int l = 0; l < L - 2; ++l)
+        for (int q = 4; q < 6; ++q) t.cache[2 * L + l][q] = c.take<float>(A * 2 * D);   // single layer: only c|g (= z) and its tangent
+    }
+  }
   t.bar_agg = c.take<float>(std::max(N, Eb) * D); t.g_agg = c.take<float>(std::max(N, Eb) * D);
   t.bar_a = c.take<float>(N * D); t.g_a = c.take<float>(N * D);
   for (int i = 0; i < 26; ++i) t.ro[i] = c.take<float>(N * D);
@@ -977,9 +995,22 @@ int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
   if (b->t2) return CHG_OK;
   Train2* t = new (std::nothrow) Train2();
   if (!t) return CHG_ENOMEM;
+  // keep the per-layer rows of the tangent forward for the reverse sweep if that still leaves a quarter of the free memory
+  size_t total = 0;
+  {
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    for (auto& a : eng->work_pool) free_b += a.second;
+    t->cached = true;
+    Carver cc{nullptr};
+    layout_train2(b, *t, cc);
+    const size_t want = (cc.pos + 255) & ~size_t(255);
+    const size_t budget = eng->memory_limit ? std::min(free_b, eng->memory_limit) : free_b;
+    if (std::getenv("CHGNET_TRAIN_NO_CACHE") || want > budget - budget / 4) t->cached = false;
+  }
   Carver c{nullptr};
   layout_train2(b, *t, c);
-  const size_t total = (c.pos + 255) & ~size_t(255);
+  total = (c.pos + 255) & ~size_t(255);
   if (eng->memory_limit && total + b->arena_bytes + b->train_bytes > eng->memory_limit) {
     delete t;
     eng->err = "chg_backward: second-order training workspace of " + std::to_string(total) + " bytes exceeds the engine's memory limit";
@@ -1053,6 +1084,13 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   }
   TRY(check());
 
+  // rows of the layer being worked on: its cache slot (filled by the tangent forward, reused by the reverse sweep) or the scratch set
+  bool reverse = false;
+  auto select_rows = [&](int id) -> bool {      // returns true when the rows are already there (reverse sweep, cached)
+    float** dst[6] = {&t.Z, &t.Zd, &t.H, &t.Hd, &t.CG, &t.CGd};
+    for (int q = 0; q < 6; ++q) *dst[q] = (t.cached && t.cache[id][q]) ? t.cache[id][q] : t.scratch6[q];
+    return t.cached && reverse;
+  };
   // ---- per-layer pieces ------------------------------------------------------------------------------------
   // tangent tables of AtomConv l:  Pd = atomd . [Wc;Wn]^T,  Qd = hbd . Wb^T  (node rows from hbcd[l])
   auto atom_tables_t = [&](int l) -> int {
@@ -1066,6 +1104,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   // z, zd (and the hidden activations) of AtomConv l for every directed edge (centre-major order), then c|g and tangents
   auto atom_rows = [&](int l) -> int {
     const ACW& aw = w.ac[l];
+    if (select_rows(l)) return CHG_OK;
     TRY(atom_tables_t(l));
     GatherZArgs a{};
     a.rows = Ed; a.t0 = b->Pl[l]; a.t1 = b->Pl[l]; a.t2 = b->Ql[l]; a.d0 = t.Pd; a.d1 = t.Pd; a.d2 = t.Qd;
@@ -1079,6 +1118,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   // the same for BondConv (hidden) / AngleUpdate (single layer) of slot; hrows / atoms / angs are the layer's inputs
   auto angle_rows = [&](int slot, bool hidden, const float* w_bij, const float* w_ctr, const float* w_ang, const GatedW& g, const float* hrowsd,
                         const float* atomsd, const float* angs, const float* angsd) -> int {
+    if (select_rows(slot < L ? L + slot : 2 * L + (slot - L))) return CHG_OK;
     TRY(rows_gemm_out2(eng, "t2_gemm_tab", hrowsd, nullptr, w_bij, w_bij + 2 * D * D, nullptr, t.Rd, 4 * D, Eb));
     TRY(gemm("t2_gemm_tab", 64, 128, atomsd, D, nullptr, w_ctr, nullptr, nullptr, 0, t.Sd, 2 * D, nullptr, N, 0));
     TRY(gemm("t2_gemm_ang", 64, 128, angs, D, nullptr, w_ang, nullptr, nullptr, 0, t.ZA, 2 * D, nullptr, A, 0));
@@ -1176,6 +1216,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   TRY(check());
 
   // ---- reverse sweep with two adjoints -----------------------------------------------------------------------
+  reverse = true;
   // gated-MLP internals common to the three layer kinds: BCG / GCG -> weight gradients of the second layer, BZ / GZ
   auto hidden_back = [&](const GatedW& g, const float* w2c_t, const float* w2g_t, int rows) -> int {
     TRY((xty<4, 4>(eng, "t2_wgrad", t.BCG, 2 * D, nullptr, t.H, 2 * D, nullptr, rows, 1.0f, G(g.w2c), D, D, G(g.b2c))));
