@@ -720,16 +720,19 @@ char* acquire_workspace(chg_engine* eng, size_t total, size_t& got) {
   }
   char* p = nullptr;
   if (hipMalloc(&p, total) != hipSuccess) {
-    for (auto& a : eng->work_pool) hipFree(a.first);   // make room and try once more
+    (void)hipGetLastError();
+    for (auto& a : eng->work_pool) hipFree(a.first);   // make room (both pools) and try once more
     eng->work_pool.clear();
-    if (hipMalloc(&p, total) != hipSuccess) return nullptr;
+    for (auto& a : eng->arena_pool) hipFree(a.first);
+    eng->arena_pool.clear();
+    if (hipMalloc(&p, total) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   }
   got = total;
   return p;
 }
 void release_workspace(chg_engine* eng, char* p, size_t bytes) {
   if (!p) return;
-  if (eng && eng->work_pool.size() < 4) eng->work_pool.emplace_back(p, bytes);
+  if (eng && eng->work_pool.size() < 2) eng->work_pool.emplace_back(p, bytes);   // one first-order + one second-order workspace
   else hipFree(p);
 }
 
@@ -1451,8 +1454,14 @@ int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
   for (auto& a : eng->arena_pool) hipFree(a.first);   // nothing fits: drop the cache before growing
   eng->arena_pool.clear();
   if (hipMalloc(&b->arena, total) != hipSuccess) {
-    eng->err = "hipMalloc of " + std::to_string(total) + " bytes failed";
-    return CHG_ENOMEM;
+    (void)hipGetLastError();
+    for (auto& a : eng->work_pool) hipFree(a.first);   // pooled training workspaces (tens of GB) go before giving up
+    eng->work_pool.clear();
+    if (hipMalloc(&b->arena, total) != hipSuccess) {
+      (void)hipGetLastError();
+      eng->err = "hipMalloc of " + std::to_string(total) + " bytes failed";
+      return CHG_ENOMEM;
+    }
   }
   b->arena_bytes = total;
   return CHG_OK;

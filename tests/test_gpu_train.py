@@ -312,3 +312,41 @@ def test_train_step_with_force_and_stress_terms(golden_weights):
     finally:
         model.release_forward_state()
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+
+
+def test_second_order_gradients_on_edge_case_batches(hip_engine, golden_weights):
+    """Stage B on batches that skip whole branches of the sweep: no angle at all (BondConv / AngleUpdate never run) and a
+    structure of isolated atoms next to a normal one."""
+    import torch
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.model import CHGNet
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+    lone = conv(Structure(Lattice(np.eye(3) * 20.0), ["H", "O"], [[0, 0, 0], [0.5, 0.5, 0.5]]))
+    cases = {"zero-angle batch": [load_case("noangle")[0]], "isolated atoms + normal": [lone, load_case("limno2")[0]]}
+    torch.set_num_threads(8)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    model = CHGNet(state_dict=golden_weights)
+    model._engine = hip_engine
+    try:
+        for label, graphs in cases.items():
+            n_atoms = sum(len(g.atomic_number) for g in graphs)
+            rng = np.random.default_rng(31)
+            ce = rng.normal(size=len(graphs)).astype(np.float32)
+            gf, gs = rng.normal(size=(n_atoms, 3)).astype(np.float32), rng.normal(size=(len(graphs), 3, 3)).astype(np.float32)
+            model.forward(graphs, task="efs")
+            got = model.backward(ce, None, gf, gs)
+            want = OracleCHGNet(golden_weights, dtype=torch.float64).parameter_gradients(
+                graphs, lambda o: (o["e"] * t(ce)).sum() + (o["f"] * t(gf)).sum() + (o["s"] * t(gs)).sum(), task="efs")
+            for k, ref in want.items():
+                scale = float(np.abs(ref).max())
+                assert np.isfinite(got[k]).all(), (label, k)
+                if scale == 0:
+                    assert float(np.abs(got[k]).max()) < 1e-9, (label, k)
+                else:
+                    assert float(np.abs(got[k] - ref).max()) <= REL_TOL_B * scale, (label, k, float(np.abs(got[k] - ref).max()), scale)
+    finally:
+        model.release_forward_state()
+        model._engine = None
