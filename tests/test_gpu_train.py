@@ -350,3 +350,32 @@ def test_second_order_gradients_on_edge_case_batches(hip_engine, golden_weights)
     finally:
         model.release_forward_state()
         model._engine = None
+
+
+def test_gradients_are_additive_over_structures_at_scale(hip_engine):
+    """Size-independent property at a size no CPU oracle reaches: with per-structure cotangents the parameter gradient of
+    a batch is the sum of the gradients of its parts (512 structures = 256 + 256), first- and second-order sweeps alike."""
+    import bench
+
+    structs = bench.workload_structures(512, 2000)
+    rng = np.random.default_rng(77)
+
+    def grads(sl, second_order):
+        batch = hip_engine.build_batch(structs[sl])
+        pb = batch.packed
+        a0 = sl.start * 40
+        hip_engine.predict(batch, "efs")
+        kw = dict(f_grad=gF[a0:a0 + pb.n_atoms], s_grad=gS[sl]) if second_order else {}
+        g = hip_engine.backward(batch, ce[sl], gm[a0:a0 + pb.n_atoms], **kw)
+        batch.free()
+        return g.astype(np.float64)
+
+    ce, gm = rng.normal(size=512).astype(np.float32), rng.normal(size=512 * 40).astype(np.float32)
+    gF, gS = rng.normal(size=(512 * 40, 3)).astype(np.float32), rng.normal(size=(512, 3, 3)).astype(np.float32)
+    for second_order in (False, True):
+        whole = grads(slice(0, 512), second_order)
+        parts = grads(slice(0, 256), second_order) + grads(slice(256, 512), second_order)
+        scale = np.abs(whole).max()
+        assert np.isfinite(whole).all() and scale > 0
+        # fp32 sums over ~2M rows in a different order: compare against the largest entry
+        assert np.abs(whole - parts).max() < 2e-4 * scale, (second_order, float(np.abs(whole - parts).max()), float(scale))
