@@ -75,6 +75,7 @@ struct chg_engine {
   std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
   std::vector<std::pair<char*, size_t>> work_pool;    // released training workspaces (tens of GB: a hipMalloc per step would dominate it)
+  std::vector<int> work_kind;                         // 0: first-order workspace, 1: second-order workspace
   bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
@@ -707,32 +708,42 @@ int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, i
   return CHG_OK;
 }
 
-// training workspaces are taken from / returned to an engine-level pool (a train step makes a new batch every iteration)
-char* acquire_workspace(chg_engine* eng, size_t total, size_t& got) {
-  int best = -1;
+// Training workspaces are taken from / returned to the engine: a train step makes a new batch every iteration, and a hipMalloc
+// of tens of GB per step would dominate it.  One slot per kind (0: first-order workspace, 1: second-order workspace); a request
+// is rounded up by 8 % so that the slightly different batches of an epoch reuse the same block.
+char* acquire_workspace(chg_engine* eng, size_t total, size_t& got, int kind) {
   for (int i = 0; i < (int)eng->work_pool.size(); ++i)
-    if (eng->work_pool[i].second >= total && (best < 0 || eng->work_pool[i].second < eng->work_pool[best].second)) best = i;
-  if (best >= 0) {
-    char* p = eng->work_pool[best].first;
-    got = eng->work_pool[best].second;
-    eng->work_pool.erase(eng->work_pool.begin() + best);
-    return p;
-  }
+    if (eng->work_kind[i] == kind && eng->work_pool[i].second >= total) {
+      char* p = eng->work_pool[i].first;
+      got = eng->work_pool[i].second;
+      eng->work_pool.erase(eng->work_pool.begin() + i);
+      eng->work_kind.erase(eng->work_kind.begin() + i);
+      return p;
+    }
+  for (int i = (int)eng->work_pool.size() - 1; i >= 0; --i)     // a pooled block of this kind that is too small is of no use any more
+    if (eng->work_kind[i] == kind) {
+      hipFree(eng->work_pool[i].first);
+      eng->work_pool.erase(eng->work_pool.begin() + i);
+      eng->work_kind.erase(eng->work_kind.begin() + i);
+    }
+  const size_t want = ((total + total / 12) + (size_t(64) << 20) - 1) & ~((size_t(64) << 20) - 1);
   char* p = nullptr;
-  if (hipMalloc(&p, total) != hipSuccess) {
-    (void)hipGetLastError();
-    for (auto& a : eng->work_pool) hipFree(a.first);   // make room (both pools) and try once more
-    eng->work_pool.clear();
-    for (auto& a : eng->arena_pool) hipFree(a.first);
-    eng->arena_pool.clear();
-    if (hipMalloc(&p, total) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  }
+  if (hipMalloc(&p, want) == hipSuccess) { got = want; return p; }
+  (void)hipGetLastError();
+  for (auto& a : eng->work_pool) hipFree(a.first);   // make room (both pools) and ask for the exact size
+  eng->work_pool.clear();
+  eng->work_kind.clear();
+  for (auto& a : eng->arena_pool) hipFree(a.first);
+  eng->arena_pool.clear();
+  if (hipMalloc(&p, total) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   got = total;
   return p;
 }
-void release_workspace(chg_engine* eng, char* p, size_t bytes) {
+void release_workspace(chg_engine* eng, char* p, size_t bytes, int kind) {
   if (!p) return;
-  if (eng && eng->work_pool.size() < 2) eng->work_pool.emplace_back(p, bytes);   // one first-order + one second-order workspace
+  bool have = false;
+  if (eng) for (int k : eng->work_kind) have = have || k == kind;
+  if (eng && !have) { eng->work_pool.emplace_back(p, bytes); eng->work_kind.push_back(kind); }
   else hipFree(p);
 }
 
@@ -758,7 +769,7 @@ int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
     return CHG_ENOMEM;
   }
   size_t got = 0;
-  char* base = acquire_workspace(eng, total, got);
+  char* base = acquire_workspace(eng, total, got, 0);
   if (!base) {
     eng->err = "hipMalloc of " + std::to_string(total) + " bytes (training workspace) failed";
     return CHG_ENOMEM;
@@ -1020,7 +1031,7 @@ int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
     return CHG_ENOMEM;
   }
   size_t got = 0;
-  char* base = acquire_workspace(eng, total, got);
+  char* base = acquire_workspace(eng, total, got, 1);
   if (!base) {
     delete t;
     eng->err = "hipMalloc of " + std::to_string(total) + " bytes (second-order training workspace) failed";
@@ -1453,10 +1464,19 @@ int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
   }
   for (auto& a : eng->arena_pool) hipFree(a.first);   // nothing fits: drop the cache before growing
   eng->arena_pool.clear();
+  // a little headroom (3 %, 16 MiB granules): the batches of an epoch / the chunks of a sweep differ slightly in size and
+  // should reuse one arena instead of paying a multi-GB hipFree + hipMalloc each
+  const size_t roomy = ((total + total / 32) + (size_t(16) << 20) - 1) & ~((size_t(16) << 20) - 1);
+  if ((!eng->memory_limit || roomy <= eng->memory_limit) && hipMalloc(&b->arena, roomy) == hipSuccess) {
+    b->arena_bytes = roomy;
+    return CHG_OK;
+  }
+  (void)hipGetLastError();
   if (hipMalloc(&b->arena, total) != hipSuccess) {
     (void)hipGetLastError();
     for (auto& a : eng->work_pool) hipFree(a.first);   // pooled training workspaces (tens of GB) go before giving up
     eng->work_pool.clear();
+    eng->work_kind.clear();
     if (hipMalloc(&b->arena, total) != hipSuccess) {
       (void)hipGetLastError();
       eng->err = "hipMalloc of " + std::to_string(total) + " bytes failed";
@@ -1922,8 +1942,8 @@ int chg_batch_free(chg_engine* eng, chg_batch* b) {
   if (!b) return CHG_OK;
   if (eng) { hipSetDevice(eng->device); hipStreamSynchronize(eng->stream); }
   if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
-  release_workspace(eng, b->train_arena, b->train_bytes);
-  release_workspace(eng, b->t2_arena, b->t2_bytes);
+  release_workspace(eng, b->train_arena, b->train_bytes, 0);
+  release_workspace(eng, b->t2_arena, b->t2_bytes, 1);
   free_train2(b);
   if (b->arena) {
     if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
