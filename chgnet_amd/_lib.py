@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = (
     "chg_debug_fetch", "chg_test_rows_gemm",
     "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
     "chg_stream_copy", "chg_backward", "chg_engine_build_stats", "chg_engine_update_weights",
+    "chg_engine_set_graph_search", "chg_engine_cell_stats",
 )
 
 
@@ -83,6 +84,8 @@ def load() -> ctypes.CDLL:
     lib.chg_last_error.argtypes = [vp]
     lib.chg_last_error.restype = ctypes.c_char_p
     lib.chg_engine_build_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.chg_engine_set_graph_search.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+    lib.chg_engine_cell_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_engine_set_memory_limit.argtypes = [vp, ctypes.c_int64]
     lib.chg_engine_memory_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_batch_bytes_required.argtypes = [ctypes.c_int32] * 6

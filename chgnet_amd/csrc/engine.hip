@@ -84,7 +84,9 @@ struct chg_engine {
   bool spec_builds = true;    // CHGNET_SPEC_BUILD=0 forces the exact three-round-trip pass
   int last_N = 0, last_Ed = 0, last_A = 0, last_Eb = 0;
   double last_r_atom = 0.0, last_r_bond = 0.0;
-  long n_spec_builds = 0, n_spec_overflows = 0;
+  long n_spec_builds = 0, n_spec_overflows = 0, n_cell_builds = 0, n_cell_fallbacks = 0;
+  int graph_search = 0;       // chg_engine_set_graph_search: 0 by size, 1 all pairs, 2 cell list
+  int cell_min_atoms = 512;   // structures at least this large are binned (by size)
   size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
 };
 
@@ -1501,11 +1503,72 @@ int d2d(chg_engine* eng, T* dst, const T* src, size_t n) {
 //    chunk of similar structures): the scratch arrays are sized from the PREVIOUS build's per-atom counts plus
 //    headroom, every kernel takes its counts from device memory, and the host reads {Ed, A, Eb, flags} once at the
 //    end.  A capacity that turns out too small raises a device-side flag and the build is repeated exactly.
-struct GraphCounts { int Ed = 0, A = 0, Eb = 0, unpaired = 0, isolated = 0; };
+struct GraphCounts { int Ed = 0, A = 0, Eb = 0, unpaired = 0, isolated = 0; bool cell_overflow = false; };
+
+// device copies of the host-side binning (one entry per structure; all-pairs structures have off = -1)
+struct CellLists { const int *off, *nb, *reach, *bin_start, *bin_atoms, *bin3, *shift; };
+
+// Bins for the structures large enough to profit (the arithmetic of host_graph.cpp neighbor_list_cells: bins at least
+// one cutoff wide along every axis, wrapped coordinates, floor shifts).  Any binning yields the same rows -- the bins
+// only propose candidates -- so the bin counts are free to differ from the host's.
+struct HostCells {
+  std::vector<int> off, nb, reach, bin_start, bin_atoms, bin3, shift;
+  bool any = false;
+};
+
+void bin_structures(const chg_structs_host* h, const std::vector<double>& hk, double r, int min_atoms, HostCells& hc) {
+  const int B = h->n_struct, N = h->n_atoms;
+  hc.off.assign(B, -1); hc.nb.assign(3 * (size_t)B, 1); hc.reach.assign(3 * (size_t)B, 0);
+  hc.bin_atoms.assign(std::max(N, 1), 0); hc.bin3.assign(3 * (size_t)std::max(N, 1), 0); hc.shift.assign(3 * (size_t)std::max(N, 1), 0);
+  hc.bin_start.clear();
+  for (int b = 0; b < B; ++b) {
+    const int a0 = h->atom_off[b], n = h->atom_off[b + 1] - a0;
+    if (n < min_atoms || n >= (1 << 21)) continue;
+    int nb[3];
+    for (int k = 0; k < 3; ++k) nb[k] = std::max(1, std::min(1024, (int)std::floor(hk[3 * b + k] / r)));
+    while ((int64_t)nb[0] * nb[1] * nb[2] > 4 * (int64_t)n + 64) {   // keep the table O(atoms)
+      const int k = nb[0] >= nb[1] && nb[0] >= nb[2] ? 0 : (nb[1] >= nb[2] ? 1 : 2);
+      nb[k] = (nb[k] + 1) / 2;
+    }
+    bool ok = true;
+    std::vector<int> bin_of(n);
+    for (int i = 0; i < n && ok; ++i)
+      for (int k = 0; k < 3; ++k) {
+        const double f = h->frac[3 * (size_t)(a0 + i) + k];
+        double fl = std::floor(f), w = f - fl;
+        if (w >= 1.0) { w -= 1.0; fl += 1.0; }
+        if (!(std::fabs(fl) < 4000.0)) { ok = false; break; }        // images must fit the sort key (and NaN lands here)
+        hc.shift[3 * (size_t)(a0 + i) + k] = (int)fl;
+        hc.bin3[3 * (size_t)(a0 + i) + k] = std::min(nb[k] - 1, (int)(w * nb[k]));
+      }
+    if (!ok) continue;
+    const int n_bins = nb[0] * nb[1] * nb[2];
+    const int base = (int)hc.bin_start.size();
+    hc.bin_start.resize(base + n_bins + 1, 0);
+    int* bs = hc.bin_start.data() + base;
+    for (int i = 0; i < n; ++i) {
+      const int* q = hc.bin3.data() + 3 * (size_t)(a0 + i);
+      bin_of[i] = (q[0] * nb[1] + q[1]) * nb[2] + q[2];
+      ++bs[bin_of[i] + 1];
+    }
+    bs[0] = a0;                                                       // positions index the batch-wide bin_atoms array
+    for (int q = 0; q < n_bins; ++q) bs[q + 1] += bs[q];
+    std::vector<int> fill(bs, bs + n_bins);
+    for (int i = 0; i < n; ++i) hc.bin_atoms[fill[bin_of[i]]++] = a0 + i;
+    for (int k = 0; k < 3; ++k) {
+      hc.nb[3 * b + k] = nb[k];
+      // |x_j + I nb - x_i| <= r nb / h in bin units: the offset is at most floor(r nb / h) + 1
+      hc.reach[3 * b + k] = (int)std::floor(r * nb[k] / hk[3 * b + k] + 1e-9) + 1;
+    }
+    hc.off[b] = base;
+    hc.any = true;
+  }
+  if (hc.bin_start.empty()) hc.bin_start.push_back(0);
+}
 
 int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const double* d_cart, const double* d_frac, const double* d_lat,
-               const double* d_reach, const int* d_owner, const int* d_aoff, double r_atom, double r_bond, double tol, bool speculative,
-               int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
+               const double* d_reach, const int* d_owner, const int* d_aoff, const CellLists* cells, double r_atom, double r_bond, double tol,
+               bool speculative, int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
                int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
                int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2) {
   const int N = h->n_atoms;
@@ -1520,7 +1583,11 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   HIP_TRY(eng, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
   NlArgs nl{};
   nl.cart = d_cart; nl.frac = d_frac; nl.lattice = d_lat; nl.reach = d_reach; nl.atom_owner = d_owner; nl.atom_off = d_aoff;
-  nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt; nl.overflow = d_flags + 2;
+  nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt; nl.overflow = d_flags + 2; nl.cell_flag = d_flags + 3;
+  if (cells) {
+    nl.cell_off = cells->off; nl.cell_nb = cells->nb; nl.cell_reach = cells->reach; nl.bin_start = cells->bin_start;
+    nl.bin_atoms = cells->bin_atoms; nl.a_bin3 = cells->bin3; nl.a_shift = cells->shift;
+  }
   const dim3 wave_per_atom((unsigned)((N + 3) / 4));
   hipLaunchKernelGGL((k_neighbors<false>), wave_per_atom, dim3(256), 0, st, nl);
   TRY(exclusive_scan(eng, tmp, d_ccnt, d_coff, N + 1));
@@ -1576,6 +1643,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     HIP_TRY(eng, hipMemcpyAsync(&A, ang_off + capU, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipStreamSynchronize(st));
+    if (flags[3]) { gc.cell_overflow = true; overflowed = true; return CHG_OK; }
     if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
     capA = A;
   }
@@ -1603,9 +1671,10 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, (const int*)(d_coff + N), (const int*)(ang_off + capU),
                        (const int*)(node_scan + capU), (const int*)d_flags, d_counts);
-    HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 7, hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipStreamSynchronize(st));
     Ed = hc[0]; A = hc[1]; Eb = hc[2]; flags[0] = hc[3]; flags[1] = hc[4]; flags[2] = hc[5];
+    if (hc[6]) { gc.cell_overflow = true; overflowed = true; return CHG_OK; }
     if (flags[2] || Ed > capE || A > capA || Eb > capEb) { overflowed = true; return CHG_OK; }
     if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
     if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
@@ -1619,7 +1688,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
   const int B = h->n_struct, N = h->n_atoms;
   hipStream_t st = eng->stream;
   // per-structure constants and float64 cartesian coordinates, computed exactly as host_graph.cpp does
-  std::vector<double> reach(3 * (size_t)B), cart(3 * (size_t)N);
+  std::vector<double> reach(3 * (size_t)B), spacing(3 * (size_t)B), cart(3 * (size_t)N);
   std::vector<int> owner(N);
   for (int b = 0; b < B; ++b) {
     const double* L = h->lattice + 9 * b;
@@ -1632,12 +1701,19 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     const double hk[3] = {std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
                           std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
                           std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
-    for (int k = 0; k < 3; ++k) reach[3 * b + k] = r_atom / hk[k];
+    for (int k = 0; k < 3; ++k) { reach[3 * b + k] = r_atom / hk[k]; spacing[3 * b + k] = hk[k]; }
     for (int i = h->atom_off[b]; i < h->atom_off[b + 1]; ++i) {
       owner[i] = b;
       for (int k = 0; k < 3; ++k)
         cart[3 * i + k] = h->frac[3 * i] * a[k] + h->frac[3 * i + 1] * bb[k] + h->frac[3 * i + 2] * c[k];
     }
+  }
+  // cell lists for the large structures (chg_engine_set_graph_search; the rows do not depend on the choice)
+  HostCells hcells;
+  bool use_cells = false;
+  if (eng->graph_search != 1) {
+    bin_structures(h, spacing, r_atom, eng->graph_search == 2 ? 0 : eng->cell_min_atoms, hcells);
+    use_cells = hcells.any;
   }
   // speculative capacities from the previous build (same cutoffs): per-atom counts + 25 % + a constant
   const bool speculate = eng->spec_builds && eng->last_N > 0 && eng->last_r_atom == r_atom && eng->last_r_bond == r_bond;
@@ -1664,15 +1740,38 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     HIP_TRY(eng, hipMemcpyAsync(d_reach, reach.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
     HIP_TRY(eng, hipMemcpyAsync(d_owner, owner.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
     HIP_TRY(eng, hipMemcpyAsync(d_aoff, h->atom_off, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+    CellLists cells{};
+    if (use_cells) {
+      auto up = [&](const std::vector<int>& v) -> const int* {
+        int* d = tmp.get<int>(v.size());
+        if (d && hipMemcpyAsync(d, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice, st) != hipSuccess) d = nullptr;
+        return d;
+      };
+      cells.off = up(hcells.off); cells.nb = up(hcells.nb); cells.reach = up(hcells.reach); cells.bin_start = up(hcells.bin_start);
+      cells.bin_atoms = up(hcells.bin_atoms); cells.bin3 = up(hcells.bin3); cells.shift = up(hcells.shift);
+      if (!cells.off || !cells.nb || !cells.reach || !cells.bin_start || !cells.bin_atoms || !cells.bin3 || !cells.shift) {
+        eng->err = "graph build: scratch allocation failed";
+        return CHG_ENOMEM;
+      }
+    }
     const bool spec = attempt == 0;
     auto cap = [&](double per_atom) { return (int)std::min<double>(2.0e9, per_atom * N * 1.25 + 4096.0); };
     int capE = spec ? (cap(eng->last_Ed / (double)eng->last_N) & ~1) : 0, capA = spec ? cap(eng->last_A / (double)eng->last_N) : 0,
         capEb = spec ? cap(eng->last_Eb / (double)eng->last_N) : 0;
     bool overflowed = false;
-    TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, r_atom, r_bond, tol, spec, capE, capA, capEb, gc, overflowed,
-                   e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr, a_b1, a_d1, a_b2, a_d2));
+    gc = GraphCounts();
+    TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, use_cells ? &cells : nullptr, r_atom, r_bond, tol, spec, capE,
+                   capA, capEb, gc, overflowed, e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr,
+                   a_b1, a_d1, a_b2, a_d2));
+    if (overflowed && gc.cell_overflow) {   // a centre with more rows than the in-LDS sort holds: same attempt again, all pairs
+      use_cells = false;
+      eng->n_cell_fallbacks++;
+      --attempt;
+      continue;
+    }
     if (overflowed) { eng->n_spec_overflows++; continue; }   // capacities too small: repeat with the exact, three-round-trip pass
     if (spec) eng->n_spec_builds++;
+    if (use_cells) eng->n_cell_builds++;
     const int Ed = gc.Ed, Eu = gc.Ed / 2, A = gc.A, Eb = gc.Eb;
     eng->last_N = N; eng->last_Ed = Ed; eng->last_A = A; eng->last_Eb = Eb; eng->last_r_atom = r_atom; eng->last_r_bond = r_bond;
 
@@ -1839,6 +1938,20 @@ int chg_engine_build_stats(chg_engine* eng, int64_t* single_pass_builds, int64_t
   if (!eng) return CHG_EINVAL;
   if (single_pass_builds) *single_pass_builds = eng->n_spec_builds;
   if (capacity_overflows) *capacity_overflows = eng->n_spec_overflows;
+  return CHG_OK;
+}
+
+int chg_engine_set_graph_search(chg_engine* eng, int32_t search, int32_t cell_min_atoms) {
+  if (!eng || search < 0 || search > 2 || cell_min_atoms < 0) return CHG_EINVAL;
+  eng->graph_search = search;
+  if (cell_min_atoms > 0) eng->cell_min_atoms = cell_min_atoms;
+  return CHG_OK;
+}
+
+int chg_engine_cell_stats(chg_engine* eng, int64_t* cell_builds, int64_t* all_pairs_fallbacks) {
+  if (!eng) return CHG_EINVAL;
+  if (cell_builds) *cell_builds = eng->n_cell_builds;
+  if (all_pairs_fallbacks) *all_pairs_fallbacks = eng->n_cell_fallbacks;
   return CHG_OK;
 }
 

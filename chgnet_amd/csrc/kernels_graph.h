@@ -41,7 +41,18 @@ struct NlArgs {
   int* e_owner;
   int cap_edges;             // fill pass: capacity of the e_* arrays (speculative sizing: rows beyond it are dropped and flagged)
   int* overflow;             // set to 1 when a capacity was exceeded
+  // cell list (structures the host binned; host_graph.cpp neighbor_list_cells): null / -1 = all pairs
+  const int* cell_off;       // [B] offset of the structure's bins in bin_start, or -1
+  const int* cell_nb;        // [B,3] bins per axis
+  const int* cell_reach;     // [B,3] bin offsets to visit per axis
+  const int* bin_start;      // per cell structure n_bins + 1 positions into bin_atoms
+  const int* bin_atoms;      // [N] atom ids grouped by bin
+  const int* a_bin3;         // [N,3] the atom's bin
+  const int* a_shift;        // [N,3] floor of the fractional coordinate
+  int* cell_flag;            // set to 1 when a centre has more rows than the in-LDS sort holds (the build repeats with all pairs)
 };
+
+constexpr int CELL_SORT_MAX = 1024;   // rows per centre the wave sorts in LDS
 
 // A count that is either known on the host (exact, two-pass build) or still on the device (single-pass build with
 // speculative capacities: the host reads all counts once, at the end).
@@ -88,13 +99,104 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
   return incl - v;
 }
 
+// Cell-list search for one centre (one wave): candidates come from the bins within reach, every candidate is tested
+// with the expression of the all-pairs path (sq_dist), and the rows are brought into (neighbour, image) order by a
+// bitonic sort of packed keys in the wave's LDS slice -- so the rows are the all-pairs rows, bit for bit.
+__device__ __forceinline__ unsigned long long cell_key(int j_local, int ia, int ib, int ic) {
+  return ((unsigned long long)j_local << 42) | ((unsigned long long)(ia + 8192) << 28) | ((unsigned long long)(ib + 8192) << 14) |
+         (unsigned long long)(ic + 8192);
+}
+
+template <bool FILL>
+__device__ void neighbors_cells(const NlArgs& p, int i, int b, int lane, unsigned long long* keys) {
+  const int a0 = p.atom_off[b];
+  const double* L = p.lattice + 9 * b;
+  const int* bs = p.bin_start + p.cell_off[b];
+  const int nb0 = p.cell_nb[3 * b], nb1 = p.cell_nb[3 * b + 1], nb2 = p.cell_nb[3 * b + 2];
+  const int r0 = p.cell_reach[3 * b], r1 = p.cell_reach[3 * b + 1], r2b = p.cell_reach[3 * b + 2];
+  const int b0 = p.a_bin3[3 * i], b1 = p.a_bin3[3 * i + 1], b2 = p.a_bin3[3 * i + 2];
+  const int s0 = p.a_shift[3 * i], s1 = p.a_shift[3 * i + 1], s2 = p.a_shift[3 * i + 2];
+  auto wrap_of = [](int x, int nb) { return x >= 0 ? x / nb : -((-x + nb - 1) / nb); };
+  int running = 0;
+  for (int oa = -r0; oa <= r0; ++oa) {
+    const int w0 = wrap_of(b0 + oa, nb0), t0 = b0 + oa - w0 * nb0;
+    for (int ob = -r1; ob <= r1; ++ob) {
+      const int w1 = wrap_of(b1 + ob, nb1), t1 = b1 + ob - w1 * nb1;
+      for (int oc = -r2b; oc <= r2b; ++oc) {
+        const int w2 = wrap_of(b2 + oc, nb2), t2 = b2 + oc - w2 * nb2;
+        const int q = (t0 * nb1 + t1) * nb2 + t2;
+        const int beg = bs[q], end = bs[q + 1];
+        for (int s = beg; s < end; s += 64) {
+          const int ss = s + lane;
+          bool hit = false;
+          unsigned long long key = 0;
+          if (ss < end) {
+            const int j = p.bin_atoms[ss];
+            const int ia = w0 - p.a_shift[3 * j] + s0, ib = w1 - p.a_shift[3 * j + 1] + s1, ic = w2 - p.a_shift[3 * j + 2] + s2;
+            const double d2 = sq_dist(p.cart, L, i, j, ia, ib, ic);
+            hit = d2 < p.r2 && sqrt(d2) > p.tol;
+            key = cell_key(j - a0, ia, ib, ic);
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (FILL && hit) {
+            const int pos = running + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < CELL_SORT_MAX) keys[pos] = key;
+          }
+          running += __popcll(mask);
+        }
+      }
+    }
+  }
+  if (!FILL) {
+    if (lane == 0) p.center_cnt[i] = running;
+    return;
+  }
+  if (running > CELL_SORT_MAX) {   // the later kernels stand down on the overflow flag; the host repeats the build with all pairs
+    if (lane == 0) { *p.cell_flag = 1; *p.overflow = 1; }
+    return;
+  }
+  int P = 64;
+  while (P < running) P <<= 1;
+  for (int idx = running + lane; idx < P; idx += 64) keys[idx] = ~0ull;
+  __builtin_amdgcn_wave_barrier();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int t = lane; t < P / 2; t += 64) {
+        const int idx = (t / jj) * 2 * jj + (t % jj), partner = idx + jj;
+        const unsigned long long x = keys[idx], y = keys[partner];
+        const bool up = (idx & k) == 0;
+        if ((x > y) == up) { keys[idx] = y; keys[partner] = x; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  const int base = p.center_off[i];
+  for (int idx = lane; idx < running; idx += 64) {
+    const unsigned long long key = keys[idx];
+    const int j = a0 + (int)(key >> 42);
+    const int ia = (int)((key >> 28) & 16383) - 8192, ib = (int)((key >> 14) & 16383) - 8192, ic = (int)(key & 16383) - 8192;
+    const int w = base + idx;
+    if (w >= p.cap_edges) { *p.overflow = 1; continue; }
+    p.e_center[w] = i;
+    p.e_nbr[w] = j;
+    p.e_img[3 * w] = ia; p.e_img[3 * w + 1] = ib; p.e_img[3 * w + 2] = ic;
+    p.e_image[3 * w] = (float)ia; p.e_image[3 * w + 1] = (float)ib; p.e_image[3 * w + 2] = (float)ic;
+    p.e_dist[w] = sqrt(sq_dist(p.cart, L, i, j, ia, ib, ic));
+    p.e_owner[w] = b;
+  }
+}
+
 // one wave per centre atom; lanes stride over the neighbour atoms j of the same structure
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_neighbors(NlArgs p) {
+  __shared__ unsigned long long sort_keys[FILL ? 4 * CELL_SORT_MAX : 1];
   const int lane = threadIdx.x & 63;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= p.n_atoms) return;
   const int b = p.atom_owner[i];
+  if (p.cell_off && p.cell_off[b] >= 0) {
+    neighbors_cells<FILL>(p, i, b, lane, sort_keys + (FILL ? (threadIdx.x >> 6) * CELL_SORT_MAX : 0));
+    return;
+  }
   const int a0 = p.atom_off[b], n = p.atom_off[b + 1] - a0;
   const double* L = p.lattice + 9 * b;
   const double* reach = p.reach + 3 * b;
@@ -252,10 +354,11 @@ __global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restr
   a_b2c[a] = u_bnode[a_b2[a]];
 }
 
-// counts of a single-pass build, gathered for one device-to-host copy: {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow}
+// counts of a single-pass build, gathered for one device-to-host copy:
+// {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow, cell-sort overflow}
 __global__ void k_collect_counts(const int* ed, const int* a, const int* eb, const int* flags, int* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2];
+    out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2]; out[6] = flags[3];
   }
 }
 

@@ -101,6 +101,17 @@ class Engine:
         self._check(self.lib.chg_engine_build_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
 
+    def set_graph_search(self, search: str = "auto", cell_min_atoms: int = 0) -> None:
+        """Neighbour search of ``build_batch``: "auto" (cell list for structures of at least ``cell_min_atoms`` atoms,
+        default 512), "all_pairs" or "cells".  The graph does not depend on the choice."""
+        self._check(self.lib.chg_engine_set_graph_search(self.handle, {"auto": 0, "all_pairs": 1, "cells": 2}[search], int(cell_min_atoms)))
+
+    def cell_stats(self) -> tuple[int, int]:
+        """(builds that used the cell list, builds repeated with all pairs because a centre had more than 1024 rows)."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.chg_engine_cell_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
     def set_memory_limit(self, n_bytes: int) -> None:
         """Refuse batch arenas above ``n_bytes`` with ``EngineOutOfMemory`` (0 = no limit)."""
         self._check(self.lib.chg_engine_set_memory_limit(self.handle, int(n_bytes)))

@@ -133,6 +133,13 @@ typedef struct chg_structs_host {
  * chg_engine_build_stats reports how many builds went each way. */
 int chg_batch_build(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
                     chg_batch** out, int32_t* counts_out);
+/* Neighbour search of chg_batch_build, the device-side twin of chg_graph_build_with's `search` (chgnet_graph.h):
+ * 0 = by size (structures with at least cell_min_atoms atoms -- default 512, 0 keeps the current value -- are binned on
+ * the host and searched through a cell list, one wave per centre, rows sorted in LDS), 1 = all pairs, 2 = cell list for
+ * every structure.  The rows are the same bit for bit either way; a centre with more than 1024 rows makes the build
+ * repeat with all pairs (counted by chg_engine_cell_stats). */
+int chg_engine_set_graph_search(chg_engine* eng, int32_t search, int32_t cell_min_atoms);
+int chg_engine_cell_stats(chg_engine* eng, int64_t* cell_builds, int64_t* all_pairs_fallbacks);
 /* int32 index array of a batch by pack.py name (e_center, e_nbr, e_d2u, u_u2d, a_ctr, ...) -- tests only */
 int chg_debug_fetch_i32(chg_engine* eng, chg_batch* batch, const char* name, int32_t* dst, int64_t capacity, int64_t* n_written);
 /* new positions / cells on an unchanged graph topology (MD with a Verlet-skin graph) */

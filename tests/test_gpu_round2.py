@@ -321,3 +321,88 @@ def test_device_graph_build_2048_atom_cell(hip_engine):
     res = hip_engine.download(batch, "ef")
     batch.free()
     assert np.isfinite(res["e"]).all() and np.abs(res["f"].sum(0)).max() < 5e-3
+
+
+def test_device_cell_list_search_is_bit_exact(hip_engine):
+    """The device cell list (chg_engine_set_graph_search): forced on for the small, oddly shaped fixture cells (a single
+    bin reached through many images, unwrapped and negative coordinates, an isolated pair) and chosen by size for a
+    mixed batch with a 2,048-atom cell -- the arrays equal the host builder's bit for bit, as with all pairs, and the
+    build time of the large cell drops."""
+    import time
+
+    import bench
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.pack import pack_batch
+    from test_gpu_parity import INT_ARRAYS
+
+    def same(batch, want):
+        for attr in ("n_struct", "n_atoms", "n_directed", "n_undirected", "n_angles", "n_bnodes"):
+            assert getattr(batch.packed, attr) == getattr(want, attr), attr
+        for name, count in INT_ARRAYS.items():
+            assert np.array_equal(hip_engine.debug_fetch_i32(batch, name, getattr(want, count)), want.arrays[name]), name
+        assert np.array_equal(hip_engine.debug_fetch(batch, "e_image", (want.n_directed, 3)), want.e_image)
+
+    try:
+        structs = _structures_for_graph_tests()
+        shifted = Structure(structs[0].lattice, structs[0].atomic_numbers, structs[0].frac_coords + np.array([3.0, -2.0, 0.999999999]))
+        structs = [*structs, shifted]
+        conv = CrystalGraphConverter(on_isolated_atoms="ignore")
+        hip_engine.set_graph_search("cells")
+        for r_atom, r_bond in ((6.0, 3.0), (4.0, 4.0)):
+            cv = CrystalGraphConverter(atom_graph_cutoff=r_atom, bond_graph_cutoff=r_bond, on_isolated_atoms="ignore")
+            want = pack_batch([cv(s) for s in structs])
+            c0, f0 = hip_engine.cell_stats()
+            batch = hip_engine.build_batch(structs, r_atom, r_bond)
+            assert hip_engine.cell_stats() == (c0 + 1, f0)
+            same(batch, want)
+            batch.free()
+        # by size: the 2,048-atom cell is binned, its small companions go through all pairs, in one batch
+        big = bench.limno2((4, 4, 2)).perturb(0.03, np.random.default_rng(9)).make_supercell([2, 2, 2])
+        mixed = [structs[0], big, structs[1]]
+        want = pack_batch([conv(s) for s in mixed])
+        hip_engine.set_graph_search("auto", 512)
+        c0, f0 = hip_engine.cell_stats()
+        batch = hip_engine.build_batch(mixed)
+        assert hip_engine.cell_stats() == (c0 + 1, f0)
+        same(batch, want)
+        hip_engine.predict(batch, "ef")
+        r_cells = hip_engine.download(batch, "ef")
+        batch.free()
+        hip_engine.set_graph_search("all_pairs")
+        batch = hip_engine.build_batch(mixed)
+        assert hip_engine.cell_stats() == (c0 + 1, f0)
+        same(batch, want)
+        hip_engine.predict(batch, "ef")
+        r_all = hip_engine.download(batch, "ef")
+        batch.free()
+        assert np.array_equal(r_cells["e"], r_all["e"])
+        # more than 1,024 rows per centre (14 A cutoff): the in-LDS sort stands down, all pairs takes over
+        dense = bench.limno2((3, 2, 2))
+        cv8 = CrystalGraphConverter(atom_graph_cutoff=14, bond_graph_cutoff=3)
+        want = pack_batch([cv8(dense)])
+        assert want.n_directed / want.n_atoms > 1024
+        hip_engine.set_graph_search("cells")
+        c0, f0 = hip_engine.cell_stats()
+        batch = hip_engine.build_batch([dense], 14.0, 3.0)
+        assert hip_engine.cell_stats() == (c0, f0 + 1)
+        same(batch, want)
+        batch.free()
+        # timing: all pairs grows with the square of the cell, the cell list with the atoms (both after a priming build)
+        for cell in ((5, 5, 5), (10, 10, 10), (16, 16, 12)):
+            huge = bench.limno2(cell).perturb(0.02, np.random.default_rng(3))
+            times = {}
+            for mode in ("all_pairs", "cells"):
+                hip_engine.set_graph_search(mode)
+                hip_engine.build_batch([huge]).free()
+                hip_engine.synchronize()
+                t0 = time.perf_counter()
+                b = hip_engine.build_batch([huge])
+                hip_engine.synchronize()
+                times[mode] = time.perf_counter() - t0
+                times[mode + "_edges"] = b.packed.n_directed
+                b.free()
+            print(f"device graph build, {len(huge)} atoms: all pairs {times['all_pairs'] * 1e3:.1f} ms, cell list {times['cells'] * 1e3:.1f} ms")
+            assert times["all_pairs_edges"] == times["cells_edges"]
+        assert times["cells"] < times["all_pairs"]
+    finally:
+        hip_engine.set_graph_search("auto", 512)
