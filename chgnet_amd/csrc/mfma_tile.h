@@ -30,7 +30,7 @@
 #if !defined(CHG_EXPERIMENTS) &&                                                                                  \
     (defined(CHG_EXP_ATOMIC_AS_STORE) || defined(CHG_EXP_GEMM_T_PLAIN) || defined(CHG_EXP_HALF_ROW_ATOMICS) ||     \
      defined(CHG_EXP_NO_GATHER) || defined(CHG_EXP_NO_ROW_ATOMICS) || defined(CHG_EXP_NO_SEG_ATOMICS) ||           \
-     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_PHASE_TIMING))
+     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_EXP_QUARTER_MFMA) || defined(CHG_PHASE_TIMING))
 #error "CHG_EXP_* / CHG_PHASE_TIMING are timing experiments: define CHG_EXPERIMENTS as well (never in a product build)"
 #endif
 
@@ -47,6 +47,11 @@ constexpr int PAD = 4;           // floats of padding per LDS row: keeps 16-B al
                                  // ds_read_b128 of consecutive rows over the banks (row stride = 4 mod 64)
 constexpr int VT = 4;            // 16-feature tiles per 64 features
 constexpr float LN_EPS = 1e-5f;
+#ifdef CHG_EXP_QUARTER_MFMA     // timing experiment only (wrong results): one MFMA of four, what a 4x faster matrix pipe would leave
+constexpr int MFMA_R = 1;
+#else
+constexpr int MFMA_R = 4;
+#endif
 
 struct V64 { f32x4 t[VT]; };     // 64 features of one row, this lane's share (16 floats)
 
@@ -98,7 +103,7 @@ __device__ __forceinline__ void gemm_dl(f32x4 (&acc)[NFT], const float* W, int w
 #pragma unroll
     for (int fo = 0; fo < NFT; ++fo) w[fo] = *reinterpret_cast<const f32x4*>(wbase + 16 * fo * ws + 16 * kt);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < MFMA_R; ++r)
 #pragma unroll
       for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[fo][r], x[kt][r], acc[fo], 0, 0, 0);
   }
@@ -145,7 +150,7 @@ __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int
     if (kt + 1 < KT) gemm_t_load<NFT>(a[(kt + 1) & 1], W, ws, kt + 1, i, g);
     gemm_t_touch<NFT>(a[kt & 1]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < MFMA_R; ++r)
 #pragma unroll
       for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt & 1][r][fo], x[kt][r], acc[fo], 0, 0, 0);
   }

@@ -40,3 +40,15 @@ tot = sum(ms for _, ms in prof.values()); n = sum(c for c, _ in prof.values())
 print(f"eager: {n} launches, kernel time {tot:.3f} ms")
 for k, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]:
     print(f"  {k:18s} launches={cnt:4d} total={ms:7.3f} ms")
+
+# clock-state check: the same replay right after a second of heavy work (a 512-structure batch), and interleaved with it
+import bench
+heavy = eng.build_batch(bench.workload_structures(512, 0))
+eng.predict(heavy, "efsm"); eng.synchronize()
+t = time.perf_counter()
+while time.perf_counter() - t < 1.0:
+    eng.predict(heavy, "efsm")
+eng.synchronize()
+print(f"replay predict right after 1 s of heavy work {wall(lambda: eng.predict(b, task), 200):.3f} ms")
+print(f"replay predict, again                        {wall(lambda: eng.predict(b, task), 200):.3f} ms")
+print(f"replay predict, 2000 in a row                {wall(lambda: eng.predict(b, task), 2000):.3f} ms")
