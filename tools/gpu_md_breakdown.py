@@ -15,7 +15,11 @@ s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]
 eng = Engine(pack_weights(W), 0)
 task = sys.argv[1] if len(sys.argv) > 1 else "ef"
 
-def wall(fn, n=50):
+N_REP = int(os.environ.get("MD_PROBE_REPS", "50"))
+
+
+def wall(fn, n=None):
+    n = n or N_REP
     fn(); eng.synchronize()
     t = time.perf_counter()
     for _ in range(n): fn()
@@ -36,6 +40,7 @@ print(f"build only {wall(build_only):.3f} ms")
 eng.profile(True)
 bb = eng.build_batch([s]); eng.predict(bb, task); eng.synchronize()
 prof = eng.profile_read()
+eng.profile(False)
 tot = sum(ms for _, ms in prof.values()); n = sum(c for c, _ in prof.values())
 print(f"eager: {n} launches, kernel time {tot:.3f} ms")
 for k, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]:
@@ -49,6 +54,6 @@ t = time.perf_counter()
 while time.perf_counter() - t < 1.0:
     eng.predict(heavy, "efsm")
 eng.synchronize()
-print(f"replay predict right after 1 s of heavy work {wall(lambda: eng.predict(b, task), 200):.3f} ms")
-print(f"replay predict, again                        {wall(lambda: eng.predict(b, task), 200):.3f} ms")
-print(f"replay predict, 2000 in a row                {wall(lambda: eng.predict(b, task), 2000):.3f} ms")
+print(f"replay predict right after 1 s of heavy work {wall(lambda: eng.predict(b, task), 4 * N_REP):.3f} ms")
+print(f"replay predict, again                        {wall(lambda: eng.predict(b, task), 4 * N_REP):.3f} ms")
+print(f"replay predict, 2000 in a row                {wall(lambda: eng.predict(b, task), 40 * N_REP):.3f} ms")
