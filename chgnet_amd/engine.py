@@ -19,6 +19,15 @@ def _ip(a: np.ndarray):
     return a.ctypes.data_as(_lib.c_int_p)
 
 
+class PreparedStructures:
+    """Contiguous host arrays of a list of structures (``Engine.prepare_structures``)."""
+
+    __slots__ = ("n_struct", "z", "atom_off", "frac", "lattice")
+
+    def __init__(self, n_struct: int, z: np.ndarray, atom_off: np.ndarray, frac: np.ndarray, lattice: np.ndarray) -> None:
+        self.n_struct, self.z, self.atom_off, self.frac, self.lattice = n_struct, z, atom_off, frac, lattice
+
+
 class EngineOutOfMemory(RuntimeError):
     """CHG_ENOMEM: the batch arena could not be allocated (or exceeds ``Engine.set_memory_limit``).
     The engine stays usable; ``CHGNet.predict_*`` answer by splitting the chunk."""
@@ -142,11 +151,9 @@ class Engine:
         packed = graphs_or_packed if isinstance(graphs_or_packed, PackedBatch) else pack_batch(graphs_or_packed)
         return DeviceBatch(self, packed)
 
-    def build_batch(self, structures, atom_graph_cutoff: float = 6.0, bond_graph_cutoff: float = 3.0,
-                    numerical_tol: float = 1e-8) -> DeviceBatch:
-        """Structures -> device-resident batch with the graph built ON the GPU (chg_batch_build):
-        same arrays, bit for bit, as ``CrystalGraphConverter`` + ``pack_batch`` + ``upload``.
-        ``batch.packed.n_isolated`` holds the number of atoms without any neighbour."""
+    def prepare_structures(self, structures) -> "PreparedStructures":
+        """Host side of ``build_batch``: structures -> contiguous arrays (atomic numbers checked).  Pure CPU work, so a
+        caller can prepare the next chunk while the device is busy with the current one."""
         structures = list(structures)
         n_at = np.array([len(s) for s in structures], dtype=np.int64)
         a_off = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int32)
@@ -154,16 +161,29 @@ class Engine:
         _check_z(z)
         frac = np.ascontiguousarray(np.concatenate([np.asarray(s.frac_coords, dtype=np.float64).reshape(-1, 3) for s in structures]))
         lattice = np.ascontiguousarray(np.stack([np.asarray(s.lattice.matrix, dtype=np.float64) for s in structures]))
-        host = _lib.StructsHost(len(structures), int(a_off[-1]), _ip(z), frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                lattice.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ip(a_off))
+        return PreparedStructures(len(structures), z, a_off, frac, lattice)
+
+    def build_prepared(self, prep: "PreparedStructures", atom_graph_cutoff: float = 6.0, bond_graph_cutoff: float = 3.0,
+                       numerical_tol: float = 1e-8) -> DeviceBatch:
+        """Device side of ``build_batch`` (chg_batch_build)."""
+        host = _lib.StructsHost(prep.n_struct, int(prep.atom_off[-1]), _ip(prep.z), prep.frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                prep.lattice.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ip(prep.atom_off))
         handle = ctypes.c_void_p()
         counts = np.zeros(6, dtype=np.int32)
         self._check(self.lib.chg_batch_build(self.handle, ctypes.byref(host), float(atom_graph_cutoff), float(bond_graph_cutoff),
                                              float(numerical_tol), ctypes.byref(handle), _ip(counts)))
-        packed = PackedBatch(len(structures), int(a_off[-1]), int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3]),
-                             {"z": z, "atom_off": a_off, "frac": frac.astype(np.float32), "lattice": lattice.astype(np.float32)})
+        packed = PackedBatch(prep.n_struct, int(prep.atom_off[-1]), int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3]),
+                             {"z": prep.z, "atom_off": prep.atom_off, "frac": prep.frac.astype(np.float32),
+                              "lattice": prep.lattice.astype(np.float32)})
         packed.n_isolated = int(counts[4])
         return DeviceBatch(self, packed, handle=handle)
+
+    def build_batch(self, structures, atom_graph_cutoff: float = 6.0, bond_graph_cutoff: float = 3.0,
+                    numerical_tol: float = 1e-8) -> DeviceBatch:
+        """Structures -> device-resident batch with the graph built ON the GPU (chg_batch_build):
+        same arrays, bit for bit, as ``CrystalGraphConverter`` + ``pack_batch`` + ``upload``.
+        ``batch.packed.n_isolated`` holds the number of atoms without any neighbour."""
+        return self.build_prepared(self.prepare_structures(structures), atom_graph_cutoff, bond_graph_cutoff, numerical_tol)
 
     def debug_fetch_i32(self, batch: DeviceBatch, name: str, n: int) -> np.ndarray:
         dst = np.empty(max(int(n), 1), np.int32)

@@ -263,22 +263,32 @@ class CHGNet:
         conv, eng = self.graph_converter, self.engine
         flags = dict(site_energies=return_site_energies, atom_feas=return_atom_feas, crystal_feas=return_crystal_feas)
 
-        def run(chunk):
-            batch = eng.build_batch(chunk, conv.atom_graph_cutoff, conv.bond_graph_cutoff)
+        def launch(chunk, prepared):
+            """Build the chunk's graphs on the device and enqueue the sweep (asynchronous)."""
+            batch = eng.build_prepared(prepared, conv.atom_graph_cutoff, conv.bond_graph_cutoff)
             try:
                 if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
                     for struct in chunk:          # raises ValueError / prints the warning like converter.py:161-174
                         conv(struct)
                 eng.predict(batch, task)
-                res = eng.download(batch, task, **flags)
+            except BaseException:
+                batch.free()
+                raise
+            return batch
+
+        def collect(batch):
+            try:
+                return eng.download(batch, task, **flags), batch.packed.atom_off
             finally:
                 batch.free()
-            return _split_results(res, batch.packed.atom_off, len(chunk))
 
-        predictions: list[dict] = []
+        def run(chunk):
+            res, atom_off = collect(launch(chunk, eng.prepare_structures(chunk)))
+            return _split_results(res, atom_off, len(chunk))
+
         floor = self.min_atoms_per_batch if min_atoms_per_batch is None else int(min_atoms_per_batch)
-        for start, stop in _plan_chunks([len(s) for s in structures], batch_size, floor):
-            predictions.extend(_run_splitting(run, structures[start:stop]))
+        chunks = [structures[a:b] for a, b in _plan_chunks([len(s) for s in structures], batch_size, floor)]
+        predictions = _run_pipelined(chunks, eng.prepare_structures, launch, collect, run)
         # like the reference, which hands the list to predict_graph: a one-element list gives a bare dict (model.py:665)
         return predictions[0] if len(structures) == 1 else predictions
 
@@ -301,20 +311,28 @@ class CHGNet:
         eng = self.engine
         flags = dict(site_energies=return_site_energies, atom_feas=return_atom_feas, crystal_feas=return_crystal_feas)
 
-        def run(chunk):
-            packed = pack_batch(chunk)
+        def launch(chunk, packed):  # noqa: ARG001
             batch = eng.upload(packed)
             try:
                 eng.predict(batch, task)
-                res = eng.download(batch, task, **flags)
+            except BaseException:
+                batch.free()
+                raise
+            return batch
+
+        def collect(batch):
+            try:
+                return eng.download(batch, task, **flags), batch.packed.atom_off
             finally:
                 batch.free()
-            return _split_results(res, packed.atom_off, len(chunk))
 
-        predictions: list[dict] = []
+        def run(chunk):
+            res, atom_off = collect(launch(chunk, pack_batch(chunk)))
+            return _split_results(res, atom_off, len(chunk))
+
         floor = self.min_atoms_per_batch if min_atoms_per_batch is None else int(min_atoms_per_batch)
-        for start, stop in _plan_chunks([len(g.atomic_number) for g in graphs], batch_size, floor):
-            predictions.extend(_run_splitting(run, graphs[start:stop]))
+        chunks = [graphs[a:b] for a, b in _plan_chunks([len(g.atomic_number) for g in graphs], batch_size, floor)]
+        predictions = _run_pipelined(chunks, pack_batch, launch, collect, run)   # the next chunk is packed during the sweep
         return predictions[0] if len(graphs) == 1 else predictions
 
     # ---- (de)serialisation (model.py:667-745) ----------------------------------------------------------
@@ -371,6 +389,45 @@ def _run_splitting(run, chunk: list) -> list[dict]:
             raise
     mid = len(chunk) // 2
     return _run_splitting(run, chunk[:mid]) + _run_splitting(run, chunk[mid:])
+
+
+def _run_pipelined(chunks: list, prepare, launch, collect, run_sync) -> list[dict]:
+    """Chunk loop of ``predict_structure`` with the host work hidden behind the device: while the device sweeps chunk i
+    the host extracts the arrays of chunk i+1 (``prepare``), and chunk i's results are cut into per-structure
+    dictionaries after chunk i+1 has been enqueued.  One batch is alive at a time, as in the plain loop.  A chunk whose
+    arena does not fit (``EngineOutOfMemory`` from ``launch``) goes through ``_run_splitting(run_sync, chunk)``."""
+    from chgnet_amd.engine import EngineOutOfMemory  # noqa: PLC0415
+
+    out: list[dict] = []
+    n = len(chunks)
+    if n == 0:
+        return out
+    i, batch, prepared = 0, None, prepare(chunks[0])
+    try:
+        while i < n:
+            if batch is None:
+                try:
+                    batch = launch(chunks[i], prepared)
+                except EngineOutOfMemory:
+                    out.extend(_run_splitting(run_sync, chunks[i]))
+                    i += 1
+                    prepared = prepare(chunks[i]) if i < n else None
+                    continue
+            nxt = prepare(chunks[i + 1]) if i + 1 < n else None        # overlaps the sweep of chunk i
+            done, batch = batch, None
+            res, atom_off = collect(done)                              # waits for chunk i, frees its batch
+            if i + 1 < n:
+                try:
+                    batch = launch(chunks[i + 1], nxt)
+                except EngineOutOfMemory:
+                    batch = None                                       # retried (and split) at the top of the next round
+            out.extend(_split_results(res, atom_off, len(chunks[i])))  # overlaps the sweep of chunk i+1
+            i += 1
+            prepared = nxt
+    finally:
+        if batch is not None:                                          # an exception with a sweep in flight
+            batch.free()
+    return out
 
 
 def _plan_chunks(n_atoms: list[int], batch_size: int, min_atoms: int) -> list[tuple[int, int]]:

@@ -406,3 +406,21 @@ def test_device_cell_list_search_is_bit_exact(hip_engine):
         assert times["cells"] < times["all_pairs"]
     finally:
         hip_engine.set_graph_search("auto", 512)
+
+
+def test_pipelined_chunks_give_the_single_chunk_results(hip_engine, golden_weights):
+    """Several chunks through the overlapped loop (next chunk prepared / packed during the sweep) == one chunk."""
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.model import CHGNet
+
+    model = CHGNet(state_dict=golden_weights)
+    structs = bench.workload_structures(10, 123) + _structures_for_graph_tests()[:3]
+    one = model.predict_structure(structs, task="efsm", return_crystal_feas=True)
+    many = model.predict_structure(structs, task="efsm", return_crystal_feas=True, batch_size=3, min_atoms_per_batch=0)
+    graphs = [CrystalGraphConverter()(s) for s in structs]
+    many_g = model.predict_graph(graphs, task="efsm", return_crystal_feas=True, batch_size=4, min_atoms_per_batch=0)
+    assert len(one) == len(many) == len(many_g) == len(structs)
+    for a, b, c in zip(one, many, many_g):
+        for key in ("e", "f", "s", "m", "crystal_fea"):
+            assert np.abs(a[key] - b[key]).max() < 2e-6 and np.abs(a[key] - c[key]).max() < 2e-6, key

@@ -150,3 +150,68 @@ def test_forward_rejects_unknown_task(golden_weights):
     model = CHGNet(state_dict=golden_weights)
     with pytest.raises(ValueError, match="Invalid task='x'"):
         model.forward([], task="x")
+
+
+def test_pipelined_chunk_loop_order_overlap_and_out_of_memory_fallback():
+    """predict_*'s chunk loop: results in input order, the next chunk prepared while one is in flight, one batch alive
+    at a time, a chunk that does not fit split through the synchronous path, and no batch left behind by an exception."""
+    import numpy as np
+
+    from chgnet_amd.engine import EngineOutOfMemory
+    from chgnet_amd.model import _run_pipelined
+
+    log, alive = [], []
+
+    class Batch:
+        def __init__(self, chunk):
+            self.chunk = chunk
+            alive.append(self)
+
+        def free(self):
+            alive.remove(self)
+
+    def prepare(chunk):
+        log.append(("prepare", chunk[0]))
+        return ("prepared", tuple(chunk))
+
+    def make_launch(too_big=(), fail_at=None):
+        def launch(chunk, prepared):
+            assert prepared == ("prepared", tuple(chunk))
+            assert not alive                                # the previous batch was collected first
+            if chunk[0] in too_big:
+                raise EngineOutOfMemory("arena")
+            if chunk[0] == fail_at:
+                raise ValueError("isolated atoms")
+            log.append(("launch", chunk[0]))
+            return Batch(chunk)
+        return launch
+
+    def collect(batch):
+        log.append(("collect", batch.chunk[0]))
+        batch.free()
+        n = len(batch.chunk)
+        return {"e": np.asarray(batch.chunk, np.float32)}, np.arange(n + 1)
+
+    def run_sync(chunk):
+        log.append(("sync", chunk[0], len(chunk)))
+        if len(chunk) > 1:
+            raise EngineOutOfMemory("still too large")
+        return [{"e": np.float32(chunk[0])}]
+
+    chunks = [[0, 1], [2, 3], [4, 5], [6]]
+    out = _run_pipelined(chunks, prepare, make_launch(), collect, run_sync)
+    assert [float(o["e"]) for o in out] == [0, 1, 2, 3, 4, 5, 6] and not alive
+    # chunk i+1 is prepared between launch(i) and collect(i)
+    assert log.index(("prepare", 2)) > log.index(("launch", 0)) and log.index(("prepare", 2)) < log.index(("collect", 0))
+    assert log.index(("launch", 2)) > log.index(("collect", 0))
+    # chunks that do not fit go through the splitting path, order kept (first, middle and last position)
+    for big in ({0}, {2}, {6}, {2, 4}):
+        log.clear()
+        out = _run_pipelined(chunks, prepare, make_launch(too_big=big), collect, run_sync)
+        assert [float(o["e"]) for o in out] == [0, 1, 2, 3, 4, 5, 6] and not alive
+        assert {e[1] for e in log if e[0] == "sync" and e[2] == 2} == {b for b in big if b != 6}
+    # an exception while a sweep is in flight frees that batch
+    with pytest.raises(ValueError):
+        _run_pipelined(chunks, prepare, make_launch(fail_at=4), collect, run_sync)
+    assert not alive
+    assert _run_pipelined([], prepare, make_launch(), collect, run_sync) == []
