@@ -377,16 +377,21 @@ class CHGNet:
         return model
 
 
-def _run_splitting(run, chunk: list) -> list[dict]:
+def _run_splitting(run, chunk: list, refused: BaseException | None = None) -> list[dict]:
     """``run(chunk)``; when the device cannot hold the chunk's arena (EngineOutOfMemory) the chunk is halved
-    and both halves are run the same way.  A single structure that does not fit raises."""
+    and both halves are run the same way.  A single structure that does not fit raises.  ``refused``: the whole chunk
+    has just been refused with this error (it is not tried again)."""
     from chgnet_amd.engine import EngineOutOfMemory  # noqa: PLC0415
 
-    try:
-        return run(chunk)
-    except EngineOutOfMemory:
+    if refused is not None:
         if len(chunk) <= 1:
-            raise
+            raise refused
+    else:
+        try:
+            return run(chunk)
+        except EngineOutOfMemory:
+            if len(chunk) <= 1:
+                raise
     mid = len(chunk) // 2
     return _run_splitting(run, chunk[:mid]) + _run_splitting(run, chunk[mid:])
 
@@ -408,8 +413,8 @@ def _run_pipelined(chunks: list, prepare, launch, collect, run_sync) -> list[dic
             if batch is None:
                 try:
                     batch = launch(chunks[i], prepared)
-                except EngineOutOfMemory:
-                    out.extend(_run_splitting(run_sync, chunks[i]))
+                except EngineOutOfMemory as err:
+                    out.extend(_run_splitting(run_sync, chunks[i], refused=err))
                     i += 1
                     prepared = prepare(chunks[i]) if i < n else None
                     continue

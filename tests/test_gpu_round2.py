@@ -66,8 +66,8 @@ def test_memory_limit_splits_chunks_and_keeps_results(hip_engine, golden_weights
     assert 0 < need <= full.device_bytes            # the arena may be a (larger) pooled one
     full.free()
     builds = []
-    orig = hip_engine.build_batch
-    hip_engine.build_batch = lambda chunk, *a, **k: (builds.append(len(chunk)), orig(chunk, *a, **k))[1]
+    orig = hip_engine.build_prepared
+    hip_engine.build_prepared = lambda prep, *a, **k: (builds.append(prep.n_struct), orig(prep, *a, **k))[1]
     try:
         hip_engine.set_memory_limit(need // 3)
         got = model.predict_structure(structs, task="efs", batch_size=48)
@@ -88,7 +88,7 @@ def test_memory_limit_splits_chunks_and_keeps_results(hip_engine, golden_weights
             model.predict_graph(load_case("limno2")[0], task="e")
     finally:
         hip_engine.set_memory_limit(0)
-        hip_engine.build_batch = orig
+        hip_engine.build_prepared = orig
         model._engine = None
     hip_engine.build_batch(structs[:2]).free()                         # still usable after the refusals
 

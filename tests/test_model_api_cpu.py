@@ -205,11 +205,16 @@ def test_pipelined_chunk_loop_order_overlap_and_out_of_memory_fallback():
     assert log.index(("prepare", 2)) > log.index(("launch", 0)) and log.index(("prepare", 2)) < log.index(("collect", 0))
     assert log.index(("launch", 2)) > log.index(("collect", 0))
     # chunks that do not fit go through the splitting path, order kept (first, middle and last position)
-    for big in ({0}, {2}, {6}, {2, 4}):
+    for big in ({0}, {2}, {4}, {2, 4}):
         log.clear()
         out = _run_pipelined(chunks, prepare, make_launch(too_big=big), collect, run_sync)
         assert [float(o["e"]) for o in out] == [0, 1, 2, 3, 4, 5, 6] and not alive
-        assert {e[1] for e in log if e[0] == "sync" and e[2] == 2} == {b for b in big if b != 6}
+        assert not [e for e in log if e[0] == "sync" and e[2] == 2]      # a refused chunk is not tried whole again
+        assert {e[1] for e in log if e[0] == "sync"} == {x for b in big for x in (b, b + 1)}
+    # a single structure that is refused raises (it would be refused again)
+    with pytest.raises(EngineOutOfMemory):
+        _run_pipelined(chunks, prepare, make_launch(too_big={6}), collect, run_sync)
+    assert not alive
     # an exception while a sweep is in flight frees that batch
     with pytest.raises(ValueError):
         _run_pipelined(chunks, prepare, make_launch(fail_at=4), collect, run_sync)
