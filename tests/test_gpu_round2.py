@@ -423,5 +423,5 @@ def test_pipelined_chunks_give_the_single_chunk_results(hip_engine, golden_weigh
     assert len(one) == len(many) == len(many_g) == len(structs)
     for a, b, c in zip(one, many, many_g):
         for key in ("e", "f", "s", "m", "crystal_fea"):
-            # crystal_fea sums ~50-sized features with atomics: one float32 ulp there is 4e-6
-            assert np.allclose(a[key], b[key], rtol=2e-6, atol=2e-6) and np.allclose(a[key], c[key], rtol=2e-6, atol=2e-6), key
+            tol = 2e-5 if key == "crystal_fea" else 2e-6   # crystal_fea: atomics-ordered sums of ~50-sized features
+            assert np.abs(a[key] - b[key]).max() < tol and np.abs(a[key] - c[key]).max() < tol, key
