@@ -79,6 +79,8 @@ struct chg_engine {
   bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
+  char* h_stage = nullptr;   // pinned staging for the inputs of chg_batch_build
+  size_t h_stage_bytes = 0;
   int num_cus = 256;
   // single-pass graph builds (chg_batch_build): counts of the previous build size the next one's scratch speculatively
   bool spec_builds = true;    // CHGNET_SPEC_BUILD=0 forces the exact three-round-trip pass
@@ -1442,6 +1444,10 @@ struct TmpPool {   // scratch device memory of one chg_batch_build call: bump al
 
 int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
   if (n <= 0) return CHG_OK;
+  if (n <= (1 << 18)) {   // one workgroup, one launch (a device-wide scan is three)
+    hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, in, out, n);
+    return CHG_OK;
+  }
   size_t bytes = 0;
   HIP_TRY(eng, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n, eng->stream));
   void* work = tmp.get<char>(bytes);
@@ -1725,21 +1731,38 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
   int *d_owner = nullptr, *d_aoff = nullptr;
   for (int attempt = speculate ? 0 : 1; attempt < 2; ++attempt) {
     TmpPool tmp(eng);
-    d_cart = tmp.get<double>(3 * (size_t)N);
-    d_frac = tmp.get<double>(3 * (size_t)N);
-    d_lat = tmp.get<double>(9 * (size_t)B);
-    double* d_reach = tmp.get<double>(3 * (size_t)B);
-    d_owner = tmp.get<int>(N);
-    d_aoff = tmp.get<int>(B + 1);
-    int* d_z = tmp.get<int>(N);     // every host buffer is consumed before the pass's round trip: nothing of the caller's is read after it
-    if (!d_cart || !d_frac || !d_lat || !d_reach || !d_owner || !d_aoff || !d_z) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-    HIP_TRY(eng, hipMemcpyAsync(d_z, h->z, sizeof(int) * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_frac, h->frac, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_lat, h->lattice, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_reach, reach.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_owner, owner.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(eng, hipMemcpyAsync(d_aoff, h->atom_off, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+    // one staged upload: the seven input arrays are laid out back to back in a pinned host buffer (doubles first) and
+    // travel in a single asynchronous copy; the buffer is free again at the round trip that ends every pass
+    const size_t n_f64 = 6 * (size_t)N + 12 * (size_t)B, n_i32 = 2 * (size_t)N + (size_t)B + 1;
+    const size_t in_bytes = n_f64 * sizeof(double) + n_i32 * sizeof(int);
+    if (in_bytes > eng->h_stage_bytes) {
+      if (eng->h_stage) hipHostFree(eng->h_stage);
+      eng->h_stage = nullptr; eng->h_stage_bytes = 0;
+      const size_t want = in_bytes + in_bytes / 4 + 4096;
+      if (hipHostMalloc(&eng->h_stage, want, hipHostMallocDefault) != hipSuccess) { eng->h_stage = nullptr; eng->err = "graph build: pinned staging allocation failed"; return CHG_ENOMEM; }
+      eng->h_stage_bytes = want;
+    }
+    char* d_in = tmp.get<char>(in_bytes);
+    if (!d_in) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+    {
+      double* hd = reinterpret_cast<double*>(eng->h_stage);
+      std::memcpy(hd, cart.data(), sizeof(double) * 3 * N);
+      std::memcpy(hd + 3 * (size_t)N, h->frac, sizeof(double) * 3 * N);
+      std::memcpy(hd + 6 * (size_t)N, h->lattice, sizeof(double) * 9 * B);
+      std::memcpy(hd + 6 * (size_t)N + 9 * (size_t)B, reach.data(), sizeof(double) * 3 * B);
+      int* hi = reinterpret_cast<int*>(hd + n_f64);
+      std::memcpy(hi, owner.data(), sizeof(int) * N);
+      std::memcpy(hi + N, h->atom_off, sizeof(int) * ((size_t)B + 1));
+      std::memcpy(hi + N + B + 1, h->z, sizeof(int) * N);
+    }
+    HIP_TRY(eng, hipMemcpyAsync(d_in, eng->h_stage, in_bytes, hipMemcpyHostToDevice, st));
+    d_cart = reinterpret_cast<double*>(d_in);
+    d_frac = d_cart + 3 * (size_t)N;
+    d_lat = d_cart + 6 * (size_t)N;
+    double* d_reach = d_lat + 9 * (size_t)B;
+    d_owner = reinterpret_cast<int*>(d_cart + n_f64);
+    d_aoff = d_owner + N;
+    int* d_z = d_aoff + B + 1;      // every host buffer is consumed before the pass's round trip: nothing of the caller's is read after it
     CellLists cells{};
     if (use_cells) {
       auto up = [&](const std::vector<int>& v) -> const int* {
@@ -1792,19 +1815,29 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       for (int k = 0; k < 9; ++k) Lf[k] = (float)h->lattice[9 * q + k];
       b->h_volume[q] = Lf[0] * (Lf[4] * Lf[8] - Lf[5] * Lf[7]) + Lf[1] * (Lf[5] * Lf[6] - Lf[3] * Lf[8]) + Lf[2] * (Lf[3] * Lf[7] - Lf[4] * Lf[6]);
     }
-    s = d2d(eng, b->z, (const int*)d_z, (size_t)N);
-    if (s == CHG_OK) s = d2d(eng, b->atom_owner, d_owner, (size_t)N);
-    if (s == CHG_OK) s = d2d(eng, b->atom_off, d_aoff, (size_t)B + 1);
-    if (s == CHG_OK) {
+    {   // every array of the new graph goes into the arena with ONE copy kernel
+      MultiCopy mc{};
+      int nseg = 0;
+      unsigned long long most = 0;
+      auto add = [&](void* dst, const void* src, size_t words) {
+        if (words == 0) return;
+        mc.dst[nseg] = dst; mc.src[nseg] = src; mc.words[nseg] = words;
+        most = std::max<unsigned long long>(most, words);
+        ++nseg;
+      };
+      add(b->z, d_z, N); add(b->atom_owner, d_owner, N); add(b->atom_off, d_aoff, (size_t)B + 1);
+      add(b->e_center, e_center, Ed); add(b->e_nbr, e_nbr, Ed); add(b->e_d2u, e_d2u, Ed); add(b->e_owner, e_owner, Ed);
+      add(b->e_rev, e_rev, Ed); add(b->p_center, p_center, Ed); add(b->p_nbr, p_nbr, Ed); add(b->e_image, e_image, 3 * (size_t)Ed);
+      add(b->u_u2d, u_u2d, Eu); add(b->u_bnode, u_bnode, Eu); add(b->bn_und, bn_und, Eb);
+      add(b->a_ctr, a_ctr, A); add(b->a_d1, a_d1, A); add(b->a_d2, a_d2, A);
+      static_assert(MULTI_COPY_MAX >= 17, "one slot per array");
+      if (nseg > 0) {
+        const unsigned gx = (unsigned)std::min<unsigned long long>((most / 4 + 255) / 256 + 1, (unsigned long long)4 * eng->num_cus);
+        hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)nseg), dim3(256), 0, st, mc);
+      }
       hipLaunchKernelGGL(k_f64_to_f32, g1(3 * (int64_t)N), dim3(256), 0, st, d_frac, b->frac, 3 * N);
       hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
     }
-#define CP(dst, src, n) if (s == CHG_OK) s = d2d(eng, b->dst, src, (size_t)(n))
-    CP(e_center, e_center, Ed); CP(e_nbr, e_nbr, Ed); CP(e_d2u, e_d2u, Ed); CP(e_owner, e_owner, Ed); CP(e_rev, e_rev, Ed);
-    CP(p_center, p_center, Ed); CP(p_nbr, p_nbr, Ed); CP(e_image, e_image, 3 * (size_t)Ed);
-    CP(u_u2d, u_u2d, Eu); CP(u_bnode, u_bnode, Eu); CP(bn_und, bn_und, Eb);
-    CP(a_ctr, a_ctr, A); CP(a_d1, a_d1, A); CP(a_d2, a_d2, A);
-#undef CP
     if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
     // the scratch (TmpPool) is reused by the next build on this same stream, so stream order protects it; overflow
     // allocations of the pool are freed by its destructor and need the copies to have finished
@@ -1926,6 +1959,7 @@ int chg_engine_destroy(chg_engine* eng) {
   for (auto& a : eng->arena_pool) hipFree(a.first);
   for (auto& a : eng->work_pool) hipFree(a.first);
   if (eng->scratch) hipFree(eng->scratch);
+  if (eng->h_stage) hipHostFree(eng->h_stage);
   if (eng->d_weights) hipFree(eng->d_weights);
   if (eng->stream) hipStreamDestroy(eng->stream);
   delete eng;

@@ -362,6 +362,55 @@ __global__ void k_collect_counts(const int* ed, const int* a, const int* eb, con
   }
 }
 
+// Exclusive prefix sum of up to a few hundred thousand ints by ONE workgroup (one launch instead of the three of a
+// device-wide scan, which is what counts for the ~1e4-element arrays of a single-structure build): each thread sums a
+// contiguous chunk, the 1024 chunk sums are scanned through LDS, each thread writes its chunk.
+__global__ __launch_bounds__(1024) void k_small_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int b = min(tid * per, n), e = min(b + per, n);
+  int s = 0;
+  for (int k = b; k < e; ++k) s += in[k];
+  int total;
+  int excl = wave_excl_scan(s, lane, total);
+  if (lane == 63) wave_tot[wave] = total;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  int run = base + excl;
+  for (int k = b; k < e; ++k) {
+    const int v = in[k];
+    out[k] = run;
+    run += v;
+  }
+}
+
+// Several device-to-device copies in one launch (the index arrays of a freshly built graph into the batch arena):
+// blockIdx.y picks the segment, the blocks of a row stride over its 4-byte words.
+constexpr int MULTI_COPY_MAX = 20;
+struct MultiCopy {
+  void* dst[MULTI_COPY_MAX];
+  const void* src[MULTI_COPY_MAX];
+  unsigned long long words[MULTI_COPY_MAX];
+};
+__global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
+  const int seg = blockIdx.y;
+  const unsigned long long n = m.words[seg];
+  const unsigned* __restrict__ src = static_cast<const unsigned*>(m.src[seg]);
+  unsigned* __restrict__ dst = static_cast<unsigned*>(m.dst[seg]);
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const unsigned long long n4 = n / 4;
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+    uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) d4[i] = s4[i];
+    for (unsigned long long i = 4 * n4 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
 __global__ void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) dst[t] = (float)src[t];
