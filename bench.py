@@ -231,7 +231,11 @@ def cpu_leg(weights: dict, graphs, checks: dict, seconds_budget: float = 24.0) -
                   f"the CPU), batch_size={best[1]}, best of 8/16/32 torch threads on {ncpu} logical CPUs"}
     torch.set_num_threads(best[3])
     parity = {}
-    for name, (gs, got) in checks.items():
+    for name, item in checks.items():
+        if item[0] == "weight-gradients":           # C5: d CombinedLoss / d parameters against torch double-backward (float64)
+            parity[name] = gradient_parity(weights, *item[1:])
+            continue
+        gs, got = item
         err = {"e": 0.0, "f": 0.0, "s": 0.0}
         for g, r in zip(gs, got):
             ref = model.predict_graph(g, "efs")
@@ -241,6 +245,37 @@ def cpu_leg(weights: dict, graphs, checks: dict, seconds_budget: float = 24.0) -
         parity[name] = {"n_checked": len(gs), "max_abs_err": {k: float(f"{v:.3g}") for k, v in err.items()},
                         "ok": bool(err["e"] < 1e-4 and err["f"] < 1e-3 and err["s"] < 1e-2)}
     return baseline, parity
+
+
+def gradient_parity(weights: dict, graphs, targets: dict, got: dict) -> dict:
+    """Parameter gradients of CombinedLoss(MSE, target efsm) for a few structures: the device's against autograd /
+    double-backward through the float64 oracle (the loss written out on tensors: trainer.py:779-869 with the default
+    ratios 1 / 1 / 0.1 / 0.1 and mean reduction)."""
+    import torch
+
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    te, tf, ts, tm = t(targets["e"]), t(np.concatenate(targets["f"])), t(np.stack(targets["s"])), t(np.concatenate(targets["m"]))
+
+    def loss(o):
+        mse = lambda a, b: ((a.reshape(-1) - b.reshape(-1)) ** 2).mean()  # noqa: E731
+        return mse(o["e"], te) + mse(o["f"], tf) + 0.1 * mse(o["s"], ts) + 0.1 * mse(o["m"], tm)
+
+    want = OracleCHGNet(weights, dtype=torch.float64).parameter_gradients(graphs, loss, task="efsm")
+    worst, worst_name, n = 0.0, "", 0
+    for k, ref in want.items():
+        if k.startswith(("angle_layers.2.", "composition_model")):      # dead layer / frozen AtomRef: zero gradient
+            continue
+        scale = float(np.abs(ref).max())
+        if scale == 0.0:
+            continue
+        rel = float(np.abs(np.asarray(got[k], np.float64) - ref).max()) / scale
+        n += 1
+        if rel > worst:
+            worst, worst_name = rel, k
+    return {"n_checked": len(graphs), "tensors": n, "max_rel_err": float(f"{worst:.3g}"), "worst_tensor": worst_name,
+            "ok": bool(np.isfinite(worst) and worst < 1e-3)}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -373,6 +408,15 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
                     "m": [np.abs(rng.normal(0.5, 0.2, len(g_.atomic_number))).astype(np.float32) for g_ in b_]}
 
         labels = [labels_for(b_) for b_ in batches]
+        if ranks.rank == 0:      # gradient sample for the CPU leg, taken before any optimizer step
+            from chgnet_amd.trainer import CombinedLoss
+
+            gs = batches[0][:3]
+            tg = {k: v[:3] for k, v in labels[0].items()}
+            pred = model.forward(gs, task="efsm")
+            _, g = CombinedLoss(target_str="efsm").gradients(tg, pred)
+            checks["C5_train_epoch"] = ("weight-gradients", gs, tg, model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s")))
+            model.release_forward_state()
         results = {}
         for targets in ("efsm", "em"):
             step = TrainStep(model, targets=targets, learning_rate=1e-4)
