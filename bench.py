@@ -146,7 +146,15 @@ class Ranks:
         self.dist = None
         self.torch = None
         self.backend = "gloo" if args.dry_run else "nccl"   # "nccl" IS RCCL on ROCm
-        if self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
+        self.comm = None
+        if args.comm == "rccl" and not args.dry_run and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
+            from chgnet_amd.distributed import RcclComm      # RCCL through the engine library's C-ABI: no torch.distributed
+
+            self.comm = RcclComm(self.rank, self.world, self.local_rank)
+            self.backend = "rccl (chg_comm_*)"
+            if self.comm.world != args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {self.comm.world} ranks")
+        elif self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
             import torch
             import torch.distributed as dist
 
@@ -169,6 +177,8 @@ class Ranks:
 
     def all_gather(self, values: np.ndarray) -> np.ndarray:
         """Equal-length float32 vectors of every rank, concatenated in rank order (RCCL all-gather)."""
+        if self.comm is not None:
+            return self.comm.all_gather(values)
         if self.dist is None:
             return values
         mine = self.torch.from_numpy(np.ascontiguousarray(values, np.float32)).to(self.device)
@@ -177,12 +187,16 @@ class Ranks:
         return allv.cpu().numpy()
 
     def barrier(self) -> None:
+        if self.comm is not None:
+            self.comm.barrier()
         if self.dist is not None:
             self.dist.barrier()
             if self.backend == "nccl":
                 self.torch.cuda.synchronize()
 
     def max_over_ranks(self, x: float) -> float:
+        if self.comm is not None:
+            return float(self.comm.all_gather(np.array([x], np.float32)).max())
         if self.dist is None:
             return x
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
@@ -190,6 +204,9 @@ class Ranks:
         return float(t.item())
 
     def close(self) -> None:
+        if self.comm is not None:
+            self.comm.barrier()
+            self.comm.close()
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -419,7 +436,7 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             model.release_forward_state()
         results = {}
         for targets in ("efsm", "em"):
-            step = TrainStep(model, targets=targets, learning_rate=1e-4)
+            step = TrainStep(model, targets=targets, learning_rate=1e-4, comm=ranks.comm)
             use = slice(0, n_steps if targets == "efsm" else min(n_steps, 3))
             step(batches[0], labels[0])                                  # warm-up: allocations, first touch
             ranks.barrier()
@@ -473,6 +490,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: process-group plumbing only (gloo)")
+    ap.add_argument("--comm", choices=("torch", "rccl"), default="torch",
+                    help="exchange steps through torch.distributed (backend nccl = RCCL) or through the engine library's own RCCL entry points")
     args = ap.parse_args()
 
     if args.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -497,7 +516,7 @@ def main() -> None:
         nonlocal gathered
         eng.predict(batch, "efs")
         res = eng.download(batch, "efs")
-        if ranks.dist is not None:
+        if ranks.dist is not None or ranks.comm is not None:
             gathered = ranks.all_gather(res["e"])
         return res
 

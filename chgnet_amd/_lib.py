@@ -20,6 +20,8 @@ EXPORTED_SYMBOLS = (
     "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
     "chg_stream_copy", "chg_backward", "chg_engine_build_stats", "chg_engine_update_weights",
     "chg_engine_set_graph_search", "chg_engine_cell_stats",
+    "chg_comm_unique_id", "chg_comm_create", "chg_comm_all_gather_f32", "chg_comm_all_reduce_sum_f32", "chg_comm_barrier",
+    "chg_comm_destroy", "chg_comm_last_error",
 )
 
 
@@ -85,6 +87,15 @@ def load() -> ctypes.CDLL:
     lib.chg_last_error.restype = ctypes.c_char_p
     lib.chg_engine_build_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_engine_set_graph_search.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    lib.chg_comm_unique_id.argtypes = [u8p]
+    lib.chg_comm_create.argtypes = [u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(vp)]
+    lib.chg_comm_all_gather_f32.argtypes = [vp, c_float_p, ctypes.c_int64, c_float_p]
+    lib.chg_comm_all_reduce_sum_f32.argtypes = [vp, c_float_p, ctypes.c_int64]
+    lib.chg_comm_barrier.argtypes = [vp]
+    lib.chg_comm_destroy.argtypes = [vp]
+    lib.chg_comm_last_error.argtypes = [vp]
+    lib.chg_comm_last_error.restype = ctypes.c_char_p
     lib.chg_engine_cell_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.chg_engine_set_memory_limit.argtypes = [vp, ctypes.c_int64]
     lib.chg_engine_memory_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]

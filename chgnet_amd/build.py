@@ -23,7 +23,7 @@ INCLUDE = os.path.join(REPO_DIR, "include")
 GRAPH_LIB = os.path.join(LIB_DIR, "libchgnet_graph.so")
 HIP_LIB = os.path.join(LIB_DIR, "libchgnet_hip.so")
 
-HIP_SOURCES = ["engine.hip"]
+HIP_SOURCES = ["engine.hip", "comm.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-munsafe-fp-atomics",      # native global_atomic_add_f32, no CAS loops

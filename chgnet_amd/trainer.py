@@ -138,10 +138,24 @@ class Adam:
         return new
 
 
-def allreduce_gradients(grads: dict, average: bool = True) -> dict:
+def allreduce_gradients(grads: dict, average: bool = True, comm=None) -> dict:
     """Sum (or average) the gradient dictionaries of all ranks: ONE all-reduce of the flattened 1.65 MB buffer
-    (``torch.distributed``: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  Without a
-    process group the gradients are returned unchanged."""
+    (``torch.distributed``: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests; or ``comm``, a
+    ``chgnet_amd.distributed.RcclComm`` -- RCCL through the engine library, no torch).  Without a process group the
+    gradients are returned unchanged."""
+    if comm is not None:
+        if comm.world == 1:
+            return grads
+        keys = sorted(grads)
+        flat = comm.all_reduce_sum(np.concatenate([np.asarray(grads[k], np.float32).reshape(-1) for k in keys]))
+        if average:
+            flat /= comm.world
+        out, pos = {}, 0
+        for k in keys:
+            n = int(np.prod(grads[k].shape))
+            out[k] = flat[pos:pos + n].reshape(grads[k].shape)
+            pos += n
+        return out
     try:
         import torch
         import torch.distributed as dist
@@ -169,11 +183,12 @@ class TrainStep:
     """forward -> CombinedLoss -> backward -> (all-reduce) -> Adam -> new weights on the engine: one iteration of the
     reference's ``Trainer._train`` loop (trainer.py:386-411)."""
 
-    def __init__(self, model, *, targets: str = "ef", criterion: str = "MSE", learning_rate: float = 1e-3, **loss_kwargs) -> None:
+    def __init__(self, model, *, targets: str = "ef", criterion: str = "MSE", learning_rate: float = 1e-3, comm=None, **loss_kwargs) -> None:
         if set(targets) - set("efsm") or "e" not in targets:
             raise ValueError(f"training targets {targets!r}: a combination of e, f, s, m that contains e (chgnet/__init__.py:15 TrainTask)")
         self.model = model
         self.targets = targets
+        self.comm = comm                      # RcclComm, or None for the torch.distributed process group (if any)
         self.loss = CombinedLoss(target_str=targets, criterion=criterion, **loss_kwargs)
         self.optimizer = Adam(model.state_dict(), lr=learning_rate, frozen=("composition_model.fc.weight",))
         self.task = "".join(k for k in "efsm" if k in targets)
@@ -202,6 +217,6 @@ class TrainStep:
         pred = model.forward(graphs, task=self.task)
         info, g = self.loss.gradients(targets, pred)
         grads = model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s"))
-        grads = allreduce_gradients(grads)
+        grads = allreduce_gradients(grads, comm=self.comm)
         model.load_state_dict(self.optimizer.step(model.state_dict(), grads))
         return info

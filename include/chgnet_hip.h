@@ -189,6 +189,24 @@ int chg_debug_fetch(chg_engine* eng, chg_batch* batch, const char* name, float* 
 /* Self-test of the MFMA tile primitives: Y[rows,nout] = X[rows,k] . Wt[nout,k]^T + bias (k, nout in {64,128}). */
 int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const float* bias, float* y, int rows, int k, int nout);
 
+/* ---- exchange steps of the multi-GPU path, straight on RCCL (one communicator per process = per GPU) ----------
+ * The reference is single-device; these carry what SURVEY 8e needs and nothing else: the all-gather of per-structure
+ * energies after a sweep sharded over independent structures, and the sum of the 412,525-float parameter gradient of a
+ * data-parallel train step (the slot is loss.backward() -> optimizer.step(), chgnet/trainer/trainer.py:399-411).
+ * librccl is opened at run time (CHG_EUNSUPPORTED when it is missing).  Rank 0 calls chg_comm_unique_id and hands the
+ * CHG_COMM_ID_BYTES bytes to the other ranks by any means (chgnet_amd/distributed.py uses a file next to MASTER_PORT);
+ * every rank then calls chg_comm_create.  Buffers are HOST pointers; counts are per rank; all calls block until done.
+ * all_gather: recv holds world * count floats in rank order. */
+#define CHG_COMM_ID_BYTES 128
+typedef struct chg_comm chg_comm;
+int chg_comm_unique_id(uint8_t* id_out);
+int chg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, chg_comm** out);
+int chg_comm_all_gather_f32(chg_comm* comm, const float* send, int64_t count, float* recv);
+int chg_comm_all_reduce_sum_f32(chg_comm* comm, float* data, int64_t count);
+int chg_comm_barrier(chg_comm* comm);
+int chg_comm_destroy(chg_comm* comm);
+const char* chg_comm_last_error(const chg_comm* comm);   /* NULL: the error of the last failed call without a communicator */
+
 #ifdef __cplusplus
 }
 #endif

@@ -425,3 +425,27 @@ def test_pipelined_chunks_give_the_single_chunk_results(hip_engine, golden_weigh
         for key in ("e", "f", "s", "m", "crystal_fea"):
             tol = 2e-5 if key == "crystal_fea" else 2e-6   # crystal_fea: atomics-ordered sums of ~50-sized features
             assert np.abs(a[key] - b[key]).max() < tol and np.abs(a[key] - c[key]).max() < tol, key
+
+
+def test_rccl_communicator_through_the_c_abi():
+    """chg_comm_*: RCCL opened by the engine library itself (no torch.distributed).  One GPU here, so the group has one
+    rank: unique id, communicator, all-gather, all-reduce and barrier run through RCCL and return the input; the sharded
+    sweep and the gradient all-reduce accept the communicator."""
+    from chgnet_amd.distributed import RcclComm, all_gather_energies
+    from chgnet_amd.trainer import allreduce_gradients
+
+    comm = RcclComm(rank=0, world=1, device=0)
+    try:
+        x = np.arange(1000, dtype=np.float32) * 0.5 - 3.0
+        assert np.array_equal(comm.all_gather(x), x)
+        assert np.array_equal(comm.all_reduce_sum(x.reshape(10, 100)), x.reshape(10, 100))
+        big = np.random.default_rng(0).normal(size=412_525).astype(np.float32)      # the parameter gradient
+        assert np.array_equal(comm.all_reduce_sum(big), big)
+        comm.barrier()
+        e = all_gather_energies(np.array([1.0, 2.0, 3.0], np.float32), [[2, 0, 1]], 3, comm=comm)
+        assert np.array_equal(e, np.array([2.0, 3.0, 1.0], np.float32))
+        g = {"a": np.ones((2, 3), np.float32), "b": np.full(4, 2.0, np.float32)}
+        out = allreduce_gradients(g, comm=comm)
+        assert np.array_equal(out["a"], g["a"]) and np.array_equal(out["b"], g["b"])
+    finally:
+        comm.close()
