@@ -126,6 +126,31 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
+_RESULT_FD = None
+
+
+def claim_stdout() -> None:
+    """stdout carries ONE line, the result.  Libraries write there too -- RCCL prints a five-line banner through C stdio,
+    which a pipe holds back until the process exits, i.e. AFTER the result -- so file descriptor 1 is pointed at stderr for
+    the whole run and the result goes to a private duplicate of the original stdout (``emit``)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: dict) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+        return
+    sys.stdout.flush()
+    while data:
+        data = data[os.write(_RESULT_FD, data):]
+
+
 def spawn_ranks(n: int, argv: list[str]) -> int:
     """Re-execute this file under torch.distributed.run with n ranks on this node; returns its exit code."""
     env = dict(os.environ)
@@ -474,7 +499,7 @@ def dry_run(args, ranks: Ranks) -> None:
             "backend": ranks.backend if ranks.dist is not None else None}
     ranks.close()
     if ranks.rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 def main() -> None:
@@ -496,6 +521,7 @@ def main() -> None:
 
     if args.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))   # not under a launcher: start the N ranks ourselves
+    claim_stdout()
     ranks = Ranks(args)
     if args.dry_run:
         return dry_run(args, ranks)
@@ -660,7 +686,7 @@ def main() -> None:
     eng.close()
     ranks.close()
     if line is not None:
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":

@@ -81,9 +81,9 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                   # ONE json line, from rank 0
-    line = json.loads(lines[0])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout                       # stdout carries ONE line, the result of rank 0: library chatter
+    line = json.loads(lines[0])                              # (gloo / RCCL banners, model banners) goes to stderr
     assert line["n_gpus"] == 2 and line["ranks_in_all_gather"] == [0, 1] and line["backend"] == "gloo"
     # under a launcher --gpus must agree with the world size
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
