@@ -257,12 +257,20 @@ def test_second_order_packed_gradients_vs_pipeline_model(hip_engine, packed_weig
     assert not msgs, f"[{terms}] " + "; ".join(msgs)
 
 
-def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_weights):
+@pytest.mark.parametrize("which", ["seed0", "trained_like"])
+def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_weights, trained_like_weights, which):
     """d( sum ce e + sum gm m + sum gF.F + sum gS:S ) / d(all parameters) against torch double-backward through the fp64 oracle
-    (the reference's create_graph=True path) on the five golden structures."""
+    (the reference's create_graph=True path) on the five golden structures; also at trained-checkpoint magnitudes
+    (saturating gates exercise the second derivatives of the activations)."""
     import torch
+    from chgnet_amd.engine import Engine
     from chgnet_amd.model import CHGNet
+    from chgnet_amd.pack import pack_weights
     from oracle.chgnet_oracle import OracleCHGNet
+
+    if which == "trained_like":
+        golden_weights = trained_like_weights
+        hip_engine = Engine(pack_weights(golden_weights), 0)
 
     graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri", "s40", "li9co7o16")]
     n_atoms = sum(len(g.atomic_number) for g in graphs)
@@ -277,6 +285,8 @@ def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_w
     finally:
         model.release_forward_state()
         model._engine = None
+        if which == "trained_like":
+            hip_engine.close()
     torch.set_num_threads(8)
     t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
     want = OracleCHGNet(golden_weights, dtype=torch.float64).parameter_gradients(
