@@ -430,6 +430,17 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             "steps_per_s": round(out["steps_per_s"], 1), "ms_per_step": round(1e3 / out["steps_per_s"], 3),
             "calculator_ms_per_step": round(1e3 * out["calculator_s"] / args.md_steps, 3),
             "temperature_K": round(out["temperature_K"], 1)}
+        # the device-resident variant: graph built with both cutoffs + skin, kept in HBM and replayed as a hipGraph
+        # while no atom has moved more than skin / 2 -- same E/F (the envelope closes the skin shell), no rebuild on most steps
+        calc_skin = CHGNetCalculator(model, skin=0.5)
+        md2 = BerendsenNVT(li9co7o16_supercell(), calc_skin, temperature_K=1000.0, timestep_fs=2.0, task="ef")
+        md2.run(10)
+        builds0 = calc_skin.n_graph_builds
+        out2 = md2.run(args.md_steps)
+        configs["C4_md"]["with_skin_0.5A"] = {
+            "steps_per_s": round(out2["steps_per_s"], 1), "ms_per_step": round(1e3 / out2["steps_per_s"], 3),
+            "graph_builds": int(calc_skin.n_graph_builds - builds0), "temperature_K": round(out2["temperature_K"], 1),
+            "what": "CHGNetCalculator(skin=0.5): positions in -> E/F out on a resident graph, rebuilt only when an atom has moved 0.25 A"}
     # ---- C5: one fine-tuning epoch, data-parallel: Trainer step with the full CombinedLoss (E + F + S + magmom) --------
     if args.train_structures > 0:
         from chgnet_amd.trainer import TrainStep
