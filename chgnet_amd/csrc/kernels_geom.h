@@ -23,10 +23,18 @@ constexpr float INV_SQRT_PI = 0.56418958354775628f;
 constexpr float INV_SQRT_2 = 0.70710678118654752f;
 constexpr float EV_A3_TO_GPA = 160.21766208f;  // model.py:532
 
+// Sum over the 64 lanes, result in every lane, entirely in the VALU: four DPP adds inside each row of 16 lanes (quad
+// swaps, then the half-row and row mirrors, which act as lane^4 / lane^8 once the smaller groups are uniform) and the
+// two gfx950 row swaps of quad_sum across the four rows.  The ds_bpermute form (__shfl_xor) made the one-wave-per-row
+// kernels wait on the LDS crossbar six times per reduction.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+#define CHG_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+  CHG_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  CHG_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  CHG_DPP_ADD(0x141);   // row_half_mirror
+  CHG_DPP_ADD(0x140);   // row_mirror
+#undef CHG_DPP_ADD
+  return quad_sum(v);
 }
 __device__ __forceinline__ float bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));

@@ -160,24 +160,47 @@ struct GatedTArgs {
   float* angd_out;
 };
 
+// Rows are centre-major (edges) / sorted by owning bond (angles): each wave takes a CONTIGUOUS block of rows, keeps what
+// depends only on the run's key in registers (weights of the owning bond) and sends one atomic row per run instead of one
+// per row.
 __global__ __launch_bounds__(256) void k2_gated_t(GatedTArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const float g1 = p.ln[lane], b1 = p.ln[D + lane], g2 = p.ln[2 * D + lane], b2 = p.ln[3 * D + lane];
-  for (int r = wave; r < p.rows; r += nwaves) {
-    const size_t o = (size_t)r * 2 * D;
-    const GatedRow s = gated_row_fwd(p.CG[o + lane], p.CG[o + D + lane], p.CGd[o + lane], p.CGd[o + D + lane], g1, b1, g2, b2);
+  const int per = (p.rows + nwaves - 1) / nwaves;
+  const int rb = min(p.rows, wave * per), re = min(p.rows, rb + per);
+  int cur = -1;
+  float acc = 0.f, w1 = 0.f, w1d = 0.f;
+  float in[4] = {0.f, 0.f, 0.f, 0.f};   // the next row's inputs are requested before this row's results are stored
+  if (rb < re) { const size_t o = (size_t)rb * 2 * D; in[0] = p.CG[o + lane]; in[1] = p.CG[o + D + lane]; in[2] = p.CGd[o + lane]; in[3] = p.CGd[o + D + lane]; }
+  for (int r = rb; r < re; ++r) {
+    const float c0 = in[0], c1 = in[1], c2 = in[2], c3 = in[3];
+    if (r + 1 < re) { const size_t o = (size_t)(r + 1) * 2 * D; in[0] = p.CG[o + lane]; in[1] = p.CG[o + D + lane]; in[2] = p.CGd[o + lane]; in[3] = p.CGd[o + D + lane]; }
+    const GatedRow s = gated_row_fwd(c0, c1, c2, c3, g1, b1, g2, b2);
+    if (p.mode == T2_ANGLE) {
+      p.angd_out[(size_t)r * D + lane] = p.angd_in[(size_t)r * D + lane] + s.yd;
+      continue;
+    }
+    const int dst = p.i_dst[r];
+    if (dst != cur) {
+      if (cur >= 0) atomicAdd(p.aggd + (size_t)cur * D + lane, acc);
+      cur = dst;
+      acc = 0.f;
+      if (p.mode == T2_BOND) {          // i_w1 == i_dst: the owning bond's weight row
+        w1 = p.w[(size_t)dst * D + lane];
+        w1d = p.wd[(size_t)dst * D + lane];
+      }
+    }
     if (p.mode == T2_ATOM) {
       const size_t k = (size_t)p.i_w1[r] * D + lane;
-      atomicAdd(p.aggd + (size_t)p.i_dst[r] * D + lane, s.yd * p.w[k] + s.y * p.wd[k]);
-    } else if (p.mode == T2_BOND) {
-      const size_t k1 = (size_t)p.i_w1[r] * D + lane, k2 = (size_t)p.i_w2[r] * D + lane;
-      const float w1 = p.w[k1], w2 = p.w[k2];
-      atomicAdd(p.aggd + (size_t)p.i_dst[r] * D + lane, s.yd * w1 * w2 + s.y * (p.wd[k1] * w2 + w1 * p.wd[k2]));
+      acc += s.yd * p.w[k] + s.y * p.wd[k];
     } else {
-      p.angd_out[(size_t)r * D + lane] = p.angd_in[(size_t)r * D + lane] + s.yd;
+      const size_t k2 = (size_t)p.i_w2[r] * D + lane;
+      const float w2 = p.w[k2];
+      acc += s.yd * w1 * w2 + s.y * (w1d * w2 + w1 * p.wd[k2]);
     }
   }
+  if (cur >= 0) atomicAdd(p.aggd + (size_t)cur * D + lane, acc);
 }
 
 struct GatedBArgs {
@@ -196,29 +219,55 @@ __global__ __launch_bounds__(256) void k2_gated_b(GatedBArgs p) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const float g1 = p.ln[lane], b1 = p.ln[D + lane], g2 = p.ln[2 * D + lane], b2 = p.ln[3 * D + lane];
   float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = wave; r < p.rows; r += nwaves) {
+  const int per = (p.rows + nwaves - 1) / nwaves;          // contiguous rows per wave: see k2_gated_t
+  const int rb = min(p.rows, wave * per), re = min(p.rows, rb + per);
+  int cur = -1;
+  float bar_a = 0.f, g_a = 0.f;                            // adjoints of the run's aggregate row
+  float w1 = 0.f, w1d = 0.f, acc_bw = 0.f, acc_gw = 0.f;   // BOND: the owning bond's weight row and its gradient sums
+  float in[4] = {0.f, 0.f, 0.f, 0.f};                      // next row's inputs in flight over this row's work (see k2_gated_t)
+  if (rb < re) { const size_t o = (size_t)rb * 2 * D; in[0] = p.CG[o + lane]; in[1] = p.CG[o + D + lane]; in[2] = p.CGd[o + lane]; in[3] = p.CGd[o + D + lane]; }
+  for (int r = rb; r < re; ++r) {
     const size_t o = (size_t)r * 2 * D;
-    const GatedRow s = gated_row_fwd(p.CG[o + lane], p.CG[o + D + lane], p.CGd[o + lane], p.CGd[o + D + lane], g1, b1, g2, b2);
+    const float c0 = in[0], c1 = in[1], c2 = in[2], c3 = in[3];
+    if (r + 1 < re) { const size_t o1 = o + 2 * D; in[0] = p.CG[o1 + lane]; in[1] = p.CG[o1 + D + lane]; in[2] = p.CGd[o1 + lane]; in[3] = p.CGd[o1 + D + lane]; }
+    const GatedRow s = gated_row_fwd(c0, c1, c2, c3, g1, b1, g2, b2);
     float bar_y, g_y;
-    if (p.mode == T2_ATOM) {
-      const size_t c = (size_t)p.i_dst[r] * D + lane, k = (size_t)p.i_w1[r] * D + lane;
-      const float bar_m = p.bar_agg[c], g_m = p.g_agg[c], w = p.w[k], wd = p.wd[k];
-      atomicAdd(p.bar_w + k, s.y * bar_m + s.yd * g_m);
-      atomicAdd(p.g_w + k, s.y * g_m);
-      bar_y = w * bar_m + wd * g_m;
-      g_y = w * g_m;
-    } else if (p.mode == T2_BOND) {
-      const size_t c = (size_t)p.i_dst[r] * D + lane, k1 = (size_t)p.i_w1[r] * D + lane, k2 = (size_t)p.i_w2[r] * D + lane;
-      const float bar_u = p.bar_agg[c], g_u = p.g_agg[c], w1 = p.w[k1], w2 = p.w[k2], w1d = p.wd[k1], w2d = p.wd[k2];
-      atomicAdd(p.bar_w + k1, s.y * w2 * bar_u + (s.yd * w2 + s.y * w2d) * g_u);
-      atomicAdd(p.bar_w + k2, s.y * w1 * bar_u + (s.yd * w1 + s.y * w1d) * g_u);
-      atomicAdd(p.g_w + k1, s.y * w2 * g_u);
-      atomicAdd(p.g_w + k2, s.y * w1 * g_u);
-      bar_y = w1 * w2 * bar_u + (w1d * w2 + w1 * w2d) * g_u;
-      g_y = w1 * w2 * g_u;
-    } else {
+    if (p.mode == T2_ANGLE) {
       bar_y = p.bar_agg[(size_t)r * D + lane];
       g_y = p.g_agg[(size_t)r * D + lane];
+    } else {
+      const int dst = p.i_dst[r];
+      if (dst != cur) {
+        if (p.mode == T2_BOND && cur >= 0) {
+          atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+          atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
+        }
+        cur = dst;
+        bar_a = p.bar_agg[(size_t)dst * D + lane];
+        g_a = p.g_agg[(size_t)dst * D + lane];
+        if (p.mode == T2_BOND) {        // i_w1 == i_dst
+          w1 = p.w[(size_t)dst * D + lane];
+          w1d = p.wd[(size_t)dst * D + lane];
+          acc_bw = acc_gw = 0.f;
+        }
+      }
+      if (p.mode == T2_ATOM) {
+        const size_t k = (size_t)p.i_w1[r] * D + lane;
+        const float w = p.w[k], wd = p.wd[k];
+        atomicAdd(p.bar_w + k, s.y * bar_a + s.yd * g_a);
+        atomicAdd(p.g_w + k, s.y * g_a);
+        bar_y = w * bar_a + wd * g_a;
+        g_y = w * g_a;
+      } else {
+        const size_t k2 = (size_t)p.i_w2[r] * D + lane;
+        const float w2 = p.w[k2], w2d = p.wd[k2];
+        acc_bw += s.y * w2 * bar_a + (s.yd * w2 + s.y * w2d) * g_a;
+        acc_gw += s.y * w2 * g_a;
+        atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
+        atomicAdd(p.g_w + k2, s.y * w1 * g_a);
+        bar_y = w1 * w2 * bar_a + (w1d * w2 + w1 * w2d) * g_a;
+        g_y = w1 * w2 * g_a;
+      }
     }
     float bar_c, bar_g, g_c, g_g;
     gated_row_bwd(s, bar_y, g_y, g1, g2, lnacc, bar_c, bar_g, g_c, g_g);
@@ -226,6 +275,10 @@ __global__ __launch_bounds__(256) void k2_gated_b(GatedBArgs p) {
     p.BCG[o + D + lane] = bar_g;
     p.GCG[o + lane] = g_c;
     p.GCG[o + D + lane] = g_g;
+  }
+  if (p.mode == T2_BOND && cur >= 0) {
+    atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+    atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, lnacc[q]);
