@@ -1444,7 +1444,7 @@ struct TmpPool {   // scratch device memory of one chg_batch_build call: bump al
 
 int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
   if (n <= 0) return CHG_OK;
-  if (n <= (1 << 18)) {   // one workgroup, one launch (a device-wide scan is three)
+  if (n <= (1 << 16)) {   // one workgroup, one launch (a device-wide scan is three); beyond this the strided chunks get slow
     hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, in, out, n);
     return CHG_OK;
   }
