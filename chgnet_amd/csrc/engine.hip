@@ -390,7 +390,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), eng->stream, a);
+    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -420,7 +420,7 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
 template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
-  const size_t lds = angle_lds<HIDDEN, NW>();
+  const size_t lds = angle_lds<HIDDEN, NW, BWD>();
   hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, tile_grid_mult() * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, a);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
@@ -839,7 +839,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       a.e_center = b->p_center; a.e_nbr = b->p_nbr;
       a.dumpG = b->t_dumpG; a.dumpH = b->t_dumpH; a.g_ln = G(aw.g.ln1_g);
       LaunchScope ls(eng, "atomconv_bwd_train");
-      hipLaunchKernelGGL(k_atomconv_bwd<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), atomconv_lds<WAVES>(), st, a);
+      hipLaunchKernelGGL(k_atomconv_bwd<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), st, a);
       HIP_TRY(eng, hipGetLastError());
     }
     TRY(gated_tail_grads(eng, b, aw.g, Ed, grad_of));
@@ -882,7 +882,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
         {
           LaunchScope ls(eng, "angleupd_bwd_train");
           hipLaunchKernelGGL((k_angle<false, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
-                             angle_lds<false>(), st, a);
+                             (angle_lds<false, WAVES, true>()), st, a);
           HIP_TRY(eng, hipGetLastError());
         }
         TRY(angle_tables_train(L + l, b->hbc[l + 1], b->atom[l + 1], b->ang[l], b->t_dumpG, uw.w_bij, uw.w_ctr, uw.b1, uw.w_ang, uw.w_bij_t,
@@ -897,7 +897,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       {
         LaunchScope ls(eng, "bondconv_bwd_train");
         hipLaunchKernelGGL((k_angle<true, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
-                           angle_lds<true>(), st, a);
+                           (angle_lds<true, WAVES, true>()), st, a);
         HIP_TRY(eng, hipGetLastError());
       }
       TRY(gated_tail_grads(eng, b, bw.g, A, grad_of));
@@ -1925,10 +1925,10 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, atomconv_lds<FWD_WAVES>()))) return s;
-  if ((s = set_lds(eng, k_atomconv_bwd<false>, atomconv_lds<WAVES>()))) return s;
-  if ((s = set_lds(eng, k_atomconv_bwd<true>, atomconv_lds<WAVES>()))) return s;
-  if ((s = set_lds(eng, (k_angle<true, true, WAVES, true>), angle_lds<true>()))) return s;
-  if ((s = set_lds(eng, (k_angle<false, true, WAVES, true>), angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd<true>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, (k_angle<true, true, WAVES, true>), (angle_lds<true, WAVES, true>())))) return s;
+  if ((s = set_lds(eng, (k_angle<false, true, WAVES, true>), (angle_lds<false, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_readout<true>, readout_lds()))) return s;
   if ((s = set_lds(eng, (k_bond_embed_t<true, true>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, (k_angle_embed_t<true, true>), angle_embed_lds()))) return s;
@@ -1937,8 +1937,8 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
   if ((s = set_lds(eng, k2_scatter_z, scatter_z_lds()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
-  if ((s = set_lds(eng, k_angle<true, true>, angle_lds<true>()))) return s;
-  if ((s = set_lds(eng, k_angle<false, true>, angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_angle<false, true>, (angle_lds<false, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
   if ((s = set_lds(eng, k_readout<false>, readout_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;

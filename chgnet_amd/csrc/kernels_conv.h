@@ -15,6 +15,7 @@
 #pragma once
 
 #include "mfma_tile.h"
+#include "mfma_split.h"
 
 namespace chg {
 
@@ -22,6 +23,11 @@ constexpr int TS = 2 * D + PAD;  // LDS tile row stride (floats) for 128-wide ro
 constexpr int WS = D + PAD;      // LDS weight row stride for K = 64
 constexpr int TILE_FLOATS = TILE_ROWS * TS;
 constexpr int VEC_SLOTS = 6;     // b2c b2g ln1_g ln1_b ln2_g ln2_b
+// Split-precision weight images (mfma_split.h), in 16-byte chunks: a 64x64 matrix is 1,024 chunks (16 KiB, both planes),
+// the 128x64 angle block 2,048 (its transposed image as well).  The BondConv adjoint is the one tile kernel that keeps
+// the f32 matrix form: its four images (128 KiB) do not fit next to the wave tiles.
+constexpr int IMG64 = 1024, IMG128 = 2048;
+constexpr bool angle_split(bool hidden, bool bwd) { return !(hidden && bwd); }
 
 struct GatedW {            // global pointers into the weight blob
   const float *w2c, *b2c, *w2g, *b2g, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -68,7 +74,8 @@ struct TrainTile {
   float ln[4];     // running column sums (column = lane): d ln1_g, d ln1_b, d ln2_g, d ln2_b
 };
 
-template <bool HIDDEN, bool SLIM = false, bool TRAIN = false>
+// SPLIT: W2c / W2g are split-precision images (mfma_split.h) instead of padded f32 rows
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, bool SPLIT = false>
 __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c, const float* W2g, const float* vecs,
                                               int j, int g, GatedState& s, V64& y, TrainTile* tt = nullptr) {
   if (HIDDEN) {
@@ -86,8 +93,13 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
     }
     s.xh1 = param64(vecs + 0 * D, g);
     s.xh2 = param64(vecs + 1 * D, g);
-    gemm_dl<VT, VT>(s.xh1.t, W2c, WS, hc.t, j, g);
-    gemm_dl<VT, VT>(s.xh2.t, W2g, WS, hg.t, j, g);
+    if (SPLIT) {
+      gemm_split<VT, VT, false>(s.xh1.t, reinterpret_cast<const h16x8*>(W2c), D, hc.t, j, g);
+      gemm_split<VT, VT, false>(s.xh2.t, reinterpret_cast<const h16x8*>(W2g), D, hg.t, j, g);
+    } else {
+      gemm_dl<VT, VT>(s.xh1.t, W2c, WS, hc.t, j, g);
+      gemm_dl<VT, VT>(s.xh2.t, W2g, WS, hg.t, j, g);
+    }
   } else {
     s.xh1 = zc;
     s.xh2 = zg;
@@ -126,7 +138,8 @@ __device__ __forceinline__ void tile_colsum2(TrainTile* tt, int j, int g, const 
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool HIDDEN, bool SLIM = false, bool TRAIN = false>
+// SPLIT: W2c / W2g are the split-precision images of W2c^T / W2g^T
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, bool SPLIT = false>
 __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, const V64& dzg, const float* W2c, const float* W2g,
                                                const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg,
                                                TrainTile* tt = nullptr) {
@@ -157,8 +170,13 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
   if (HIDDEN) {
     gzc = zero64();
     gzg = zero64();
-    gemm_dl_t<VT, VT>(gzc.t, W2c, WS, gn1.t, j, g);
-    gemm_dl_t<VT, VT>(gzg.t, W2g, WS, gn2.t, j, g);
+    if (SPLIT) {
+      gemm_split<VT, VT, true>(gzc.t, reinterpret_cast<const h16x8*>(W2c), D, gn1.t, j, g);
+      gemm_split<VT, VT, true>(gzg.t, reinterpret_cast<const h16x8*>(W2g), D, gn2.t, j, g);
+    } else {
+      gemm_dl_t<VT, VT>(gzc.t, W2c, WS, gn1.t, j, g);
+      gemm_dl_t<VT, VT>(gzg.t, W2g, WS, gn2.t, j, g);
+    }
     CHG_EW(ft, r) {
       gzc.t[ft][r] *= dzc.t[ft][r];
       gzg.t[ft][r] *= dzg.t[ft][r];
@@ -371,20 +389,23 @@ struct AtomConvArgs {
   float* g_ln;         // [4][64] gradient of ln1_g, ln1_b, ln2_g, ln2_b (accumulated with atomics)
 };
 
-template <int NW = WAVES>
-constexpr size_t atomconv_lds() { return sizeof(float) * (2 * D * WS + VEC_SLOTS * D + NW * TILE_FLOATS); }
+// LDS: split images of W2c, W2g (the adjoint: and of their transposes), the gated-MLP vectors, one tile per wave
+template <int NW = WAVES, bool BWD = false>
+constexpr size_t atomconv_lds() { return 16 * (size_t)(BWD ? 4 : 2) * IMG64 + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS); }
 
 // NW waves per workgroup: the forward kernel needs only ~106 VGPRs, so 12 waves (3 per SIMD) fit
 template <int NW>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W2c = smem;
-  float* W2g = W2c + D * WS;
-  float* vecs = W2g + D * WS;
+  h16x8* I2c = reinterpret_cast<h16x8*>(smem);
+  h16x8* I2g = I2c + IMG64;
+  float* vecs = reinterpret_cast<float*>(I2g + IMG64);
   float* tiles = vecs + VEC_SLOTS * D;
+  const float* W2c = reinterpret_cast<const float*>(I2c);
+  const float* W2g = reinterpret_cast<const float*>(I2g);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_weights(W2c, p.gw.w2c, D, D, tid);
-  stage_weights(W2g, p.gw.w2g, D, D, tid);
+  stage_split<false>(I2c, p.gw.w2c, D, D, tid, 64 * NW);
+  stage_split<false>(I2g, p.gw.w2g, D, D, tid, 64 * NW);
   stage_gated_vecs(vecs, p.gw, true, tid);
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
     V64 y;
-    gated_forward<true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    gated_forward<true, false, false, true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 m;
     CHG_EW(ft, r) m.t[ft][r] = y.t[ft][r] * wv.t[ft][r];
@@ -514,14 +535,22 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
 template <bool TRAIN>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W2c = smem;
-  float* W2g = W2c + D * WS;
-  float* vecs = W2g + D * WS;
+  h16x8* I2c = reinterpret_cast<h16x8*>(smem);
+  h16x8* I2g = I2c + IMG64;
+  h16x8* I2cT = I2g + IMG64;
+  h16x8* I2gT = I2cT + IMG64;
+  float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
   float* tiles = vecs + VEC_SLOTS * D;
+  const float* W2c = reinterpret_cast<const float*>(I2c);
+  const float* W2g = reinterpret_cast<const float*>(I2g);
+  const float* W2cT = reinterpret_cast<const float*>(I2cT);
+  const float* W2gT = reinterpret_cast<const float*>(I2gT);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  stage_weights(W2c, p.gw.w2c, D, D, tid);
-  stage_weights(W2g, p.gw.w2g, D, D, tid);
+  stage_split<false>(I2c, p.gw.w2c, D, D, tid, BLOCK);
+  stage_split<false>(I2g, p.gw.w2g, D, D, tid, BLOCK);
+  stage_split<true>(I2cT, p.gw.w2c, D, D, tid, BLOCK);
+  stage_split<true>(I2gT, p.gw.w2g, D, D, tid, BLOCK);
   stage_gated_vecs(vecs, p.gw, true, tid);
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
@@ -569,7 +598,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
     V64 y;
-    gated_forward<true, false, TRAIN>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
+    gated_forward<true, false, TRAIN, true>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
     CHG_EW(ft, r) {
@@ -592,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
           if (b < nb) dst[(size_t)b * D] = prev[b];
       }
     }
-    gated_backward<true, false, TRAIN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg, &tt);
+    gated_backward<true, false, TRAIN, true>(gy, zc, zg, W2cT, W2gT, vecs, j, g, s, gzc, gzg, &tt);
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
@@ -640,9 +669,10 @@ struct AngleArgs {
   float* g_ln;         // [4][64] gradient of ln1_g, ln1_b, ln2_g, ln2_b
 };
 
-template <bool HIDDEN, int NW = WAVES>
+template <bool HIDDEN, int NW = WAVES, bool BWD = false>
 constexpr size_t angle_lds() {
-  return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + NW * TILE_FLOATS);
+  if (!angle_split(HIDDEN, BWD)) return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + NW * TILE_FLOATS);
+  return 16 * (size_t)((BWD ? 2 : 1) * IMG128 + (HIDDEN ? 2 * IMG64 : 0)) + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
 }
 
 // Phase timing (diagnostic builds, -DCHG_PHASE_TIMING): s_memtime deltas between the phases of a tile,
@@ -664,16 +694,28 @@ template <bool HIDDEN, bool BWD, int NW = WAVES, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wang = smem;                                  // [128][WS]
-  float* W2c = Wang + 2 * D * WS;
-  float* W2g = W2c + (HIDDEN ? D * WS : 0);
-  float* vecs = W2g + (HIDDEN ? D * WS : 0);
+  constexpr bool SPLIT = angle_split(HIDDEN, BWD);
+  // f32 form: Wang [128][WS], W2c, W2g [64][WS].  Split form: images of Wang (and, adjoint, of Wang^T), W2c, W2g.
+  float* Wang = smem;
+  float* WangT = SPLIT ? Wang + 4 * IMG128 : Wang;     // 4 floats per 16-byte chunk
+  float* W2c = SPLIT ? WangT + (BWD ? 4 * IMG128 : 0) : Wang + 2 * D * WS;
+  float* W2g = W2c + (HIDDEN ? (SPLIT ? 4 * IMG64 : D * WS) : 0);
+  float* vecs = W2g + (HIDDEN ? (SPLIT ? 4 * IMG64 : D * WS) : 0);
   float* tiles = vecs + VEC_SLOTS * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_weights(Wang, p.w_ang, 2 * D, D, tid);
-  if (HIDDEN) {
-    stage_weights(W2c, p.gw.w2c, D, D, tid);
-    stage_weights(W2g, p.gw.w2g, D, D, tid);
+  if (SPLIT) {
+    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
+    if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, 64 * NW);
+    if (HIDDEN) {
+      stage_split<false>(reinterpret_cast<h16x8*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
+      stage_split<false>(reinterpret_cast<h16x8*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
+    }
+  } else {
+    stage_weights(Wang, p.w_ang, 2 * D, D, tid);
+    if (HIDDEN) {
+      stage_weights(W2c, p.gw.w2c, D, D, tid);
+      stage_weights(W2g, p.gw.w2g, D, D, tid);
+    }
   }
   stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   __syncthreads();
@@ -757,7 +799,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     PH(1)   // table gather
     Rows64 gy_rows;
     if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
-    gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+    if (SPLIT) gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
+    else gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
     if (BWD && !HIDDEN) {
       __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
@@ -767,7 +810,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     GatedState s;
     V64 y;
     constexpr bool SLIM = HIDDEN && BWD;   // the BondConv adjoint is the one kernel that spills otherwise (3.41 -> 3.36 ms)
-    gated_forward<HIDDEN, SLIM, TRAIN>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
+    gated_forward<HIDDEN, SLIM, TRAIN, SPLIT>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     __builtin_amdgcn_wave_barrier();
     PH(3)   // gated forward
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
@@ -807,7 +850,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
       PH(4)   // weight rows / Gang rows, dE/dy, (BondConv) Gwbgc scatter
-      gated_backward<HIDDEN, SLIM, TRAIN>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg, &tt);
+      gated_backward<HIDDEN, SLIM, TRAIN, SPLIT>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg, &tt);
       PH(5)   // gated backward
       // dE/d(angle in) += W_ang^T gz   (the residual identity is already in Gang)
       f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
@@ -832,7 +875,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         PH(6)   // W_ang^T contraction
         scatter_rows64_add(T, TS, p.Gang, a, nvalid, lane, gang_old);
       } else {
-        gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
+        if (SPLIT) gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
+        else gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         PH(6)   // W_ang^T contraction

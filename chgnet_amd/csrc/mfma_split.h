@@ -1,0 +1,184 @@
+// mfma_split.h -- fp32-accurate 64-wide contractions on the f16 matrix pipe (gfx950).
+//
+// v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (32 cycles per 2,048 flop per SIMD); the six
+// message-passing kernels spend 16k of a tile's 30k cycles in it (profiles/r02_experiments.md: a four
+// times faster matrix pipe is +24 % on the step, +80 % once the adjoints' atomics are out of the way).
+// v_mfma_f32_16x16x32_f16 does 16,384 flop in 16 cycles, so three of them on split operands
+//
+//     x = xh + xl,  w = wh + wl      (xh = f16(x) round-to-nearest, xl = f16(x - xh): 22 significand bits)
+//     x.w ~= xh.wh + xl.wh + xh.wl   (the dropped xl.wl term is 2^-22 relative), f32 accumulation
+//
+// cost 3 x 2 x 16 = 96 cycles per 16x16x64 block against 512 for the f32 form: 5.3x less matrix-pipe
+// time at a per-product error of ~2^-22 (f32: 2^-24).  Measured on the float64 pipeline model
+// (tests/test_split_numerics.py): the split contractions add 2e-8 eV/atom, 1.5e-6 eV/A, 1.2e-5 GPa at
+// trained-checkpoint magnitudes -- a tenth of the f32 pipeline's own rounding error (1.4e-5 eV/A).
+//
+// f16 range: forward operands (activations O(1), weights) are used as they are; the adjoint operands
+// (gradient rows, 1e-3 .. 1e-7) are scaled per row by a power of two first (exact), else their low
+// halves fall into the f16 subnormals (measured: 10x the error).  The low planes of both operands are
+// carried scaled by 2^LO_SHIFT in their own accumulator so that they stay normal numbers whatever
+// the matrix pipe does with f16 subnormals.
+//
+// Layouts.  Rows keep the accumulator ("D") layout of mfma_tile.h: lane = j + 16 g holds features
+// 16 ft + 4 g + r of row j.  One K = 32 MFMA takes from lane (j, g) the 8 values
+//     k(mk, g, e) = 32 mk + 16 (e >> 2) + 4 g + (e & 3),   e = 0..7
+// i.e. exactly this lane's registers of feature tiles 2 mk and 2 mk + 1: chained layers still never
+// leave registers.  The hardware pairs element e of lane group g of A with the same (g, e) of B, so any
+// such enumeration of k is a valid contraction order as long as the weights are stored to match:
+//     LDS image  [plane hi|lo][mk][g][f][8 x f16]     (16-byte chunk per (mk, g, f))
+// A operand of output tile fo for lane (i, g): chunk ((plane * MK + mk) * 4 + g) * F + 16 fo + i --
+// one ds_read_b128, conflict-free (the 16 lanes of every b128 group hold 16 different i, and the g
+// stride F * 16 B is a multiple of the 256-B bank row).  The adjoint contractions (sum over the OUTPUT
+// index of W) use a second image built from W^T.
+#pragma once
+
+#include "mfma_tile.h"
+
+namespace chg {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef CHG_SPLIT_LO_SEPARATE
+#define CHG_SPLIT_LO_SEPARATE 0
+#endif
+constexpr bool LO_SEPARATE = CHG_SPLIT_LO_SEPARATE;   // low planes scaled by 2^11 in their own accumulator (see above)
+constexpr float LO_SCALE = LO_SEPARATE ? 2048.0f : 1.0f, LO_UNSCALE = 1.0f / LO_SCALE;
+
+// bytes of one split image of a [F][K] matrix (both planes)
+constexpr size_t split_image_bytes(int F, int K) { return (size_t)F * K * 4; }
+
+// ---- staging: global fp32 W[F][K] (row-major, ld = ldw) -> LDS split image ------------------------
+// TRANSPOSE: the image of W^T, i.e. the contraction then runs over the rows of W (F_img = K, K_img = F).
+template <bool TRANSPOSE>
+__device__ __forceinline__ void stage_split(h16x8* img, const float* __restrict__ W, int F, int K, int tid, int nthreads) {
+  const int Fi = TRANSPOSE ? K : F, Ki = TRANSPOSE ? F : K;      // image dims: Fi outputs, Ki contraction
+  const int MK = Ki / 32;
+  const int nchunks = MK * 4 * Fi;
+  for (int c = tid; c < nchunks; c += nthreads) {
+    const int f = c % Fi, g = (c / Fi) & 3, mk = c / (4 * Fi);
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * mk + 16 * (e >> 2) + 4 * g + (e & 3);
+      w[e] = TRANSPOSE ? W[(size_t)k * K + f] : W[(size_t)f * K + k];
+    }
+    h16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      hi[e] = (_Float16)w[e];
+      lo[e] = (_Float16)((w[e] - (float)hi[e]) * LO_SCALE);
+    }
+    img[c] = hi;
+    img[nchunks + c] = lo;
+  }
+}
+
+// ---- operand split of 32 contraction values held by this lane (feature tiles 2 mk, 2 mk + 1) -------
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h16x8& hi, h16x8& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * LO_SCALE);
+}
+
+// max over the four lanes that share a tile row (cf. quad_sum)
+__device__ __forceinline__ float quad_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const unsigned w = __float_as_uint(s);
+  const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
+// power-of-two row scale that brings the largest |x| of the row into [1, 2): returns the exponent e with
+// max|x| in [2^e, 2^(e+1)); rows of zeros (and non-finite rows) get e = 0
+template <int KT>
+__device__ __forceinline__ int row_exponent(const f32x4 (&x)[KT]) {
+  float m = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) m = fmaxf(fmaxf(m, fmaxf(fabsf(x[kt][0]), fabsf(x[kt][1]))), fmaxf(fabsf(x[kt][2]), fabsf(x[kt][3])));
+  m = quad_max(m);
+  const int e = __builtin_amdgcn_frexp_expf(m) - 1;          // m = f * 2^(e+1), f in [0.5, 1)
+  return (m > 0.f && m < 3.0e38f) ? e : 0;
+}
+
+// ---- the contraction ------------------------------------------------------------------------------
+// acc[fo] += sum_k W[16 fo + i][k] x[k],  k over the 16 KT values this row holds in D layout.
+// img: split image with F outputs (as staged above).  SCALED: x is an adjoint row -- scaled per row by a
+// power of two before the split, the product scaled back.  Output tiles are produced four at a time so
+// that the operands of one K = 32 step (4 x (hi, lo) weights = 32 registers) and the accumulators stay small.
+template <int MK>
+struct SplitRow { h16x8 hi[MK], lo[MK]; int ex; };
+
+template <int KT, bool SCALED>
+__device__ __forceinline__ void split_row(SplitRow<KT / 2>& s, const f32x4 (&x)[KT]) {
+  static_assert(KT % 2 == 0, "K must be a multiple of 32");
+  s.ex = 0;
+  if (SCALED) s.ex = row_exponent<KT>(x);
+#pragma unroll
+  for (int mk = 0; mk < KT / 2; ++mk) {
+    f32x4 a = x[2 * mk], b = x[2 * mk + 1];
+    if (SCALED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = __builtin_ldexpf(a[r], -s.ex); b[r] = __builtin_ldexpf(b[r], -s.ex); }
+    }
+    split8(a, b, s.hi[mk], s.lo[mk]);
+  }
+}
+
+// four output tiles fo0 .. fo0+3 from an already split row
+template <int MK, bool SCALED>
+__device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int fo0, int i, int g) {
+  const int nchunks = MK * 4 * F;
+  f32x4 hi_acc[4], lo_acc[LO_SEPARATE ? 4 : 1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hi_acc[q] = (SCALED || LO_SEPARATE) ? zero4() : acc[q];
+  if (LO_SEPARATE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = zero4();
+  }
+#pragma unroll
+  for (int mk = 0; mk < MK; ++mk) {
+    const h16x8* base = img + (mk * 4 + g) * F + 16 * fo0 + i;
+    h16x8 wh[4], wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], hi_acc[q], 0, 0, 0);
+    if (LO_SEPARATE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], lo_acc[LO_SEPARATE ? q : 0], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], lo_acc[LO_SEPARATE ? q : 0], 0, 0, 0);
+    } else {   // the matrix pipe keeps f16 subnormals (tools/split_lab.hip T2): one accumulator for all three products
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], hi_acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], hi_acc[q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = hi_acc[q][r];
+      if (LO_SEPARATE) v += LO_UNSCALE * lo_acc[LO_SEPARATE ? q : 0][r];
+      if (SCALED) v = __builtin_ldexpf(v, s.ex);
+      if (SCALED || LO_SEPARATE) acc[q][r] += v;
+      else acc[q][r] = v;
+    }
+}
+
+template <int KT, int NFT, bool SCALED>
+__device__ __forceinline__ void gemm_split(f32x4 (&acc)[NFT], const h16x8* img, int F, const f32x4 (&x)[KT], int i, int g) {
+  static_assert(NFT % 4 == 0, "output width must be a multiple of 64");
+  SplitRow<KT / 2> s;
+  split_row<KT, SCALED>(s, x);
+#pragma unroll
+  for (int fo0 = 0; fo0 < NFT; fo0 += 4) gemm_split4<KT / 2, SCALED>(acc + fo0, img, F, s, fo0, i, g);
+}
+
+}  // namespace chg
