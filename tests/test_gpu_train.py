@@ -302,6 +302,45 @@ def test_force_and_stress_loss_gradients_vs_double_backward(hip_engine, golden_w
     assert not msgs, "; ".join(msgs)
 
 
+@pytest.mark.parametrize("fname,which", [("grad_five_seed0.npz", "seed0"), ("grad_five_trained_like.npz", "trained_like"),
+                                         ("grad_mixed_seed0.npz", "seed0")])
+def test_loss_gradients_vs_the_reference_backward_fixtures(hip_engine, golden_weights, trained_like_weights, fname, which):
+    """The same loss against gradients the UNMODIFIED reference produced with loss.backward() in train mode
+    (tests/golden/make_grad_golden.py; model.py:517-535, trainer.py:399-411): reference-held numbers, fp32 on the CPU.
+    Tolerance: the fixture itself is fp32 (its distance to the float64 oracle is up to 2e-5 relative), so 3e-4 + that."""
+    import os
+
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.model import CHGNet
+    from chgnet_amd.pack import pack_weights
+    from conftest import GOLDEN
+
+    d = np.load(os.path.join(GOLDEN, fname))
+    want = {k[len("grad/"):]: d[k] for k in d.files if k.startswith("grad/")}
+    weights = golden_weights if which == "seed0" else trained_like_weights
+    eng = hip_engine if which == "seed0" else Engine(pack_weights(weights), 0)
+    graphs = [load_case(str(n))[0] for n in d["order"]]
+    model = CHGNet(state_dict=weights)
+    model._engine = eng
+    try:
+        model.forward(graphs, task="efsm")
+        got = model.backward(d["cot_e"], d["cot_m"], d["cot_f"], d["cot_s"])
+    finally:
+        model.release_forward_state()
+        model._engine = None
+        if which != "seed0":
+            eng.close()
+    msgs = []
+    for k, ref in want.items():
+        if k.startswith(("angle_layers.2.", "composition_model", "site_wise")) and not np.any(ref):
+            assert not np.any(got[k]), k
+            continue
+        scale, err = float(np.abs(ref).max()), float(np.abs(got[k] - ref).max())
+        if not np.isfinite(got[k]).all() or not err <= 3.2e-4 * scale:
+            msgs.append(f"{k}: {err:.3e} / {scale:.3e} = {err / max(scale, 1e-300):.1e}")
+    assert not msgs, "; ".join(msgs)
+
+
 def test_train_step_with_force_and_stress_terms(golden_weights):
     """All four terms of CombinedLoss through the device: energy, force, stress, magmom labels a small coherent shift away
     from the current predictions; Adam steps bring the loss down and the engine runs on the updated weights."""

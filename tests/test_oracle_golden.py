@@ -118,3 +118,40 @@ def test_oracle_matches_live_reference_on_fresh_input(golden_weights):
     out = OracleCHGNet(golden_weights).predict_graph(g, "efsm", return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
     for key in ref:
         assert np.abs(out[key] - ref[key]).max() <= 5 * TOL[key], key
+
+
+# ---- gradient goldens: the reference's OWN loss.backward() (tests/golden/make_grad_golden.py) ----------------
+GRAD_FIXTURES = [("grad_five_seed0.npz", "seed0"), ("grad_five_trained_like.npz", "trained_like"), ("grad_mixed_seed0.npz", "seed0")]
+GRAD_REL_TOL = 1e-4      # fp32 reference backward vs the float64 oracle (measured: <= 2e-5)
+
+
+def load_grad_fixture(fname):
+    d = np.load(os.path.join(GOLDEN, fname))
+    grads = {k[len("grad/"):]: d[k] for k in d.files if k.startswith("grad/")}
+    return [str(n) for n in d["order"]], (d["cot_e"], d["cot_m"], d["cot_f"], d["cot_s"]), grads
+
+
+@pytest.mark.parametrize("fname,wset", GRAD_FIXTURES)
+def test_oracle_parameter_gradients_match_the_reference_backward(fname, wset, golden_weights, trained_like_weights):
+    """SURVEY 8f-3 pin: d(sum ce e + sum gm m + sum gF.f + sum gS:s)/d(every parameter) from torch autograd through the
+    RESTATEMENT equals what the unmodified reference produced with loss.backward() in train mode
+    (model.py:517-535 create_graph=True, trainer.py:399-411) -- so the GPU gradient tests, which check the engine
+    against the oracle, are anchored to reference-produced numbers."""
+    names, (ce, gm, gf, gs), want = load_grad_fixture(fname)
+    weights = golden_weights if wset == "seed0" else trained_like_weights
+    graphs = [load_case(n)[0] for n in names]
+    torch.set_num_threads(4)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    got = OracleCHGNet(weights, dtype=torch.float64).parameter_gradients(
+        graphs, lambda o: (o["e"] * t(ce)).sum() + (o["m"] * t(gm)).sum() + (o["f"] * t(gf)).sum() + (o["s"] * t(gs)).sum(), task="efsm")
+    assert set(got) == set(want) and len(want) == 136
+    worst = {}
+    for k, ref in want.items():
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got[k] - ref).max())
+        if scale == 0.0:
+            assert err == 0.0, k      # dead parameters (third AngleUpdate, frozen AtomRef) are exact zeros on both sides
+            continue
+        worst[k] = err / scale
+    bad = {k: v for k, v in worst.items() if v > GRAD_REL_TOL}
+    assert not bad, f"{fname}: " + "; ".join(f"{k} {v:.1e}" for k, v in sorted(bad.items(), key=lambda kv: -kv[1])[:8])
