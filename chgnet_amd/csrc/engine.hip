@@ -24,13 +24,13 @@
 #include <vector>
 
 #include "kernels_conv.h"
+#include "kernels_angle_w.h"
 #include "kernels_embed.h"
 #include "kernels_geom.h"
 #include "kernels_graph.h"
 #include "kernels_train.h"
 #include "kernels_train2.h"
 
-#include <hipcub/hipcub.hpp>
 
 using namespace chg;
 
@@ -124,6 +124,9 @@ struct chg_batch {
   // reverse sweep
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GQ, *Gagg, *Grk, *Gu;
   float* phase = nullptr;   // CHG_PHASE_TIMING builds: per-phase shader-clock totals of the angle kernels
+  WinIndex win{};           // centre-major row order + window slots of the angle adjoints (kernels_angle_w.h), built by prepare_windows
+  int *win_tmp = nullptr, *win_scan = nullptr, *win_wave_atom = nullptr;
+  int win_grid = 1;         // workgroups of the per-atom adjoints (fixed when the index is built)
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
   // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
@@ -336,6 +339,24 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     if (_s != CHG_OK) return _s; \
   } while (0)
 
+// scratch ints exclusive_scan_with needs for n elements
+inline size_t scan_scratch_ints(int n) { return n <= (1 << 16) ? 1 : 2 * ((size_t)n / SCAN_CHUNK + 2); }
+
+int exclusive_scan_with(chg_engine* eng, int* scratch, const int* in, int* out, int n) {
+  if (n <= 0) return CHG_OK;
+  if (n <= (1 << 16)) {   // one workgroup, one launch; beyond this the strided chunks of k_small_scan get slow
+    hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, in, out, n);
+    return CHG_OK;
+  }
+  const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;          // <= 2^18 for n < 2^31
+  int *totals = scratch, *offs = scratch + nchunks + 1;
+  hipLaunchKernelGGL(k_scan_totals, dim3(nchunks), dim3(1024), 0, eng->stream, in, totals, n);
+  TRY(exclusive_scan_with(eng, nullptr, totals, offs, nchunks));   // nchunks <= 65536 up to n = 5e8: one level is enough
+  hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, eng->stream, in, out, offs, n);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
 inline dim3 g1(int64_t n, int b = 256) { return dim3((unsigned)std::max<int64_t>(1, (n + b - 1) / b)); }
 inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4 waves per block, grid-stride
   return (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 16 * (int64_t)eng->num_cus));
@@ -414,14 +435,34 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   a.w_ang = w_ang; a.gw = g; a.out = out;
   a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
   a.first_gang = slot == b->L - 2;   // slot l < L is BondConv l; the sweep's first angle kernel is BondConv L-2
+  a.skip_flag = b->win.flag;
   return a;
+}
+
+// Which adjoints run per atom (kernels_angle_w.h).  AngleUpdate: 2.23 -> 1.60 ms.  BondConv: its f32 weights leave no LDS for
+// private rows of the bond-weight gradients and it stays bound by the f32 matrix pipe either way (3.99 vs 3.48 ms): plain kernel.
+// CHGNET_PER_ATOM_BONDCONV=1 switches it on for A/B timing.
+static bool per_atom_adjoint(bool hidden) {
+  static const bool bc = [] { const char* e = std::getenv("CHGNET_PER_ATOM_BONDCONV"); return e && std::atoi(e) != 0; }();
+  return !hidden || bc;
 }
 
 template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
+  AngleArgs plain = a;
+  if (BWD && per_atom_adjoint(HIDDEN)) {
+    // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the plain one: both are
+    // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
+    AngleWArgs w{};
+    w.a = a; w.w = b->win; w.wave_atom = b->win_wave_atom;
+    hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
+    HIP_TRY(eng, hipGetLastError());
+  } else {
+    plain.skip_flag = nullptr;
+  }
   const size_t lds = angle_lds<HIDDEN, NW, BWD>();
-  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, tile_grid_mult() * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, a);
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, tile_grid_mult() * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
@@ -635,8 +676,42 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->Gagg = c.take<float>(Eb * D);
   b->Grk = c.take<float>(Eu);
   b->phase = c.take<float>(64);
+  {   // windowed angle adjoints (kernels_angle_w.h)
+    WinIndex& w = b->win;
+    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1);
+    w.head = c.take<int>(Ed); w.rank = c.take<int>(Ed); w.list = c.take<int>(A ? N * WIN_LIST : 0);
+    w.q_a = c.take<int>(A); w.q_ctr = c.take<int>(A); w.q_b1c = c.take<int>(A); w.q_b2c = c.take<int>(A); w.q_ab1 = c.take<int>(A); w.q_ab2 = c.take<int>(A);
+    w.abbond = c.take<int>(2 * Eb);
+    b->win_tmp = c.take<int>(N + 1);
+    b->win_scan = c.take<int>(scan_scratch_ints((int)N + 1));
+    b->win_wave_atom = c.take<int>(A ? WIN_MAX_WAVES + 1 : 0);
+  }
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
   total = (c.pos + 255) & ~size_t(255);
+}
+
+// Centre-major row order and (atom, bond) pair indices of the angle adjoints (kernels_angle_w.h): once per batch topology,
+// stream-ordered, no host round trip; a graph without the canonical structure leaves win.flag[0] = 0.
+int prepare_windows(chg_engine* eng, chg_batch* b) {
+  hipStream_t st = eng->stream;
+  WinIndex& w = b->win;
+  HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
+  if (b->A == 0) return CHG_OK;
+  if ((size_t)b->N / SCAN_CHUNK + 1 > (1u << 16)) return CHG_OK;      // beyond the two-level scan: plain adjoints
+  HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+  HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w);
+  hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
+  TRY(exclusive_scan_with(eng, b->win_scan, w.na, w.boff, b->N + 1));
+  hipLaunchKernelGGL(k_win_counts, g1((int64_t)b->N + 1), dim3(256), 0, st, b->N, w, b->win_tmp);
+  TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
+  hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
+  hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+  b->win_grid = std::max(1, std::min({grid_for(b->A, tile_grid_mult() * eng->num_cus), WIN_MAX_WAVES / WAVES}));
+  hipLaunchKernelGGL(k_win_partition, g1((int64_t)b->win_grid * WAVES + 1), dim3(256), 0, st, b->N, b->A, b->win_grid * WAVES, w, b->win_wave_atom);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
 }
 
 void register_names(chg_batch* b) {
@@ -1444,16 +1519,10 @@ struct TmpPool {   // scratch device memory of one chg_batch_build call: bump al
 
 int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
   if (n <= 0) return CHG_OK;
-  if (n <= (1 << 16)) {   // one workgroup, one launch (a device-wide scan is three); beyond this the strided chunks get slow
-    hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, in, out, n);
-    return CHG_OK;
-  }
-  size_t bytes = 0;
-  HIP_TRY(eng, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n, eng->stream));
-  void* work = tmp.get<char>(bytes);
-  if (!work) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-  HIP_TRY(eng, hipcub::DeviceScan::ExclusiveSum(work, bytes, in, out, n, eng->stream));
-  return CHG_OK;
+  if ((size_t)n / SCAN_CHUNK + 1 > (1u << 16)) { eng->err = "graph build: array too long for the two-level scan"; return CHG_EINVAL; }
+  int* scratch = tmp.get<int>(scan_scratch_ints(n));
+  if (!scratch) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  return exclusive_scan_with(eng, scratch, in, out, n);
 }
 
 int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
@@ -1839,6 +1908,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
     }
     if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
+    if (s == CHG_OK) s = prepare_windows(eng, b);
     // the scratch (TmpPool) is reused by the next build on this same stream, so stream order protects it; overflow
     // allocations of the pool are freed by its destructor and need the copies to have finished
     if (s == CHG_OK && !tmp.extra.empty() && hipStreamSynchronize(st) != hipSuccess) { eng->err = "graph build: synchronisation failed"; s = CHG_EHIP; }
@@ -1936,6 +2006,8 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_xty<4, 4>), (xty_lds<4, 4>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
   if ((s = set_lds(eng, k2_scatter_z, scatter_z_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, (angle_lds<false, WAVES, true>())))) return s;
@@ -2050,6 +2122,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   UP(u_u2d, Eu); UP(u_bnode, Eu); UP(bn_und, Eb);
   UP(a_ctr, A); UP(a_b1c, A); UP(a_b2c, A); UP(a_d1, A); UP(a_d2, A);
 #undef UP
+  if (s == CHG_OK) s = prepare_windows(eng, b);
   if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "chg_batch_upload: sync failed"; s = CHG_EHIP; }
   if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
   *out = b;

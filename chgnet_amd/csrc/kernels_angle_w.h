@@ -1,0 +1,401 @@
+// kernels_angle_w.h -- adjoints of BondConv / AngleUpdate with the second-bond scatter aggregated per ATOM in LDS.
+//
+// Why (profiles/r03_experiments.md): the per-row fp32 atomics of the angle adjoints (the second bond of every angle:
+// 939 B per angle for BondConv) are executed at the memory side of the fabric -- the per-XCD L2s cannot own a
+// line -- at ~1.2 TB/s chip-wide, and that, not the matrix pipe or the gathers, is what bounded both kernels
+// (no atomics: -28 % / -13 %; no atomics AND a 4x faster matrix pipe: -50 % / -55 %).
+//
+// Order.  The reference emits angles sorted by their first bond (graph.py:283-327).  All n (n - 1) angles around one atom
+// only touch that atom's n short bonds: they form the off-diagonal of an n x n matrix (first bond, second bond).  k_win_*
+// build, once per batch topology and entirely on the device, the CENTRE-ATOM-major order
+//   q_a[row]            the angle (index into the reference-ordered per-angle arrays) processed as row `row`
+//   q_ctr, q_b1c, q_b2c its centre atom and compact bond indices
+//   q_ab1, q_ab2        the (atom, bond) pair index  boff[centre] + rank of the bond among the centre's short bonds
+//   abbond[ab]          the compact bond index behind a pair;  aoff[c] the first row of atom c
+// Inside one atom: by directed-edge index of the first bond, then the reference's order -- deterministic.
+// Graphs without this structure (hand-made bond graphs: incomplete angle sets, groups that are not contiguous) and batches too
+// small to give every wave a few atoms clear flag[0]; both adjoint kernels are always launched and the one that does not
+// apply returns at once, so there is no host round trip and a captured hipGraph stays valid.
+//
+// Scatter.  One WAVE owns whole atoms (contiguous ranges, balanced by row count).  While it walks the rows of an atom
+//   * the first-bond sums and the centre sum are run sums in registers (rows arrive sorted by first bond): one 256-byte
+//     atomic per 64 columns when a run ends,
+//   * the second-bond sums -- the 15.8-distinct-rows-per-tile scatter of the row-order kernels -- accumulate in a
+//     wave-private LDS array [rank of the bond at this atom][128] by plain read-modify-write (no other wave ever touches it;
+//     LDS float ATOMICS were tried first for workgroup-shared windows and are serialised per lane: 5x slower), flushed with one
+//     atomic row per bond when the atom is done: n instead of n (n - 1) second-bond rows leave the workgroup.
+// No barrier, no flag, no LDS atomic.  Bonds of rank >= NS (atoms with more short bonds than the array has rows) and rows whose
+// second bond is not a first bond at the same atom fall back to direct row atomics.
+#pragma once
+
+#include "kernels_conv.h"
+
+namespace chg {
+
+constexpr int TS64 = D + PAD;                  // row stride of the 64-wide wave tiles of this kernel
+constexpr int TILE64_FLOATS = TILE_ROWS * TS64;
+constexpr int WIN_LIST = 32;                   // short bonds per atom the fast path handles
+constexpr int WIN_MAX_WAVES = 8 * 4096;        // capacity of the wave partition (grid <= 4096 workgroups)
+constexpr int WIN_MIN_ATOMS_PER_WAVE = 3;      // below this the atom-per-wave order leaves most of the chip idle: plain adjoints
+
+struct WinIndex {             // built by k_win_*; all in the batch arena
+  int* flag;                  // [4]  flag[0] = 1: the windowed order is valid for this batch
+  int *na, *boff, *aoff;      // [N+1] short bonds per atom, exclusive scans of na and na (na - 1)
+  int *head, *rank;           // [Ed] first row of the group whose first bond is this directed edge (-1: none); its rank at the centre
+  int* list;                  // [N][WIN_LIST] directed edges of the groups of an atom (unordered)
+  int *q_a, *q_ctr, *q_b1c, *q_b2c, *q_ab1, *q_ab2;   // [A]
+  int* abbond;                // [2 Eb]
+};
+
+// ---- index construction ---------------------------------------------------------------------------------
+__global__ void k_win_init(WinIndex w) { w.flag[0] = 1; }
+
+__global__ void k_win_heads(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, int A, int Ed, int N, WinIndex w) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const int d1 = a_d1[a];
+  if (d1 < 0 || d1 >= Ed) { w.flag[0] = 0; return; }
+  if (a > 0 && a_d1[a - 1] == d1) return;
+  const int c = a_ctr[a];
+  if (atomicCAS(w.head + d1, -1, a) != -1 || c < 0 || c >= N) { w.flag[0] = 0; return; }   // a second group with the same first bond
+  const int pos = atomicAdd(w.na + c, 1);
+  if (pos < WIN_LIST) w.list[(size_t)c * WIN_LIST + pos] = d1;
+  else w.flag[0] = 0;
+}
+
+__global__ void k_win_counts(int N, WinIndex w, int* __restrict__ nang) {   // nang[c] = na (na - 1): rows of atom c
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > N) return;
+  const int n = c < N ? w.na[c] : 0;
+  nang[c] = n * (n - 1);
+}
+
+__global__ void k_win_ranks(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, int A, int N,
+                            WinIndex w) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A || w.flag[0] == 0) return;
+  const int d1 = a_d1[a];
+  if (w.head[d1] != a) return;                      // group heads only
+  const int c = a_ctr[a], n = w.na[c];
+  int r = 0;
+  for (int q = 0; q < n; ++q) r += w.list[(size_t)c * WIN_LIST + q] < d1;
+  w.rank[d1] = r;
+  w.abbond[w.boff[c] + r] = a_b1c[a];
+  // the group must be exactly the n - 1 rows a .. a + n - 2
+  const int last = a + n - 2;
+  if (n < 2 || last >= A || a_d1[last] != d1 || (last + 1 < A && a_d1[last + 1] == d1)) w.flag[0] = 0;
+}
+
+__global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, const int* __restrict__ a_b2c,
+                           const int* __restrict__ a_d1, const int* __restrict__ a_d2, int A, int N, int Ed, WinIndex w) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a == 0 && w.aoff[N] != A) w.flag[0] = 0;     // every atom's angle set must be the complete n (n - 1) block
+  if (a >= A || w.flag[0] == 0) return;
+  const int d1 = a_d1[a], d2 = a_d2[a], c = a_ctr[a];
+  const int h = w.head[d1];
+  if (h < 0 || a_ctr[h] != c) { w.flag[0] = 0; return; }
+  const int n = w.na[c], q = a - h, r = w.rank[d1];
+  const long row = (long)w.aoff[c] + (long)r * (n - 1) + q;
+  if (q < 0 || q >= n - 1 || row < 0 || row >= A) { w.flag[0] = 0; return; }
+  int r2 = -1;
+  if (d2 >= 0 && d2 < Ed) {
+    const int h2 = w.head[d2];
+    if (h2 >= 0 && a_ctr[h2] == c) r2 = w.rank[d2];
+  }
+  w.q_a[row] = a; w.q_ctr[row] = c; w.q_b1c[row] = a_b1c[a]; w.q_b2c[row] = a_b2c[a];
+  w.q_ab1[row] = w.boff[c] + r;
+  w.q_ab2[row] = r2 >= 0 ? w.boff[c] + r2 : -1;
+}
+
+// wave_atom[i] = first atom of wave i: atom ranges of equal row counts (up to one atom), i = 0 .. nwaves
+__global__ void k_win_partition(int N, int A, int nwaves, WinIndex w, int* __restrict__ wave_atom) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && (long)N < (long)WIN_MIN_ATOMS_PER_WAVE * nwaves) w.flag[0] = 0;
+  if (i > nwaves) return;
+  if (i == nwaves) { wave_atom[i] = N; return; }
+  const long target = (long)A * i / nwaves;
+  int lo = 0, hi = N;                      // first atom c with aoff[c + 1] > target
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (w.aoff[mid + 1] > target) hi = mid; else lo = mid + 1;
+  }
+  wave_atom[i] = lo;
+}
+
+// ---- the adjoint kernel ---------------------------------------------------------------------------------
+struct AngleWArgs {
+  AngleArgs a;                // tables, weights, gradient buffers as for k_angle
+  WinIndex w;
+  const int* wave_atom;       // [gridDim.x * WAVES + 1] first atom of every wave (k_win_partition)
+};
+
+template <bool HIDDEN> constexpr int win_ns() { return HIDDEN ? 13 : 14; }   // private second-bond rows per wave
+constexpr int WIN_PST = 2 * D;                                               // their stride (floats)
+
+template <bool HIDDEN>
+constexpr size_t angle_w_lds() {
+  const size_t weights = HIDDEN ? sizeof(float) * (4 * D * WS) : 16 * (size_t)(2 * IMG128);
+  return weights + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE64_FLOATS + WAVES * win_ns<HIDDEN>() * WIN_PST);
+}
+
+// sum of three 64-wide table row halves into a 64-wide tile: 16 lanes per row, 4 rows per load instruction
+struct Gather64 { f32x4 a[TILE_ROWS / 4], b[TILE_ROWS / 4], c[TILE_ROWS / 4]; };
+__device__ __forceinline__ void gather64_issue(Gather64& gr, const float* __restrict__ t0, int i0, int ld0, const float* __restrict__ t1, int i1,
+                                               int ld1, const float* __restrict__ t2, int i2, int ld2, int lane) {
+  const int sub = lane >> 4, t = lane & 15;
+  int r0[TILE_ROWS / 4], r1[TILE_ROWS / 4], r2[TILE_ROWS / 4];
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) {
+    const int rr = 4 * it + sub;
+    r0[it] = __shfl(i0, rr); r1[it] = __shfl(i1, rr); r2[it] = __shfl(i2, rr);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) {
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
+    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
+  }
+}
+__device__ __forceinline__ void gather64_commit(const Gather64& gr, float* tile, int lane) {
+  const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it)
+    *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * TS64 + 4 * t) = (gr.a[it] + gr.b[it]) + gr.c[it];
+}
+
+// A 64-wide tile held column-wise: lane = column, v[rr] = row rr.  Transposed through the wave's LDS tile; all 16 row
+// reads are issued together (one LDS round trip) and every scatter below then works on registers -- reading the rows one by
+// one inside data-dependent branches serialised the LDS latency 16 times per pass (measured: half of the kernel).
+struct Cols64 { float v[TILE_ROWS]; };
+__device__ __forceinline__ void to_columns(const V64& x, float* T, float* Trow, int g, int lane, Cols64& c) {
+  write_dl<VT>(Trow, g, x.t);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int rr = 0; rr < TILE_ROWS; ++rr) c.v[rr] = T[rr * TS64 + lane];
+  __builtin_amdgcn_wave_barrier();
+}
+// Run sum for a key that is sorted along the rows, carried across tiles (`sum` / `cur` live in the caller); a finished run
+// leaves with one 256-byte atomic.
+__device__ __forceinline__ void run_sum64(const Cols64& c, int nvalid, int key, float& sum, int& cur, float* __restrict__ dst, int ld, int lane) {
+#pragma unroll
+  for (int rr = 0; rr < TILE_ROWS; ++rr) {
+    if (rr < nvalid) {
+      const int k = __builtin_amdgcn_readlane(key, rr);
+      if (k != cur) {
+        if (cur >= 0) atomicAdd(dst + (size_t)cur * ld + lane, sum);
+        sum = 0.f;
+        cur = k;
+      }
+      sum += c.v[rr];
+    }
+  }
+}
+__device__ __forceinline__ void run_flush64(float& sum, int& cur, float* __restrict__ dst, int ld, int lane) {
+  if (cur >= 0) atomicAdd(dst + (size_t)cur * ld + lane, sum);
+  sum = 0.f;
+  cur = -1;
+}
+__device__ __forceinline__ void row_add64(const Cols64& c, int nvalid, float* __restrict__ base, int row, int ld, int lane) {
+#pragma unroll
+  for (int rr = 0; rr < TILE_ROWS; ++rr)
+    if (rr < nvalid) atomicAdd(base + (size_t)__builtin_amdgcn_readlane(row, rr) * ld + lane, c.v[rr]);
+}
+// Second-bond rows of both halves into the wave-private LDS rows: plain read-modify-write, two rows per step (neighbouring
+// rows of the centre-major order never share a second bond; rows further apart may, and the LDS executes a wave's accesses in
+// order).  Rows past the end, and rows without a private row (slot < 0), go to `dump` (the idle wave tile) -- the latter are
+// then sent as direct atomics by the caller's slow path.
+__device__ __forceinline__ void private_add(const Cols64& c0, const Cols64& c1, int nvalid, int slot, float* pacc, float* dump, int lane) {
+#pragma unroll
+  for (int rr = 0; rr < TILE_ROWS; rr += 2) {
+    const int sa = __builtin_amdgcn_readlane(slot, rr), sb = __builtin_amdgcn_readlane(slot, rr + 1);
+    float* pa = (rr < nvalid && sa >= 0) ? pacc + sa * WIN_PST : dump;
+    float* pb = (rr + 1 < nvalid && sb >= 0) ? pacc + sb * WIN_PST : dump + 2 * D;
+    const float a0 = pa[lane], a1 = pa[D + lane], b0 = pb[lane], b1 = pb[D + lane];
+    pa[lane] = a0 + c0.v[rr]; pa[D + lane] = a1 + c1.v[rr];
+    pb[lane] = b0 + c0.v[rr + 1]; pb[D + lane] = b1 + c1.v[rr + 1];
+  }
+}
+
+template <bool HIDDEN>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs pw) {
+  const AngleArgs& p = pw.a;
+  const WinIndex& w = pw.w;
+  if (w.flag[0] != 1) return;                   // this batch runs the plain adjoint (k_angle<.., true>)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool SPLIT = !HIDDEN;               // the BondConv adjoint keeps the f32 matrix form (LDS: see kernels_conv.h)
+  constexpr int NS = win_ns<HIDDEN>();
+  float* Wang = smem;
+  float* WangT = SPLIT ? Wang + 4 * IMG128 : Wang;
+  float* W2c = SPLIT ? WangT + 4 * IMG128 : Wang + 2 * D * WS;
+  float* W2g = W2c + (HIDDEN ? D * WS : 0);
+  float* vecs = W2g + (HIDDEN ? D * WS : 0);
+  float* tiles = vecs + VEC_SLOTS * D;
+  float* paccs = tiles + WAVES * TILE64_FLOATS;   // [WAVES][NS][128]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (SPLIT) {
+    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
+    stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
+  } else {
+    stage_weights(Wang, p.w_ang, 2 * D, D, tid);
+    stage_weights(W2c, p.gw.w2c, D, D, tid);
+    stage_weights(W2g, p.gw.w2g, D, D, tid);
+  }
+  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
+  for (int q = tid; q < WAVES * NS * WIN_PST; q += BLOCK) paccs[q] = 0.f;
+  __syncthreads();
+  float* T = tiles + wave * TILE64_FLOATS;
+  float* Trow = T + j * TS64;
+  float* pacc = paccs + wave * NS * WIN_PST;
+  // workgroup b is dispatched to XCD b % 8: neighbouring atom ranges on one XCD (tile_range's mapping)
+  const int G = gridDim.x;
+  int lb = blockIdx.x;
+  if ((G & 7) == 0) lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int c_begin = pw.wave_atom[lb * WAVES + wave], c_end = pw.wave_atom[lb * WAVES + wave + 1];
+  PH_DECL
+  for (int c = c_begin; c < c_end; ++c) {
+    const int n = w.na[c];
+    if (n < 2) continue;
+    const int r_begin = w.aoff[c], r_end = r_begin + n * (n - 1), ab0 = w.boff[c];
+    // run sums carried over the tiles of this atom (lane = column): first bond (core | gate halves), centre, bond weights
+    float ri0 = 0.f, ri1 = 0.f, rs0 = 0.f, rs1 = 0.f, rg = 0.f;
+    int cur0 = -1, cur1 = -1, curg = -1;
+    int a_n, b1_n, b2_n, ab2_n;
+    {
+      const int row = min(r_begin + j, r_end - 1);
+      a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
+    }
+    for (int row0 = r_begin; row0 < r_end; row0 += TILE_ROWS) {
+      const int nvalid = min(TILE_ROWS, r_end - row0);
+      const int a = a_n, b1 = b1_n, b2 = b2_n, ab2 = ab2_n;
+      if (row0 + TILE_ROWS < r_end) {
+        const int row = min(row0 + TILE_ROWS + j, r_end - 1);
+        a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
+      }
+      int s2 = ab2 - ab0;                         // rank of the second bond at this atom = private row
+      if (ab2 < 0 || s2 < 0 || s2 >= NS) s2 = -1;
+      // ---- gathers: angle rows, then the two halves of the table sum ----
+      Gather64 gc, gg;
+      gather64_issue(gc, p.R, b1, 4 * D, p.R + 2 * D, b2, 4 * D, p.S, c, 2 * D, lane);
+      gather64_issue(gg, p.R + D, b1, 4 * D, p.R + 3 * D, b2, 4 * D, p.S + D, c, 2 * D, lane);
+      gather_rows64(T, TS64, p.ang, a, lane);
+      __builtin_amdgcn_wave_barrier();
+      V64 x;
+      read_dl<VT>(Trow, g, x.t);
+      __builtin_amdgcn_wave_barrier();
+      f32x4 z[2 * VT];
+      gather64_commit(gc, T, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[0]));
+      __builtin_amdgcn_wave_barrier();
+      gather64_commit(gg, T, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[VT]));
+      __builtin_amdgcn_wave_barrier();
+      PH(0)   // indices + gathers
+      Rows64 gy_rows;
+      if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);
+      if (SPLIT) gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
+      else gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+      V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
+      GatedState s;
+      V64 y;
+      constexpr bool SLIM = HIDDEN;
+      gated_forward<HIDDEN, SLIM, false, SPLIT>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+      V64 gy;
+      if (HIDDEN) {
+        V64 w1, w2, gu;
+        read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
+        read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
+        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
+        V64 g1, g2;
+        CHG_EW(ft, r) {
+          g1.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w2.t[ft][r];      // dE/d wbgc[b1]
+          g2.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w1.t[ft][r];      // dE/d wbgc[b2]
+          gy.t[ft][r] = gu.t[ft][r] * w1.t[ft][r] * w2.t[ft][r];
+        }
+        // the bond-weight gradients leave now (two vectors less to carry through the adjoint of the gated MLP):
+        // first bond as a run sum, second bond one atomic row per angle
+        {
+          Cols64 c1, c2;
+          to_columns(g1, T, Trow, g, lane, c1);
+          to_columns(g2, T, Trow, g, lane, c2);
+          run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane);
+          row_add64(c2, nvalid, p.Gwbgc, b2, D, lane);
+        }
+        PH(6)   // bond-weight gradient scatter
+      } else {
+        rows64_commit(gy_rows, T, TS64, lane);
+        __builtin_amdgcn_wave_barrier();
+        read_dl<VT>(Trow, g, gy.t);
+        __builtin_amdgcn_wave_barrier();
+      }
+      V64 gzc, gzg;
+      gated_backward<HIDDEN, SLIM, false, SPLIT>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+      PH(1)   // contractions + gated MLP, forward and adjoint
+      // ---- dE/d(angle in) += W_ang^T gz ----
+      {
+        f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
+        V64 ga = zero64();
+        Rows64 gang_old;
+        const bool fresh = HIDDEN && p.first_gang;
+        if (fresh) {
+#pragma unroll
+          for (int it = 0; it < TILE_ROWS / 4; ++it) gang_old.v[it] = zero4();
+        } else {
+          rows64_issue(gang_old, p.Gang, a, lane);
+        }
+        if (SPLIT) gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
+        else gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
+        write_dl<VT>(Trow, g, ga.t);
+        __builtin_amdgcn_wave_barrier();
+        scatter_rows64_add(T, TS64, p.Gang, a, nvalid, lane, gang_old);
+        __builtin_amdgcn_wave_barrier();
+      }
+      PH(2)   // W_ang^T contraction + Gang update
+      // ---- scatter: first bond and centre as carried run sums, second bond into the private rows ----
+      {
+        Cols64 c0, c1;
+        to_columns(gzc, T, Trow, g, lane, c0);
+        to_columns(gzg, T, Trow, g, lane, c1);
+#pragma unroll
+        for (int rr = 0; rr < TILE_ROWS; ++rr)
+          if (rr < nvalid) { rs0 += c0.v[rr]; rs1 += c1.v[rr]; }
+        run_sum64(c0, nvalid, b1, ri0, cur0, p.GR, 4 * D, lane);
+        run_sum64(c1, nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane);
+        private_add(c0, c1, nvalid, s2, pacc, T, lane);
+        if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
+#pragma unroll
+          for (int rr = 0; rr < TILE_ROWS; ++rr)
+            if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
+              float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
+              atomicAdd(d, c0.v[rr]);
+              atomicAdd(d + D, c1.v[rr]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      PH(3)   // scatter
+    }
+    // ---- the atom is done: runs, centre sum, private second-bond rows ----
+    run_flush64(ri0, cur0, p.GR, 4 * D, lane);
+    run_flush64(ri1, cur1, p.GR + D, 4 * D, lane);
+    if (HIDDEN) run_flush64(rg, curg, p.Gwbgc, D, lane);
+    atomicAdd(p.GS + (size_t)c * 2 * D + lane, rs0);
+    atomicAdd(p.GS + (size_t)c * 2 * D + D + lane, rs1);
+    const int nrows = min(n, NS);
+    const int bond_of = w.abbond[ab0 + min(lane, nrows - 1)];
+    for (int sl = 0; sl < nrows; ++sl) {
+      const int bond = __builtin_amdgcn_readlane(bond_of, sl);
+      float* src = pacc + sl * WIN_PST;
+      const float v0 = src[lane], v1 = src[D + lane];
+      src[lane] = 0.f; src[D + lane] = 0.f;
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
+    }
+    PH(4)   // per-atom flush
+  }
+  PH_FLUSH(HIDDEN ? 40 : 50)
+}
+
+}  // namespace chg

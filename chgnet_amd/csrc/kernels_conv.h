@@ -662,6 +662,7 @@ struct AngleArgs {
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
   int first_gang;      // BondConv adjoint of the last layer: first writer of Gang in the sweep (store, do not read: not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
+  const int* skip_flag; // plain adjoints (BWD, not TRAIN): return at once when *skip_flag == 1 (the windowed kernel of kernels_angle_w.h runs)
   // training (k_angle<.., true, .., true>) only
   float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
   float* dumpH;        // [A,128] hidden activations (BondConv)
@@ -693,6 +694,7 @@ constexpr size_t angle_lds() {
 template <bool HIDDEN, bool BWD, int NW = WAVES, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
+  if (BWD && !TRAIN && p.skip_flag && *p.skip_flag == 1) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool SPLIT = angle_split(HIDDEN, BWD);
   // f32 form: Wang [128][WS], W2c, W2g [64][WS].  Split form: images of Wang (and, adjoint, of Wang^T), W2c, W2g.

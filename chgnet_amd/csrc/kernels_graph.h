@@ -386,6 +386,49 @@ __global__ __launch_bounds__(1024) void k_small_scan(const int* __restrict__ in,
   }
 }
 
+// Exclusive prefix sum of longer arrays: chunks of SCAN_CHUNK ints per workgroup -- chunk totals (k_scan_totals), one
+// k_small_scan over the totals, then every workgroup rescans its chunk from its offset (k_scan_apply).  Three launches,
+// 2 reads + 1 write per element; replaces the library scan the first rounds used.
+constexpr int SCAN_CHUNK = 8192;
+__device__ __forceinline__ int block_sum_1024(int v, int* wave_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if (lane == 0) wave_tot[wave] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < 16; ++w) t += wave_tot[w];
+  return t;
+}
+__global__ __launch_bounds__(1024) void k_scan_totals(const int* __restrict__ in, int* __restrict__ totals, int n) {
+  __shared__ int wave_tot[16];
+  const int b0 = blockIdx.x * SCAN_CHUNK;
+  int s = 0;
+  for (int k = b0 + threadIdx.x; k < min(b0 + SCAN_CHUNK, n); k += 1024) s += in[k];
+  const int t = block_sum_1024(s, wave_tot);
+  if (threadIdx.x == 0) totals[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(const int* __restrict__ in, int* __restrict__ out, const int* __restrict__ chunk_off, int n) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = SCAN_CHUNK / 1024;
+  const int b = min(blockIdx.x * SCAN_CHUNK + tid * PER, n), e = min(b + PER, n);
+  int v[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { v[k] = b + k < e ? in[b + k] : 0; s += v[k]; }
+  int total;
+  const int excl = wave_excl_scan(s, lane, total);
+  if (lane == 63) wave_tot[wave] = total;
+  __syncthreads();
+  int run = chunk_off[blockIdx.x] + excl;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (b + k < e) out[b + k] = run;
+    run += v[k];
+  }
+}
+
 // Several device-to-device copies in one launch (the index arrays of a freshly built graph into the batch arena):
 // blockIdx.y picks the segment, the blocks of a row stride over its 4-byte words.
 constexpr int MULTI_COPY_MAX = 20;

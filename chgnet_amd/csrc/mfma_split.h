@@ -16,8 +16,10 @@
 // f16 range: forward operands (activations O(1), weights) are used as they are; the adjoint operands
 // (gradient rows, 1e-3 .. 1e-7) are scaled per row by a power of two first (exact), else their low
 // halves fall into the f16 subnormals (measured: 10x the error).  The low planes of both operands are
-// carried scaled by 2^LO_SHIFT in their own accumulator so that they stay normal numbers whatever
-// the matrix pipe does with f16 subnormals.
+// carried scaled by 2^11 so that they stay normal f16 numbers: the matrix pipe does keep f16 subnormals
+// (tools/split_lab.hip T2), but their fixed 2^-24 spacing costs bits -- with unscaled low planes the force
+// error at trained-checkpoint magnitudes was 2.4x the f32 engine's (5.5e-5 vs 2.3e-5 eV/A on the 32-atom golden
+// case), with scaled ones it is the f32 engine's to two digits (tools/gpu_precision_probe.py).
 //
 // Layouts.  Rows keep the accumulator ("D") layout of mfma_tile.h: lane = j + 16 g holds features
 // 16 ft + 4 g + r of row j.  One K = 32 MFMA takes from lane (j, g) the 8 values
@@ -40,7 +42,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef CHG_SPLIT_LO_SEPARATE
-#define CHG_SPLIT_LO_SEPARATE 0
+#define CHG_SPLIT_LO_SEPARATE 1
 #endif
 constexpr bool LO_SEPARATE = CHG_SPLIT_LO_SEPARATE;   // low planes scaled by 2^11 in their own accumulator (see above)
 constexpr float LO_SCALE = LO_SEPARATE ? 2048.0f : 1.0f, LO_UNSCALE = 1.0f / LO_SCALE;
@@ -129,47 +131,54 @@ __device__ __forceinline__ void split_row(SplitRow<KT / 2>& s, const f32x4 (&x)[
   }
 }
 
-// four output tiles fo0 .. fo0+3 from an already split row
+// four output tiles fo0 .. fo0+3 from an already split row.  LO_SEPARATE: the low-order products (low planes scaled by 2^11)
+// are accumulated first, the sum is scaled back -- powers of two, exact -- and the high-order products follow into the SAME
+// accumulators: separate scaled accumulators without a second register set (the forward kernels carry the next tile's
+// gathered rows in registers and spilled ~100 dwords with one).
 template <int MK, bool SCALED>
 __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int fo0, int i, int g) {
   const int nchunks = MK * 4 * F;
-  f32x4 hi_acc[4], lo_acc[LO_SEPARATE ? 4 : 1];
+  const h16x8* base0 = img + g * F + 16 * fo0 + i;
+  f32x4 t[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) hi_acc[q] = (SCALED || LO_SEPARATE) ? zero4() : acc[q];
-  if (LO_SEPARATE) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = zero4();
-  }
+  for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : (LO_SEPARATE ? acc[q] * LO_SCALE : acc[q]);
 #pragma unroll
   for (int mk = 0; mk < MK; ++mk) {
-    const h16x8* base = img + (mk * 4 + g) * F + 16 * fo0 + i;
+    const h16x8* base = base0 + mk * 4 * F;
     h16x8 wh[4], wl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], hi_acc[q], 0, 0, 0);
-    if (LO_SEPARATE) {
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], lo_acc[LO_SEPARATE ? q : 0], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
+    if (!LO_SEPARATE) {   // the matrix pipe keeps f16 subnormals (tools/split_lab.hip T2): one pass for all three products
 #pragma unroll
-      for (int q = 0; q < 4; ++q) lo_acc[LO_SEPARATE ? q : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], lo_acc[LO_SEPARATE ? q : 0], 0, 0, 0);
-    } else {   // the matrix pipe keeps f16 subnormals (tools/split_lab.hip T2): one accumulator for all three products
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
+    }
+  }
+  if (LO_SEPARATE) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], hi_acc[q], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) t[q] *= LO_UNSCALE;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hi_acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], hi_acc[q], 0, 0, 0);
+    for (int mk = 0; mk < MK; ++mk) {
+      const h16x8* base = base0 + mk * 4 * F;
+      h16x8 wh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wh[q] = base[16 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 4; ++q) {
+    if (SCALED) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = hi_acc[q][r];
-      if (LO_SEPARATE) v += LO_UNSCALE * lo_acc[LO_SEPARATE ? q : 0][r];
-      if (SCALED) v = __builtin_ldexpf(v, s.ex);
-      if (SCALED || LO_SEPARATE) acc[q][r] += v;
-      else acc[q][r] = v;
+      for (int r = 0; r < 4; ++r) acc[q][r] += __builtin_ldexpf(t[q][r], s.ex);
+    } else {
+      acc[q] = t[q];
     }
+  }
 }
 
 template <int KT, int NFT, bool SCALED>
