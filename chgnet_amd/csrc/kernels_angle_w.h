@@ -129,13 +129,16 @@ struct AngleWArgs {
   const int* wave_atom;       // [gridDim.x * WAVES + 1] first atom of every wave (k_win_partition)
 };
 
-template <bool HIDDEN> constexpr int win_ns() { return HIDDEN ? 13 : 14; }   // private second-bond rows per wave
-constexpr int WIN_PST = 2 * D;                                               // their stride (floats)
+// Private second-bond rows per wave.  AngleUpdate: dE/dR_j (128 wide), 14 rows.  BondConv: the angle block runs in split
+// precision like everywhere else (its two images, 64 KiB), the hidden layer keeps the f32 form (its four images would be
+// another 64 KiB), and what LDS is left holds the bond-weight gradients (64 wide), 12 rows; dE/dR_j then leaves as row atomics.
+template <bool HIDDEN> constexpr int win_ns() { return HIDDEN ? 12 : 14; }
+template <bool HIDDEN> constexpr int win_pst() { return HIDDEN ? D : 2 * D; }   // stride of a private row (floats)
 
 template <bool HIDDEN>
 constexpr size_t angle_w_lds() {
-  const size_t weights = HIDDEN ? sizeof(float) * (4 * D * WS) : 16 * (size_t)(2 * IMG128);
-  return weights + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE64_FLOATS + WAVES * win_ns<HIDDEN>() * WIN_PST);
+  const size_t weights = 16 * (size_t)(2 * IMG128) + (HIDDEN ? sizeof(float) * (2 * D * WS) : 0);
+  return weights + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE64_FLOATS + WAVES * win_ns<HIDDEN>() * win_pst<HIDDEN>());
 }
 
 // sum of three 64-wide table row halves into a 64-wide tile: 16 lanes per row, 4 rows per load instruction
@@ -200,19 +203,22 @@ __device__ __forceinline__ void row_add64(const Cols64& c, int nvalid, float* __
   for (int rr = 0; rr < TILE_ROWS; ++rr)
     if (rr < nvalid) atomicAdd(base + (size_t)__builtin_amdgcn_readlane(row, rr) * ld + lane, c.v[rr]);
 }
-// Second-bond rows of both halves into the wave-private LDS rows: plain read-modify-write, two rows per step (neighbouring
-// rows of the centre-major order never share a second bond; rows further apart may, and the LDS executes a wave's accesses in
-// order).  Rows past the end, and rows without a private row (slot < 0), go to `dump` (the idle wave tile) -- the latter are
-// then sent as direct atomics by the caller's slow path.
-__device__ __forceinline__ void private_add(const Cols64& c0, const Cols64& c1, int nvalid, int slot, float* pacc, float* dump, int lane) {
+// Second-bond rows (NB column blocks of 64) into the wave-private LDS rows: plain read-modify-write, two rows per step
+// (neighbouring rows of the centre-major order never share a second bond; rows further apart may, and the LDS executes a
+// wave's accesses in order).  Rows past the end, and rows without a private row (slot < 0), go to `dump` (the idle wave tile) --
+// the latter are then sent as direct atomics by the caller's slow path.
+template <int NB>
+__device__ __forceinline__ void private_add(const Cols64 (&c)[NB], int nvalid, int slot, float* pacc, float* dump, int lane) {
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; rr += 2) {
     const int sa = __builtin_amdgcn_readlane(slot, rr), sb = __builtin_amdgcn_readlane(slot, rr + 1);
-    float* pa = (rr < nvalid && sa >= 0) ? pacc + sa * WIN_PST : dump;
-    float* pb = (rr + 1 < nvalid && sb >= 0) ? pacc + sb * WIN_PST : dump + 2 * D;
-    const float a0 = pa[lane], a1 = pa[D + lane], b0 = pb[lane], b1 = pb[D + lane];
-    pa[lane] = a0 + c0.v[rr]; pa[D + lane] = a1 + c1.v[rr];
-    pb[lane] = b0 + c0.v[rr + 1]; pb[D + lane] = b1 + c1.v[rr + 1];
+    float* pa = (rr < nvalid && sa >= 0) ? pacc + sa * (NB * D) : dump;
+    float* pb = (rr + 1 < nvalid && sb >= 0) ? pacc + sb * (NB * D) : dump + NB * D;
+    float a[NB], b[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { a[q] = pa[q * D + lane]; b[q] = pb[q * D + lane]; }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { pa[q * D + lane] = a[q] + c[q].v[rr]; pb[q * D + lane] = b[q] + c[q].v[rr + 1]; }
   }
 }
 
@@ -222,31 +228,28 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
   const WinIndex& w = pw.w;
   if (w.flag[0] != 1) return;                   // this batch runs the plain adjoint (k_angle<.., true>)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool SPLIT = !HIDDEN;               // the BondConv adjoint keeps the f32 matrix form (LDS: see kernels_conv.h)
-  constexpr int NS = win_ns<HIDDEN>();
-  float* Wang = smem;
-  float* WangT = SPLIT ? Wang + 4 * IMG128 : Wang;
-  float* W2c = SPLIT ? WangT + 4 * IMG128 : Wang + 2 * D * WS;
+  constexpr int NS = win_ns<HIDDEN>(), PST = win_pst<HIDDEN>();
+  float* Wang = smem;                           // split images of W_ang and W_ang^T
+  float* WangT = Wang + 4 * IMG128;
+  float* W2c = WangT + 4 * IMG128;              // BondConv: hidden layer in the f32 form [64][WS] x 2
   float* W2g = W2c + (HIDDEN ? D * WS : 0);
   float* vecs = W2g + (HIDDEN ? D * WS : 0);
   float* tiles = vecs + VEC_SLOTS * D;
-  float* paccs = tiles + WAVES * TILE64_FLOATS;   // [WAVES][NS][128]
+  float* paccs = tiles + WAVES * TILE64_FLOATS;   // [WAVES][NS][PST]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (SPLIT) {
-    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
-    stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
-  } else {
-    stage_weights(Wang, p.w_ang, 2 * D, D, tid);
+  stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
+  stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
+  if (HIDDEN) {
     stage_weights(W2c, p.gw.w2c, D, D, tid);
     stage_weights(W2g, p.gw.w2g, D, D, tid);
   }
   stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
-  for (int q = tid; q < WAVES * NS * WIN_PST; q += BLOCK) paccs[q] = 0.f;
+  for (int q = tid; q < WAVES * NS * PST; q += BLOCK) paccs[q] = 0.f;
   __syncthreads();
   float* T = tiles + wave * TILE64_FLOATS;
   float* Trow = T + j * TS64;
-  float* pacc = paccs + wave * NS * WIN_PST;
+  float* pacc = paccs + wave * NS * PST;
   // workgroup b is dispatched to XCD b % 8: neighbouring atom ranges on one XCD (tile_range's mapping)
   const int G = gridDim.x;
   int lb = blockIdx.x;
@@ -295,13 +298,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       PH(0)   // indices + gathers
       Rows64 gy_rows;
       if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);
-      if (SPLIT) gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
-      else gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+      gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
       V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
       GatedState s;
       V64 y;
       constexpr bool SLIM = HIDDEN;
-      gated_forward<HIDDEN, SLIM, false, SPLIT>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+      gated_forward<HIDDEN, SLIM, false, false>(zc, zg, W2c, W2g, vecs, j, g, s, y);
       V64 gy;
       if (HIDDEN) {
         V64 w1, w2, gu;
@@ -317,11 +319,18 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         // the bond-weight gradients leave now (two vectors less to carry through the adjoint of the gated MLP):
         // first bond as a run sum, second bond one atomic row per angle
         {
-          Cols64 c1, c2;
+          Cols64 c1, c2[1];
           to_columns(g1, T, Trow, g, lane, c1);
-          to_columns(g2, T, Trow, g, lane, c2);
+          to_columns(g2, T, Trow, g, lane, c2[0]);
           run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane);
-          row_add64(c2, nvalid, p.Gwbgc, b2, D, lane);
+          private_add<1>(c2, nvalid, s2, pacc, T, lane);
+          if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
+#pragma unroll
+            for (int rr = 0; rr < TILE_ROWS; ++rr)
+              if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0)
+                atomicAdd(p.Gwbgc + (size_t)__builtin_amdgcn_readlane(b2, rr) * D + lane, c2[0].v[rr]);
+          }
+          __builtin_amdgcn_wave_barrier();
         }
         PH(6)   // bond-weight gradient scatter
       } else {
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         __builtin_amdgcn_wave_barrier();
       }
       V64 gzc, gzg;
-      gated_backward<HIDDEN, SLIM, false, SPLIT>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+      gated_backward<HIDDEN, SLIM, false, false>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
       PH(1)   // contractions + gated MLP, forward and adjoint
       // ---- dE/d(angle in) += W_ang^T gz ----
       {
@@ -345,8 +354,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         } else {
           rows64_issue(gang_old, p.Gang, a, lane);
         }
-        if (SPLIT) gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
-        else gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
+        gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         scatter_rows64_add(T, TS64, p.Gang, a, nvalid, lane, gang_old);
@@ -355,25 +363,30 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       PH(2)   // W_ang^T contraction + Gang update
       // ---- scatter: first bond and centre as carried run sums, second bond into the private rows ----
       {
-        Cols64 c0, c1;
-        to_columns(gzc, T, Trow, g, lane, c0);
-        to_columns(gzg, T, Trow, g, lane, c1);
+        Cols64 cc[2];
+        to_columns(gzc, T, Trow, g, lane, cc[0]);
+        to_columns(gzg, T, Trow, g, lane, cc[1]);
 #pragma unroll
         for (int rr = 0; rr < TILE_ROWS; ++rr)
-          if (rr < nvalid) { rs0 += c0.v[rr]; rs1 += c1.v[rr]; }
-        run_sum64(c0, nvalid, b1, ri0, cur0, p.GR, 4 * D, lane);
-        run_sum64(c1, nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane);
-        private_add(c0, c1, nvalid, s2, pacc, T, lane);
-        if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
+          if (rr < nvalid) { rs0 += cc[0].v[rr]; rs1 += cc[1].v[rr]; }
+        run_sum64(cc[0], nvalid, b1, ri0, cur0, p.GR, 4 * D, lane);
+        run_sum64(cc[1], nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane);
+        if (HIDDEN) {   // the private rows hold the bond-weight gradients: dE/dR_j leaves row by row
+          row_add64(cc[0], nvalid, p.GR + 2 * D, b2, 4 * D, lane);
+          row_add64(cc[1], nvalid, p.GR + 3 * D, b2, 4 * D, lane);
+        } else {
+          private_add<2>(cc, nvalid, s2, pacc, T, lane);
+          if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
 #pragma unroll
-          for (int rr = 0; rr < TILE_ROWS; ++rr)
-            if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
-              float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
-              atomicAdd(d, c0.v[rr]);
-              atomicAdd(d + D, c1.v[rr]);
-            }
+            for (int rr = 0; rr < TILE_ROWS; ++rr)
+              if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
+                float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
+                atomicAdd(d, cc[0].v[rr]);
+                atomicAdd(d + D, cc[1].v[rr]);
+              }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
       }
       PH(3)   // scatter
     }
@@ -387,11 +400,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     const int bond_of = w.abbond[ab0 + min(lane, nrows - 1)];
     for (int sl = 0; sl < nrows; ++sl) {
       const int bond = __builtin_amdgcn_readlane(bond_of, sl);
-      float* src = pacc + sl * WIN_PST;
-      const float v0 = src[lane], v1 = src[D + lane];
-      src[lane] = 0.f; src[D + lane] = 0.f;
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
+      float* src = pacc + sl * PST;
+      if (HIDDEN) {
+        const float v0 = src[lane];
+        src[lane] = 0.f;
+        atomicAdd(p.Gwbgc + (size_t)bond * D + lane, v0);
+      } else {
+        const float v0 = src[lane], v1 = src[D + lane];
+        src[lane] = 0.f; src[D + lane] = 0.f;
+        atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
+        atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
+      }
     }
     PH(4)   // per-atom flush
   }
