@@ -44,6 +44,12 @@ if REPO not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8 TB/s (spec)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense f16 / bf16 MFMA
+# Which matrix form a tile kernel's contractions run in (csrc/mfma_split.h): every f32 product as three f16 MFMAs on hi/lo
+# operand halves with f32 accumulation (22+ significand bits; measured parity = the f32 form's), or the f32 MFMA itself.
+# fractions in `tile_kernels` stay relative to the f32 MFMA peak so that they compare with earlier rounds; a split kernel's own
+# matrix-pipe ceiling is PEAK_F16_MFMA_TFLOPS / 3 f32-equivalent TFLOP/s.
+SPLIT_KERNELS = {"atomconv_fwd", "atomconv_bwd", "bondconv_fwd", "angleupd_fwd", "angleupd_bwd"}
 
 # Algorithmic work per unit of the dominant kernels in the engine's (factorised) formulation, derived in
 # DESIGN.md "Roofline accounting": (unit, MFMA flop per unit, compulsory HBM bytes per unit)
@@ -107,14 +113,14 @@ def sweep_structure(i: int):
     return Structure(Lattice(np.diag([a, b, vol / (a * b)])), rng.choice([3, 25, 27, 8], size=n), frac)
 
 
-def li9co7o16_supercell():
-    """2x2x2 supercell (256 atoms) of mp-1175469 Li9Co7O16 (reference fixture examples/mp-1175469-Li9Co7O16.cif;
+def li9co7o16_supercell(scale=(2, 2, 2)):
+    """Supercell (2x2x2 = 256 atoms by default) of mp-1175469 Li9Co7O16 (reference fixture examples/mp-1175469-Li9Co7O16.cif;
     the cell is stored with the golden cases)."""
     from chgnet_amd import Structure
     from chgnet_amd.graph.structure import Lattice
 
     d = np.load(os.path.join(REPO, "tests", "golden", "case_li9co7o16.npz"))
-    return Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell([2, 2, 2])
+    return Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell(list(scale))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -172,13 +178,25 @@ class Ranks:
         self.torch = None
         self.backend = "gloo" if args.dry_run else "nccl"   # "nccl" IS RCCL on ROCm
         self.comm = None
+        self.comm_note = None
+        self.rccl_info = None
         if args.comm == "rccl" and not args.dry_run and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
             from chgnet_amd.distributed import RcclComm      # RCCL through the engine library's C-ABI: no torch.distributed
 
-            self.comm = RcclComm(self.rank, self.world, self.local_rank)
+            try:
+                self.comm = RcclComm(self.rank, self.world, self.local_rank)
+            except Exception as exc:  # noqa: BLE001 -- a scaling run must not die on the rendezvous: torch.distributed instead
+                self.comm = None
+                self.comm_note = f"RcclComm failed ({type(exc).__name__}: {exc}); torch.distributed used instead"
+        if self.comm is not None:
             self.backend = "rccl (chg_comm_*)"
-            if self.comm.world != args.gpus:
-                raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {self.comm.world} ranks")
+            info = self.comm.info()
+            if info["nranks"] != args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but RCCL reports {info['nranks']} ranks")
+            devices = self.comm.all_gather(np.array([info["device"]], np.float32)).astype(int).tolist()
+            if len(set(devices)) != self.world and not os.environ.get("CHGNET_BENCH_FORCE_DIST"):
+                raise SystemExit(f"bench.py: ranks share a GPU (hipGetDevice per rank: {devices})")
+            self.rccl_info = {"nranks_from_ncclCommCount": info["nranks"], "device_per_rank": devices}
         elif self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL leg on one GPU
             import torch
             import torch.distributed as dist
@@ -272,6 +290,21 @@ def cpu_leg(weights: dict, graphs, checks: dict, seconds_budget: float = 24.0) -
                   f"without the per-graph BatchedGraph.from_graphs loop and without the dead third AngleUpdate, so it flatters "
                   f"the CPU), batch_size={best[1]}, best of 8/16/32 torch threads on {ncpu} logical CPUs"}
     torch.set_num_threads(best[3])
+    # SURVEY 8d "informative second baseline": the same torch restatement through torch-ROCm EAGER on this GPU -- the
+    # "recompile PyTorch for ROCm" route the engine replaces (host batching included, like the CPU figure)
+    # (own process: torch-ROCm brings its own HIP runtime, which finds no device once the engine library's runtime owns it)
+    try:
+        import re
+        import subprocess
+
+        probe = os.path.join(REPO, "tools", "gpu_torch_baseline_probe.py")
+        out = subprocess.run([sys.executable, probe, "64", "64"], capture_output=True, text=True, timeout=300).stdout
+        m = re.search(r"= ([0-9.]+) structures/s", out)
+        baseline["gpu_eager_baseline"] = {"value": float(m.group(1)) if m else None, "unit": "structures/s",
+                                          "what": "oracle/chgnet_oracle.py on cuda:0 through torch-ROCm eager, batch_size=64, 64 structures "
+                                                  "(tools/gpu_torch_baseline_probe.py in its own process)"}
+    except Exception as exc:  # noqa: BLE001 -- informative only
+        baseline["gpu_eager_baseline"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:200]}
     parity = {}
     for name, item in checks.items():
         if item[0] == "weight-gradients":           # C5: d CombinedLoss / d parameters against torch double-backward (float64)
@@ -329,7 +362,7 @@ def hbm_model(packed) -> dict:
         "gemm_GQ": Eu * (512 + 256 + 256),          # read GQ row (128), read-modify-write Gb row (64)
         "bond_embed_fwd": Eu * (16 + 8 + 512) + Eb * 256,   # ev + 2 indices in; hb0, wag (and wbgc for bond-graph nodes) out
         "angle_embed_fwd": A * (8 + 256) + Ed * 16,         # 2 indices in, unit vectors once, angle row out
-        "edge_force": Ed * (16 + 16 + 16 + 4 * 4) + Eu * 8 + N * 12,   # ev, eu, Gu, 4 index arrays, (Grk, u2d) per bond, forces out
+        "edge_force": Ed * (16 + 16 + 16 + 16 + 4 * 6) + N * 12,   # ev, eu, Gu, Gu[e_rev], d2u / rev / owner / centre / u2d[k] / Grk[k], forces out
     }
 
 
@@ -430,6 +463,15 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             "steps_per_s": round(out["steps_per_s"], 1), "ms_per_step": round(1e3 / out["steps_per_s"], 3),
             "calculator_ms_per_step": round(1e3 * out["calculator_s"] / args.md_steps, 3),
             "temperature_K": round(out["temperature_K"], 1)}
+        # BASELINE.json says "~512 atoms": the 4x2x2 cell next to the 2x2x2 one (same path, rebuilt every step)
+        cell512 = li9co7o16_supercell((4, 2, 2))
+        md5 = BerendsenNVT(cell512, CHGNetCalculator(model), temperature_K=1000.0, timestep_fs=2.0, task="ef")
+        md5.run(10)
+        n512 = max(100, args.md_steps // 2)
+        out5 = md5.run(n512)
+        configs["C4_md"]["cell_4x2x2_512_atoms"] = {
+            "atoms": len(cell512), "steps": n512, "steps_per_s": round(out5["steps_per_s"], 1),
+            "ms_per_step": round(1e3 / out5["steps_per_s"], 3), "temperature_K": round(out5["temperature_K"], 1)}
         # the device-resident variant: graph built with both cutoffs + skin, kept in HBM and replayed as a hipGraph
         # while no atom has moved more than skin / 2 -- same E/F (the envelope closes the skin shell), no rebuild on most steps
         calc_skin = CHGNetCalculator(model, skin=0.5)
@@ -519,15 +561,16 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1024, help="structures per GPU per step")
-    ap.add_argument("--sweep-structures", type=int, default=4000, help="C3: structures per GPU")
+    ap.add_argument("--sweep-structures", type=int, default=12500, help="C3: structures per GPU (BASELINE: 100k over 8 GPUs)")
     ap.add_argument("--sweep-chunk", type=int, default=1000, help="C3: batch_size handed to predict_structure")
-    ap.add_argument("--md-steps", type=int, default=300, help="C4: timed MD steps")
+    ap.add_argument("--md-steps", type=int, default=1000, help="C4: timed MD steps (BASELINE: 1000)")
     ap.add_argument("--train-structures", type=int, default=10240, help="C5: structures in the fine-tuning epoch (all ranks together); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: process-group plumbing only (gloo)")
-    ap.add_argument("--comm", choices=("torch", "rccl"), default="torch",
-                    help="exchange steps through torch.distributed (backend nccl = RCCL) or through the engine library's own RCCL entry points")
+    ap.add_argument("--comm", choices=("torch", "rccl"), default="rccl",
+                    help="exchange steps through the engine library's own RCCL entry points (default; falls back to torch.distributed "
+                         "if the communicator cannot be created) or through torch.distributed (backend nccl = RCCL)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -553,7 +596,9 @@ def main() -> None:
         nonlocal gathered
         eng.predict(batch, "efs")
         res = eng.download(batch, "efs")
-        if ranks.dist is not None or ranks.comm is not None:
+        if ranks.comm is not None:      # all-gather of the energies from HBM on the engine's stream (chg_batch_all_gather_energy)
+            gathered = eng.all_gather_energy(batch, ranks.comm, args.structures)
+        elif ranks.dist is not None:
             gathered = ranks.all_gather(res["e"])
         return res
 
@@ -644,8 +689,12 @@ def main() -> None:
                 fl = getattr(packed, unit_attr) * flop_u
                 step_flop += fl * n_l / prof_steps
                 tile[k] = {"avg_launch_ms": round(t_ms / n_l, 4), "tflops": round(fl / (t_ms / n_l * 1e-3) / 1e12, 2),
-                           "frac": round(fl / (t_ms / n_l * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                           "frac": round(fl / (t_ms / n_l * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "matrix_form": "3 x f16 16x16x32 split, f32 accumulate" if k in SPLIT_KERNELS else "f32 16x16x4"}
         roofline["tile_kernels"] = tile
+        roofline["peak_note"] = (f"frac = factorised f32-equivalent TFLOP/s / {PEAK_FP32_MFMA_TFLOPS} (dense f32 MFMA); split-form kernels "
+                                 f"issue 3 f16 MFMAs per f32 product, their matrix-pipe ceiling is {PEAK_F16_MFMA_TFLOPS:.0f} / 3 = "
+                                 f"{PEAK_F16_MFMA_TFLOPS / 3:.0f} f32-equivalent TFLOP/s; the dominant kernel ({dom}) runs the f32 form")
         roofline["whole_step_frac"] = round(step_flop / (dev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE runs, summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction)
@@ -672,12 +721,15 @@ def main() -> None:
             "value": round(value, 2), "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "f32 storage, f32 accumulation; contractions of 5 of the 6 tile kernels as 3 x f16 MFMA on split f32 operands "
+                          "(error of the split contraction <= the f32 MFMA's, profiles/r03_split_lab.txt; E/F/S parity unchanged)",
             "config": {"workload": f"{args.structures} x LiMnO2 5x1x1 (40 atoms, sigma=0.01 frac perturbation) per GPU, task efs",
                        "structures_per_gpu": args.structures, "atoms": int(packed.n_atoms), "directed_bonds": int(packed.n_directed),
                        "angles": int(packed.n_angles), "bond_graph_nodes": int(packed.n_bnodes),
                        "weights": "random-init 0.3.0 architecture (tests/golden/weights_seed0.npz)",
                        "parallelism": f"structures sharded over {world} GPU(s), RCCL all-gather of energies only",
-                       "process_group_ranks": world, "energies_in_all_gather": energies_in_gather},
+                       "process_group_ranks": world, "energies_in_all_gather": energies_in_gather,
+                       "comm": ranks.backend if world > 1 else "none (single rank)", "rccl": ranks.rccl_info, "comm_note": ranks.comm_note},
             "device_ms_per_step": round(dev_ms, 3),
             "end_to_end": {"what": "host structures -> device graph build (chg_batch_build) -> predict -> E/F/S on host, per GPU",
                            "ms": round(e2e_ms, 3), "structures_per_s": round(args.structures / (e2e_ms * 1e-3), 1)},

@@ -22,6 +22,8 @@ EXPORTED_SYMBOLS = (
     "chg_engine_set_graph_search", "chg_engine_cell_stats",
     "chg_comm_unique_id", "chg_comm_create", "chg_comm_all_gather_f32", "chg_comm_all_reduce_sum_f32", "chg_comm_barrier",
     "chg_comm_destroy", "chg_comm_last_error",
+    "chg_comm_all_gather_f32_device", "chg_comm_all_reduce_sum_f32_device", "chg_comm_reserve", "chg_comm_info",
+    "chg_backward_allreduce", "chg_batch_all_gather_energy", "chg_engine_stream", "chg_engine_device",
 )
 
 
@@ -92,6 +94,10 @@ def load() -> ctypes.CDLL:
     lib.chg_comm_create.argtypes = [u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(vp)]
     lib.chg_comm_all_gather_f32.argtypes = [vp, c_float_p, ctypes.c_int64, c_float_p]
     lib.chg_comm_all_reduce_sum_f32.argtypes = [vp, c_float_p, ctypes.c_int64]
+    lib.chg_comm_all_gather_f32_device.argtypes = [vp, vp, ctypes.c_int64, vp, vp]
+    lib.chg_comm_all_reduce_sum_f32_device.argtypes = [vp, vp, ctypes.c_int64, vp]
+    lib.chg_comm_reserve.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(vp)]
+    lib.chg_comm_info.argtypes = [vp, c_int_p, c_int_p, c_int_p]
     lib.chg_comm_barrier.argtypes = [vp]
     lib.chg_comm_destroy.argtypes = [vp]
     lib.chg_comm_last_error.argtypes = [vp]
@@ -112,6 +118,11 @@ def load() -> ctypes.CDLL:
     lib.chg_predict.argtypes = [vp, vp, ctypes.c_uint32]
     lib.chg_synchronize.argtypes = [vp]
     lib.chg_backward.argtypes = [vp, vp, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    lib.chg_backward_allreduce.argtypes = [vp, vp, c_float_p, c_float_p, c_float_p, c_float_p, vp, c_float_p]
+    lib.chg_batch_all_gather_energy.argtypes = [vp, vp, vp, ctypes.c_int64, c_float_p]
+    lib.chg_engine_stream.argtypes = [vp]
+    lib.chg_engine_stream.restype = ctypes.c_void_p
+    lib.chg_engine_device.argtypes = [vp]
     lib.chg_engine_update_weights.argtypes = [vp, c_float_p]
     lib.chg_batch_download.argtypes = [vp, vp, ctypes.POINTER(OutHost)]
     lib.chg_timer_start.argtypes = [vp]

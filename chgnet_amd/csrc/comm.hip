@@ -5,10 +5,18 @@
 // One communicator per process = per GPU.  librccl is opened at run time (dlopen): the engine library keeps loading on
 // machines without RCCL, and a process that already has torch's bundled librccl mapped reuses THAT copy instead of
 // mapping a second one.  Rendezvous (handing rank 0's ncclUniqueId to the other ranks) is the caller's job -- the
-// Python host side does it through a file next to MASTER_PORT (chgnet_amd/distributed.py), a launcher may use anything.
+// Python host side does it over a TCP socket on MASTER_ADDR (chgnet_amd/distributed.py), a launcher may use anything.
+//
+// The handful of RCCL types used here are declared locally (they are ABI-stable NCCL 2 types): the engine library builds on
+// ROCm installs without the RCCL headers, as it loads without librccl.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;     // ncclFloat32
+typedef enum { ncclSum = 0 } ncclRedOp_t;
 
 #include <cstring>
 #include <string>
@@ -24,6 +32,7 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -45,6 +54,7 @@ Rccl& rccl() {
     x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
     x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
     x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+    x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
     return x;
   }();
@@ -157,6 +167,45 @@ int chg_comm_all_reduce_sum_f32(chg_comm* c, float* data, int64_t count) {
   if (s == CHG_OK) s = check_hip(c, hipMemcpyAsync(data, c->buf, sizeof(float) * count, hipMemcpyDeviceToHost, c->stream), "download");
   if (s == CHG_OK) s = check_hip(c, hipStreamSynchronize(c->stream), "synchronize");
   return s;
+}
+
+// ---- device-pointer forms: enqueued on the caller's stream (the engine stream: energies and the gradient blob are already
+// in HBM), no host bounce, no synchronisation -----------------------------------------------------------------------------
+int chg_comm_all_gather_f32_device(chg_comm* c, const float* d_send, int64_t count, float* d_recv, void* stream) {
+  if (!c || count < 0 || (count > 0 && (!d_send || !d_recv))) return CHG_EINVAL;
+  if (count == 0) return CHG_OK;
+  int s = check_hip(c, hipSetDevice(c->device), "hipSetDevice");
+  if (s == CHG_OK) s = check_nccl(c, rccl().AllGather(d_send, d_recv, (size_t)count, ncclFloat, c->comm, static_cast<hipStream_t>(stream)), "ncclAllGather");
+  return s;
+}
+
+int chg_comm_all_reduce_sum_f32_device(chg_comm* c, float* d_data, int64_t count, void* stream) {
+  if (!c || count < 0 || (count > 0 && !d_data)) return CHG_EINVAL;
+  if (count == 0) return CHG_OK;
+  int s = check_hip(c, hipSetDevice(c->device), "hipSetDevice");
+  if (s == CHG_OK) s = check_nccl(c, rccl().AllReduce(d_data, d_data, (size_t)count, ncclFloat, ncclSum, c->comm, static_cast<hipStream_t>(stream)), "ncclAllReduce");
+  return s;
+}
+
+int chg_comm_reserve(chg_comm* c, int64_t floats, float** device_ptr) {
+  if (!c || floats < 0 || !device_ptr) return CHG_EINVAL;
+  int s = check_hip(c, hipSetDevice(c->device), "hipSetDevice");
+  if (s == CHG_OK) s = reserve(c, (size_t)floats);
+  if (s == CHG_OK) *device_ptr = c->buf;
+  return s;
+}
+
+int chg_comm_info(chg_comm* c, int32_t* rank, int32_t* nranks, int32_t* device) {
+  if (!c) return CHG_EINVAL;
+  int n = c->world;
+  if (rccl().CommCount) {
+    const int s = check_nccl(c, rccl().CommCount(c->comm, &n), "ncclCommCount");
+    if (s != CHG_OK) return s;
+  }
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = n;           // what RCCL reports for this communicator
+  if (device) *device = c->device;
+  return CHG_OK;
 }
 
 int chg_comm_barrier(chg_comm* c) {

@@ -127,6 +127,7 @@ struct chg_batch {
   WinIndex win{};           // centre-major row order + window slots of the angle adjoints (kernels_angle_w.h), built by prepare_windows
   int *win_tmp = nullptr, *win_scan = nullptr, *win_wave_atom = nullptr;
   int win_grid = 1;         // workgroups of the per-atom adjoints (fixed when the index is built)
+  bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
   // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
@@ -451,7 +452,7 @@ template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
   AngleArgs plain = a;
-  if (BWD && per_atom_adjoint(HIDDEN)) {
+  if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
     // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the plain one: both are
     // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
     AngleWArgs w{};
@@ -695,9 +696,13 @@ void carve(chg_batch* b, char* base, size_t& total) {
 int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;
-  HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
-  if (b->A == 0) return CHG_OK;
+  b->win_built = false;
+  b->win_grid = std::max(1, std::min({grid_for(b->A, tile_grid_mult() * eng->num_cus), WIN_MAX_WAVES / WAVES}));
+  // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle -- plain adjoints, and nothing to build
+  if (b->A == 0 || (long)b->N < (long)WIN_MIN_ATOMS_PER_WAVE * b->win_grid * WAVES) return CHG_OK;
   if ((size_t)b->N / SCAN_CHUNK + 1 > (1u << 16)) return CHG_OK;      // beyond the two-level scan: plain adjoints
+  b->win_built = true;
+  HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
   HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
   HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
   HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
@@ -708,7 +713,6 @@ int prepare_windows(chg_engine* eng, chg_batch* b) {
   TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
   hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
   hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
-  b->win_grid = std::max(1, std::min({grid_for(b->A, tile_grid_mult() * eng->num_cus), WIN_MAX_WAVES / WAVES}));
   hipLaunchKernelGGL(k_win_partition, g1((int64_t)b->win_grid * WAVES + 1), dim3(256), 0, st, b->N, b->A, b->win_grid * WAVES, w, b->win_wave_atom);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
@@ -2212,8 +2216,8 @@ int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
   return CHG_OK;
 }
 
-int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
-                 const float* force_cotangent, const float* stress_cotangent, float* grad_blob) {
+static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                         const float* force_cotangent, const float* stress_cotangent, chg_comm* comm, float* grad_blob) {
   if (!eng || !b || !grad_blob) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
@@ -2250,11 +2254,52 @@ int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, c
   }
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
   TRY(second_order ? run_backward2(eng, b) : run_backward(eng, b));
+  if (comm) {   // data-parallel step: sum of the blob over the ranks, in HBM, on this stream
+    if (chg_comm_all_reduce_sum_f32_device(comm, b->t_grad, (int64_t)eng->desc.n_weights, eng->stream) != CHG_OK) {
+      eng->err = std::string("chg_backward_allreduce: ") + chg_comm_last_error(comm);
+      return CHG_EHIP;
+    }
+  }
   HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyDeviceToHost, eng->stream));
   TRY(chg_synchronize(eng));
   grad_blob[eng->w.mlp_b3 - eng->d_weights] = (float)g_b3;
   return CHG_OK;
 }
+
+int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                 const float* force_cotangent, const float* stress_cotangent, float* grad_blob) {
+  return backward_impl(eng, b, energy_cotangent, magmom_cotangent, force_cotangent, stress_cotangent, nullptr, grad_blob);
+}
+
+int chg_backward_allreduce(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                           const float* force_cotangent, const float* stress_cotangent, chg_comm* comm, float* grad_blob) {
+  return backward_impl(eng, b, energy_cotangent, magmom_cotangent, force_cotangent, stress_cotangent, comm, grad_blob);
+}
+
+int chg_batch_all_gather_energy(chg_engine* eng, chg_batch* b, chg_comm* comm, int64_t width, float* table) {
+  if (!eng || !b || !comm || !table || width < b->B) return CHG_EINVAL;
+  if (b->last_task == 0) { eng->err = "chg_batch_all_gather_energy: run chg_predict on this batch first"; return CHG_EINVAL; }
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  int32_t nranks = 1;
+  float* stage = nullptr;
+  if (chg_comm_info(comm, nullptr, &nranks, nullptr) != CHG_OK || chg_comm_reserve(comm, width * (int64_t)(nranks + 1), &stage) != CHG_OK) {
+    eng->err = std::string("chg_batch_all_gather_energy: ") + chg_comm_last_error(comm);
+    return CHG_EHIP;
+  }
+  hipStream_t st = eng->stream;
+  HIP_TRY(eng, hipMemsetAsync(stage, 0, sizeof(float) * (size_t)width, st));
+  HIP_TRY(eng, hipMemcpyAsync(stage, b->energy, sizeof(float) * (size_t)b->B, hipMemcpyDeviceToDevice, st));
+  if (chg_comm_all_gather_f32_device(comm, stage, width, stage + width, st) != CHG_OK) {
+    eng->err = std::string("chg_batch_all_gather_energy: ") + chg_comm_last_error(comm);
+    return CHG_EHIP;
+  }
+  HIP_TRY(eng, hipMemcpyAsync(table, stage + width, sizeof(float) * (size_t)width * nranks, hipMemcpyDeviceToHost, st));
+  HIP_TRY(eng, hipStreamSynchronize(st));
+  return CHG_OK;
+}
+
+void* chg_engine_stream(chg_engine* eng) { return eng ? static_cast<void*>(eng->stream) : nullptr; }
+int chg_engine_device(chg_engine* eng) { return eng ? eng->device : -1; }
 
 int chg_synchronize(chg_engine* eng) {
   if (!eng) return CHG_EINVAL;

@@ -145,39 +145,41 @@ struct ForceArgs {
   float* virial;              // [B,9] zeroed
 };
 
-// dE/dv of one directed edge: lengths enter only via the representative edge u2d[k]
-__device__ __forceinline__ void edge_gv(const ForceArgs& p, int e, float (&gv)[3], f32x4& vr) {
-  vr = p.ev[e];
-  const f32x4 u = p.eu[e];
-  const int k = p.e_d2u[e];
-  const float gr = (p.u_u2d[k] == e) ? p.Grk[k] : 0.f;
-  const f32x4 gu = *reinterpret_cast<const f32x4*>(p.Gu + 4 * (size_t)e);
-  const float dotp = gu[0] * u[0] + gu[1] * u[1] + gu[2] * u[2];
-  const float inv_r = 1.0f / vr[3];
-#pragma unroll
-  for (int k3 = 0; k3 < 3; ++k3) gv[k3] = gr * u[k3] + (gu[k3] - dotp * u[k3]) * inv_r;
-}
-
-// F_i = -sum_{c_e = i} gv_e + sum_{n_e = i} gv_e, and every edge with n_e = i is the reverse of an edge
-// with c_e = i, so each thread forms gv_rev(e) - gv_e for its own edge and the force is a segmented sum
-// over runs of equal centre (edges are centre-major): a wave-level segmented scan and one atomic per
-// run end replace 6 same-address atomics per edge.  Runs are delimited by head flags (lane 0 or a key
-// change), not by key equality alone, so hand-built graphs whose edges are not centre-major ([A,B,A])
-// stay correct: they only make the runs shorter.
+// F_i = -sum_{c_e = i} gv_e + sum_{n_e = i} gv_e with gv_e = dE/dv_e, and every edge with n_e = i is the reverse of an edge
+// with c_e = i, so each thread forms gv_rev(e) - gv_e for its own edge and the force is a segmented sum over runs of equal
+// centre (edges are centre-major): a wave-level segmented scan and one atomic per run end replace 6 same-address atomics
+// per edge.  Runs are delimited by head flags (lane 0 or a key change), not by key equality alone, so hand-built graphs whose
+// edges are not centre-major ([A,B,A]) stay correct: they only make the runs shorter.
+//
+// The reverse edge shares everything but the angular gradient with its partner (v_rev = -v, u_rev = -u, same length, same
+// undirected bond, and exactly one of the two is the bond's representative u2d[k] that carries dE/dr), so ONE random 16-byte
+// gather (Gu[e_rev]) replaces the three geometry rows and three index hops the first version re-read for it: 88 B per edge
+// instead of ~140, one gather instead of six.  The virial is reduced per workgroup through LDS (one atomic set per 256 edges
+// of a structure instead of one per wave).
 __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
+  __shared__ float vir[4][9];
+  __shared__ int vown[4];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool valid = e < p.n_edges;
   float gv[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   int owner = -1, key = -1;
   if (valid) {
-    f32x4 vr, vr2;
-    float gr2[3];
-    edge_gv(p, e, gv, vr);
-    edge_gv(p, p.e_rev[e], gr2, vr2);
+    const f32x4 vr = p.ev[e], u = p.eu[e];
+    const int k = p.e_d2u[e], er = p.e_rev[e];
+    const float grk = p.Grk[k];
+    const bool rep = p.u_u2d[k] == e;                      // lengths enter only via the representative edge of the bond
+    const float gr = rep ? grk : 0.f, gr_rev = rep ? 0.f : grk;
+    const f32x4 gu = *reinterpret_cast<const f32x4*>(p.Gu + 4 * (size_t)e);
+    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.Gu + 4 * (size_t)er);
+    const float dotp = gu[0] * u[0] + gu[1] * u[1] + gu[2] * u[2];
+    const float dotr = gw[0] * u[0] + gw[1] * u[1] + gw[2] * u[2];
+    const float inv_r = 1.0f / vr[3];
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3) {
-      d[k3] = gr2[k3] - gv[k3];
+      gv[k3] = gr * u[k3] + (gu[k3] - dotp * u[k3]) * inv_r;
+      const float gvr = -gr_rev * u[k3] + (gw[k3] - dotr * u[k3]) * inv_r;   // u_rev = -u: (gw - (gw.u_rev) u_rev) = gw - (gw.u) u
+      d[k3] = gvr - gv[k3];
       v[k3] = vr[k3];
     }
     owner = p.e_owner[e];
@@ -201,9 +203,10 @@ __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3) atomicAdd(p.force + 3 * (size_t)key + k3, d[k3]);
   }
-  // virial: dE/d eps[a][b] = sum_e v_e[a] * gv_e[b]; reduce across the wave when it sits in one structure
+  // virial: dE/d eps[a][b] = sum_e v_e[a] * gv_e[b]; wave sums when the wave sits in one structure, combined per workgroup
   const int first = __builtin_amdgcn_readfirstlane(owner);
   const bool uniform = __all(owner == first || owner < 0) != 0;
+  if (lane == 0) vown[wave] = uniform ? first : -2;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -211,11 +214,28 @@ __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
       const float t = v[a] * gv[b];
       if (uniform) {
         const float s = wave_sum(t);
-        if (lane == 0 && first >= 0) atomicAdd(p.virial + 9 * (size_t)first + 3 * a + b, s);
+        if (lane == 0) vir[wave][3 * a + b] = s;
       } else if (valid) {
         atomicAdd(p.virial + 9 * (size_t)owner + 3 * a + b, t);
       }
     }
+  __syncthreads();
+  if (threadIdx.x < 9) {   // waves of one structure leave as one atomic per component
+    const int c = threadIdx.x;
+    int cur = -2;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int o = vown[w];
+      if (o != cur) {
+        if (cur >= 0) atomicAdd(p.virial + 9 * (size_t)cur + c, s);
+        s = 0.f;
+        cur = o;
+      }
+      if (o >= 0) s += vir[w][c];
+    }
+    if (cur >= 0) atomicAdd(p.virial + 9 * (size_t)cur + c, s);
+  }
 }
 
 // ---- per-structure finalisation: energy normalisation, AtomRef, stress scaling ---------------------

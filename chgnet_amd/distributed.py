@@ -39,18 +39,90 @@ def shard_indices(costs: Sequence[float], world_size: int) -> list[list[int]]:
     return [sorted(s) for s in shards]
 
 
+def exchange_unique_id(rank: int, world: int, ident: bytes | None, *, addr: str | None = None, port: int | None = None,
+                       timeout_s: float = 120.0, nbytes: int = 128) -> bytes:
+    """Single-node rendezvous of the RCCL communicator: rank 0 hands its ``ncclUniqueId`` (``ident``, ``nbytes`` bytes) to every
+    other rank over a TCP socket on ``addr:port`` (default ``MASTER_ADDR`` : ``CHGNET_RCCL_PORT`` or ``MASTER_PORT + 1``, next to
+    the launcher's own store).  Nothing is left on disk and nothing can be stale: a rank that arrives early retries the
+    connection until rank 0 listens (any order, any delay up to ``timeout_s``), a rank that arrives late finds rank 0 still
+    accepting -- rank 0 serves until all ``world - 1`` peers have been answered.  Every peer introduces itself with a
+    launch token (``TORCHELASTIC_RUN_ID`` / ``CHGNET_RCCL_TOKEN``) and its rank; a connection from another job, a repeated rank
+    or a rank out of range is refused and does not count.  Returns the id (rank 0: ``ident`` itself)."""
+    import os  # noqa: PLC0415
+    import socket  # noqa: PLC0415
+    import struct  # noqa: PLC0415
+    import time  # noqa: PLC0415
+
+    if world <= 1:
+        if ident is None:
+            raise ValueError("exchange_unique_id: a single rank passes its own id")
+        return ident
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if port is None:
+        port = int(os.environ["CHGNET_RCCL_PORT"]) if "CHGNET_RCCL_PORT" in os.environ else int(os.environ.get("MASTER_PORT", "29500")) + 1
+    token = (os.environ.get("CHGNET_RCCL_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or "chgnet").encode()[:64].ljust(64, b"\0")
+    deadline = time.monotonic() + timeout_s
+    if rank == 0:
+        if ident is None or len(ident) != nbytes:
+            raise ValueError("exchange_unique_id: rank 0 passes the id")
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            served: set[int] = set()
+            while len(served) < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError(f"RcclComm rendezvous: {world - 1 - len(served)} of {world - 1} ranks did not connect to {addr}:{port}")
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                with conn:
+                    conn.settimeout(5.0)
+                    try:
+                        hello = _recv_exact(conn, 68)
+                    except (OSError, EOFError):
+                        continue
+                    peer = struct.unpack("<i", hello[64:])[0]
+                    if hello[:64] != token or not (0 < peer < world) or peer in served:
+                        continue                              # another job, or a repeated / impossible rank: not ours
+                    conn.sendall(ident)
+                    served.add(peer)
+        return ident
+    hello = token + struct.pack("<i", rank)
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=max(0.1, min(5.0, deadline - time.monotonic()))) as conn:
+                conn.sendall(hello)
+                return _recv_exact(conn, nbytes)
+        except (OSError, EOFError):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"RcclComm rendezvous: rank {rank} could not fetch the id from {addr}:{port}") from None
+            time.sleep(0.05)
+
+
+def _recv_exact(conn, n: int) -> bytes:
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise EOFError("connection closed")
+        buf += chunk
+    return buf
+
+
 class RcclComm:
     """One RCCL communicator per process through the engine library's own entry points (``chg_comm_*``): the multi-GPU
     path without ``torch.distributed``.  Rank / world size / device come from the launcher's environment
-    (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK``); rank 0's ``ncclUniqueId`` reaches the other ranks of the node through a
-    file named after ``MASTER_PORT`` (written atomically, removed by rank 0 on ``close``)."""
+    (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK``); rank 0's ``ncclUniqueId`` reaches the other ranks of the node over a TCP
+    socket (``exchange_unique_id``)."""
 
-    def __init__(self, rank: int | None = None, world: int | None = None, device: int | None = None, *, rendezvous_dir: str | None = None,
-                 timeout_s: float = 120.0) -> None:
+    def __init__(self, rank: int | None = None, world: int | None = None, device: int | None = None, *, timeout_s: float = 120.0,
+                 addr: str | None = None, port: int | None = None) -> None:
         import ctypes  # noqa: PLC0415
         import os  # noqa: PLC0415
-        import tempfile  # noqa: PLC0415
-        import time  # noqa: PLC0415
 
         from chgnet_amd import _lib  # noqa: PLC0415
 
@@ -60,33 +132,20 @@ class RcclComm:
         self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
         self.handle = ctypes.c_void_p()
         ident = (ctypes.c_uint8 * 128)()
-        self._id_file = None
-        if self.world > 1:
-            root = rendezvous_dir or tempfile.gettempdir()
-            path = os.path.join(root, f"chgnet_rccl_{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}.id")
-            if self.rank == 0:
-                self._check(self.lib.chg_comm_unique_id(ident))
-                with open(path + ".tmp", "wb") as fh:
-                    fh.write(bytes(ident))
-                os.replace(path + ".tmp", path)
-                self._id_file = path
-            else:
-                started = time.time()
-                deadline = started + timeout_s
-                # a file left behind by a run that died is older than this process by more than the launcher's spread
-                while not (os.path.exists(path) and os.path.getmtime(path) >= started - 30.0):
-                    if time.time() > deadline:
-                        raise TimeoutError(f"RcclComm: rank 0 did not publish {path}")
-                    time.sleep(0.01)
-                with open(path, "rb") as fh:
-                    ident = (ctypes.c_uint8 * 128).from_buffer_copy(fh.read(128))
-        else:
+        if self.rank == 0:
             self._check(self.lib.chg_comm_unique_id(ident))
+        raw = exchange_unique_id(self.rank, self.world, bytes(ident) if self.rank == 0 else None, addr=addr, port=port, timeout_s=timeout_s)
+        ident = (ctypes.c_uint8 * 128).from_buffer_copy(raw)
         self._check(self.lib.chg_comm_create(ident, self.rank, self.world, self.device, ctypes.byref(self.handle)))
         self.barrier()
-        if self._id_file:                      # every rank has read it once the first barrier is through
-            os.remove(self._id_file)
-            self._id_file = None
+
+    def info(self) -> dict:
+        """What RCCL reports for this communicator: ``{"rank", "nranks" (ncclCommCount), "device"}``."""
+        import ctypes  # noqa: PLC0415
+
+        r, n, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self.lib.chg_comm_info(self.handle, ctypes.byref(r), ctypes.byref(n), ctypes.byref(d)))
+        return {"rank": int(r.value), "nranks": int(n.value), "device": int(d.value)}
 
     def _check(self, status: int) -> None:
         if status != 0:

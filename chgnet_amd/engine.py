@@ -197,10 +197,11 @@ class Engine:
         """Enqueue E(+F,S,M) for the batch on the engine stream (asynchronous)."""
         self._check(self.lib.chg_predict(self.handle, batch.handle, _lib.task_mask(task)))
 
-    def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None, f_grad=None, s_grad=None) -> np.ndarray:
+    def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None) -> np.ndarray:
         """Gradient blob (weight-blob layout) of ``sum e_grad*e + sum m_grad*m + sum f_grad.f + sum s_grad:s`` after
         ``predict`` on ``batch`` (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names.
-        ``f_grad`` [N,3] / ``s_grad`` [B,3,3] switch to the second-order sweep."""
+        ``f_grad`` [N,3] / ``s_grad`` [B,3,3] switch to the second-order sweep.  ``comm`` (an ``RcclComm``): the blob is
+        summed over the ranks in HBM on the engine's stream before it comes to the host (chg_backward_allreduce)."""
         pb = batch.packed
         grad = np.zeros(self.weights.blob.size, np.float32)
 
@@ -217,8 +218,18 @@ class Engine:
         fcot = arg(f_grad, 3 * pb.n_atoms, "f_grad")
         scot = arg(s_grad, 9 * pb.n_struct, "s_grad")
         ptr = lambda a: _fp(a) if a is not None else None  # noqa: E731
-        self._check(self.lib.chg_backward(self.handle, batch.handle, ptr(cot), ptr(mcot), ptr(fcot), ptr(scot), _fp(grad)))
+        if comm is not None and getattr(comm, "world", 1) > 1:
+            self._check(self.lib.chg_backward_allreduce(self.handle, batch.handle, ptr(cot), ptr(mcot), ptr(fcot), ptr(scot), comm.handle, _fp(grad)))
+        else:
+            self._check(self.lib.chg_backward(self.handle, batch.handle, ptr(cot), ptr(mcot), ptr(fcot), ptr(scot), _fp(grad)))
         return grad
+
+    def all_gather_energy(self, batch: DeviceBatch, comm, width: int) -> np.ndarray:
+        """[nranks, width] table of the per-structure energies of every rank's batch (zero-padded to ``width``), gathered
+        from HBM on the engine's stream (chg_batch_all_gather_energy).  After ``predict``."""
+        table = np.empty(comm.world * int(width), np.float32)
+        self._check(self.lib.chg_batch_all_gather_energy(self.handle, batch.handle, comm.handle, int(width), _fp(table)))
+        return table.reshape(comm.world, int(width))
 
     def update_weights(self, weights: PackedWeights) -> None:
         """Replace the parameter values (optimizer step); same architecture / blob layout."""

@@ -205,13 +205,14 @@ class CHGNet:
 
     __call__ = forward
 
-    def backward(self, e_grad=None, m_grad=None, f_grad=None, s_grad=None) -> dict:
+    def backward(self, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None) -> dict:
         """Parameter gradients of ``sum_b e_grad[b] e[b] + sum_i m_grad[i] m[i] + sum_i f_grad[i].f[i] + sum_b s_grad[b]:s[b]``
         for the batch of the last ``forward`` call -- the cotangents are d loss / d prediction as ``CombinedLoss.gradients``
         returns them (``e_grad`` defaults to ones, the others to none; ``f_grad`` [N,3] over all atoms of the batch,
         ``s_grad`` [B,3,3]).  Returns ``{state_dict key: float32 array}``: what ``loss.backward()`` leaves in ``param.grad``
         in the reference's train step (trainer.py:399-411).  AtomRef is frozen (model.py:179-182): zeros.  Force / stress
-        terms run the second-order sweep (one tangent pass + a two-adjoint reverse pass)."""
+        terms run the second-order sweep (one tangent pass + a two-adjoint reverse pass).  ``comm`` (``RcclComm``): the
+        gradients are SUMMED over the ranks on the device before they are returned."""
         from chgnet_amd.pack import unpack_weight_grads  # noqa: PLC0415
 
         batch = getattr(self, "_fwd_batch", None)
@@ -219,7 +220,7 @@ class CHGNet:
             raise RuntimeError("backward() needs the device state of a preceding forward() call")
         if any(k.endswith("mlp_out.layers.1.bias") for k in self._state_dict):
             raise NotImplementedError("parameter gradients are not implemented for models with mlp_out bias (0.2.0)")
-        return unpack_weight_grads(self.engine.backward(batch, e_grad, m_grad, f_grad, s_grad), self._weights)
+        return unpack_weight_grads(self.engine.backward(batch, e_grad, m_grad, f_grad, s_grad, comm=comm), self._weights)
 
     def load_state_dict(self, state_dict: dict) -> None:
         """New parameter values (same keys and shapes), e.g. after an optimizer step; the engine is updated in place."""

@@ -163,6 +163,17 @@ int chg_synchronize(chg_engine* eng);
  * currently unfused.  Overwrites the batch's gradient workspace: download forces / stress before calling. */
 int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent,
                  const float* force_cotangent, const float* stress_cotangent, float* grad_blob);
+/* The same, for a data-parallel step: the gradient blob is summed over the ranks of `comm` (ncclAllReduce on the engine's
+ * stream, in HBM) before it is copied to the host -- every rank receives the summed blob.  comm = NULL: chg_backward. */
+struct chg_comm;
+int chg_backward_allreduce(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent,
+                           const float* force_cotangent, const float* stress_cotangent, struct chg_comm* comm, float* grad_blob);
+/* All-gather of the batch's per-structure energies (after chg_predict) from HBM on the engine's stream: every rank
+ * contributes `width` floats (its n_struct energies, zero-padded), table: host [nranks * width] in rank order. */
+int chg_batch_all_gather_energy(chg_engine* eng, chg_batch* batch, struct chg_comm* comm, int64_t width, float* table);
+/* The engine's HIP stream (a hipStream_t) and device ordinal, for callers that enqueue their own device work behind it. */
+void* chg_engine_stream(chg_engine* eng);
+int chg_engine_device(chg_engine* eng);
 /* New parameter values for an existing engine (optimizer step): same blob layout and length as at creation. */
 int chg_engine_update_weights(chg_engine* eng, const float* weights_blob);
 int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* out);
@@ -194,7 +205,7 @@ int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const f
  * energies after a sweep sharded over independent structures, and the sum of the 412,525-float parameter gradient of a
  * data-parallel train step (the slot is loss.backward() -> optimizer.step(), chgnet/trainer/trainer.py:399-411).
  * librccl is opened at run time (CHG_EUNSUPPORTED when it is missing).  Rank 0 calls chg_comm_unique_id and hands the
- * CHG_COMM_ID_BYTES bytes to the other ranks by any means (chgnet_amd/distributed.py uses a file next to MASTER_PORT);
+ * CHG_COMM_ID_BYTES bytes to the other ranks by any means (chgnet_amd/distributed.py uses a TCP socket on MASTER_ADDR);
  * every rank then calls chg_comm_create.  Buffers are HOST pointers; counts are per rank; all calls block until done.
  * all_gather: recv holds world * count floats in rank order. */
 #define CHG_COMM_ID_BYTES 128
@@ -203,6 +214,12 @@ int chg_comm_unique_id(uint8_t* id_out);
 int chg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, chg_comm** out);
 int chg_comm_all_gather_f32(chg_comm* comm, const float* send, int64_t count, float* recv);
 int chg_comm_all_reduce_sum_f32(chg_comm* comm, float* data, int64_t count);
+/* Device-pointer forms, enqueued on `stream` (a hipStream_t, e.g. chg_engine_stream) without synchronisation: the two
+ * exchange steps of the path act on buffers that already live in HBM (per-structure energies, the gradient blob). */
+int chg_comm_all_gather_f32_device(chg_comm* comm, const float* d_send, int64_t count, float* d_recv, void* stream);
+int chg_comm_all_reduce_sum_f32_device(chg_comm* comm, float* d_data, int64_t count, void* stream);
+int chg_comm_reserve(chg_comm* comm, int64_t floats, float** device_ptr);   /* grow-only device staging of the communicator */
+int chg_comm_info(chg_comm* comm, int32_t* rank, int32_t* nranks, int32_t* device);   /* nranks = ncclCommCount */
 int chg_comm_barrier(chg_comm* comm);
 int chg_comm_destroy(chg_comm* comm);
 const char* chg_comm_last_error(const chg_comm* comm);   /* NULL: the error of the last failed call without a communicator */

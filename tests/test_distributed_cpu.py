@@ -101,3 +101,64 @@ def test_sharding_accepts_structures_without_graphs():
     shards = shard_indices(costs, 2)
     loads = [sum(costs[i] for i in sh) for sh in shards]
     assert abs(loads[0] - loads[1]) <= max(costs)
+
+
+# ---- RcclComm rendezvous (chgnet_amd/distributed.py:exchange_unique_id): real processes, no GPU --------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rdv_worker(rank: int, world: int, port: int, delay: float, token: str, q):
+    import time
+
+    sys.path.insert(0, REPO)
+    os.environ["CHGNET_RCCL_TOKEN"] = token
+    from chgnet_amd.distributed import exchange_unique_id
+
+    time.sleep(delay)
+    ident = bytes(range(128)) if rank == 0 else None
+    try:
+        got = exchange_unique_id(rank, world, ident, addr="127.0.0.1", port=port, timeout_s=20.0)
+        q.put((rank, got == bytes(range(128))))
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, repr(exc)))
+
+
+@pytest.mark.parametrize("delays", [(0.0, 1.5, 0.0), (1.5, 0.0, 0.2)], ids=["peers_late", "rank0_late"])
+def test_rccl_rendezvous_any_arrival_order(delays):
+    """Three ranks, staggered by more than a second either way: every rank ends up with rank 0's 128 bytes.  (The file
+    rendezvous of round 2 rejected ids older than 30 s and accepted ids a crashed run left behind.)"""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_rdv_worker, args=(r, 3, port, delays[r], "job-a", q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res == {0: True, 1: True, 2: True}, res
+
+
+def test_rccl_rendezvous_ignores_other_jobs_and_times_out():
+    """A peer of ANOTHER launch (different token) on the same port is refused and does not count as a rank; without rank 0 a
+    peer gives up with TimeoutError instead of hanging."""
+    from chgnet_amd.distributed import exchange_unique_id
+
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    stranger = ctx.Process(target=_rdv_worker, args=(1, 2, port, 0.0, "job-b", q))      # wrong token: never served
+    mine = [ctx.Process(target=_rdv_worker, args=(r, 2, port, 0.3 * r, "job-a", q)) for r in range(2)]
+    stranger.start()
+    for p in mine:
+        p.start()
+    first = dict(q.get(timeout=60) for _ in range(2))
+    assert first == {0: True, 1: True}, first
+    stranger.join(timeout=40)                                                           # runs into its own timeout
+    late = q.get(timeout=40)
+    assert late[0] == 1 and "TimeoutError" in str(late[1]), late
+    for p in mine:
+        p.join(timeout=30)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, None, addr="127.0.0.1", port=_free_port(), timeout_s=0.5)
