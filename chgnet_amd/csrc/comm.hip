@@ -3,8 +3,7 @@
 // (reference: none -- chgnet is single-device; trainer.py:399-411 is the step the all-reduce slots into).
 //
 // One communicator per process = per GPU.  librccl is opened at run time (dlopen): the engine library keeps loading on
-// machines without RCCL, and a process that already has torch's bundled librccl mapped reuses THAT copy instead of
-// mapping a second one.  Rendezvous (handing rank 0's ncclUniqueId to the other ranks) is the caller's job -- the
+// machines without RCCL; the copy next to the HIP runtime in use is preferred (see rccl()).  Rendezvous (handing rank 0's ncclUniqueId to the other ranks) is the caller's job -- the
 // Python host side does it over a TCP socket on MASTER_ADDR (chgnet_amd/distributed.py), a launcher may use anything.
 //
 // The handful of RCCL types used here are declared locally (they are ABI-stable NCCL 2 types): the engine library builds on
@@ -40,12 +39,22 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r = [] {
     Rccl x;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)   // a copy that is already mapped (torch's) first
-      if ((x.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
-    for (const char* n : names) {
-      if (x.handle) break;
-      x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    // RCCL must sit on the HIP runtime this library runs on.  A process that imported torch FIRST runs on torch's bundled
+    // runtime (the loader resolved libamdhip64 to the copy already mapped) and must use torch's bundled librccl; one that
+    // loaded this library first runs on the system runtime, and a torch imported later only ADDS its librccl to the process --
+    // picking that copy up by name gave "ncclCommInitRank: unhandled cuda error" (two ROCm releases in one call chain).
+    std::string beside;
+    Dl_info hip_at{};
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &hip_at) && hip_at.dli_fname) {
+      beside = hip_at.dli_fname;
+      const size_t slash = beside.rfind('/');
+      beside = slash == std::string::npos ? std::string() : beside.substr(0, slash);
+    }
+    const std::string candidates[] = {beside.empty() ? std::string() : beside + "/librccl.so.1", beside.empty() ? std::string() : beside + "/librccl.so",
+                                      "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    for (const std::string& n : candidates) {
+      if (n.empty()) continue;
+      if ((x.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
     }
     if (!x.handle) { x.error = std::string("librccl not found: ") + dlerror(); return x; }
     auto sym = [&](const char* s) { void* p = dlsym(x.handle, s); if (!p && x.error.empty()) x.error = std::string("librccl lacks ") + s; return p; };

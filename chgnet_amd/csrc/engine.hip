@@ -743,6 +743,8 @@ void register_names(chg_batch* b) {
   mi["e_rev"] = {b->e_rev, Ed}; mi["p_center"] = {b->p_center, Ed}; mi["p_nbr"] = {b->p_nbr, Ed};
   mi["u_u2d"] = {b->u_u2d, Eu}; mi["u_bnode"] = {b->u_bnode, Eu}; mi["bn_und"] = {b->bn_und, Eb};
   mi["a_ctr"] = {b->a_ctr, A}; mi["a_b1c"] = {b->a_b1c, A}; mi["a_b2c"] = {b->a_b2c, A}; mi["a_d1"] = {b->a_d1, A}; mi["a_d2"] = {b->a_d2, A};
+  mi["win_flag"] = {b->win.flag, 4}; mi["win_q_a"] = {b->win.q_a, A}; mi["win_q_ctr"] = {b->win.q_ctr, A}; mi["win_na"] = {b->win.na, N + 1};
+  mi["win_aoff"] = {b->win.aoff, N + 1}; mi["win_q_ab1"] = {b->win.q_ab1, A}; mi["win_q_ab2"] = {b->win.q_ab2, A};
 }
 
 template <class T>

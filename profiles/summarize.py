@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 LABELS = {  # kernel-name substring -> bench.py label
     "k_angle<true, true": "bondconv_bwd", "k_angle<true, false": "bondconv_fwd",
-    "k_angle<false, true": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",
+    "k_angle_bwd_w<false": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",   # (the plain k_angle<false, true> launch returns at once)
     "k_atomconv_bwd": "atomconv_bwd", "k_atomconv_fwd": "atomconv_fwd",
 }
 

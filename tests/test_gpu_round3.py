@@ -1,0 +1,142 @@
+"""Round-3 GPU tests: the per-atom AngleUpdate adjoint (csrc/kernels_angle_w.h) and the multi-GPU entry points on one rank.
+
+All through the C-ABI (ctypes).  The per-atom path needs a batch that gives every wave a few atoms (>= ~12k atoms on
+256 CUs); smaller batches -- every other GPU test -- run the plain adjoint."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_STRUCT = 384          # x 40 atoms = 15,360 atoms: enough for the per-atom order on a 256-CU device
+
+
+def _reordered(pb, perm):
+    from chgnet_amd.pack import PackedBatch
+
+    arr = dict(pb.arrays)
+    for k in ("a_ctr", "a_b1", "a_d1", "a_b2", "a_d2", "a_b1c", "a_b2c"):
+        arr[k] = np.ascontiguousarray(arr[k][perm])
+    return PackedBatch(pb.n_struct, pb.n_atoms, pb.n_directed, pb.n_undirected, pb.n_angles, pb.n_bnodes, arr)
+
+
+@pytest.fixture(scope="module")
+def big_batch():
+    import bench
+    from chgnet_amd.pack import pack_batch
+
+    return pack_batch(bench.build_workload(N_STRUCT, 7000))
+
+
+def test_per_atom_index_is_a_permutation_with_the_block_structure(hip_engine, big_batch):
+    """k_win_*: centre-major row order built on the device -- a bijection of the angles, rows of one atom contiguous and
+    complete (n (n - 1) rows for n short bonds), (atom, bond) pair indices consistent with the compact bond indices."""
+    pb = big_batch
+    batch = hip_engine.upload(pb)
+    try:
+        A, N = pb.n_angles, pb.n_atoms
+        flag = hip_engine.debug_fetch_i32(batch, "win_flag", 4)
+        assert flag[0] == 1, "canonical reference-ordered graphs must take the per-atom path at this size"
+        q_a = hip_engine.debug_fetch_i32(batch, "win_q_a", A)
+        q_ctr = hip_engine.debug_fetch_i32(batch, "win_q_ctr", A)
+        na = hip_engine.debug_fetch_i32(batch, "win_na", N + 1)[:N]
+        aoff = hip_engine.debug_fetch_i32(batch, "win_aoff", N + 1)
+        ab1 = hip_engine.debug_fetch_i32(batch, "win_q_ab1", A)
+        ab2 = hip_engine.debug_fetch_i32(batch, "win_q_ab2", A)
+        assert np.array_equal(np.sort(q_a), np.arange(A))
+        assert np.array_equal(q_ctr, pb.a_ctr[q_a]) and np.all(np.diff(q_ctr) >= 0)
+        assert np.array_equal(np.diff(aoff), na * (na - 1)) and aoff[-1] == A
+        assert np.array_equal(np.bincount(pb.a_ctr, minlength=N), na * (na - 1))
+        boff = np.concatenate([[0], np.cumsum(na)])
+        r1, r2 = ab1 - boff[q_ctr], ab2 - boff[q_ctr]
+        assert r1.min() >= 0 and (r1 < na[q_ctr]).all() and r2.min() >= 0 and (r2 < na[q_ctr]).all() and (r1 != r2).all()
+        # one pair index <-> one compact bond per atom
+        for ab, bc in ((ab1, pb.a_b1c[q_a]), (ab2, pb.a_b2c[q_a])):
+            first = {}
+            sample = np.random.default_rng(0).choice(A, 20000, replace=False)
+            for i in sample:
+                assert first.setdefault(int(ab[i]), int(bc[i])) == int(bc[i])
+    finally:
+        batch.free()
+
+
+def test_per_atom_adjoint_equals_the_plain_adjoint(hip_engine, big_batch):
+    """The same batch with its angle rows shuffled inside every structure has no group structure: the device clears the flag
+    and the plain adjoint runs.  Forces / stress of the two paths agree to fp32 reassociation."""
+    pb = big_batch
+    rng = np.random.default_rng(3)
+    off = pb.ang_off
+    perm = np.concatenate([off[b] + rng.permutation(off[b + 1] - off[b]) for b in range(pb.n_struct)])
+    out = []
+    for p, want_flag in ((pb, 1), (_reordered(pb, perm), 0)):
+        batch = hip_engine.upload(p)
+        try:
+            hip_engine.predict(batch, "efs")
+            out.append(hip_engine.download(batch, "efs"))
+            assert hip_engine.debug_fetch_i32(batch, "win_flag", 4)[0] == want_flag
+        finally:
+            batch.free()
+    a, b = out
+    assert np.isfinite(a["f"]).all() and np.abs(a["f"]).max() > 1e-3
+    assert np.abs(a["e"] - b["e"]).max() < 2e-6
+    assert np.abs(a["f"] - b["f"]).max() < 2e-6
+    assert np.abs(a["s"] - b["s"]).max() < 2e-5
+
+
+def test_per_atom_adjoint_matches_the_oracle(hip_engine, golden_weights, big_batch):
+    """A few structures of the big batch against the CPU oracle (the other GPU parity tests run batches too small to take
+    the per-atom path)."""
+    import bench
+    import torch
+
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    pb = big_batch
+    batch = hip_engine.upload(pb)
+    try:
+        hip_engine.predict(batch, "efs")
+        res = hip_engine.download(batch, "efs")
+    finally:
+        batch.free()
+    torch.set_num_threads(8)
+    oracle = OracleCHGNet(golden_weights)
+    graphs = bench.build_workload(N_STRUCT, 7000)
+    o = pb.atom_off
+    for i in (0, N_STRUCT // 2, N_STRUCT - 1):
+        ref = oracle.predict_graph(graphs[i], "efs")
+        assert abs(res["e"][i] - ref["e"]) < 5e-6
+        assert np.abs(res["f"][o[i]:o[i + 1]] - ref["f"]).max() < 1e-5
+        assert np.abs(res["s"][i] - ref["s"]).max() < 1e-4
+
+
+def test_device_pointer_collectives_on_one_rank(hip_engine, golden_weights):
+    """chg_batch_all_gather_energy / chg_backward_allreduce / chg_comm_info through a one-rank RCCL communicator: the table is
+    the batch's energies zero-padded to the width, the all-reduced gradient is the plain one, ncclCommCount says 1."""
+    from chgnet_amd.distributed import RcclComm
+    from conftest import load_case
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    comm = RcclComm(0, 1, 0)
+    try:
+        assert comm.info() == {"rank": 0, "nranks": 1, "device": 0}
+        batch = hip_engine.upload(graphs)
+        try:
+            hip_engine.predict(batch, "efs")
+            res = hip_engine.download(batch, "efs")
+            table = hip_engine.all_gather_energy(batch, comm, 8)
+            assert table.shape == (1, 8) and np.array_equal(table[0, :3], res["e"]) and not table[0, 3:].any()
+            cot = np.array([0.5, -1.0, 2.0], np.float32)
+            plain = hip_engine.backward(batch, cot)
+            comm.world = 2                      # route through chg_backward_allreduce (the communicator still has one rank)
+            try:
+                reduced = hip_engine.backward(batch, cot, comm=comm)
+            finally:
+                comm.world = 1
+            scale = float(np.abs(plain).max())      # two sweeps differ by fp32 reassociation (atomics), nothing else
+            assert scale > 0 and np.abs(plain - reduced).max() <= 1e-4 * scale
+        finally:
+            batch.free()
+    finally:
+        comm.close()

@@ -1,0 +1,135 @@
+"""Numerics of the split-precision contractions (csrc/mfma_split.h) on the float64 pipeline model (oracle/staged_ref.py):
+every per-row GEMM of the six tile kernels is replaced by its f16 hi/lo emulation -- operands split as the kernels split them
+(round-to-nearest f16 high half, low half scaled by 2^11, adjoint rows scaled per row by a power of two), products
+xh.wh + xl.wh + xh.wl accumulated in float32 -- while everything else stays float64, so the difference to the unmodified model
+is the error the split contractions ADD.  CPU only; the hardware side is tools/split_lab.hip (T1-T4) and the GPU parity suite.
+
+Pinned here:
+  * the added error at trained-checkpoint magnitudes is an order below the float32 pipeline's own rounding error
+    (and far below the north-star bars 1e-4 eV / 1e-3 eV/A),
+  * without the per-row scaling of the adjoint operands the force error is several times larger -- why SCALED exists."""
+
+from __future__ import annotations
+
+import inspect
+import textwrap
+
+import numpy as np
+import pytest
+
+import oracle.staged_ref as sr
+from chgnet_amd.pack import pack_batch, pack_weights
+from conftest import load_case
+from oracle.staged_ref import StagedModel, dsilu, ln_bwd, ln_fwd, sigmoid, silu
+
+LO_SCALE = 2048.0
+
+
+def _split(x, scale_rows):
+    x = np.ascontiguousarray(x, np.float32)
+    s = np.float32(1)
+    if scale_rows:
+        m = np.abs(x).max(1, keepdims=True)
+        m[m == 0] = 1
+        s = np.exp2(-np.floor(np.log2(m))).astype(np.float32)
+    xs = x * s
+    hi = xs.astype(np.float16).astype(np.float32)
+    lo = ((xs - hi) * np.float32(LO_SCALE)).astype(np.float16).astype(np.float32)
+    return hi, lo, s
+
+
+def split_matmul(X, Wt, scaled):
+    """X [rows, K] . Wt[F, K]^T like gemm_split<.., SCALED>: float32 accumulation of the three f16 products."""
+    xh, xl, s = _split(X, scaled)
+    wh, wl, _ = _split(Wt, False)
+    acc = (xl @ wh.T + xh @ wl.T) * np.float32(1.0 / LO_SCALE) + xh @ wh.T
+    return (acc / s).astype(np.float64)
+
+
+class SplitModel(StagedModel):
+    scale_adjoint = True
+
+    def gated_fwd(self, z, p, hidden):
+        W, D = self.W, 64
+        if hidden:
+            H = silu(z)
+            c = split_matmul(H[:, :D], W(p + "w2c"), False) + W(p + "b2c")
+            g = split_matmul(H[:, D:], W(p + "w2g"), False) + W(p + "b2g")
+        else:
+            H, c, g = None, z[:, :D], z[:, D:]
+        n1, xh1, rs1 = ln_fwd(c, W(p + "ln1_g"), W(p + "ln1_b"))
+        n2, xh2, rs2 = ln_fwd(g, W(p + "ln2_g"), W(p + "ln2_b"))
+        a1, a2 = silu(n1), sigmoid(n2)
+        return a1 * a2, (z, H, n1, xh1, rs1, n2, xh2, rs2, a1, a2)
+
+    def gated_bwd(self, gy, cache, p, hidden, wg=None):
+        W, D = self.W, 64
+        z, H, n1, xh1, rs1, n2, xh2, rs2, a1, a2 = cache
+        gc = ln_bwd(gy * a2 * dsilu(n1), W(p + "ln1_g"), xh1, rs1)
+        gg = ln_bwd(gy * a1 * a2 * (1 - a2), W(p + "ln2_g"), xh2, rs2)
+        if hidden:
+            sc = self.scale_adjoint
+            gH = np.concatenate([split_matmul(gc, W(p + "w2c").T, sc), split_matmul(gg, W(p + "w2g").T, sc)], axis=1)
+            return gH * dsilu(z)
+        return np.concatenate([gc, gg], axis=1)
+
+
+def _patched_run():
+    """StagedModel.run with the two angle-block contractions routed through split_matmul (the source is patched textually so
+    that the test follows the pipeline model instead of duplicating it)."""
+    src = textwrap.dedent(inspect.getsource(StagedModel.run))
+    fwd, bwd = 'ang[l] @ W(p + "w_ang").T', 'Gang[:] += Gz @ W(p + "w_ang")'
+    assert src.count(fwd) == 2 and src.count(bwd) == 1
+    src = src.replace(fwd, 'split_matmul(ang[l], W(p + "w_ang"), False)').replace(bwd, 'Gang[:] += split_matmul(Gz, W(p + "w_ang").T, self.scale_adjoint)')
+    ns = dict(sr.__dict__)
+    ns["split_matmul"] = split_matmul
+    exec(src, ns)  # noqa: S102
+    return ns["run"]
+
+
+SplitModel.run = _patched_run()
+
+
+@pytest.fixture(scope="module")
+def tl_case(trained_like_weights):
+    pw = pack_weights(trained_like_weights)
+    pb = pack_batch([load_case(n)[0] for n in ("limno2", "s16tri", "li9co7o16")])
+    return pw, pb, StagedModel(pw, np.float64).run(pb)
+
+
+def _errs(got, ref):
+    return {k: float(np.abs(got[k] - ref[k]).max()) for k in ("e", "f", "s")}
+
+
+def test_split_contractions_add_less_than_the_f32_pipeline_itself(tl_case):
+    pw, pb, ref = tl_case
+    f32 = _errs(StagedModel(pw, np.float32).run(pb), ref)                # everything in float32: the engine's own error class
+    add = _errs(SplitModel(pw, np.float64).run(pb), ref)                 # float64 everywhere except the split contractions
+    assert np.abs(ref["f"]).max() > 2.0                                   # eV/A-scale forces: the regime the bars are meant for
+    assert add["e"] < 1e-6 and add["f"] < 5e-6 and add["s"] < 5e-5, add   # north star: 1e-4 eV, 1e-3 eV/A
+    assert add["f"] < 0.35 * f32["f"] and add["s"] < 0.35 * f32["s"], (add, f32)
+
+
+def test_row_scale_keeps_small_adjoint_rows_exact_and_is_neutral_otherwise(tl_case):
+    """Adjoint rows can be arbitrarily small (far atoms, saturated gates).  With the low half carried at 2^11 the split holds
+    its precision down to |x| ~ 1e-7 without any row scale (the pipeline result is the same either way), below that the f16 high
+    half underflows; the power-of-two row scale (SCALED) removes the floor."""
+    pw, pb, ref = tl_case
+    scaled = _errs(SplitModel(pw, np.float64).run(pb), ref)
+    m = SplitModel(pw, np.float64)
+    m.scale_adjoint = False
+    unscaled = _errs(m.run(pb), ref)
+    assert abs(unscaled["e"] - scaled["e"]) < 1e-9 and unscaled["f"] < 2.0 * scaled["f"] + 1e-7
+    rng = np.random.default_rng(0)
+    W = rng.normal(0, 0.3, (64, 64))
+    for mag, worst_unscaled in ((1e-3, 1e-6), (1e-10, None)):
+        X = rng.normal(0, mag, (256, 64))
+        exact = X @ W.T
+        denom = np.abs(X) @ np.abs(W).T
+        err_s = (np.abs(split_matmul(X, W, True) - exact) / denom).max()
+        err_u = (np.abs(split_matmul(X, W, False) - exact) / denom).max()
+        assert err_s < 3e-7, (mag, err_s)
+        if worst_unscaled is None:
+            assert err_u > 1e-3, (mag, err_u)              # 1e-10 rows: the unscaled f16 halves are all subnormal
+        else:
+            assert err_u < worst_unscaled, (mag, err_u)
