@@ -440,12 +440,13 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   return a;
 }
 
-// Which adjoints run per atom (kernels_angle_w.h).  AngleUpdate: 2.23 -> 1.60 ms.  BondConv: its f32 weights leave no LDS for
-// private rows of the bond-weight gradients and it stays bound by the f32 matrix pipe either way (3.99 vs 3.48 ms): plain kernel.
-// CHGNET_PER_ATOM_BONDCONV=1 switches it on for A/B timing.
+// Which adjoints run per atom (kernels_angle_w.h): both.  AngleUpdate 2.23 -> 1.60 ms; BondConv 3.44 -> 3.03 ms once all of its
+// contractions run in split precision from row-major images.  CHGNET_PER_ATOM_BONDCONV=0 / CHGNET_PER_ATOM_ANGLEUPD=0 switch back to
+// the plain kernels for A/B timing.
 static bool per_atom_adjoint(bool hidden) {
-  static const bool bc = [] { const char* e = std::getenv("CHGNET_PER_ATOM_BONDCONV"); return e && std::atoi(e) != 0; }();
-  return !hidden || bc;
+  static const bool bc = [] { const char* e = std::getenv("CHGNET_PER_ATOM_BONDCONV"); return !e || std::atoi(e) != 0; }();
+  static const bool au = [] { const char* e = std::getenv("CHGNET_PER_ATOM_ANGLEUPD"); return !e || std::atoi(e) != 0; }();
+  return hidden ? bc : au;
 }
 
 template <bool HIDDEN, bool BWD, int NW = WAVES>

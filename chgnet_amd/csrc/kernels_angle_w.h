@@ -129,15 +129,17 @@ struct AngleWArgs {
   const int* wave_atom;       // [gridDim.x * WAVES + 1] first atom of every wave (k_win_partition)
 };
 
-// Private second-bond rows per wave.  AngleUpdate: dE/dR_j (128 wide), 14 rows.  BondConv: the angle block runs in split
-// precision like everywhere else (its two images, 64 KiB), the hidden layer keeps the f32 form (its four images would be
-// another 64 KiB), and what LDS is left holds the bond-weight gradients (64 wide), 12 rows; dE/dR_j then leaves as row atomics.
-template <bool HIDDEN> constexpr int win_ns() { return HIDDEN ? 12 : 14; }
-template <bool HIDDEN> constexpr int win_pst() { return HIDDEN ? D : 2 * D; }   // stride of a private row (floats)
+// Private second-bond rows per wave: dE/dR_j (128 wide).  AngleUpdate: the angle block as two split images (64 KiB), 14 rows.
+// BondConv: ALL contractions in split precision from ONE row-major image per matrix (mfma_split.h: 72 KiB for the angle block and
+// the hidden layer, both directions -- the two-image form would need 128 KiB), 13 rows; the bond-weight gradients of the second
+// bond leave as one atomic row per angle (no LDS left for private rows of theirs).
+template <bool HIDDEN> constexpr int win_ns() { return HIDDEN ? 13 : 14; }
+template <bool HIDDEN> constexpr int win_pst() { return 2 * D; }   // stride of a private row (floats)
+constexpr size_t WIN_RM_ANG = rm_image_bytes(2 * D, D), WIN_RM_W2 = rm_image_bytes(D, D);
 
 template <bool HIDDEN>
 constexpr size_t angle_w_lds() {
-  const size_t weights = 16 * (size_t)(2 * IMG128) + (HIDDEN ? sizeof(float) * (2 * D * WS) : 0);
+  const size_t weights = HIDDEN ? WIN_RM_ANG + 2 * WIN_RM_W2 : 16 * (size_t)(2 * IMG128);
   return weights + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE64_FLOATS + WAVES * win_ns<HIDDEN>() * win_pst<HIDDEN>());
 }
 
@@ -229,20 +231,24 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
   if (w.flag[0] != 1) return;                   // this batch runs the plain adjoint (k_angle<.., true>)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NS = win_ns<HIDDEN>(), PST = win_pst<HIDDEN>();
-  float* Wang = smem;                           // split images of W_ang and W_ang^T
-  float* WangT = Wang + 4 * IMG128;
-  float* W2c = WangT + 4 * IMG128;              // BondConv: hidden layer in the f32 form [64][WS] x 2
-  float* W2g = W2c + (HIDDEN ? D * WS : 0);
-  float* vecs = W2g + (HIDDEN ? D * WS : 0);
+  // AngleUpdate: split images of W_ang and W_ang^T.  BondConv: row-major images of W_ang, W2c, W2g (each serves both directions).
+  constexpr int MODE = HIDDEN ? 2 : 1;
+  float* Wang = smem;
+  float* WangT = HIDDEN ? Wang : Wang + 4 * IMG128;
+  float* W2c = HIDDEN ? Wang + WIN_RM_ANG / 4 : WangT + 4 * IMG128;
+  float* W2g = W2c + (HIDDEN ? WIN_RM_W2 / 4 : 0);
+  float* vecs = W2g + (HIDDEN ? WIN_RM_W2 / 4 : 0);
   float* tiles = vecs + VEC_SLOTS * D;
   float* paccs = tiles + WAVES * TILE64_FLOATS;   // [WAVES][NS][PST]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
-  stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
   if (HIDDEN) {
-    stage_weights(W2c, p.gw.w2c, D, D, tid);
-    stage_weights(W2g, p.gw.w2g, D, D, tid);
+    stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
+    stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, BLOCK);
+    stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, BLOCK);
+  } else {
+    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
+    stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
   }
   stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   for (int q = tid; q < WAVES * NS * PST; q += BLOCK) paccs[q] = 0.f;
@@ -298,12 +304,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       PH(0)   // indices + gathers
       Rows64 gy_rows;
       if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);
-      gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
+      if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
+      else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
       V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
       GatedState s;
       V64 y;
       constexpr bool SLIM = HIDDEN;
-      gated_forward<HIDDEN, SLIM, false, false>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+      gated_forward<HIDDEN, SLIM, false, MODE>(zc, zg, W2c, W2g, vecs, j, g, s, y);
       V64 gy;
       if (HIDDEN) {
         V64 w1, w2, gu;
@@ -323,14 +330,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
           to_columns(g1, T, Trow, g, lane, c1);
           to_columns(g2, T, Trow, g, lane, c2[0]);
           run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane);
-          private_add<1>(c2, nvalid, s2, pacc, T, lane);
-          if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
-#pragma unroll
-            for (int rr = 0; rr < TILE_ROWS; ++rr)
-              if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0)
-                atomicAdd(p.Gwbgc + (size_t)__builtin_amdgcn_readlane(b2, rr) * D + lane, c2[0].v[rr]);
-          }
-          __builtin_amdgcn_wave_barrier();
+          row_add64(c2[0], nvalid, p.Gwbgc, b2, D, lane);
         }
         PH(6)   // bond-weight gradient scatter
       } else {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         __builtin_amdgcn_wave_barrier();
       }
       V64 gzc, gzg;
-      gated_backward<HIDDEN, SLIM, false, false>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
+      gated_backward<HIDDEN, SLIM, false, MODE>(gy, zc, zg, W2c, W2g, vecs, j, g, s, gzc, gzg);
       PH(1)   // contractions + gated MLP, forward and adjoint
       // ---- dE/d(angle in) += W_ang^T gz ----
       {
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         } else {
           rows64_issue(gang_old, p.Gang, a, lane);
         }
-        gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
+        if (HIDDEN) gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane);
+        else gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         scatter_rows64_add(T, TS64, p.Gang, a, nvalid, lane, gang_old);
@@ -371,22 +372,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
           if (rr < nvalid) { rs0 += cc[0].v[rr]; rs1 += cc[1].v[rr]; }
         run_sum64(cc[0], nvalid, b1, ri0, cur0, p.GR, 4 * D, lane);
         run_sum64(cc[1], nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane);
-        if (HIDDEN) {   // the private rows hold the bond-weight gradients: dE/dR_j leaves row by row
-          row_add64(cc[0], nvalid, p.GR + 2 * D, b2, 4 * D, lane);
-          row_add64(cc[1], nvalid, p.GR + 3 * D, b2, 4 * D, lane);
-        } else {
-          private_add<2>(cc, nvalid, s2, pacc, T, lane);
-          if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
+        private_add<2>(cc, nvalid, s2, pacc, T, lane);
+        if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
 #pragma unroll
-            for (int rr = 0; rr < TILE_ROWS; ++rr)
-              if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
-                float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
-                atomicAdd(d, cc[0].v[rr]);
-                atomicAdd(d + D, cc[1].v[rr]);
-              }
-          }
-          __builtin_amdgcn_wave_barrier();
+          for (int rr = 0; rr < TILE_ROWS; ++rr)
+            if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
+              float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
+              atomicAdd(d, cc[0].v[rr]);
+              atomicAdd(d + D, cc[1].v[rr]);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
       }
       PH(3)   // scatter
     }
@@ -401,16 +397,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     for (int sl = 0; sl < nrows; ++sl) {
       const int bond = __builtin_amdgcn_readlane(bond_of, sl);
       float* src = pacc + sl * PST;
-      if (HIDDEN) {
-        const float v0 = src[lane];
-        src[lane] = 0.f;
-        atomicAdd(p.Gwbgc + (size_t)bond * D + lane, v0);
-      } else {
-        const float v0 = src[lane], v1 = src[D + lane];
-        src[lane] = 0.f; src[D + lane] = 0.f;
-        atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
-        atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
-      }
+      const float v0 = src[lane], v1 = src[D + lane];
+      src[lane] = 0.f; src[D + lane] = 0.f;
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
     }
     PH(4)   // per-atom flush
   }

@@ -74,8 +74,8 @@ struct TrainTile {
   float ln[4];     // running column sums (column = lane): d ln1_g, d ln1_b, d ln2_g, d ln2_b
 };
 
-// SPLIT: W2c / W2g are split-precision images (mfma_split.h) instead of padded f32 rows
-template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, bool SPLIT = false>
+// SPLIT: 0 = W2c / W2g are padded f32 rows, 1 = split-precision images, 2 = row-major split images (mfma_split.h)
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, int SPLIT = 0>
 __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c, const float* W2g, const float* vecs,
                                               int j, int g, GatedState& s, V64& y, TrainTile* tt = nullptr) {
   if (HIDDEN) {
@@ -93,7 +93,10 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
     }
     s.xh1 = param64(vecs + 0 * D, g);
     s.xh2 = param64(vecs + 1 * D, g);
-    if (SPLIT) {
+    if (SPLIT == 2) {
+      gemm_rm<VT, VT, false, false>(s.xh1.t, reinterpret_cast<const _Float16*>(W2c), D, D, hc.t, j, g, j + 16 * g);
+      gemm_rm<VT, VT, false, false>(s.xh2.t, reinterpret_cast<const _Float16*>(W2g), D, D, hg.t, j, g, j + 16 * g);
+    } else if (SPLIT == 1) {
       gemm_split<VT, VT, false>(s.xh1.t, reinterpret_cast<const h16x8*>(W2c), D, hc.t, j, g);
       gemm_split<VT, VT, false>(s.xh2.t, reinterpret_cast<const h16x8*>(W2g), D, hg.t, j, g);
     } else {
@@ -138,8 +141,8 @@ __device__ __forceinline__ void tile_colsum2(TrainTile* tt, int j, int g, const 
   __builtin_amdgcn_wave_barrier();
 }
 
-// SPLIT: W2c / W2g are the split-precision images of W2c^T / W2g^T
-template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, bool SPLIT = false>
+// SPLIT: 1 = W2c / W2g are the split-precision images of W2c^T / W2g^T, 2 = the row-major images of W2c / W2g themselves
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, int SPLIT = 0>
 __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, const V64& dzg, const float* W2c, const float* W2g,
                                                const float* vecs, int j, int g, const GatedState& s, V64& gzc, V64& gzg,
                                                TrainTile* tt = nullptr) {
@@ -170,7 +173,10 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
   if (HIDDEN) {
     gzc = zero64();
     gzg = zero64();
-    if (SPLIT) {
+    if (SPLIT == 2) {
+      gemm_rm<VT, VT, true, true>(gzc.t, reinterpret_cast<const _Float16*>(W2c), D, D, gn1.t, j, g, j + 16 * g);
+      gemm_rm<VT, VT, true, true>(gzg.t, reinterpret_cast<const _Float16*>(W2g), D, D, gn2.t, j, g, j + 16 * g);
+    } else if (SPLIT == 1) {
       gemm_split<VT, VT, true>(gzc.t, reinterpret_cast<const h16x8*>(W2c), D, gn1.t, j, g);
       gemm_split<VT, VT, true>(gzg.t, reinterpret_cast<const h16x8*>(W2g), D, gn2.t, j, g);
     } else {

@@ -190,4 +190,104 @@ __device__ __forceinline__ void gemm_split(f32x4 (&acc)[NFT], const h16x8* img, 
   for (int fo0 = 0; fo0 < NFT; fo0 += 4) gemm_split4<KT / 2, SCALED>(acc + fo0, img, F, s, fo0, i, g);
 }
 
+// ---- row-major images: ONE LDS copy for both contraction directions -------------------------------------------------
+// The images above need a second copy of W^T for the adjoint contractions (8 bytes per weight for both directions) -- too much
+// for the BondConv adjoint (16,384 weights).  A plain row-major f16 matrix [F][K + 8] per plane serves both:
+//   forward  (sum over k):  lane (i, g) reads W[16 fo + i][32 mk + 4 g ..+3] and [.. + 16 ..]       -- two ds_read_b64
+//   adjoint  (sum over f):  ds_read_b64_tr_b16 -- in every 16-lane group lanes 4 r + q point at row f0 + r, columns 16 ko + 4 q ..+3
+//                           and lane c RECEIVES W[f0 + 0..3][16 ko + c] (tools/split_lab.hip T5) -- two of them per operand
+// 4 bytes per weight for both directions; the row stride K + 8 halves (= 4 banks mod 64 for K = 64) keeps both patterns
+// conflict-free.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+constexpr int rm_stride(int K) { return K + 8; }                                   // halves per row
+constexpr size_t rm_image_bytes(int F, int K) { return (size_t)2 * F * rm_stride(K) * 2; }   // both planes
+
+__device__ __forceinline__ void stage_rm(_Float16* img, const float* __restrict__ W, int F, int K, int tid, int nthreads) {
+  const int S = rm_stride(K), k4 = K / 4;
+  _Float16* lo_plane = img + F * S;
+  for (int idx = tid; idx < F * k4; idx += nthreads) {
+    const int f = idx / k4, c = 4 * (idx - f * k4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)f * K + c);
+    h16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (_Float16)w[e];
+      lo[e] = (_Float16)((w[e] - (float)hi[e]) * LO_SCALE);
+    }
+    *reinterpret_cast<h16x4*>(img + f * S + c) = hi;
+    *reinterpret_cast<h16x4*>(lo_plane + f * S + c) = lo;
+  }
+}
+
+__device__ __forceinline__ h16x8 join8(h16x4 a, h16x4 b) { return h16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ h16x4 tr_read4(const _Float16* p) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+  return __builtin_bit_cast(h16x4, v);
+}
+
+// operand of output tile `o` and contraction step `m` for this lane; plane = 0 hi, 1 lo
+template <bool ADJOINT>
+__device__ __forceinline__ h16x8 rm_operand(const _Float16* img, int F, int K, int plane, int o, int m, int i, int g, int lane) {
+  const int S = rm_stride(K);
+  const _Float16* base = img + plane * F * S;
+  if (!ADJOINT) {          // forward: output feature 16 o + i, k = 32 m + 4 g + (0..3 | 16..19)
+    const _Float16* p = base + (16 * o + i) * S + 32 * m + 4 * g;
+    return join8(*reinterpret_cast<const h16x4*>(p), *reinterpret_cast<const h16x4*>(p + 16));
+  }
+  // adjoint: output column 16 o + i, f = 32 m + 4 g + (0..3 | 16..19); this lane ADDRESSES row f0 + (q >> 2), columns 4 (q & 3)
+  const int q = lane & 15;
+  const _Float16* p = base + (32 * m + 4 * g + (q >> 2)) * S + 16 * o + 4 * (q & 3);
+  return join8(tr_read4(p), tr_read4(p + 16 * S));
+}
+
+// four output tiles o0 .. o0 + 3 from an already split row; contraction over MS steps of 32
+template <int MS, bool SCALED, bool ADJOINT>
+__device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F, int K, const SplitRow<MS>& s, int o0, int i, int g, int lane) {
+  f32x4 t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    h16x8 wh[4], wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wh[q] = rm_operand<ADJOINT>(img, F, K, 0, o0 + q, m, i, g, lane); wl[q] = rm_operand<ADJOINT>(img, F, K, 1, o0 + q, m, i, g, lane); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[m], t[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[m], t[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] *= LO_UNSCALE;
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    h16x8 wh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wh[q] = rm_operand<ADJOINT>(img, F, K, 0, o0 + q, m, i, g, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[m], t[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (SCALED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] += __builtin_ldexpf(t[q][r], s.ex);
+    } else {
+      acc[q] = t[q];
+    }
+  }
+}
+
+// acc[o] += W x (forward: W [F][K], x has K values, F / 16 output tiles) or W^T x (adjoint: x has F values, K / 16 output tiles)
+template <int KT, int NOT, bool SCALED, bool ADJOINT>
+__device__ __forceinline__ void gemm_rm(f32x4 (&acc)[NOT], const _Float16* img, int F, int K, const f32x4 (&x)[KT], int i, int g, int lane) {
+  static_assert(NOT % 4 == 0 && KT % 2 == 0, "widths are multiples of 64 / 32");
+  static_assert(LO_SEPARATE, "row-major images carry the low plane scaled");
+  SplitRow<KT / 2> s;
+  split_row<KT, SCALED>(s, x);
+#pragma unroll
+  for (int o0 = 0; o0 < NOT; o0 += 4) gemm_rm4<KT / 2, SCALED, ADJOINT>(acc + o0, img, F, K, s, o0, i, g, lane);
+}
+
 }  // namespace chg

@@ -62,27 +62,37 @@ def test_per_atom_index_is_a_permutation_with_the_block_structure(hip_engine, bi
         batch.free()
 
 
-def test_per_atom_adjoint_equals_the_plain_adjoint(hip_engine, big_batch):
+@pytest.mark.parametrize("which", ["seed0", "trained_like"])
+def test_per_atom_adjoint_equals_the_plain_adjoint(hip_engine, trained_like_weights, big_batch, which):
     """The same batch with its angle rows shuffled inside every structure has no group structure: the device clears the flag
-    and the plain adjoint runs.  Forces / stress of the two paths agree to fp32 reassociation."""
+    and the plain adjoints run (BondConv then in the f32 matrix form, per atom in split precision).  Forces / stress of the two
+    paths agree to fp32 rounding -- also at trained-checkpoint magnitudes (|F| up to several eV/A, saturated gates)."""
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.pack import pack_weights
+
     pb = big_batch
+    eng = hip_engine if which == "seed0" else Engine(pack_weights(trained_like_weights), 0)
+    tol = {"e": 2e-6, "f": 2e-6, "s": 2e-5} if which == "seed0" else {"e": 1e-5, "f": 1e-4, "s": 1e-3}
     rng = np.random.default_rng(3)
     off = pb.ang_off
     perm = np.concatenate([off[b] + rng.permutation(off[b + 1] - off[b]) for b in range(pb.n_struct)])
     out = []
-    for p, want_flag in ((pb, 1), (_reordered(pb, perm), 0)):
-        batch = hip_engine.upload(p)
-        try:
-            hip_engine.predict(batch, "efs")
-            out.append(hip_engine.download(batch, "efs"))
-            assert hip_engine.debug_fetch_i32(batch, "win_flag", 4)[0] == want_flag
-        finally:
-            batch.free()
+    try:
+        for p, want_flag in ((pb, 1), (_reordered(pb, perm), 0)):
+            batch = eng.upload(p)
+            try:
+                eng.predict(batch, "efs")
+                out.append(eng.download(batch, "efs"))
+                assert eng.debug_fetch_i32(batch, "win_flag", 4)[0] == want_flag
+            finally:
+                batch.free()
+    finally:
+        if which != "seed0":
+            eng.close()
     a, b = out
-    assert np.isfinite(a["f"]).all() and np.abs(a["f"]).max() > 1e-3
-    assert np.abs(a["e"] - b["e"]).max() < 2e-6
-    assert np.abs(a["f"] - b["f"]).max() < 2e-6
-    assert np.abs(a["s"] - b["s"]).max() < 2e-5
+    assert np.isfinite(a["f"]).all() and np.abs(a["f"]).max() > (1e-3 if which == "seed0" else 1.0)
+    for k, t in tol.items():
+        assert np.abs(a[k] - b[k]).max() < t, (k, float(np.abs(a[k] - b[k]).max()))
 
 
 def test_per_atom_adjoint_matches_the_oracle(hip_engine, golden_weights, big_batch):

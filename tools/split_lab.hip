@@ -53,6 +53,89 @@ __global__ __launch_bounds__(512) void k_gemm(const float* X, const float* W, fl
   }
 }
 
+// T6: gemm_rm (one row-major image, both directions) against float64
+template <int K, int F, bool ADJOINT, bool SCALED>
+__global__ __launch_bounds__(512) void k_gemm_rm(const float* X, const float* W, float* Y, int rows, int reps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* img = reinterpret_cast<_Float16*>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  stage_rm(img, W, F, K, tid, 512);                   // W is always [F][K]
+  __syncthreads();
+  constexpr int NIN = ADJOINT ? F : K, NOUT = ADJOINT ? K : F;
+  constexpr int KT = NIN / 16, NOT = NOUT / 16;
+  for (int row0 = (blockIdx.x * 8 + wave) * 16; row0 < rows; row0 += gridDim.x * 128) {
+    f32x4 x[KT];
+    read_dl<KT>(X + (size_t)(row0 + j) * NIN, g, x);
+    f32x4 acc[NOT];
+    for (int o = 0; o < NOT; ++o) acc[o] = zero4();
+    for (int rep = 0; rep < reps; ++rep) {
+      gemm_rm<KT, NOT, SCALED, ADJOINT>(acc, img, F, K, x, j, g, lane);
+      if (reps > 1) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) x[kt][0] += 1e-9f * acc[kt % NOT][0];
+      }
+    }
+    write_dl<NOT>(Y + (size_t)(row0 + j) * NOUT, g, acc);
+  }
+}
+
+template <int K, int F, bool ADJOINT, bool SCALED>
+static void check_rm(const char* label, float xscale) {
+  const int rows = 256;
+  constexpr int NIN = ADJOINT ? F : K, NOUT = ADJOINT ? K : F;
+  std::vector<float> X(rows * NIN), W(F * K), Y(rows * NOUT);
+  for (auto& v : X) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * xscale * (rand() % 7 == 0 ? 1e-3f : 1.f);
+  for (auto& v : W) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.3f;
+  float *dX, *dW, *dY;
+  CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dY, Y.size() * 4));
+  CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+  k_gemm_rm<K, F, ADJOINT, SCALED><<<2, 512, rm_image_bytes(F, K)>>>(dX, dW, dY, rows, 1);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+  double worst_rel = 0;
+  for (int r = 0; r < rows; ++r) {
+    double rowmax = 0;
+    std::vector<double> ref(NOUT);
+    for (int o = 0; o < NOUT; ++o) {
+      double sdot = 0, sa = 0;
+      for (int c = 0; c < NIN; ++c) {
+        const double w = ADJOINT ? W[c * K + o] : W[o * K + c];
+        sdot += w * X[r * NIN + c]; sa += std::fabs(w * X[r * NIN + c]);
+      }
+      ref[o] = sdot; rowmax = std::fmax(rowmax, sa);
+    }
+    for (int o = 0; o < NOUT; ++o) worst_rel = std::fmax(worst_rel, std::fabs(Y[r * NOUT + o] - ref[o]) / (rowmax + 1e-300));
+  }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int trows = 256 * 128 * 4, reps = 64;
+  float *tX, *tY;
+  CK(hipMalloc(&tX, (size_t)trows * NIN * 4)); CK(hipMalloc(&tY, (size_t)trows * NOUT * 4)); CK(hipMemset(tX, 0, (size_t)trows * NIN * 4));
+  const size_t lds = rm_image_bytes(F, K) + 64 * 1024;
+  CK(hipFuncSetAttribute((const void*)k_gemm_rm<K, F, ADJOINT, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float best = 1e9;
+  for (int it = 0; it < 3; ++it) {
+    CK(hipEventRecord(e0));
+    k_gemm_rm<K, F, ADJOINT, SCALED><<<256, 512, lds>>>(tX, dW, tY, trows, reps);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::fmin(best, ms);
+  }
+  printf("T6 row-major image %-26s max err / sum|w x| %.3e   %.1f TFLOP/s (f32-equivalent)\n", label, worst_rel, 2.0 * trows * K * F * reps / best * 1e-9);
+  hipFree(dX); hipFree(dW); hipFree(dY); hipFree(tX); hipFree(tY);
+}
+
+// T5: ds_read_b64_tr_b16.  LDS holds a row-major f16 matrix M[64][72]; in every 16-lane group, lanes 4 r + q point at the four
+// columns 16 + 4 q .. + 3 of row f0 + r (f0 = 4 * group).  Hypothesis: lane c of the group receives M[f0 + j][16 + c], j = 0..3.
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__global__ void k_tr(float* out) {
+  __shared__ _Float16 M[64 * 72];
+  for (int i = threadIdx.x; i < 64 * 72; i += 64) M[i] = (_Float16)(float)((i / 72) * 32 + (i % 72) % 32);
+  __syncthreads();
+  const int l = threadIdx.x, q = l & 15;
+  const _Float16* p = M + (4 * (l >> 4) + (q >> 2)) * 72 + 16 + 4 * (q & 3);
+  const auto v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p);
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (float)v[j];
+}
+
 static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 
 template <int K, int F, bool TRANSPOSE, bool SCALED>
@@ -152,6 +235,24 @@ int main() {
     CK(hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
     printf("T2 subnormal x subnormal: D = %.6e (exact: %.6e)\n", d[0], 32 * 9.5367431640625e-07 * 9.5367431640625e-07);
   }
+  {
+    float* dd; std::vector<float> d(256);
+    CK(hipMalloc(&dd, 1024));
+    k_tr<<<1, 64>>>(dd); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
+      const int row = 4 * (l >> 4) + j, col = 16 + (l & 15);
+      if (d[l * 4 + j] != (float)(row * 32 + col % 32)) ++bad;
+    }
+    printf("T5 ds_read_b64_tr_b16: lane c of a 16-lane group gets M[f0 + j][c0 + c] (rows from lanes 4 r + q): %s (%d mismatches; lane 5 got %g %g %g %g)\n",
+           bad ? "NO" : "yes", bad, d[20], d[21], d[22], d[23]);
+    hipFree(dd);
+  }
+  check_rm<64, 64, false, false>("64->64 forward", 1.f);
+  check_rm<64, 128, false, false>("64->128 forward", 3.f);
+  check_rm<64, 64, true, true>("64<-64 adjoint, scaled", 1e-4f);
+  check_rm<64, 128, true, true>("64<-128 adjoint, scaled", 1e-6f);
   check<64, 64, false, false>("64->64 forward", 1.f);
   check<64, 128, false, false>("64->128 forward", 3.f);
   check<64, 64, true, true>("64->64 transposed, scaled", 1e-4f);
