@@ -24,10 +24,10 @@ constexpr int WS = D + PAD;      // LDS weight row stride for K = 64
 constexpr int TILE_FLOATS = TILE_ROWS * TS;
 constexpr int VEC_SLOTS = 6;     // b2c b2g ln1_g ln1_b ln2_g ln2_b
 // Split-precision weight images (mfma_split.h), in 16-byte chunks: a 64x64 matrix is 1,024 chunks (16 KiB, both planes),
-// the 128x64 angle block 2,048 (its transposed image as well).  The BondConv adjoint is the one tile kernel that keeps
-// the f32 matrix form: its four images (128 KiB) do not fit next to the wave tiles.
+// the 128x64 angle block 2,048 (its transposed image as well).  The BondConv adjoint needs both directions of three matrices:
+// it uses ONE row-major image per matrix (mode 2: 72 KiB; the two-image form would be 128 KiB and does not fit next to the tiles).
 constexpr int IMG64 = 1024, IMG128 = 2048;
-constexpr bool angle_split(bool hidden, bool bwd) { return !(hidden && bwd); }
+constexpr int angle_split(bool hidden, bool bwd) { return (hidden && bwd) ? 2 : 1; }
 
 struct GatedW {            // global pointers into the weight blob
   const float *w2c, *b2c, *w2g, *b2g, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -678,7 +678,7 @@ struct AngleArgs {
 
 template <bool HIDDEN, int NW = WAVES, bool BWD = false>
 constexpr size_t angle_lds() {
-  if (!angle_split(HIDDEN, BWD)) return sizeof(float) * (2 * D * WS + (HIDDEN ? 2 * D * WS : 0) + VEC_SLOTS * D + NW * TILE_FLOATS);
+  if (angle_split(HIDDEN, BWD) == 2) return rm_image_bytes(2 * D, D) + 2 * rm_image_bytes(D, D) + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
   return 16 * (size_t)((BWD ? 2 : 1) * IMG128 + (HIDDEN ? 2 * IMG64 : 0)) + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
 }
 
@@ -702,27 +702,25 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
   if (BWD && !TRAIN && p.skip_flag && *p.skip_flag == 1) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool SPLIT = angle_split(HIDDEN, BWD);
-  // f32 form: Wang [128][WS], W2c, W2g [64][WS].  Split form: images of Wang (and, adjoint, of Wang^T), W2c, W2g.
+  constexpr int SPLIT = angle_split(HIDDEN, BWD);
+  // mode 1: split images of Wang (and, adjoint, of Wang^T), W2c, W2g.  mode 2 (BondConv adjoint): one row-major image each.
   float* Wang = smem;
-  float* WangT = SPLIT ? Wang + 4 * IMG128 : Wang;     // 4 floats per 16-byte chunk
-  float* W2c = SPLIT ? WangT + (BWD ? 4 * IMG128 : 0) : Wang + 2 * D * WS;
-  float* W2g = W2c + (HIDDEN ? (SPLIT ? 4 * IMG64 : D * WS) : 0);
-  float* vecs = W2g + (HIDDEN ? (SPLIT ? 4 * IMG64 : D * WS) : 0);
+  float* WangT = SPLIT == 2 ? Wang : Wang + 4 * IMG128;     // 4 floats per 16-byte chunk
+  float* W2c = SPLIT == 2 ? Wang + rm_image_bytes(2 * D, D) / 4 : WangT + (BWD ? 4 * IMG128 : 0);
+  float* W2g = W2c + (HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0);
+  float* vecs = W2g + (HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0);
   float* tiles = vecs + VEC_SLOTS * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  if (SPLIT) {
+  if (SPLIT == 2) {
+    stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
+    stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
+    stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
+  } else {
     stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
     if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, 64 * NW);
     if (HIDDEN) {
       stage_split<false>(reinterpret_cast<h16x8*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
       stage_split<false>(reinterpret_cast<h16x8*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
-    }
-  } else {
-    stage_weights(Wang, p.w_ang, 2 * D, D, tid);
-    if (HIDDEN) {
-      stage_weights(W2c, p.gw.w2c, D, D, tid);
-      stage_weights(W2g, p.gw.w2g, D, D, tid);
     }
   }
   stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
@@ -807,8 +805,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     PH(1)   // table gather
     Rows64 gy_rows;
     if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
-    if (SPLIT) gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
-    else gemm_dl<VT, 2 * VT>(z, Wang, WS, x.t, j, g);
+    if (SPLIT == 2) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
+    else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
     if (BWD && !HIDDEN) {
       __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
@@ -875,16 +873,13 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         } else {
           rows64_issue(gang_old, p.Gang, a, lane);
         }
-        gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
-        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
+        gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         PH(6)   // W_ang^T contraction
         scatter_rows64_add(T, TS, p.Gang, a, nvalid, lane, gang_old);
       } else {
-        if (SPLIT) gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
-        else gemm_dl_t<2 * VT, VT>(ga.t, Wang, WS, gz, j, g);
+        gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         PH(6)   // W_ang^T contraction
