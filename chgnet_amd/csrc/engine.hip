@@ -364,11 +364,18 @@ inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4
 }
 
 // ---- AtomConv ----------------------------------------------------------------------------------------
-// tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half),  Q = h_bond^l . Wb^T
+// tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half).  The bond partial Q = h_bond^l . Wb^T is contracted inside
+// k_atomconv_fwd, which leaves it behind as a table when a reverse sweep follows; chg_backward after an energy-only predict builds
+// the tables itself (atomconv_q_table).
 int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
-  float *P = b->Pl[l], *Q = b->Ql[l];
-  TRY(rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, P, 4 * D, b->N));
+  return rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, b->Pl[l], 4 * D, b->N);
+}
+
+int atomconv_q_table(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  float* Q = b->Ql[l];
+  if (b->Eu == 0) return CHG_OK;
   // q_bias: constant shift of the bonds outside the bond graph when mlp_out has a bias (0.2.0 only; zero otherwise);
   // the reference runs BondConv only when the batch has angles (model.py:460)
   TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, b->A > 0 ? w.q_bias : nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
@@ -384,18 +391,24 @@ AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   a.gw = eng->w.ac[l].g;
   a.agg = b->agg_l[l]; a.GA = b->GA; a.GP = b->GP_l[l]; a.GQ = b->GQ; a.Gwag = b->Gwag;
   a.first_wag = l == b->L - 1;   // the reverse sweep starts with the last AtomConv
+  a.hb0 = b->hb0;
+  a.hbc = (b->Eb > 0 && b->hbc[l] != b->hbc[0]) ? b->hbc[l] : nullptr;   // bond-graph nodes carry layer-l features
+  a.u_bnode = b->u_bnode;
+  a.w_bond = eng->w.ac[l].w_bond;
+  a.q_bias = b->A > 0 ? eng->w.ac[l].q_bias : nullptr;
   return a;
 }
 
-int atomconv_fwd(chg_engine* eng, chg_batch* b, int l) {
+int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
   const ACW& w = eng->w.ac[l];
   if (b->Ed > 0) {
     TRY(atomconv_tables(eng, b, l));
     LaunchScope ls(eng, "atomconv_fwd");
-    const size_t lds = atomconv_lds<FWD_WAVES>();
+    const size_t lds = atomconv_lds<FWD_WAVES, false, true>();
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;   // bond-pair order
     a.e_nbr = b->p_nbr;
+    a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
     hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
@@ -557,7 +570,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   // ---- message passing (model.py:442-496) ----
   TRY(zero(eng, b->zero1, (size_t)((char*)b->zero1_end - (char*)b->zero1)));   // every forward scatter target + crystal_fea
   for (int l = 0; l < L - 1; ++l) {
-    TRY(atomconv_fwd(eng, b, l));
+    TRY(atomconv_fwd(eng, b, l, want_grad));
     if (b->A > 0) {
       TRY(bondconv_fwd(eng, b, l));
       if (l < L - 2) TRY(angleupd_fwd(eng, b, l));   // the last AngleUpdate's output is never consumed
@@ -567,7 +580,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     LaunchScope ls(eng, "magmom");
     hipLaunchKernelGGL(k_magmom, dim3(wave_grid(eng, b->N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->magmom, b->N);
   }
-  TRY(atomconv_fwd(eng, b, L - 1));
+  TRY(atomconv_fwd(eng, b, L - 1, want_grad));
 
   // ---- readout (model.py:497-509) and its adjoint ----
   {
@@ -2001,7 +2014,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
-  if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, atomconv_lds<FWD_WAVES>()))) return s;
+  if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<true>, (atomconv_lds<WAVES, true>())))) return s;
   if ((s = set_lds(eng, (k_angle<true, true, WAVES, true>), (angle_lds<true, WAVES, true>())))) return s;
@@ -2256,6 +2269,8 @@ static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cota
     HIP_TRY(eng, hipMemcpyAsync(b->t2->Wst, wst.data(), sizeof(float) * wst.size(), hipMemcpyHostToDevice, eng->stream));
   }
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
+  // the forward kernels contract the bond partials in place (and store them only for force / stress tasks); the training sweeps gather them as tables
+  if (b->Ed > 0) for (int l = 0; l < b->L; ++l) TRY(atomconv_q_table(eng, b, l));
   TRY(second_order ? run_backward2(eng, b) : run_backward(eng, b));
   if (comm) {   // data-parallel step: sum of the blob over the ranks, in HBM, on this stream
     if (chg_comm_all_reduce_sum_f32_device(comm, b->t_grad, (int64_t)eng->desc.n_weights, eng->stream) != CHG_OK) {

@@ -382,6 +382,11 @@ struct AtomConvArgs {
   const int *e_center, *e_nbr, *e_d2u;
   int n_edges;
   GatedW gw;
+  // forward: bond partial contracted in the kernel (no gemm_Q / gemm_Qnode launches):  Q[k] = hb[k] . W_bond^T (+ q_bias)
+  const float *hb0, *hbc;      // [Eu,64] embedding rows; [Eb,64] layer features of the bond-graph nodes (null: every bond uses hb0)
+  const int* u_bnode;          // [Eu] compact node index or -1
+  const float *w_bond, *q_bias;   // [128][64]; [128] shift of the bonds outside the bond graph (0.2.0 checkpoints) or null
+  float* Qout;                 // forward: [Eu,128] the partial stored as a table for the adjoint sweep, or null (energy-only tasks)
   float* agg;          // fwd out: [N,64], zeroed by the caller
   // backward only
   const float* GA;     // [N,64] dE/d agg
@@ -395,69 +400,114 @@ struct AtomConvArgs {
   float* g_ln;         // [4][64] gradient of ln1_g, ln1_b, ln2_g, ln2_b (accumulated with atomics)
 };
 
-// LDS: split images of W2c, W2g (the adjoint: and of their transposes), the gated-MLP vectors, one tile per wave
-template <int NW = WAVES, bool BWD = false>
-constexpr size_t atomconv_lds() { return 16 * (size_t)(BWD ? 4 : 2) * IMG64 + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS); }
+// LDS: split images of W2c, W2g (the TRAIN adjoint: and of their transposes), the gated-MLP vectors, one tile per wave.
+// FUSEQ (inference): plus the bond block W_bond -- forward: its split image; adjoint: W2c, W2g, W_bond as row-major images (each
+// serves both directions) -- and two vector slots for q_bias.
+constexpr int AC_VEC_SLOTS = VEC_SLOTS + 2;
+template <int NW = WAVES, bool BWD = false, bool FUSEQ = false>
+constexpr size_t atomconv_lds() {
+  if (FUSEQ) return 16 * (size_t)(2 * IMG64 + IMG128) + sizeof(float) * (AC_VEC_SLOTS * D + NW * TILE_FLOATS);
+  return 16 * (size_t)(BWD ? 4 : 2) * IMG64 + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
+}
 
-// NW waves per workgroup: the forward kernel needs only ~106 VGPRs, so 12 waves (3 per SIMD) fit
+// row of h_bond that feeds bond k's partial, as an offset from hb0 (floats); node: the row carries layer features (no q_bias)
+__device__ __forceinline__ long bond_row_offset(const AtomConvArgs& p, int k, bool& node) {
+  const int bn = p.hbc ? p.u_bnode[k] : -1;
+  node = bn >= 0;
+  return node ? (p.hbc - p.hb0) + (long)bn * D : (long)k * D;
+}
+
+// NW waves per workgroup.  The bond partial Q[k] = hb[k] . W_bond^T is contracted here (one more split contraction per tile)
+// instead of being read from a table: no gemm_Q / gemm_Qnode launches, 256 B instead of 512 B read per bond.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h16x8* I2c = reinterpret_cast<h16x8*>(smem);
   h16x8* I2g = I2c + IMG64;
-  float* vecs = reinterpret_cast<float*>(I2g + IMG64);
-  float* tiles = vecs + VEC_SLOTS * D;
+  h16x8* Ib = I2g + IMG64;
+  float* vecs = reinterpret_cast<float*>(Ib + IMG128);
+  float* tiles = vecs + AC_VEC_SLOTS * D;
   const float* W2c = reinterpret_cast<const float*>(I2c);
   const float* W2g = reinterpret_cast<const float*>(I2g);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   stage_split<false>(I2c, p.gw.w2c, D, D, tid, 64 * NW);
   stage_split<false>(I2g, p.gw.w2g, D, D, tid, 64 * NW);
+  stage_split<false>(Ib, p.w_bond, 2 * D, D, tid, 64 * NW);
   stage_gated_vecs(vecs, p.gw, true, tid);
+  for (int q = tid; q < 2 * D; q += 64 * NW) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
   int tb, te;
   tile_range(ntiles, tb, te);
-  // Software pipeline over tiles: the row gather of tile t+1 (24 loads) is issued before tile t's MFMA /
-  // VALU phase and committed to LDS after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of
-  // wave time with the gather issued and awaited in place.)
+  // Software pipeline over tiles: the row gather of tile t+1 is issued before tile t's MFMA / VALU phase and committed to LDS
+  // after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of wave time with the gather issued and awaited in place.)
   const int tstride = TILE_ROWS * NW;
   auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_edges - 1); };
-  GatherRegs gr;
+  GatherPH gr;
   V64 wv_nx;
   int c_nx = 0, n_nx = 0, c_n2 = 0, n_n2 = 0;
+  long h_nx = 0, h_n2 = 0;
+  bool node_nx = false, node_n2 = false;
   if (tb < te) {
     const int r0 = row_of(tb);
     c_nx = p.e_center[r0]; n_nx = p.e_nbr[r0];
-    gather_issue128(gr, p.P, c_nx, p.P + 2 * D, n_nx, p.Q, r0 >> 1, 4 * D, 4 * D, 2 * D, lane);
+    h_nx = bond_row_offset(p, r0 >> 1, node_nx);
+    gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
     read_dl<VT>(p.wag + (size_t)(r0 >> 1) * D, g, wv_nx.t);
     const int r1 = row_of(tb + 1);
     c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
+    h_n2 = bond_row_offset(p, r1 >> 1, node_n2);
   }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
-    // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): Q[k] and w_ag[k] are fetched once per bond
+    // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): hb[k] and w_ag[k] are fetched once per bond (the second
+    // row's copy comes from L1)
     const int c = c_nx;
+    const bool node = node_nx;
     const V64 wv = wv_nx;
-    gather_commit128(gr, T, TS, lane);
-    c_nx = c_n2; n_nx = n_n2;
+    gather_commit_h(gr, T, TS, lane);      // hb rows first: the tile's left half is reused by the table sums below
+    __builtin_amdgcn_wave_barrier();
+    V64 x;
+    read_dl<VT>(Trow, g, x.t);
+    __builtin_amdgcn_wave_barrier();
+    gather_commit_p(gr, T, TS, lane);
+    __builtin_amdgcn_wave_barrier();
+    c_nx = c_n2; n_nx = n_n2; h_nx = h_n2; node_nx = node_n2;
     if (tile + 1 < te) {
       const int r1 = row_of(tile + 1);
-      gather_issue128(gr, p.P, c_nx, p.P + 2 * D, n_nx, p.Q, r1 >> 1, 4 * D, 4 * D, 2 * D, lane);
+      gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
       read_dl<VT>(p.wag + (size_t)(r1 >> 1) * D, g, wv_nx.t);
       const int r2 = row_of(tile + 2);
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
+      h_n2 = bond_row_offset(p, r2 >> 1, node_n2);
     }
     if (nvalid <= 0) continue;
-    __builtin_amdgcn_wave_barrier();
-    V64 zc, zg;
-    read_dl<VT>(Trow, g, zc.t);
-    read_dl<VT>(Trow + D, g, zg.t);
+    f32x4 z[2 * VT];
+    if (!node) {   // bonds outside the bond graph: constant shift of the 0.2.0 checkpoints (zeros otherwise)
+      read_dl<2 * VT>(vecs + VEC_SLOTS * D, g, z);
+    } else {
+#pragma unroll
+      for (int ft = 0; ft < 2 * VT; ++ft) z[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    gemm_split<VT, 2 * VT, false>(z, Ib, 2 * D, x.t, j, g);
+    if (p.Qout && !(j & 1) && j < nvalid) {   // the adjoint sweep gathers the partial as a table: one row per bond, from the even rows
+      float* q = p.Qout + (size_t)((row0 + j) >> 1) * 2 * D + 4 * g;
+#pragma unroll
+      for (int ft = 0; ft < 2 * VT; ++ft) *reinterpret_cast<f32x4*>(q + 16 * ft) = z[ft];
+    }
+    {
+      f32x4 ps[2 * VT];
+      read_dl<2 * VT>(Trow, g, ps);
+#pragma unroll
+      for (int ft = 0; ft < 2 * VT; ++ft) z[ft] += ps[ft];
+    }
+    V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     GatedState s;
     V64 y;
-    gated_forward<true, false, false, true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    gated_forward<true, false, false, 1>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 m;
     CHG_EW(ft, r) m.t[ft][r] = y.t[ft][r] * wv.t[ft][r];

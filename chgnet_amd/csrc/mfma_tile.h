@@ -368,6 +368,44 @@ __device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* ti
     *reinterpret_cast<f32x4*>(tile + (2 * it + hw) * stride + 4 * t) = (gr.a[it] + gr.b[it]) + gr.c[it];
 }
 
+// Two 128-wide table rows summed + one 64-wide row per tile row (its address as an offset from `hbase`, in floats): the AtomConv
+// gather when the bond partial is contracted in the kernel (kernels_conv.h FUSEQ) instead of read from a table.
+struct GatherPH { f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], h[TILE_ROWS / 4]; };
+__device__ __forceinline__ void gather_issue_ph(GatherPH& gr, const float* __restrict__ t0, int i0, const float* __restrict__ t1, int i1, int ld0,
+                                                int ld1, const float* __restrict__ hbase, long hoff, int lane) {
+  const int hw = lane >> 5, t = lane & 31, sub = lane >> 4, t16 = lane & 15;
+  int r0[TILE_ROWS / 2], r1[TILE_ROWS / 2];
+  long ho[TILE_ROWS / 4];
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    const int rr = 2 * it + hw;
+    r0[it] = __shfl(i0, rr); r1[it] = __shfl(i1, rr);
+  }
+  const int hlo = (int)(hoff & 0xffffffffL), hhi = (int)(hoff >> 32);
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) {
+    const int rr = 4 * it + sub;
+    ho[it] = ((long)__shfl(hhi, rr) << 32) | (unsigned)__shfl(hlo, rr);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) {
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) gr.h[it] = *reinterpret_cast<const f32x4*>(hbase + ho[it] + 4 * t16);
+}
+__device__ __forceinline__ void gather_commit_p(const GatherPH& gr, float* tile, int stride, int lane) {
+  const int hw = lane >> 5, t = lane & 31;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) *reinterpret_cast<f32x4*>(tile + (2 * it + hw) * stride + 4 * t) = gr.a[it] + gr.b[it];
+}
+__device__ __forceinline__ void gather_commit_h(const GatherPH& gr, float* tile, int stride, int lane) {
+  const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = gr.h[it];
+}
+
 // The read half of a row-wise read-modify-write, issued early (its round trip then runs under the
 // contraction that produces the increment); scatter_rows64_add finishes it.
 struct Rows64 { f32x4 v[TILE_ROWS / 4]; };
