@@ -49,12 +49,14 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense f16 / bf16 MFMA
 # operand halves with f32 accumulation (22+ significand bits; measured parity = the f32 form's), or the f32 MFMA itself.
 # fractions in `tile_kernels` stay relative to the f32 MFMA peak so that they compare with earlier rounds; a split kernel's own
 # matrix-pipe ceiling is PEAK_F16_MFMA_TFLOPS / 3 f32-equivalent TFLOP/s.
-SPLIT_KERNELS = {"atomconv_fwd", "atomconv_bwd", "bondconv_fwd", "angleupd_fwd", "angleupd_bwd"}
+SPLIT_KERNELS = {"atomconv_fwd", "atomconv_bwd", "bondconv_fwd", "bondconv_bwd", "angleupd_fwd", "angleupd_bwd"}
 
 # Algorithmic work per unit of the dominant kernels in the engine's (factorised) formulation, derived in
 # DESIGN.md "Roofline accounting": (unit, MFMA flop per unit, compulsory HBM bytes per unit)
 KERNEL_MODEL = {
-    "atomconv_fwd": ("n_directed", 16384, 410),
+    # two 64x64 second-layer blocks per direction + the bond block W_bond (64 -> 128) once per BOND (the kernel contracts it per
+    # direction; the algorithmic count is per bond); h_bond 128 + w_ag 128 read, Q table 256 written for the reverse sweep, per direction
+    "atomconv_fwd": ("n_directed", 24576, 538),
     "atomconv_bwd": ("n_directed", 32768, 900),
     "bondconv_fwd": ("n_angles", 32768, 300),
     "bondconv_bwd": ("n_angles", 65536, 800),
@@ -694,7 +696,8 @@ def main() -> None:
         roofline["tile_kernels"] = tile
         roofline["peak_note"] = (f"frac = factorised f32-equivalent TFLOP/s / {PEAK_FP32_MFMA_TFLOPS} (dense f32 MFMA); split-form kernels "
                                  f"issue 3 f16 MFMAs per f32 product, their matrix-pipe ceiling is {PEAK_F16_MFMA_TFLOPS:.0f} / 3 = "
-                                 f"{PEAK_F16_MFMA_TFLOPS / 3:.0f} f32-equivalent TFLOP/s; the dominant kernel ({dom}) runs the f32 form")
+                                 f"{PEAK_F16_MFMA_TFLOPS / 3:.0f} f32-equivalent TFLOP/s; these kernels are bound by vector-ALU issue "
+                                 f"(operand splits, LayerNorm, activations), profiles/r03_experiments.md")
         roofline["whole_step_frac"] = round(step_flop / (dev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE runs, summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction)

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,7 @@
 #include "kernels_graph.h"
 #include "kernels_train.h"
 #include "kernels_train2.h"
+#include "kernels_train2_tile.h"
 
 
 using namespace chg;
@@ -1249,9 +1251,41 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   };
 
   // ---- tangent forward ---------------------------------------------------------------------------------------
+  // fused tile kernels (kernels_train2_tile.h); CHGNET_T2_UNFUSED=1 keeps the row-array pipeline of kernels_train2.h (A/B, debugging)
+  static const bool fused = !std::getenv("CHGNET_T2_UNFUSED");
+  auto atom2_args = [&](int l) {
+    Atom2Args a{};
+    a.n_edges = Ed; a.e_center = b->p_center; a.e_nbr = b->p_nbr;
+    a.P = b->Pl[l]; a.Q = b->Ql[l]; a.Pd = t.Pd; a.Qd = t.Qd; a.gw = w.ac[l].g; a.wag = b->wag; a.wagd = t.wagd;
+    a.aggd = t.aggd[l]; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wag; a.g_w = t.g_wag;
+    a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG;
+    a.barP = t.barP; a.gP = t.gP; a.barQ = t.barQ; a.gQ = t.gQ; a.g_ln = G(w.ac[l].g.ln1_g);
+    return a;
+  };
+  // tangent tables of an angle layer:  Rd = hrowsd . [Wi;Wj]^T,  Sd = atomsd . Wctr^T
+  auto angle_tables_t = [&](const float* w_bij, const float* w_ctr, const float* hrowsd, const float* atomsd) -> int {
+    TRY(rows_gemm_out2(eng, "t2_gemm_tab", hrowsd, nullptr, w_bij, w_bij + 2 * D * D, nullptr, t.Rd, 4 * D, Eb));
+    return gemm("t2_gemm_tab", 64, 128, atomsd, D, nullptr, w_ctr, nullptr, nullptr, 0, t.Sd, 2 * D, nullptr, N, 0);
+  };
+  auto angle2_args = [&](int slot, const float* w_ang, const GatedW& g, const float* angs, const float* angsd) {
+    Angle2Args a{};
+    a.n_angles = A; a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c;
+    a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.Rd = t.Rd; a.Sd = t.Sd; a.ang = angs; a.angd = angsd; a.w_ang = w_ang; a.gw = g;
+    a.w = b->wbgc; a.wd = t.wbgcd; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wbg; a.g_w = t.g_wbg;
+    a.bar_ang = t.bar_ang; a.g_ang = t.g_ang;
+    a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG; a.BZ = t.BZ; a.GZ = t.GZ;
+    a.barR = t.barR; a.gR = t.gR; a.barS = t.barS; a.gS = t.gS; a.g_ln = G(g.ln1_g);
+    return a;
+  };
+  const dim3 angle_grid(grid_for(std::max(A, 1), tile_grid_mult() * eng->num_cus));
   auto atomconv_t = [&](int l) -> int {
     const ACW& aw = w.ac[l];
-    if (Ed > 0) {
+    if (Ed > 0 && fused) {
+      TRY(atom_tables_t(l));
+      LaunchScope ls(eng, "t2_atom_t");
+      hipLaunchKernelGGL(k2_atom<false>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), t2_atom_lds(), st, atom2_args(l));
+      HIP_TRY(eng, hipGetLastError());
+    } else if (Ed > 0) {
       TRY(atom_rows(l));
       GatedTArgs a{};
       a.rows = Ed; a.mode = T2_ATOM; a.CG = t.CG; a.CGd = t.CGd; a.ln = aw.g.ln1_g; a.i_dst = b->e_center; a.i_w1 = b->e_d2u;
@@ -1265,6 +1299,14 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     TRY(atomconv_t(l));
     if (angles) {
       const BCW& bw = w.bc[l];
+      if (fused) {
+        TRY(angle_tables_t(bw.w_bij, bw.w_ctr, t.hbcd[l], t.atomd[l + 1]));
+        Angle2Args a = angle2_args(l, bw.w_ang, bw.g, b->ang[l], t.angd[l]);
+        a.aggd = t.aggBd[l];
+        LaunchScope ls(eng, "t2_bond_t");
+        hipLaunchKernelGGL((k2_angle<true, false>), angle_grid, dim3(BLOCK), t2_angle_lds<true>(), st, a);
+        HIP_TRY(eng, hipGetLastError());
+      } else {
       TRY(angle_rows(l, true, bw.w_bij, bw.w_ctr, bw.w_ang, bw.g, t.hbcd[l], t.atomd[l + 1], b->ang[l], t.angd[l]));
       {
         GatedTArgs a{};
@@ -1273,8 +1315,17 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
         LaunchScope ls(eng, "t2_gated_t");
         hipLaunchKernelGGL(k2_gated_t, wave_rows_grid(eng, A), dim3(256), 0, st, a);
       }
+      }
       TRY(gemm("t2_gemm_out", 64, 64, t.aggBd[l], D, nullptr, bw.w_out, nullptr, t.hbcd[l], D, t.hbcd[l + 1], D, nullptr, Eb, 0));
-      if (l < L - 2) {
+      if (l < L - 2 && fused) {
+        const AUW& uw = w.au[l];
+        TRY(angle_tables_t(uw.w_bij, uw.w_ctr, t.hbcd[l + 1], t.atomd[l + 1]));
+        Angle2Args a = angle2_args(L + l, uw.w_ang, uw.g, b->ang[l], t.angd[l]);
+        a.angd_out = t.angd[l + 1];
+        LaunchScope ls(eng, "t2_angle_t");
+        hipLaunchKernelGGL((k2_angle<false, false>), angle_grid, dim3(BLOCK), t2_angle_lds<false>(), st, a);
+        HIP_TRY(eng, hipGetLastError());
+      } else if (l < L - 2) {
         const AUW& uw = w.au[l];
         TRY(angle_rows(L + l, false, uw.w_bij, uw.w_ctr, uw.w_ang, uw.g, t.hbcd[l + 1], t.atomd[l + 1], b->ang[l], t.angd[l]));
         GatedTArgs a{};
@@ -1351,6 +1402,18 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     if (Ed == 0) return CHG_OK;
     TRY(gemm("t2_gemm_out", 64, 64, t.bar_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, N, 0));
     TRY(gemm("t2_gemm_out", 64, 64, t.g_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.g_agg, D, nullptr, N, 0));
+    if (fused) {
+      TRY(atom_tables_t(l));
+      TRY(zero(eng, t.barP, sizeof(float) * (size_t)N * 4 * D)); TRY(zero(eng, t.gP, sizeof(float) * (size_t)N * 4 * D));
+      const Atom2Args a = atom2_args(l);
+      { LaunchScope ls(eng, "t2_atom_b");
+        hipLaunchKernelGGL(k2_atom<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), t2_atom_lds(), st, a);
+        HIP_TRY(eng, hipGetLastError()); }
+      TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG, 2 * D, nullptr, a.H, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D, G(aw.g.b2c))));
+      TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG, 2 * D, nullptr, a.Hd, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D)));
+      TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG + D, 2 * D, nullptr, a.H + D, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2g), D, D, G(aw.g.b2g))));
+      TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG + D, 2 * D, nullptr, a.Hd + D, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2g), D, D)));
+    } else {
     TRY(atom_rows(l));
     {
       GatedBArgs a{};
@@ -1367,6 +1430,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       ScatterZArgs a{Ed, t.BZ, t.GZ, t.barP, t.barP, t.barQ, t.gP, t.gP, t.gQ, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->e_center, b->e_nbr, b->e_d2u};
       LaunchScope ls(eng, "t2_scatter_z");
       hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, (Ed + TILE_ROWS - 1) / TILE_ROWS), dim3(256), scatter_z_lds(), st, a);
+    }
     }
     // first layer (factorised): table gradients contract with the rows the tables were made from, bar with primal and G with tangent
     for (int half = 0; half < 2; ++half) {
@@ -1391,10 +1455,12 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   // tail shared by BondConv / AngleUpdate: BZ / GZ [A,128] -> table gradients, weight gradients, adjoints of the inputs
   auto angle_back = [&](const float* w_bij, const float* w_ctr, const float* b1, const float* w_ang, const float* w_bij_t, const float* w_ctr_t,
                         const float* w_ang_t, const float* hrows, const float* hrowsd, const float* atoms, const float* atomsd,
-                        const float* angs, const float* angsd) -> int {
+                        const float* angs, const float* angsd, const std::function<int()>& fused_kernel) -> int {
     TRY(zero(eng, t.barR, sizeof(float) * (size_t)Eb * 4 * D)); TRY(zero(eng, t.gR, sizeof(float) * (size_t)Eb * 4 * D));
     TRY(zero(eng, t.barS, sizeof(float) * (size_t)N * 2 * D)); TRY(zero(eng, t.gS, sizeof(float) * (size_t)N * 2 * D));
-    {
+    if (fused) {
+      TRY(fused_kernel());     // first-layer adjoints scattered to the tables and contracted back to the angle features in the kernel
+    } else {
       ScatterZArgs a{A, t.BZ, t.GZ, t.barR, t.barR, t.barS, t.gR, t.gR, t.gS, 4 * D, 4 * D, 2 * D, 0, 2 * D, 0, b->a_b1c, b->a_b2c, b->a_ctr};
       LaunchScope ls(eng, "t2_scatter_z");
       hipLaunchKernelGGL(k2_scatter_z, wave_rows_grid(eng, (A + TILE_ROWS - 1) / TILE_ROWS), dim3(256), scatter_z_lds(), st, a);
@@ -1411,6 +1477,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.gR, 4 * D, w_bij_t, w_bij_t + 2 * D * D, t.g_b, b->bn_und, Eb, 1));
     TRY(gemm("t2_gemm_tab", 128, 64, t.barS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, t.bar_a, D, nullptr, N, 1));
     TRY(gemm("t2_gemm_tab", 128, 64, t.gS, 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, t.g_a, D, nullptr, N, 1));
+    if (fused) return CHG_OK;
     TRY(gemm("t2_gemm_ang", 128, 64, t.BZ, 2 * D, nullptr, w_ang_t, nullptr, nullptr, 0, t.bar_ang, D, nullptr, A, 1));
     return gemm("t2_gemm_ang", 128, 64, t.GZ, 2 * D, nullptr, w_ang_t, nullptr, nullptr, 0, t.g_ang, D, nullptr, A, 1);
   };
@@ -1425,14 +1492,24 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     if (angles) {
       if (l < L - 2) {
         const AUW& uw = w.au[l];
+        if (fused) {
+          TRY(angle_tables_t(uw.w_bij, uw.w_ctr, t.hbcd[l + 1], t.atomd[l + 1]));
+        } else {
         TRY(angle_rows(L + l, false, uw.w_bij, uw.w_ctr, uw.w_ang, uw.g, t.hbcd[l + 1], t.atomd[l + 1], b->ang[l], t.angd[l]));
         GatedBArgs a{};
         a.rows = A; a.mode = T2_ANGLE; a.CG = t.CG; a.CGd = t.CGd; a.ln = uw.g.ln1_g; a.bar_agg = t.bar_ang; a.g_agg = t.g_ang;
         a.BCG = t.BZ; a.GCG = t.GZ; a.g_ln = G(uw.g.ln1_g);      // single layer: bar(c|g) IS bar(z)
         { LaunchScope ls(eng, "t2_gated_b");
           hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, A), dim3(256), 0, st, a); }
+        }
         TRY(angle_back(uw.w_bij, uw.w_ctr, uw.b1, uw.w_ang, uw.w_bij_t, uw.w_ctr_t, uw.w_ang_t, b->hbc[l + 1], t.hbcd[l + 1], b->atom[l + 1],
-                       t.atomd[l + 1], b->ang[l], t.angd[l]));
+                       t.atomd[l + 1], b->ang[l], t.angd[l], [&]() -> int {
+                         LaunchScope ls(eng, "t2_angle_b");
+                         hipLaunchKernelGGL((k2_angle<false, true>), angle_grid, dim3(BLOCK), t2_angle_lds<false>(), st,
+                                            angle2_args(L + l, uw.w_ang, uw.g, b->ang[l], t.angd[l]));
+                         HIP_TRY(eng, hipGetLastError());
+                         return CHG_OK;
+                       }));
       }
       const BCW& bw = w.bc[l];
       // hbc[l+1] = aggB . Wout^T + hbc[l]; its adjoints live in the node rows of bar_b / g_b
@@ -1440,6 +1517,9 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       TRY((xty<4, 4>(eng, "t2_wgrad", t.g_b, D, b->bn_und, t.aggBd[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
       TRY(gemm("t2_gemm_out", 64, 64, t.bar_b, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, Eb, 0));
       TRY(gemm("t2_gemm_out", 64, 64, t.g_b, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, t.g_agg, D, nullptr, Eb, 0));
+      if (fused) {
+        TRY(angle_tables_t(bw.w_bij, bw.w_ctr, t.hbcd[l], t.atomd[l + 1]));
+      } else {
       TRY(angle_rows(l, true, bw.w_bij, bw.w_ctr, bw.w_ang, bw.g, t.hbcd[l], t.atomd[l + 1], b->ang[l], t.angd[l]));
       {
         GatedBArgs a{};
@@ -1450,8 +1530,18 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
         hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, A), dim3(256), 0, st, a);
       }
       TRY(hidden_back(bw.g, bw.w2c_t, bw.w2g_t, A));
+      }
       TRY(angle_back(bw.w_bij, bw.w_ctr, bw.b1, bw.w_ang, bw.w_bij_t, bw.w_ctr_t, bw.w_ang_t, b->hbc[l], t.hbcd[l], b->atom[l + 1], t.atomd[l + 1],
-                     b->ang[l], t.angd[l]));
+                     b->ang[l], t.angd[l], [&]() -> int {
+                       const Angle2Args a = angle2_args(l, bw.w_ang, bw.g, b->ang[l], t.angd[l]);
+                       { LaunchScope ls(eng, "t2_bond_b");
+                         hipLaunchKernelGGL((k2_angle<true, true>), angle_grid, dim3(BLOCK), t2_angle_lds<true>(), st, a);
+                         HIP_TRY(eng, hipGetLastError()); }
+                       TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG, 2 * D, nullptr, a.H, 2 * D, nullptr, A, 1.0f, G(bw.g.w2c), D, D, G(bw.g.b2c))));
+                       TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG, 2 * D, nullptr, a.Hd, 2 * D, nullptr, A, 1.0f, G(bw.g.w2c), D, D)));
+                       TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG + D, 2 * D, nullptr, a.H + D, 2 * D, nullptr, A, 1.0f, G(bw.g.w2g), D, D, G(bw.g.b2g))));
+                       return xty<4, 4>(eng, "t2_wgrad", a.GCG + D, 2 * D, nullptr, a.Hd + D, 2 * D, nullptr, A, 1.0f, G(bw.g.w2g), D, D);
+                     }));
     }
     TRY(atomconv_b(l));
   }
@@ -2017,6 +2107,12 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<true>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k2_atom<false>, t2_atom_lds()))) return s;
+  if ((s = set_lds(eng, k2_atom<true>, t2_atom_lds()))) return s;
+  if ((s = set_lds(eng, k2_angle<true, false>, t2_angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, k2_angle<true, true>, t2_angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, k2_angle<false, false>, t2_angle_lds<false>()))) return s;
+  if ((s = set_lds(eng, k2_angle<false, true>, t2_angle_lds<false>()))) return s;
   if ((s = set_lds(eng, (k_angle<true, true, WAVES, true>), (angle_lds<true, WAVES, true>())))) return s;
   if ((s = set_lds(eng, (k_angle<false, true, WAVES, true>), (angle_lds<false, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_readout<true>, readout_lds()))) return s;

@@ -1,0 +1,560 @@
+// kernels_train2_tile.h -- the second-order fine-tuning sweep (kernels_train2.h: derivation, reference lines) FUSED per layer:
+// one tile kernel per layer kind and direction instead of the chain  gather_z -> 4 row GEMMs -> gated_t | gated_b -> 4 row GEMMs
+// -> hidden_b -> scatter_z  over [rows,128] arrays in HBM (a dozen array passes per layer visit; the sweep was HBM-bound at
+// ~3.5 TB/s for 215 ms per 1024-structure step).
+//
+// One wave = 16 rows, as in the first-order kernels (mfma_tile.h).  Linear pieces run on the matrix pipe in the accumulator
+// layout (split-precision contractions against row-major weight images in LDS, mfma_split.h: one image serves W and W^T); the
+// row-local nonlinear piece -- LayerNorm, activations, their tangents and the two-adjoint backward -- reuses gated_row_fwd /
+// gated_row_bwd of the unfused sweep verbatim in their layout (one row at a time, lane = feature): the tile goes through the
+// wave's LDS tile eight rows at a time.  Only what the weight-gradient contractions (k_xty) need leaves the kernel as rows:
+// H, Hd, bar(c|g), G(c|g).  Nothing of the tangent forward is kept: the reverse kernel recomputes it from the tables.
+#pragma once
+
+#include "kernels_conv.h"
+#include "kernels_train2.h"
+
+namespace chg {
+
+constexpr int T2_AS = 4 * D + 4;     // row stride of the 8-row staging area inside the wave's tile: c | g | cd | gd
+static_assert(8 * T2_AS <= TILE_FLOATS, "the staging area reuses the wave's gather tile");
+
+constexpr size_t t2_atom_lds() { return 2 * rm_image_bytes(D, D) + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE_FLOATS); }
+
+// silu, silu' and silu'' zd of a pre-activation vector with tangent: h, hd = silu'(z) zd, d1 = silu'(z), e = silu''(z) zd
+__device__ __forceinline__ void hidden_t(const V64& z, const V64& zd, V64& h, V64& hd, V64& d1, V64& e) {
+  CHG_EW(ft, r) {
+    const float x = z.t[ft][r], s = sigmoidf_(x);
+    h.t[ft][r] = x * s;
+    const float d = s * (1.0f + x * (1.0f - s));
+    d1.t[ft][r] = d;
+    hd.t[ft][r] = d * zd.t[ft][r];
+    e.t[ft][r] = s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s)) * zd.t[ft][r];
+  }
+}
+
+struct Atom2Args {
+  int n_edges;
+  const int *e_center, *e_nbr;        // pair order (rows 2k, 2k+1 = the two directions of bond k)
+  const float *P, *Q, *Pd, *Qd;       // first-layer tables [N,256], [Eu,128] and their tangents
+  GatedW gw;
+  const float *wag, *wagd;            // [Eu,64] smooth bond weights and tangents
+  float* aggd;                        // tangent forward: [N,64] tangent of the aggregate (zeroed)
+  // reverse sweep
+  const float *bar_agg, *g_agg;       // [N,64] the two adjoints of the aggregate
+  float *bar_w, *g_w;                 // [Eu,64] adjoints of wag, accumulated over the layers (zeroed once per sweep)
+  float *H, *Hd, *BCG, *GCG;          // [Ed,128] pair order: operands of the second-layer weight gradients
+  float *barP, *gP;                   // [N,256] (zeroed): adjoints of the P table
+  float *barQ, *gQ;                   // [Eu,128]: adjoints of the Q table, plain stores (the tile owns its bonds)
+  float* g_ln;                        // [4][64] LayerNorm-affine gradients
+};
+
+// AtomConv l: tangent forward (REVERSE = false: aggd only) or reverse sweep with the two adjoints.
+template <bool REVERSE>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* I2c = reinterpret_cast<_Float16*>(smem);
+  _Float16* I2g = I2c + rm_image_bytes(D, D) / 2;
+  float* vecs = reinterpret_cast<float*>(I2g + rm_image_bytes(D, D) / 2);
+  float* tiles = vecs + VEC_SLOTS * D;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_rm(I2c, p.gw.w2c, D, D, tid, BLOCK);
+  stage_rm(I2g, p.gw.w2g, D, D, tid, BLOCK);
+  stage_gated_vecs(vecs, p.gw, true, tid);
+  __syncthreads();
+  float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
+  float* Arow = T + (j & 7) * T2_AS;
+  const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
+  float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  const int last_row = p.n_edges - 1;
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
+    if (nvalid <= 0) break;
+    const int row = min(row0 + j, last_row);
+    const int c = p.e_center[row], n = p.e_nbr[row], k = row >> 1, k0 = row0 >> 1;
+    // ---- first layer from the tables (primal and tangent), hidden activation, second layer: core branch, then gate branch ----
+    // (branch by branch: with both in flight the reverse kernel, which keeps silu' and silu'' zd of every row for the way back,
+    // spilled 180 registers)
+    V64 cc, cg, cdc, cdg, d1c, d1g, ec, eg;
+    {
+      GatherRegs gr;
+      gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+      GatherRegs gd;
+      gather_issue128(gd, p.Pd, c, p.Pd + 2 * D, n, p.Qd, k, 4 * D, 4 * D, 2 * D, lane);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gr, T, TS, lane);
+      __builtin_amdgcn_wave_barrier();
+      V64 zc, zg;
+      read_dl<VT>(Trow, g, zc.t);
+      read_dl<VT>(Trow + D, g, zg.t);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gd, T, TS, lane);
+      __builtin_amdgcn_wave_barrier();
+      float* hrow = p.H + (size_t)(row0 + j) * 2 * D;      // B operands of dW2 = bar(c|g)^T H + G(c|g)^T Hd
+      float* hdrow = p.Hd + (size_t)(row0 + j) * 2 * D;
+      {
+        V64 zd, h, hd;
+        read_dl<VT>(Trow, g, zd.t);
+        hidden_t(zc, zd, h, hd, d1c, ec);
+#ifndef T2_EXP_NO_DUMP
+        if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
+#endif
+        cc = param64(vecs + 0 * D, g);
+        cdc = zero64();
+        gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane);
+        gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane);
+      }
+      {
+        V64 zd, h, hd;
+        read_dl<VT>(Trow + D, g, zd.t);
+        hidden_t(zg, zd, h, hd, d1g, eg);
+#ifndef T2_EXP_NO_DUMP
+        if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
+#endif
+        cg = param64(vecs + 1 * D, g);
+        cdg = zero64();
+        gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane);
+        gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane);
+      }
+    }
+    // ---- row-local part, eight rows at a time through the tile (lane = feature) ----
+    // Rolled loops: unrolled, the sixteen copies of the row math cost 175 spilled registers.  One bond (two rows) per step; what the
+    // next bond needs from memory (adjoints of its two atoms' aggregates, its weight row, the old rows of the weight adjoints) is
+    // requested a step ahead.
+    float acc1 = 0.f, acc2 = 0.f;                                   // tangent forward: run sums of the aggregate tangent
+    int cur1 = __builtin_amdgcn_readlane(c, 0), cur2 = __builtin_amdgcn_readlane(c, 1);
+    const int nb = nvalid >> 1;
+    struct BondIn { float ba0, ga0, ba1, ga1, w, wd, obw, ogw; };
+    auto fetch = [&](int b) {                                        // b: bond of the tile (clamped: harmless reads past the end)
+      BondIn v{};
+      const int bb = min(b, nb - 1);
+      const size_t kb = (size_t)(k0 + bb) * D + lane;
+      v.w = p.wag[kb]; v.wd = p.wagd[kb];
+      if (REVERSE) {
+        const int c0 = __builtin_amdgcn_readlane(c, 2 * bb), c1 = __builtin_amdgcn_readlane(c, 2 * bb + 1);
+        v.ba0 = p.bar_agg[(size_t)c0 * D + lane]; v.ga0 = p.g_agg[(size_t)c0 * D + lane];
+        v.ba1 = p.bar_agg[(size_t)c1 * D + lane]; v.ga1 = p.g_agg[(size_t)c1 * D + lane];
+        v.obw = p.bar_w[kb]; v.ogw = p.g_w[kb];
+      }
+      return v;
+    };
+    BondIn nx = fetch(0);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_wave_barrier();
+      if ((j >> 3) == half) {
+        write_dl<VT>(Arow, g, cc.t); write_dl<VT>(Arow + D, g, cg.t);
+        write_dl<VT>(Arow + 2 * D, g, cdc.t); write_dl<VT>(Arow + 3 * D, g, cdg.t);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int pb = 0; pb < 4; ++pb) {
+        const int b = 4 * half + pb;                     // bond of the tile
+        if (b >= nb) break;
+        const BondIn in = nx;
+        nx = fetch(b + 1);
+        float pair_bw = 0.f, pair_gw = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {                    // the two directions
+          float* a = T + (2 * pb + d) * T2_AS + lane;
+          const GatedRow s = gated_row_fwd(a[0], a[D], a[2 * D], a[3 * D], ln_g1, ln_b1, ln_g2, ln_b2);
+          if (!REVERSE) {
+            const float m = s.yd * in.w + s.y * in.wd;
+            const int ci = __builtin_amdgcn_readlane(c, 2 * b + d);
+            if (d) {
+              if (ci != cur2) { tile_atomic_add(p.aggd + (size_t)cur2 * D + lane, acc2); acc2 = 0.f; cur2 = ci; }
+              acc2 += m;
+            } else {
+              if (ci != cur1) { tile_atomic_add(p.aggd + (size_t)cur1 * D + lane, acc1); acc1 = 0.f; cur1 = ci; }
+              acc1 += m;
+            }
+          } else {
+            const float bar_a = d ? in.ba1 : in.ba0, g_a = d ? in.ga1 : in.ga0;
+            pair_bw += s.y * bar_a + s.yd * g_a;
+            pair_gw += s.y * g_a;
+            float bar_c, bar_g, g_c, g_g;
+#ifdef T2_EXP_NO_ROWBWD
+            bar_c = s.y; bar_g = s.yd; g_c = s.a1; g_g = s.a2;
+#else
+            gated_row_bwd(s, in.w * bar_a + in.wd * g_a, in.w * g_a, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
+#endif
+            a[0] = bar_c; a[D] = bar_g; a[2 * D] = g_c; a[3 * D] = g_g;
+          }
+        }
+        if (REVERSE) {                                   // the tile owns bond k0 + b: plain update of the weight adjoints
+          const size_t kb = (size_t)(k0 + b) * D + lane;
+          p.bar_w[kb] = in.obw + pair_bw;
+          p.g_w[kb] = in.ogw + pair_gw;
+        }
+      }
+      if (REVERSE) {
+        __builtin_amdgcn_wave_barrier();
+        if ((j >> 3) == half) {
+          read_dl<VT>(Arow, g, cc.t); read_dl<VT>(Arow + D, g, cg.t);
+          read_dl<VT>(Arow + 2 * D, g, cdc.t); read_dl<VT>(Arow + 3 * D, g, cdg.t);
+        }
+      }
+    }
+    if (!REVERSE) {
+      tile_atomic_add(p.aggd + (size_t)cur1 * D + lane, acc1);
+      tile_atomic_add(p.aggd + (size_t)cur2 * D + lane, acc2);
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    // cc | cg = bar(c | g), cdc | cdg = G(c | g)
+#ifdef T2_EXP_NO_DUMP
+    if (false) {
+#else
+    if (j < nvalid) {               // A operands of dW2 (column sums of bar(c|g) = d b2)
+#endif
+      float* brow = p.BCG + (size_t)(row0 + j) * 2 * D;
+      float* grow = p.GCG + (size_t)(row0 + j) * 2 * D;
+      write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
+      write_dl<VT>(grow, g, cdc.t); write_dl<VT>(grow + D, g, cdg.t);
+    }
+    // ---- back through the second layer and the hidden activation, branch by branch:
+    //      bar(z) = silu'(z) bar(H) + silu''(z) zd G(H),  G(z) = silu'(z) G(H);  bar(z) goes to the tile at once ----
+    __builtin_amdgcn_wave_barrier();
+    {
+      V64 bh = zero64(), gh = zero64();
+      gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane);
+      gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane);
+      CHG_EW(ft, r) {
+        bh.t[ft][r] = d1c.t[ft][r] * bh.t[ft][r] + ec.t[ft][r] * gh.t[ft][r];
+        cdc.t[ft][r] = d1c.t[ft][r] * gh.t[ft][r];
+      }
+      write_dl<VT>(Trow, g, bh.t);
+    }
+    {
+      V64 bh = zero64(), gh = zero64();
+      gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane);
+      gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane);
+      CHG_EW(ft, r) {
+        bh.t[ft][r] = d1g.t[ft][r] * bh.t[ft][r] + eg.t[ft][r] * gh.t[ft][r];
+        cdg.t[ft][r] = d1g.t[ft][r] * gh.t[ft][r];
+      }
+      write_dl<VT>(Trow + D, g, bh.t);
+    }
+    // ---- first-layer adjoints back to the tables (pair order: Q rows owned, both atoms as run sums) ----
+    AtomConvArgs sc{};
+    __builtin_amdgcn_wave_barrier();
+    sc.GP = p.barP; sc.GQ = p.barQ;
+#ifndef T2_EXP_NO_SCATTER
+    acbwd_scatter(T, c, nvalid, k0, sc, lane);
+#endif
+    __builtin_amdgcn_wave_barrier();
+    write_dl<VT>(Trow, g, cdc.t);
+    write_dl<VT>(Trow + D, g, cdg.t);
+    __builtin_amdgcn_wave_barrier();
+    sc.GP = p.gP; sc.GQ = p.gQ;
+#ifndef T2_EXP_NO_SCATTER
+    acbwd_scatter(T, c, nvalid, k0, sc, lane);
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (REVERSE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, lnacc[q]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BondConv (HIDDEN) / AngleUpdate (single layer): rows are angles in the batch's order (owning bond b1 and centre atom sorted,
+// second bond b2 not).  z = R[b1] + R[b2]' + S[ctr] + W_ang . ang: the angle block is contracted here (no [A,128] product arrays).
+// ---------------------------------------------------------------------------------------------------------
+struct Angle2Args {
+  int n_angles;
+  const int *a_ctr, *a_b1c, *a_b2c;
+  const float *R, *S, *Rd, *Sd;       // tables [Eb,256], [N,128] and tangents
+  const float *ang, *angd;            // [A,64] angle features of the layer and tangents
+  const float* w_ang;                 // [128][64]
+  GatedW gw;
+  // BondConv: u = y * wbg[b1] * wbg[b2] summed over the angles of bond b1
+  const float *w, *wd;                // [Eb,64] smooth bond weights (bond graph) and tangents
+  float* aggd;                        // tangent forward: [Eb,64] (zeroed)
+  const float *bar_agg, *g_agg;       // reverse: [Eb,64]
+  float *bar_w, *g_w;                 // reverse: [Eb,64] adjoints of wbg, accumulated over the layers (atomics)
+  // AngleUpdate: ang' = ang + y
+  float* angd_out;                    // tangent forward: [A,64]
+  // reverse, both kinds
+  float *bar_ang, *g_ang;             // [A,64] adjoints of the angle features: read (AngleUpdate: adjoint of ang'), updated in place
+  float *H, *Hd, *BCG, *GCG;          // [A,128] HIDDEN: operands of the second-layer weight gradients
+  float *BZ, *GZ;                     // [A,128] first-layer adjoints: operands of the W_ang gradient
+  float *barR, *gR, *barS, *gS;       // [Eb,256], [N,128] (zeroed)
+  float* g_ln;
+};
+
+template <bool HIDDEN>
+constexpr size_t t2_angle_lds() {
+  return rm_image_bytes(2 * D, D) + (HIDDEN ? 2 * rm_image_bytes(D, D) : 0) + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE_FLOATS);
+}
+
+template <bool HIDDEN, bool REVERSE>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* Iang = reinterpret_cast<_Float16*>(smem);
+  _Float16* I2c = Iang + rm_image_bytes(2 * D, D) / 2;
+  _Float16* I2g = I2c + rm_image_bytes(D, D) / 2;
+  float* vecs = reinterpret_cast<float*>(HIDDEN ? I2g + rm_image_bytes(D, D) / 2 : I2c);
+  float* tiles = vecs + VEC_SLOTS * D;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_rm(Iang, p.w_ang, 2 * D, D, tid, BLOCK);
+  if (HIDDEN) {
+    stage_rm(I2c, p.gw.w2c, D, D, tid, BLOCK);
+    stage_rm(I2g, p.gw.w2g, D, D, tid, BLOCK);
+  }
+  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
+  __syncthreads();
+  float* T = tiles + wave * TILE_FLOATS;
+  float* Trow = T + j * TS;
+  float* Arow = T + (j & 7) * T2_AS;
+  const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
+  float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  int tb, te;
+  tile_range(ntiles, tb, te);
+  const int last_row = p.n_angles - 1;
+  for (int tile = tb; tile < te; ++tile) {
+    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int nvalid = min(TILE_ROWS, p.n_angles - row0);
+    if (nvalid <= 0) break;
+    const int row = min(row0 + j, last_row);
+    const int b1 = p.a_b1c[row], b2 = p.a_b2c[row], ct = p.a_ctr[row];
+    // ---- first layer: table sums + the angle block, primal and tangent; hidden activation and second layer branch by branch ----
+    V64 cc, cg, cdc, cdg, d1c, d1g, ec, eg;
+    {
+      GatherRegs gr;
+      gather_issue128(gr, p.R, b1, p.R + 2 * D, b2, p.S, ct, 4 * D, 4 * D, 2 * D, lane);
+      GatherRegs gd;
+      gather_issue128(gd, p.Rd, b1, p.Rd + 2 * D, b2, p.Sd, ct, 4 * D, 4 * D, 2 * D, lane);
+      V64 x, xd;
+      read_dl<VT>(p.ang + (size_t)row * D, g, x.t);
+      read_dl<VT>(p.angd + (size_t)row * D, g, xd.t);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gr, T, TS, lane);
+      __builtin_amdgcn_wave_barrier();
+      f32x4 z[2 * VT], zd[2 * VT];
+      read_dl<2 * VT>(Trow, g, z);
+      __builtin_amdgcn_wave_barrier();
+      gather_commit128(gd, T, TS, lane);
+      __builtin_amdgcn_wave_barrier();
+      read_dl<2 * VT>(Trow, g, zd);
+      __builtin_amdgcn_wave_barrier();
+      gemm_rm<VT, 2 * VT, false, false>(z, Iang, 2 * D, D, x.t, j, g, lane);
+      gemm_rm<VT, 2 * VT, true, false>(zd, Iang, 2 * D, D, xd.t, j, g, lane);
+#pragma unroll
+      for (int ft = 0; ft < VT; ++ft) { cc.t[ft] = z[ft]; cg.t[ft] = z[VT + ft]; cdc.t[ft] = zd[ft]; cdg.t[ft] = zd[VT + ft]; }
+      if (HIDDEN) {
+        float* hrow = p.H + (size_t)(row0 + j) * 2 * D;      // B operands of dW2 = bar(c|g)^T H + G(c|g)^T Hd
+        float* hdrow = p.Hd + (size_t)(row0 + j) * 2 * D;
+        {
+          V64 h, hd;
+          hidden_t(cc, cdc, h, hd, d1c, ec);
+          if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
+          cc = param64(vecs + 0 * D, g);
+          cdc = zero64();
+          gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane);
+          gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane);
+        }
+        {
+          V64 h, hd;
+          hidden_t(cg, cdg, h, hd, d1g, eg);
+          if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
+          cg = param64(vecs + 1 * D, g);
+          cdg = zero64();
+          gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane);
+          gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane);
+        }
+      }
+    }
+    // ---- row-local part, eight rows at a time through the tile (lane = feature); what the next row needs from memory is
+    //      requested a row ahead ----
+    float acc = 0.f, acc_bw = 0.f, acc_gw = 0.f;      // BondConv: run sums over the owning bond
+    float w1 = 0.f, w1d = 0.f, bar_a = 0.f, g_a = 0.f;
+    int cur = -1;
+    struct RowIn { float w2, w2d, by, gy; };
+    auto fetch = [&](int rt) {                         // rt: row of the tile (clamped)
+      RowIn v{};
+      const int rc = min(rt, nvalid - 1);
+      if (HIDDEN) {
+        const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rc) * D + lane;
+        v.w2 = p.w[k2]; v.w2d = p.wd[k2];
+      } else if (REVERSE) {
+        const size_t o = (size_t)(row0 + rc) * D + lane;
+        v.by = p.bar_ang[o]; v.gy = p.g_ang[o];
+      } else {
+        v.by = p.angd[(size_t)(row0 + rc) * D + lane];
+      }
+      return v;
+    };
+    RowIn nx = fetch(0);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_wave_barrier();
+      if ((j >> 3) == half) {
+        write_dl<VT>(Arow, g, cc.t); write_dl<VT>(Arow + D, g, cg.t);
+        write_dl<VT>(Arow + 2 * D, g, cdc.t); write_dl<VT>(Arow + 3 * D, g, cdg.t);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int rr = 0; rr < 8; ++rr) {
+        const int rt = 8 * half + rr;
+        if (rt >= nvalid) break;
+        const RowIn in = nx;
+        nx = fetch(rt + 1);
+        float* a = T + rr * T2_AS + lane;
+        const GatedRow s = gated_row_fwd(a[0], a[D], a[2 * D], a[3 * D], ln_g1, ln_b1, ln_g2, ln_b2);
+        float bar_y = 0.f, g_y = 0.f;
+        if (HIDDEN) {
+          const int dst = __builtin_amdgcn_readlane(b1, rt);
+          if (dst != cur) {                              // a new owning bond: flush the run, fetch its rows
+            if (cur >= 0) {
+              if (!REVERSE) {
+                tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
+              } else {
+                atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+                atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
+              }
+            }
+            cur = dst;
+            acc = acc_bw = acc_gw = 0.f;
+            w1 = p.w[(size_t)dst * D + lane];
+            w1d = p.wd[(size_t)dst * D + lane];
+            if (REVERSE) {
+              bar_a = p.bar_agg[(size_t)dst * D + lane];
+              g_a = p.g_agg[(size_t)dst * D + lane];
+            }
+          }
+          if (!REVERSE) {
+            acc += s.yd * w1 * in.w2 + s.y * (w1d * in.w2 + w1 * in.w2d);
+          } else {
+            acc_bw += s.y * in.w2 * bar_a + (s.yd * in.w2 + s.y * in.w2d) * g_a;
+            acc_gw += s.y * in.w2 * g_a;
+            const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane;
+            atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
+            atomicAdd(p.g_w + k2, s.y * w1 * g_a);
+            bar_y = w1 * in.w2 * bar_a + (w1d * in.w2 + w1 * in.w2d) * g_a;
+            g_y = w1 * in.w2 * g_a;
+          }
+        } else if (!REVERSE) {
+          p.angd_out[(size_t)(row0 + rt) * D + lane] = in.by + s.yd;
+        } else {
+          bar_y = in.by;
+          g_y = in.gy;
+        }
+        if (REVERSE) {
+          float bar_c, bar_g, g_c, g_g;
+          gated_row_bwd(s, bar_y, g_y, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
+          a[0] = bar_c; a[D] = bar_g; a[2 * D] = g_c; a[3 * D] = g_g;
+        }
+      }
+      if (REVERSE) {
+        __builtin_amdgcn_wave_barrier();
+        if ((j >> 3) == half) {
+          read_dl<VT>(Arow, g, cc.t); read_dl<VT>(Arow + D, g, cg.t);
+          read_dl<VT>(Arow + 2 * D, g, cdc.t); read_dl<VT>(Arow + 3 * D, g, cdg.t);
+        }
+      }
+    }
+    if (HIDDEN && cur >= 0) {
+      if (!REVERSE) {
+        tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
+      } else {
+        atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+        atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
+      }
+    }
+    if (!REVERSE) {
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    // cc | cg = bar(c | g), cdc | cdg = G(c | g)
+    if (HIDDEN) {
+      if (j < nvalid) {               // A operands of dW2 (column sums of bar(c|g) = d b2)
+        float* brow = p.BCG + (size_t)(row0 + j) * 2 * D;
+        float* grow = p.GCG + (size_t)(row0 + j) * 2 * D;
+        write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
+        write_dl<VT>(grow, g, cdc.t); write_dl<VT>(grow + D, g, cdg.t);
+      }
+      // back through the second layer and the hidden activation, branch by branch
+      {
+        V64 bh = zero64(), gh = zero64();
+        gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane);
+        gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane);
+        CHG_EW(ft, r) {
+          cc.t[ft][r] = d1c.t[ft][r] * bh.t[ft][r] + ec.t[ft][r] * gh.t[ft][r];
+          cdc.t[ft][r] = d1c.t[ft][r] * gh.t[ft][r];
+        }
+      }
+      {
+        V64 bh = zero64(), gh = zero64();
+        gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane);
+        gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane);
+        CHG_EW(ft, r) {
+          cg.t[ft][r] = d1g.t[ft][r] * bh.t[ft][r] + eg.t[ft][r] * gh.t[ft][r];
+          cdg.t[ft][r] = d1g.t[ft][r] * gh.t[ft][r];
+        }
+      }
+    }
+    // cc | cg = bar(z), cdc | cdg = G(z)
+    if (j < nvalid) {                 // A operands of the W_ang gradient
+      float* brow = p.BZ + (size_t)(row0 + j) * 2 * D;
+      float* grow = p.GZ + (size_t)(row0 + j) * 2 * D;
+      write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
+      write_dl<VT>(grow, g, cdc.t); write_dl<VT>(grow + D, g, cdg.t);
+    }
+    const int k1 = j < nvalid ? b1 : -1, k2 = j < nvalid ? b2 : -1, k3 = j < nvalid ? ct : -1;
+    // ---- bar: angle features (rows owned: plain update), then the tables ----
+    {
+      V64 old, up = zero64();
+      float* arow = p.bar_ang + (size_t)row * D;
+      read_dl<VT>(arow, g, old.t);
+      f32x4 bz[2 * VT];
+#pragma unroll
+      for (int ft = 0; ft < VT; ++ft) { bz[ft] = cc.t[ft]; bz[VT + ft] = cg.t[ft]; }
+      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, bz, j, g, lane);
+      CHG_EW(ft, r) up.t[ft][r] += old.t[ft][r];
+      if (j < nvalid) write_dl<VT>(arow, g, up.t);
+    }
+    __builtin_amdgcn_wave_barrier();
+    write_dl<VT>(Trow, g, cc.t);
+    write_dl<VT>(Trow + D, g, cg.t);
+    __builtin_amdgcn_wave_barrier();
+    seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane);
+    row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane);
+    seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane);
+    __builtin_amdgcn_wave_barrier();
+    // ---- G ----
+    {
+      V64 old, up = zero64();
+      float* arow = p.g_ang + (size_t)row * D;
+      read_dl<VT>(arow, g, old.t);
+      f32x4 gz[2 * VT];
+#pragma unroll
+      for (int ft = 0; ft < VT; ++ft) { gz[ft] = cdc.t[ft]; gz[VT + ft] = cdg.t[ft]; }
+      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, gz, j, g, lane);
+      CHG_EW(ft, r) up.t[ft][r] += old.t[ft][r];
+      if (j < nvalid) write_dl<VT>(arow, g, up.t);
+    }
+    write_dl<VT>(Trow, g, cdc.t);
+    write_dl<VT>(Trow + D, g, cdg.t);
+    __builtin_amdgcn_wave_barrier();
+    seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.gR, 4 * D, lane);
+    row_atomic_add<2 * D>(T, TS, k2, nvalid, p.gR + 2 * D, 4 * D, lane);
+    seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.gS, 2 * D, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (REVERSE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, lnacc[q]);
+  }
+}
+
+}  // namespace chg
