@@ -1055,6 +1055,7 @@ struct Train2 {
   bool cached = false;
   float *bar_a, *g_a, *bar_b, *g_b, *bar_wag, *g_wag, *bar_wbg, *g_wbg, *bar_ang, *g_ang, *bar_agg, *g_agg;
   float *barP, *gP, *barQ, *gQ, *barR, *gR, *barS, *gS;
+  float *gP0, *gR0, *gS0;                            // this workspace's own G(P), G(R), G(S) (gP / gR / gS may point into the batch)
   float* ro[26];                                     // readout planes [N,64]
   float *zero_lo, *zero_hi;                          // range cleared at the start of every call
 };
@@ -1104,6 +1105,7 @@ void layout_train2(chg_batch* b, Train2& t, Carver& c) {
   // table gradients: cleared before every layer
   t.barP = c.take<float>(N * 4 * D); t.gP = c.take<float>(N * 4 * D); t.barQ = c.take<float>(Eu * 2 * D); t.gQ = c.take<float>(Eu * 2 * D);
   t.barR = c.take<float>(Eb * 4 * D); t.gR = c.take<float>(Eb * 4 * D); t.barS = c.take<float>(N * 2 * D); t.gS = c.take<float>(N * 2 * D);
+  t.gP0 = t.gP; t.gR0 = t.gR; t.gS0 = t.gS;
 }
 
 int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
@@ -1168,6 +1170,17 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     return gemm("t2_gemm_w2", 64, 64, X + D, 2 * D, nullptr, Wg, bg, nullptr, 0, Y + D, 2 * D, nullptr, rows, 0);
   };
   auto check = [&]() -> int { HIP_TRY(eng, hipGetLastError()); return CHG_OK; };
+  // fused tile kernels (kernels_train2_tile.h); CHGNET_T2_UNFUSED=1 keeps the row-array pipeline of kernels_train2.h (A/B, debugging).
+  // The fused sweep does not re-form the G adjoints (seed 1) of quantities that only leave it: those are the first-order adjoints the
+  // force sweep of chg_predict left in the batch (chg_backward makes sure that sweep has run): Gwag, Gwbgc and, per layer, GP / GR / GS.
+  static const bool fused = !std::getenv("CHGNET_T2_UNFUSED");
+  const float* g_wag = fused ? b->Gwag : t.g_wag;
+  const float* g_wbg = fused ? b->Gwbgc : t.g_wbg;
+  auto table_adjoints_of = [&](int atom_layer, int angle_slot) {   // where G(P) / G(R), G(S) of the layer being swept live
+    t.gP = (fused && atom_layer >= 0) ? b->GP_l[atom_layer] : t.gP0;
+    t.gR = (fused && angle_slot >= 0) ? b->GR_l[angle_slot] : t.gR0;
+    t.gS = (fused && angle_slot >= 0) ? b->GS_l[angle_slot] : t.gS0;
+  };
 
   // ---- direction -> tangent of geometry, bases, embeddings ---------------------------------------------
   if (Ed > 0) {
@@ -1251,15 +1264,13 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   };
 
   // ---- tangent forward ---------------------------------------------------------------------------------------
-  // fused tile kernels (kernels_train2_tile.h); CHGNET_T2_UNFUSED=1 keeps the row-array pipeline of kernels_train2.h (A/B, debugging)
-  static const bool fused = !std::getenv("CHGNET_T2_UNFUSED");
   auto atom2_args = [&](int l) {
     Atom2Args a{};
     a.n_edges = Ed; a.e_center = b->p_center; a.e_nbr = b->p_nbr;
     a.P = b->Pl[l]; a.Q = b->Ql[l]; a.Pd = t.Pd; a.Qd = t.Qd; a.gw = w.ac[l].g; a.wag = b->wag; a.wagd = t.wagd;
-    a.aggd = t.aggd[l]; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wag; a.g_w = t.g_wag;
+    a.aggd = t.aggd[l]; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wag;
     a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG;
-    a.barP = t.barP; a.gP = t.gP; a.barQ = t.barQ; a.gQ = t.gQ; a.g_ln = G(w.ac[l].g.ln1_g);
+    a.barP = t.barP; a.barQ = t.barQ; a.gQ = t.gQ; a.g_ln = G(w.ac[l].g.ln1_g);
     return a;
   };
   // tangent tables of an angle layer:  Rd = hrowsd . [Wi;Wj]^T,  Sd = atomsd . Wctr^T
@@ -1271,10 +1282,10 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     Angle2Args a{};
     a.n_angles = A; a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c;
     a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.Rd = t.Rd; a.Sd = t.Sd; a.ang = angs; a.angd = angsd; a.w_ang = w_ang; a.gw = g;
-    a.w = b->wbgc; a.wd = t.wbgcd; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wbg; a.g_w = t.g_wbg;
+    a.w = b->wbgc; a.wd = t.wbgcd; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wbg;
     a.bar_ang = t.bar_ang; a.g_ang = t.g_ang;
     a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG; a.BZ = t.BZ; a.GZ = t.GZ;
-    a.barR = t.barR; a.gR = t.gR; a.barS = t.barS; a.gS = t.gS; a.g_ln = G(g.ln1_g);
+    a.barR = t.barR; a.barS = t.barS; a.g_ln = G(g.ln1_g);
     return a;
   };
   const dim3 angle_grid(grid_for(std::max(A, 1), tile_grid_mult() * eng->num_cus));
@@ -1402,9 +1413,10 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     if (Ed == 0) return CHG_OK;
     TRY(gemm("t2_gemm_out", 64, 64, t.bar_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, N, 0));
     TRY(gemm("t2_gemm_out", 64, 64, t.g_a, D, nullptr, aw.w_out_t, nullptr, nullptr, 0, t.g_agg, D, nullptr, N, 0));
+    table_adjoints_of(l, -1);
     if (fused) {
       TRY(atom_tables_t(l));
-      TRY(zero(eng, t.barP, sizeof(float) * (size_t)N * 4 * D)); TRY(zero(eng, t.gP, sizeof(float) * (size_t)N * 4 * D));
+      TRY(zero(eng, t.barP, sizeof(float) * (size_t)N * 4 * D));
       const Atom2Args a = atom2_args(l);
       { LaunchScope ls(eng, "t2_atom_b");
         hipLaunchKernelGGL(k2_atom<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), t2_atom_lds(), st, a);
@@ -1456,8 +1468,9 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   auto angle_back = [&](const float* w_bij, const float* w_ctr, const float* b1, const float* w_ang, const float* w_bij_t, const float* w_ctr_t,
                         const float* w_ang_t, const float* hrows, const float* hrowsd, const float* atoms, const float* atomsd,
                         const float* angs, const float* angsd, const std::function<int()>& fused_kernel) -> int {
-    TRY(zero(eng, t.barR, sizeof(float) * (size_t)Eb * 4 * D)); TRY(zero(eng, t.gR, sizeof(float) * (size_t)Eb * 4 * D));
-    TRY(zero(eng, t.barS, sizeof(float) * (size_t)N * 2 * D)); TRY(zero(eng, t.gS, sizeof(float) * (size_t)N * 2 * D));
+    TRY(zero(eng, t.barR, sizeof(float) * (size_t)Eb * 4 * D));
+    TRY(zero(eng, t.barS, sizeof(float) * (size_t)N * 2 * D));
+    if (!fused) { TRY(zero(eng, t.gR, sizeof(float) * (size_t)Eb * 4 * D)); TRY(zero(eng, t.gS, sizeof(float) * (size_t)N * 2 * D)); }
     if (fused) {
       TRY(fused_kernel());     // first-layer adjoints scattered to the tables and contracted back to the angle features in the kernel
     } else {
@@ -1502,6 +1515,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
         { LaunchScope ls(eng, "t2_gated_b");
           hipLaunchKernelGGL(k2_gated_b, wave_rows_grid(eng, A), dim3(256), 0, st, a); }
         }
+        table_adjoints_of(-1, L + l);
         TRY(angle_back(uw.w_bij, uw.w_ctr, uw.b1, uw.w_ang, uw.w_bij_t, uw.w_ctr_t, uw.w_ang_t, b->hbc[l + 1], t.hbcd[l + 1], b->atom[l + 1],
                        t.atomd[l + 1], b->ang[l], t.angd[l], [&]() -> int {
                          LaunchScope ls(eng, "t2_angle_b");
@@ -1531,6 +1545,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       }
       TRY(hidden_back(bw.g, bw.w2c_t, bw.w2g_t, A));
       }
+      table_adjoints_of(-1, l);
       TRY(angle_back(bw.w_bij, bw.w_ctr, bw.b1, bw.w_ang, bw.w_bij_t, bw.w_ctr_t, bw.w_ang_t, b->hbc[l], t.hbcd[l], b->atom[l + 1], t.atomd[l + 1],
                      b->ang[l], t.angd[l], [&]() -> int {
                        const Angle2Args a = angle2_args(l, bw.w_ang, bw.g, b->ang[l], t.angd[l]);
@@ -1552,17 +1567,17 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_b, D, nullptr, t.X6, KB2, nullptr, Eu, 1.0f, G(w.w_bond_emb), NRAD, NRAD)));
     TRY((xty<4, 2>(eng, "t2_wgrad", t.g_b, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_bond_emb), NRAD, NRAD)));
     TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_wag, D, nullptr, t.X6, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
-    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_wag, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", g_wag, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
     TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_wbg, D, nullptr, t.X3, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
-    TRY((xty<4, 2>(eng, "t2_wgrad", t.g_wbg, D, nullptr, t.X3d, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
+    TRY((xty<4, 2>(eng, "t2_wgrad", g_wbg, D, nullptr, t.X3d, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
     {
       FreqGradArgs a{Eu, nullptr, b->ev, t.vd4, b->u_u2d, w.freq_ag, eng->desc.atom_graph_cutoff, env, t.bar_b, t.g_b, w.w_bond_emb,
-                     t.bar_wag, t.g_wag, w.w_wag, G(w.freq_ag)};
+                     t.bar_wag, g_wag, w.w_wag, G(w.freq_ag)};
       LaunchScope ls(eng, "t2_freq");
       hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eu), dim3(256), 0, st, a);
     }
     if (Eb > 0) {
-      FreqGradArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, t.g_wbg, w.w_wbg,
+      FreqGradArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, g_wbg, w.w_wbg,
                      nullptr, nullptr, nullptr, G(w.freq_bg)};
       LaunchScope ls(eng, "t2_freq");
       hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eb), dim3(256), 0, st, a);
@@ -2269,7 +2284,14 @@ int chg_batch_update_geometry(chg_engine* eng, chg_batch* b, const float* frac, 
   HIP_TRY(eng, hipSetDevice(eng->device));
   int s = CHG_OK;
   if (frac) s = h2d(eng, b->frac, frac, (size_t)3 * b->N);
-  if (s == CHG_OK && lattice) s = h2d(eng, b->lattice, lattice, (size_t)9 * b->B);
+  if (s == CHG_OK && lattice) {
+    s = h2d(eng, b->lattice, lattice, (size_t)9 * b->B);
+    b->h_volume.resize(b->B);      // chg_backward scales the stress cotangent with the host copy of the cell volumes
+    for (int q = 0; q < b->B; ++q) {
+      const float* Lf = lattice + 9 * (size_t)q;
+      b->h_volume[q] = Lf[0] * (Lf[4] * Lf[8] - Lf[5] * Lf[7]) + Lf[1] * (Lf[5] * Lf[6] - Lf[3] * Lf[8]) + Lf[2] * (Lf[3] * Lf[7] - Lf[4] * Lf[6]);
+    }
+  }
   if (s == CHG_OK) HIP_TRY(eng, hipStreamSynchronize(eng->stream));
   return s;
 }
@@ -2351,9 +2373,9 @@ static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cota
   std::vector<float> ux, wst;
   if (second_order) {
     // direction of the one tangent sweep: ux = -dL/dF,  W_b = (160.21766208 / V_b) dL/d sigma_b   (kernels_train2.h)
-    if (b->last_task == 0 || !(b->last_task & (CHG_TASK_F | CHG_TASK_S))) {
-      // any task leaves the activations the sweep needs; nothing to check beyond "a forward has run"
-    }
+    // the sweep reuses the first-order adjoints (seed 1) that the force / stress sweep of chg_predict leaves in the batch: run it
+    // if the last prediction was energy-only
+    if (!(b->last_task & (CHG_TASK_F | CHG_TASK_S))) TRY(run_predict(eng, b, b->last_task | CHG_TASK_F));
     TRY(ensure_train2_buffers(eng, b));
     ux.assign((size_t)3 * b->N, 0.f);
     wst.assign((size_t)9 * b->B, 0.f);

@@ -42,10 +42,12 @@ struct Atom2Args {
   float* aggd;                        // tangent forward: [N,64] tangent of the aggregate (zeroed)
   // reverse sweep
   const float *bar_agg, *g_agg;       // [N,64] the two adjoints of the aggregate
-  float *bar_w, *g_w;                 // [Eu,64] adjoints of wag, accumulated over the layers (zeroed once per sweep)
+  float* bar_w;                       // [Eu,64] bar adjoint of wag, accumulated over the layers (zeroed once per sweep)
   float *H, *Hd, *BCG, *GCG;          // [Ed,128] pair order: operands of the second-layer weight gradients
-  float *barP, *gP;                   // [N,256] (zeroed): adjoints of the P table
+  float* barP;                        // [N,256] (zeroed): bar adjoint of the P table
   float *barQ, *gQ;                   // [Eu,128]: adjoints of the Q table, plain stores (the tile owns its bonds)
+  // The G adjoints of everything that only LEAVES the sweep -- G(wag), G(P) -- are the first-order adjoints with seed 1: the
+  // force sweep of chg_predict has left them in Gwag / GP_l[l]; only G(Q), which that sweep keeps for one layer at a time, is formed here.
   float* g_ln;                        // [4][64] LayerNorm-affine gradients
 };
 
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     float acc1 = 0.f, acc2 = 0.f;                                   // tangent forward: run sums of the aggregate tangent
     int cur1 = __builtin_amdgcn_readlane(c, 0), cur2 = __builtin_amdgcn_readlane(c, 1);
     const int nb = nvalid >> 1;
-    struct BondIn { float ba0, ga0, ba1, ga1, w, wd, obw, ogw; };
+    struct BondIn { float ba0, ga0, ba1, ga1, w, wd, obw; };
     auto fetch = [&](int b) {                                        // b: bond of the tile (clamped: harmless reads past the end)
       BondIn v{};
       const int bb = min(b, nb - 1);
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         const int c0 = __builtin_amdgcn_readlane(c, 2 * bb), c1 = __builtin_amdgcn_readlane(c, 2 * bb + 1);
         v.ba0 = p.bar_agg[(size_t)c0 * D + lane]; v.ga0 = p.g_agg[(size_t)c0 * D + lane];
         v.ba1 = p.bar_agg[(size_t)c1 * D + lane]; v.ga1 = p.g_agg[(size_t)c1 * D + lane];
-        v.obw = p.bar_w[kb]; v.ogw = p.g_w[kb];
+        v.obw = p.bar_w[kb];
       }
       return v;
     };
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         if (b >= nb) break;
         const BondIn in = nx;
         nx = fetch(b + 1);
-        float pair_bw = 0.f, pair_gw = 0.f;
+        float pair_bw = 0.f;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {                    // the two directions
           float* a = T + (2 * pb + d) * T2_AS + lane;
@@ -177,7 +179,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
           } else {
             const float bar_a = d ? in.ba1 : in.ba0, g_a = d ? in.ga1 : in.ga0;
             pair_bw += s.y * bar_a + s.yd * g_a;
-            pair_gw += s.y * g_a;
             float bar_c, bar_g, g_c, g_g;
 #ifdef T2_EXP_NO_ROWBWD
             bar_c = s.y; bar_g = s.yd; g_c = s.a1; g_g = s.a2;
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         if (REVERSE) {                                   // the tile owns bond k0 + b: plain update of the weight adjoints
           const size_t kb = (size_t)(k0 + b) * D + lane;
           p.bar_w[kb] = in.obw + pair_bw;
-          p.g_w[kb] = in.ogw + pair_gw;
         }
       }
       if (REVERSE) {
@@ -249,13 +249,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     acbwd_scatter(T, c, nvalid, k0, sc, lane);
 #endif
     __builtin_amdgcn_wave_barrier();
+    // G side: G(P) is the first-order adjoint the force sweep of chg_predict left in GP_l[l] -- only the Q rows are formed here
     write_dl<VT>(Trow, g, cdc.t);
     write_dl<VT>(Trow + D, g, cdg.t);
     __builtin_amdgcn_wave_barrier();
-    sc.GP = p.gP; sc.GQ = p.gQ;
-#ifndef T2_EXP_NO_SCATTER
-    acbwd_scatter(T, c, nvalid, k0, sc, lane);
-#endif
+#pragma unroll
+    for (int b = 0; b < TILE_ROWS / 2; ++b)
+      if (2 * b < nvalid) {
+        float* q = p.gQ + (size_t)(k0 + b) * 2 * D + lane;
+        q[0] = T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
+        q[64] = T[(2 * b) * TS + 64 + lane] + T[(2 * b + 1) * TS + 64 + lane];
+      }
     __builtin_amdgcn_wave_barrier();
   }
   if (REVERSE) {
@@ -279,14 +283,15 @@ struct Angle2Args {
   const float *w, *wd;                // [Eb,64] smooth bond weights (bond graph) and tangents
   float* aggd;                        // tangent forward: [Eb,64] (zeroed)
   const float *bar_agg, *g_agg;       // reverse: [Eb,64]
-  float *bar_w, *g_w;                 // reverse: [Eb,64] adjoints of wbg, accumulated over the layers (atomics)
+  float* bar_w;                       // reverse: [Eb,64] bar adjoint of wbg, accumulated over the layers (atomics); G(wbg), like
+                                      // G(R) and G(S), is the first-order adjoint chg_predict's force sweep left behind
   // AngleUpdate: ang' = ang + y
   float* angd_out;                    // tangent forward: [A,64]
   // reverse, both kinds
   float *bar_ang, *g_ang;             // [A,64] adjoints of the angle features: read (AngleUpdate: adjoint of ang'), updated in place
   float *H, *Hd, *BCG, *GCG;          // [A,128] HIDDEN: operands of the second-layer weight gradients
   float *BZ, *GZ;                     // [A,128] first-layer adjoints: operands of the W_ang gradient
-  float *barR, *gR, *barS, *gS;       // [Eb,256], [N,128] (zeroed)
+  float *barR, *barS;                 // [Eb,256], [N,128] (zeroed)
   float* g_ln;
 };
 
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     }
     // ---- row-local part, eight rows at a time through the tile (lane = feature); what the next row needs from memory is
     //      requested a row ahead ----
-    float acc = 0.f, acc_bw = 0.f, acc_gw = 0.f;      // BondConv: run sums over the owning bond
+    float acc = 0.f, acc_bw = 0.f;                    // BondConv: run sums over the owning bond
     float w1 = 0.f, w1d = 0.f, bar_a = 0.f, g_a = 0.f;
     int cur = -1;
     struct RowIn { float w2, w2d, by, gy; };
@@ -420,11 +425,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
                 tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
               } else {
                 atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
-                atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
               }
             }
             cur = dst;
-            acc = acc_bw = acc_gw = 0.f;
+            acc = acc_bw = 0.f;
             w1 = p.w[(size_t)dst * D + lane];
             w1d = p.wd[(size_t)dst * D + lane];
             if (REVERSE) {
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
             acc += s.yd * w1 * in.w2 + s.y * (w1d * in.w2 + w1 * in.w2d);
           } else {
             acc_bw += s.y * in.w2 * bar_a + (s.yd * in.w2 + s.y * in.w2d) * g_a;
-            acc_gw += s.y * in.w2 * g_a;
             const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane;
+#ifndef T2_EXP_NO_ROWATOM
             atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
-            atomicAdd(p.g_w + k2, s.y * w1 * g_a);
+#endif
             bar_y = w1 * in.w2 * bar_a + (w1d * in.w2 + w1 * in.w2d) * g_a;
             g_y = w1 * in.w2 * g_a;
           }
@@ -451,7 +455,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         }
         if (REVERSE) {
           float bar_c, bar_g, g_c, g_g;
+#ifdef T2_EXP_NO_ROWBWD
+          bar_c = s.y + bar_y; bar_g = s.yd + g_y; g_c = s.a1; g_g = s.a2;
+#else
           gated_row_bwd(s, bar_y, g_y, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
+#endif
           a[0] = bar_c; a[D] = bar_g; a[2 * D] = g_c; a[3 * D] = g_g;
         }
       }
@@ -468,7 +476,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
       } else {
         atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
-        atomicAdd(p.g_w + (size_t)cur * D + lane, acc_gw);
       }
     }
     if (!REVERSE) {
@@ -504,7 +511,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
     }
     // cc | cg = bar(z), cdc | cdg = G(z)
+#ifdef T2_EXP_NO_DUMP
+    if (false) {
+#else
     if (j < nvalid) {                 // A operands of the W_ang gradient
+#endif
       float* brow = p.BZ + (size_t)(row0 + j) * 2 * D;
       float* grow = p.GZ + (size_t)(row0 + j) * 2 * D;
       write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
@@ -528,10 +539,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     write_dl<VT>(Trow + D, g, cg.t);
     __builtin_amdgcn_wave_barrier();
     seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane);
+#ifndef T2_EXP_NO_ROWATOM
     row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane);
+#endif
     seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane);
     __builtin_amdgcn_wave_barrier();
-    // ---- G ----
+    // ---- G: only the angle features (an input of the earlier layers); G(R), G(S) are the first-order table adjoints ----
     {
       V64 old, up = zero64();
       float* arow = p.g_ang + (size_t)row * D;
@@ -543,13 +556,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       CHG_EW(ft, r) up.t[ft][r] += old.t[ft][r];
       if (j < nvalid) write_dl<VT>(arow, g, up.t);
     }
-    write_dl<VT>(Trow, g, cdc.t);
-    write_dl<VT>(Trow + D, g, cdg.t);
-    __builtin_amdgcn_wave_barrier();
-    seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.gR, 4 * D, lane);
-    row_atomic_add<2 * D>(T, TS, k2, nvalid, p.gR + 2 * D, 4 * D, lane);
-    seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.gS, 2 * D, lane);
-    __builtin_amdgcn_wave_barrier();
   }
   if (REVERSE) {
 #pragma unroll

@@ -67,7 +67,8 @@ class CombinedLoss:
             else:   # torch: mean over an empty tensor is nan; the reference would propagate it
                 out["loss"] += float("nan")
                 out[f"{key}_MAE"] = float("nan")
-            return g, int(valid.sum())
+            # trainer.py:783-812: with masking the sizes count label ELEMENTS, without it the rows of the [N,3] / [3B,3] targets
+            return g, int(valid.sum()) if self.allow_missing_labels else int(t.shape[0])
 
         if "e" in self.target_str:
             grads["e"], _ = term("e", self.energy_loss_ratio, targets["e"], prediction["e"])
@@ -190,7 +191,13 @@ class TrainStep:
         self.targets = targets
         self.comm = comm                      # RcclComm, or None for the torch.distributed process group (if any)
         self.loss = CombinedLoss(target_str=targets, criterion=criterion, **loss_kwargs)
-        self.optimizer = Adam(model.state_dict(), lr=learning_rate, frozen=("composition_model.fc.weight",))
+        state = model.state_dict()
+        if any(k.endswith("mlp_out.layers.1.bias") for k in state):   # fail before the first forward, not at the first backward
+            raise NotImplementedError("training a model with mlp_out bias (CHGNet 0.2.0 checkpoints) is not supported by the engine's backward")
+        frozen = ["composition_model.fc.weight"]
+        if not getattr(model, "model_args", {}).get("learnable_rbf", True):   # buffers in the reference (basis.py:31-40, 87-98): never updated
+            frozen += [k for k in state if k.endswith(".frequencies")]
+        self.optimizer = Adam(state, lr=learning_rate, frozen=tuple(frozen))
         self.task = "".join(k for k in "efsm" if k in targets)
         if self.task not in ("e", "ef", "em", "efs", "efsm"):       # the engine's task strings (chgnet/__init__.py:15 PredTask)
             self.task = "efsm" if "m" in targets else "efs"

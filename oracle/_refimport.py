@@ -85,16 +85,32 @@ def build_cygraph(scratch: str | None = None) -> str:
     have = [f for f in (os.listdir(os.path.join(pkg, "graph")) if os.path.isdir(os.path.join(pkg, "graph")) else [])
             if f.startswith("cygraph") and f.endswith(".so")]
     if not have:
-        if os.path.isdir(scratch):
-            shutil.rmtree(scratch)
-        os.makedirs(scratch)
-        shutil.copytree(os.path.join(REFERENCE_ROOT, "chgnet"), pkg, ignore=shutil.ignore_patterns("__pycache__", "pretrained"))
-        setup_py = os.path.join(scratch, "setup_cygraph.py")
+        import tempfile  # noqa: PLC0415
+
+        marker = ".chgnet_reference_build"      # only directories this function made are ever removed
+        if os.path.isdir(scratch) and not os.path.exists(os.path.join(scratch, marker)):
+            raise RuntimeError(f"{scratch} exists and was not created by build_cygraph (no {marker} file): refusing to replace it; "
+                               "point CHGNET_REFERENCE_BUILD at a fresh path")
+        parent = os.path.dirname(os.path.abspath(scratch)) or "."
+        os.makedirs(parent, exist_ok=True)
+        work = tempfile.mkdtemp(prefix=os.path.basename(scratch) + ".", dir=parent)   # private: parallel test processes do not collide
+        open(os.path.join(work, marker), "w").close()
+        shutil.copytree(os.path.join(REFERENCE_ROOT, "chgnet"), os.path.join(work, "chgnet"),
+                        ignore=shutil.ignore_patterns("__pycache__", "pretrained"))
+        setup_py = os.path.join(work, "setup_cygraph.py")
         with open(setup_py, "w") as fh:   # the reference's setup.py:1-10, minus the package metadata
             fh.write("import numpy as np\nfrom Cython.Build import cythonize\nfrom setuptools import Extension, setup\n"
                      "setup(name='cygraph_build', ext_modules=cythonize([Extension('chgnet.graph.cygraph', ['chgnet/graph/cygraph.pyx'],"
                      " include_dirs=[np.get_include()])], language_level=3), script_args=['build_ext', '--inplace'])\n")
-        subprocess.run([sys.executable, setup_py], cwd=scratch, check=True, capture_output=True)
+        subprocess.run([sys.executable, setup_py], cwd=work, check=True, capture_output=True)
+        try:
+            if os.path.isdir(scratch):
+                shutil.rmtree(scratch)            # carries the marker (checked above)
+            os.rename(work, scratch)
+        except OSError:                           # another process won the race: use its build
+            shutil.rmtree(work, ignore_errors=True)
+            if not os.path.isdir(os.path.join(scratch, "chgnet", "graph")):
+                raise
     return scratch
 
 

@@ -428,3 +428,35 @@ def test_gradients_are_additive_over_structures_at_scale(hip_engine):
         assert np.isfinite(whole).all() and scale > 0
         # fp32 sums over ~2M rows in a different order: compare against the largest entry
         assert np.abs(whole - parts).max() < 2e-4 * scale, (second_order, float(np.abs(whole - parts).max()), float(scale))
+
+
+def test_stress_term_after_a_cell_update_uses_the_new_volume(hip_engine):
+    """chg_batch_update_geometry(lattice) refreshes the host copy of the cell volumes that scales the stress cotangent: a
+    backward on a resident batch whose cell was rescaled by 0.5 % (graph topology unchanged) equals the backward on a batch
+    uploaded with the new cell."""
+    import bench
+
+    from chgnet_amd.pack import PackedBatch, pack_batch
+
+    pb = pack_batch(bench.build_workload(4, 4100))
+    scale = 1.005
+    rng = np.random.default_rng(5)
+    gs = rng.normal(size=(4, 3, 3)).astype(np.float32)
+    ce = rng.normal(size=4).astype(np.float32)
+    resident = hip_engine.upload(pb)
+    try:
+        resident.update_geometry(lattice=np.asarray(pb.arrays["lattice"], np.float32).reshape(-1, 3, 3) * scale)
+        hip_engine.predict(resident, "efs")
+        got = hip_engine.backward(resident, ce, s_grad=gs)
+        arr = dict(pb.arrays)
+        arr["lattice"] = np.ascontiguousarray(np.asarray(arr["lattice"]) * scale)
+        fresh = hip_engine.upload(PackedBatch(pb.n_struct, pb.n_atoms, pb.n_directed, pb.n_undirected, pb.n_angles, pb.n_bnodes, arr))
+        try:
+            hip_engine.predict(fresh, "efs")
+            want = hip_engine.backward(fresh, ce, s_grad=gs)
+        finally:
+            fresh.free()
+    finally:
+        resident.free()
+    ref = float(np.abs(want).max())
+    assert ref > 0 and np.abs(got - want).max() <= 1e-4 * ref, float(np.abs(got - want).max() / ref)

@@ -32,9 +32,10 @@ def _batch(rng, missing: bool):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/chgnet"), reason="live reference only in the build container")
 @pytest.mark.parametrize("criterion", ["MSE", "MAE", "Huber"])
-@pytest.mark.parametrize("missing", [False, True])
-def test_combined_loss_equals_the_references(criterion, missing):
-    """Loss value, MAEs, MAE sizes and d loss / d prediction against chgnet.trainer.trainer.CombinedLoss + autograd."""
+@pytest.mark.parametrize(("missing", "allow"), [(False, True), (True, True), (False, False)])
+def test_combined_loss_equals_the_references(criterion, missing, allow):
+    """Loss value, MAEs, MAE sizes and d loss / d prediction against chgnet.trainer.trainer.CombinedLoss + autograd; also without
+    label masking, where the reference's sizes count target ROWS ([N,3], [3B,3]) instead of elements (trainer.py:826, 840)."""
     from oracle._refimport import load_reference
 
     load_reference(fast_graph=True)
@@ -43,7 +44,7 @@ def test_combined_loss_equals_the_references(criterion, missing):
     rng = np.random.default_rng(3)
     targ, pred = _batch(rng, missing)
     kw = dict(target_str="efsm", criterion=criterion, energy_loss_ratio=1.3, force_loss_ratio=0.7, stress_loss_ratio=0.2,
-              mag_loss_ratio=0.4, delta=0.3)
+              mag_loss_ratio=0.4, delta=0.3, allow_missing_labels=allow)
     ours, grads = CombinedLoss(**kw).gradients(targ, pred)
     tp = {"e": torch.tensor(pred["e"], requires_grad=True), "f": [torch.tensor(x, requires_grad=True) for x in pred["f"]],
           "s": [torch.tensor(x, requires_grad=True) for x in pred["s"]], "m": [torch.tensor(x, requires_grad=True) for x in pred["m"]]}
