@@ -64,38 +64,52 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
   for (int c = 0; c < (M + 63) / 64; ++c) asum[c] = 0.f;
   constexpr int LA = M / 4, RA = 64 / LA;    // lanes per A row (float4 each), rows per load step
   constexpr int LB = N / 4, RB = 64 / LB;
-  for (int tile = tb; tile < te; ++tile) {
+  constexpr int NA = TILE_ROWS / RA, NB = TILE_ROWS / RB;
+  // Software pipeline over tiles: the rows of tile t+1 are requested before tile t's MFMAs and committed to LDS after them (the
+  // HBM-bound contractions of the second-order sweep ran at 2.7 TB/s with load -> wait -> contract per tile).
+  f32x4 va[NA], vb[NB];
+  int nvalid_n = 0;
+  auto issue = [&](int tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
-    const int nvalid = min(TILE_ROWS, p.rows - row0);
-    if (nvalid <= 0) continue;
-    const int row = row0 + (i < nvalid ? i : 0);
+    nvalid_n = min(TILE_ROWS, p.rows - row0);
+    if (nvalid_n <= 0) return;
+    const int row = row0 + (i < nvalid_n ? i : 0);
     const int ra = p.a_idx ? p.a_idx[row] : row;
     const int rb = p.b_idx ? p.b_idx[row] : row;
     {
       const int sub = lane / LA, t = lane % LA;
-      f32x4 v[TILE_ROWS / RA];
 #pragma unroll
-      for (int it = 0; it < TILE_ROWS / RA; ++it) {
+      for (int it = 0; it < NA; ++it) {
         const int rr = RA * it + sub;
         const int r = __shfl(ra, rr);
-        v[it] = rr < nvalid ? *reinterpret_cast<const f32x4*>(p.A + (size_t)r * p.lda + 4 * t) : zero4();   // rows past the end add nothing
+        va[it] = rr < nvalid_n ? *reinterpret_cast<const f32x4*>(p.A + (size_t)r * p.lda + 4 * t) : zero4();   // rows past the end add nothing
       }
-#pragma unroll
-      for (int it = 0; it < TILE_ROWS / RA; ++it) *reinterpret_cast<f32x4*>(TA + (RA * it + sub) * SA + 4 * t) = v[it];
     }
     {
       const int sub = lane / LB, t = lane % LB;
-      f32x4 v[TILE_ROWS / RB];
 #pragma unroll
-      for (int it = 0; it < TILE_ROWS / RB; ++it) {
+      for (int it = 0; it < NB; ++it) {
         const int rr = RB * it + sub;
         const int r = __shfl(rb, rr);
-        v[it] = rr < nvalid ? *reinterpret_cast<const f32x4*>(p.B + (size_t)r * p.ldb + 4 * t) : zero4();
+        vb[it] = rr < nvalid_n ? *reinterpret_cast<const f32x4*>(p.B + (size_t)r * p.ldb + 4 * t) : zero4();
       }
+    }
+  };
+  if (tb < te) issue(tb);
+  for (int tile = tb; tile < te; ++tile) {
+    if (nvalid_n <= 0) break;                  // waves past the end of the last tile (a wave's tiles only move up)
+    {
+      const int sub = lane / LA, t = lane % LA;
 #pragma unroll
-      for (int it = 0; it < TILE_ROWS / RB; ++it) *reinterpret_cast<f32x4*>(TB + (RB * it + sub) * SB + 4 * t) = v[it];
+      for (int it = 0; it < NA; ++it) *reinterpret_cast<f32x4*>(TA + (RA * it + sub) * SA + 4 * t) = va[it];
+    }
+    {
+      const int sub = lane / LB, t = lane % LB;
+#pragma unroll
+      for (int it = 0; it < NB; ++it) *reinterpret_cast<f32x4*>(TB + (RB * it + sub) * SB + 4 * t) = vb[it];
     }
     __builtin_amdgcn_wave_barrier();
+    if (tile + 1 < te) issue(tile + 1); else nvalid_n = 0;
     if (p.a_colsum) {   // rows past the end were zero-filled: all 16 rows may be summed
 #pragma unroll
       for (int c = 0; c < (M + 63) / 64; ++c)
