@@ -719,12 +719,25 @@ def main() -> None:
                 gbs = nbytes / (t_ms * 1e-3) / 1e9
                 hbm["kernels"][k] = {"bytes_per_launch": int(nbytes), "avg_launch_ms": round(t_ms, 4), "achieved_gbs": round(gbs, 1),
                                      "frac_of_stream": round(gbs / stream_gbs, 4), "frac_of_spec": round(gbs / PEAK_HBM_GBS, 4)}
+        # what the wave slots of each kernel spend their cycles on (rocprofv3 --pmc SQ_* pass of this command, profiles/summarize.py):
+        # the embedding kernels are neither HBM- nor matrix-bound, the copy-rate fractions above are quoted for continuity only
+        try:
+            with open(os.path.join(REPO, "profiles", "sq_latest.json")) as fh:
+                sqc = json.load(fh)
+            for k, v in sqc["kernels"].items():
+                if k in hbm["kernels"]:
+                    hbm["kernels"][k]["sq_counters"] = v
+                elif k in roofline.get("tile_kernels", {}):
+                    roofline["tile_kernels"][k]["sq_counters"] = v
+            hbm["sq_counters_unit"] = sqc["unit"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "structures/s (energy+force+stress) on batched ~50-atom crystals",
             "value": round(value, 2), "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "f32 storage, f32 accumulation; contractions of 5 of the 6 tile kernels as 3 x f16 MFMA on split f32 operands "
+            "arithmetic": "f32 storage, f32 accumulation; contractions of the six tile kernels as 3 x f16 MFMA on split f32 operands "
                           "(error of the split contraction <= the f32 MFMA's, profiles/r03_split_lab.txt; E/F/S parity unchanged)",
             "config": {"workload": f"{args.structures} x LiMnO2 5x1x1 (40 atoms, sigma=0.01 frac perturbation) per GPU, task efs",
                        "structures_per_gpu": args.structures, "atoms": int(packed.n_atoms), "directed_bonds": int(packed.n_directed),

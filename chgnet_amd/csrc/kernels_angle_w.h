@@ -304,6 +304,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       PH(0)   // indices + gathers
       Rows64 gy_rows;
       if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);
+      V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
+      if (HIDDEN) {
+        read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
+        read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
+        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
+      }
       if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
       else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
       V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
@@ -313,10 +319,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       gated_forward<HIDDEN, SLIM, false, MODE>(zc, zg, W2c, W2g, vecs, j, g, s, y);
       V64 gy;
       if (HIDDEN) {
-        V64 w1, w2, gu;
-        read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
-        read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
-        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
         V64 g1, g2;
         CHG_EW(ft, r) {
           g1.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w2.t[ft][r];      // dE/d wbgc[b1]

@@ -18,8 +18,8 @@ if not os.path.isdir(SRC):
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 LABELS = {  # kernel-name substring -> bench.py label
-    "k_angle<true, true": "bondconv_bwd", "k_angle<true, false": "bondconv_fwd",
-    "k_angle_bwd_w<false": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",   # (the plain k_angle<false, true> launch returns at once)
+    "k_angle_bwd_w<true": "bondconv_bwd", "k_angle<true, false": "bondconv_fwd",     # per-atom adjoints (kernels_angle_w.h); the plain
+    "k_angle_bwd_w<false": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",   # k_angle<*, true> launches return at once
     "k_atomconv_bwd": "atomconv_bwd", "k_atomconv_fwd": "atomconv_fwd",
 }
 
@@ -44,7 +44,7 @@ for name in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))
     hbm = (2.0 * f + w) * 1024.0
     rows.append([name, n, round(f, 1), round(w, 1), int(hbm)])
     for sub, label in LABELS.items():
-        if sub in name:
+        if sub in name and label not in latest:      # rows are sorted by traffic: the launch that did the work comes first
             latest[label] = {"hbm_bytes_per_launch": int(hbm), "fetch_kib_reported": round(f, 1), "write_kib_reported": round(w, 1),
                              "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB), MI355X_MICROARCH.md HBM section", "profile": f"profiles/{tag}_pmc_summary.csv"}
 with open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.csv"), "w", newline="") as fh:
@@ -54,3 +54,34 @@ with open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.csv"), "w", newline
 json.dump(latest, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)
 for r in rows[:12]:
     print(r)
+
+
+# ---- SQ counters (separate --pmc pass): what the wave slots of each kernel spend their cycles on -> profiles/sq_latest.json,
+#      quoted by bench.py next to the roofline fractions (classification: matrix pipe / vector issue / waiting on memory)
+SQ_LABELS = dict(LABELS, **{"k_bond_embed_t<false": "bond_embed_fwd", "k_bond_embed_t<true": "bond_embed_bwd",
+                            "k_angle_embed_t<false": "angle_embed_fwd", "k_angle_embed_t<true": "angle_embed_bwd",
+                            "k_edge_force": "edge_force", "k_rows_gemm<128, 64, 1>": "gemm_GQ"})
+sq_path = os.path.join(SRC, "pmc_sq_counter_collection.csv")
+if os.path.exists(sq_path):
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    with open(sq_path) as fh:
+        for row in csv.DictReader(fh):
+            for sub, lab in SQ_LABELS.items():
+                if sub in row["Kernel_Name"]:
+                    a = acc[lab][row["Counter_Name"]]
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+    sq = {}
+    for lab, cs in acc.items():
+        c = {k: v[1] / max(v[0], 1) for k, v in cs.items()}
+        wc, gui = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0, c.get("GRBM_GUI_ACTIVE", 0.0)
+        sq[lab] = {"wait_any": round(c.get("SQ_WAIT_ANY", 0) / wc, 3), "wait_inst_any": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                   "active_inst_any": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3), "active_inst_valu": round(c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
+                   "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui / 8 * 1024), 3) if gui else None}
+        s_ = sq[lab]
+        s_["bound"] = ("memory (wave slots idle: HBM bandwidth / latency)" if s_["active_inst_any"] < 0.2 else
+                       "memory latency (waits on LDS / L2 / atomics)" if s_["wait_any"] >= 0.45 else "vector-ALU issue")
+    json.dump({"unit": "fraction of SQ_WAVE_CYCLES (mfma_busy: of the SIMD cycles of the launch)", "profile": f"gpurun_out/{tag}/prof/pmc_sq_*",
+               "kernels": sq}, open(os.path.join(REPO, "profiles", "sq_latest.json"), "w"), indent=1)
+    for k, v in sq.items():
+        print(k, v)
