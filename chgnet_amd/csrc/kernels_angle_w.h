@@ -283,7 +283,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       }
       int s2 = ab2 - ab0;                         // rank of the second bond at this atom = private row
       if (ab2 < 0 || s2 < 0 || s2 >= NS) s2 = -1;
-      // ---- gathers: angle rows, then the two halves of the table sum ----
+      // ---- gathers: angle rows, then the two halves of the table sum.  (Requesting tile t+1's rows ahead -- before tile t's scatter
+      // phase -- was tried: 112 loop-carried registers for the table rows cost 225 spills (2x slower), 16 for the angle rows alone 51
+      // spills (+14 %): this kernel has no registers left to pipeline with.) ----
       Gather64 gc, gg;
       gather64_issue(gc, p.R, b1, 4 * D, p.R + 2 * D, b2, 4 * D, p.S, c, 2 * D, lane);
       gather64_issue(gg, p.R + D, b1, 4 * D, p.R + 3 * D, b2, 4 * D, p.S + D, c, 2 * D, lane);

@@ -231,14 +231,35 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
   int tb, te;
   tile_range(ntiles, tb, te);
   float fas[4] = {0.f, 0.f, 0.f, 0.f}, fac[4] = {0.f, 0.f, 0.f, 0.f};   // TRAIN: d freq through the sin / cos columns of this lane
+  // Software pipeline over tiles (three dependent memory round trips per tile -- indices, unit vectors, adjoint rows -- left the waves
+  // waiting 55-73 % of their cycles): indices two tiles ahead, unit vectors and the adjoint rows one tile ahead.
+  const int last_angle = p.n_angles - 1;
+  auto angle_of = [&](int tile) { return min(tile * BLOCK_ROWS + wave * TILE_ROWS + j, last_angle); };   // clamped: loads stay valid
+  int a_n = 0, d1_n = 0, d2_n = 0, a_n2 = 0, d1_n2 = 0, d2_n2 = 0;
+  f32x4 u1_n = zero4(), u2_n = zero4();
+  Rows64 gin_n;
+  if (tb < te) {
+    a_n = angle_of(tb); d1_n = p.a_d1[a_n]; d2_n = p.a_d2[a_n];
+    a_n2 = angle_of(tb + 1); d1_n2 = p.a_d1[a_n2]; d2_n2 = p.a_d2[a_n2];
+    u1_n = p.eu[d1_n]; u2_n = p.eu[d2_n];
+    if (BWD) rows64_issue(gin_n, p.Gang, a_n, lane);
+  }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
-    if (nvalid <= 0) continue;
     const bool valid = j < nvalid;
     const int a = row0 + (valid ? j : 0);
-    const int d1 = p.a_d1[a], d2 = p.a_d2[a];
-    const f32x4 u1 = p.eu[d1], u2 = p.eu[d2];
+    const int d1 = d1_n, d2 = d2_n;
+    const f32x4 u1 = u1_n, u2 = u2_n;
+    Rows64 gin_rows;
+    if (BWD) gin_rows = gin_n;
+    a_n = a_n2; d1_n = d1_n2; d2_n = d2_n2;
+    if (tile + 1 < te) {
+      u1_n = p.eu[d1_n]; u2_n = p.eu[d2_n];
+      if (BWD) rows64_issue(gin_n, p.Gang, a_n, lane);
+      a_n2 = angle_of(tile + 2); d1_n2 = p.a_d1[a_n2]; d2_n2 = p.a_d2[a_n2];
+    }
+    if (nvalid <= 0) continue;
     const float cosv = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]) * KAPPA;   // encoders.py:144
     const float theta = acosf(cosv);
     f32x4 x[2], dx[2];
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
     } else {
       f32x4 t[2] = {zero4(), zero4()};
       V64 gin;
-      gather_rows64(T, ETS, p.Gang, a, lane);
+      rows64_commit(gin_rows, T, ETS, lane);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, gin.t);
       gemm_dl_t<VT, 2>(t, We, WSB, gin.t, j, g);
