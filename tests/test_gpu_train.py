@@ -460,3 +460,48 @@ def test_stress_term_after_a_cell_update_uses_the_new_volume(hip_engine):
         resident.free()
     ref = float(np.abs(want).max())
     assert ref > 0 and np.abs(got - want).max() <= 1e-4 * ref, float(np.abs(got - want).max() / ref)
+
+
+def test_fused_second_order_sweep_equals_the_row_array_pipeline():
+    """kernels_train2_tile.h against kernels_train2.h (CHGNET_T2_UNFUSED=1, chosen once per process: the unfused run is a child
+    process): same gradient blob to fp32 reassociation, on a batch large enough for full tiles, ragged tails and long runs."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bench
+from chgnet_amd.engine import Engine
+from chgnet_amd.pack import pack_batch, pack_weights
+W = dict(np.load(sys.argv[1] + "/tests/golden/weights_seed0.npz"))
+pb = pack_batch(bench.build_workload(24, 5200))
+rng = np.random.default_rng(11)
+ce = rng.normal(size=24).astype(np.float32); gm = rng.normal(size=pb.n_atoms).astype(np.float32)
+gf = rng.normal(size=(pb.n_atoms, 3)).astype(np.float32); gs = rng.normal(size=(24, 3, 3)).astype(np.float32)
+eng = Engine(pack_weights(W), 0)
+b = eng.upload(pb)
+eng.predict(b, "e")            # energy-only: chg_backward has to run the force sweep itself before the second-order sweep
+g1 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
+eng.predict(b, "efsm")
+g2 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
+np.save(sys.argv[2], np.stack([g1, g2]))
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("fused", "unfused"):
+            env = dict(os.environ)
+            env.pop("CHGNET_T2_UNFUSED", None)
+            if mode == "unfused":
+                env["CHGNET_T2_UNFUSED"] = "1"
+            path = os.path.join(tmp, mode + ".npy")
+            subprocess.run([sys.executable, "-c", code, repo, path], check=True, env=env, timeout=600)
+            out[mode] = np.load(path).astype(np.float64)
+    scale = np.abs(out["unfused"][1]).max()
+    assert scale > 0 and np.isfinite(out["fused"]).all()
+    # after an energy-only prediction == after a full one (the sweep's first-order inputs are rebuilt)
+    assert np.abs(out["fused"][0] - out["fused"][1]).max() <= 1e-5 * scale
+    assert np.abs(out["fused"][1] - out["unfused"][1]).max() <= 1e-4 * scale, float(np.abs(out["fused"][1] - out["unfused"][1]).max() / scale)
