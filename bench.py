@@ -64,6 +64,17 @@ KERNEL_MODEL = {
     "angleupd_bwd": ("n_angles", 32768, 780),
 }
 
+# Reverse kernels of the fused second-order training sweep (csrc/kernels_train2_tile.h): (unit, flop per unit, compulsory bytes per
+# unit, what).  Flops: every contraction once for the primal / bar row and once for the tangent / G row -- BondConv: W_ang 64->128
+# (16,384) x 2, W2c + W2g (16,384) x 2, their transposes x 2 -> 131,072; AngleUpdate: the angle block and its transpose -> 65,536;
+# AtomConv: second layer and its transpose, two rows each -> 65,536.  Bytes: the row dumps the weight-gradient contractions read back
+# (BondConv 6 x 512, AngleUpdate 2 x 512, AtomConv 4 x 512) + angle rows in (2 x 256) and adjoint rows updated (2 x 2 x 256).
+TRAIN_KERNEL_MODEL = {
+    "t2_bond_b": ("n_angles", 131072, 6 * 512 + 512 + 1024, "k2_angle<BondConv, reverse>"),
+    "t2_angle_b": ("n_angles", 65536, 2 * 512 + 512 + 1024 + 512, "k2_angle<AngleUpdate, reverse>"),
+    "t2_atom_b": ("n_directed", 65536, 4 * 512 + 256, "k2_atom<reverse>"),
+}
+
 # HBM-bound kernels: (unit, compulsory bytes per unit) -- every distinct input read once, every output written once
 # (DESIGN.md "Roofline accounting", HBM regime).  Eb/Eu-dependent terms are added in hbm_model().
 LIMNO2_FRAC = [[0.5, 0.5, 0.3797505], [0, 0, 0.6202495], [0.5, 0.5, 0.8632525], [0, 0, 0.1367475],
@@ -527,6 +538,15 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
             dt = ranks.max_over_ranks(time.perf_counter() - t0)
             n_done = sum(len(b_) for b_ in batches[use]) * ranks.world
             results[targets] = (n_done, dt, len(losses), losses)
+            if targets == "efsm" and ranks.rank == 0:   # one more step with per-kernel HIP events (outside the timed region)
+                eng.profile(True)
+                eng.profile_reset()
+                step(batches[0], labels[0])
+                eng.synchronize()
+                train_prof = eng.profile_read()
+                eng.profile(False)
+                n_angles_b = sum(len(g_.bond_graph) for g_ in batches[0])
+                n_dir_b = sum(len(g_.atom_graph) for g_ in batches[0])
         model.release_forward_state()
         if ranks.rank == 0:
             n_done, dt, ns, losses = results["efsm"]
@@ -541,6 +561,25 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
                 "loss_first_last": [float(f"{losses[0]:.4g}"), float(f"{losses[-1]:.4g}")],
                 "energy_magmom_terms_only": {"structures_per_s": round(n1 / dt1, 1), "ms_per_step": round(1e3 * dt1 / ns1, 2),
                                              "what": "target em: first-order reverse sweep only (fused kernels)"}}
+            # the training step's own kernels (HIP events of one step): labels t2_* = fused second-order sweep
+            # (csrc/kernels_train2_tile.h), t2_wgrad = k_xty weight-gradient contractions, the rest = forward + force sweep
+            ranked_t = sorted(train_prof.items(), key=lambda kv: -kv[1][1])
+            configs["C5_train_epoch"]["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in ranked_t[:16]}
+            configs["C5_train_epoch"]["device_ms_per_step"] = round(sum(ms for _, ms in train_prof.values()), 2)
+            dom_t = next((k for k, _ in ranked_t if k in TRAIN_KERNEL_MODEL), None)
+            if dom_t is not None:
+                unit, flop_u, byte_u, what = TRAIN_KERNEL_MODEL[dom_t]
+                n_l, ms_t = train_prof[dom_t]
+                units = n_angles_b if unit == "n_angles" else n_dir_b
+                tfl = units * flop_u / (ms_t / n_l * 1e-3) / 1e12
+                configs["C5_train_epoch"]["roofline_train"] = {
+                    "kernel": dom_t, "what": what, "launches_per_step": n_l, "avg_launch_ms": round(ms_t / n_l, 3), "units_per_launch": int(units),
+                    "flop_per_unit": flop_u, "bytes_per_unit": byte_u, "bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tfl / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "algorithmic_gbs": round(units * byte_u / (ms_t / n_l * 1e-3) / 1e9, 1),
+                    "note": "factorised f32-equivalent flops of the contractions the kernel runs (primal + tangent forward, two adjoints back), "
+                            "split f16 MFMA form; rocprofv3 of one training step: profiles/r03_train_kernel_stats.csv, experiments: "
+                            "profiles/r03_experiments.md section 10"}
     model._engine = None   # the bench owns the engine
     return configs, checks
 

@@ -85,3 +85,24 @@ if os.path.exists(sq_path):
                "kernels": sq}, open(os.path.join(REPO, "profiles", "sq_latest.json"), "w"), indent=1)
     for k, v in sq.items():
         print(k, v)
+
+
+# ---- one training step (tools/gpu_train_probe.py): kernel stats verbatim, HBM counters of the second-order sweep's kernels
+for name in ("train", "md"):
+    src = os.path.join(SRC, f"{name}_kernel_stats.csv")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(REPO, "profiles", f"{tag}_{name}_kernel_stats.csv"))
+tf, tw = os.path.join(SRC, "train_fetch_counter_collection.csv"), os.path.join(SRC, "train_write_counter_collection.csv")
+if os.path.exists(tf) and os.path.exists(tw):
+    fetch_t, write_t = mean_counter(tf, "FETCH_SIZE"), mean_counter(tw, "WRITE_SIZE")
+    rows_t = []
+    for name in sorted(set(fetch_t) | set(write_t), key=lambda k: -(fetch_t.get(k, (0, 0))[0] * (2 * fetch_t.get(k, (0, 0))[1] + write_t.get(k, (0, 0))[1]))):
+        n, f = fetch_t.get(name, (0, 0.0))
+        _, w = write_t.get(name, (0, 0.0))
+        rows_t.append([name, n, round(f, 1), round(w, 1), int((2.0 * f + w) * 1024.0), int(n * (2.0 * f + w) * 1024.0)])
+    with open(os.path.join(REPO, "profiles", f"{tag}_train_pmc_summary.csv"), "w", newline="") as fh:
+        w_ = csv.writer(fh)
+        w_.writerow(["kernel", "launches_in_probe", "mean_FETCH_SIZE_KiB_reported", "mean_WRITE_SIZE_KiB_reported", "hbm_bytes_per_launch_corrected",
+                     "hbm_bytes_total_in_probe"])
+        w_.writerows(rows_t[:40])
+    print("train pmc:", rows_t[:6])
