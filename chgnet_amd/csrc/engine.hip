@@ -621,7 +621,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
       f.e_center = b->e_center; f.e_d2u = b->e_d2u; f.e_owner = b->e_owner; f.e_rev = b->e_rev; f.u_u2d = b->u_u2d;
       f.n_edges = b->Ed; f.force = b->force; f.virial = b->virial;
       LaunchScope ls(eng, "edge_force");
-      hipLaunchKernelGGL(k_edge_force, g1(b->Ed), dim3(256), 0, st, f);
+      hipLaunchKernelGGL(k_edge_force, g1(b->Ed, EF_EDGES_PER_BLOCK), dim3(256), 0, st, f);
     }
     HIP_TRY(eng, hipGetLastError());
   }
