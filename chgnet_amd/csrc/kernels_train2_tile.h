@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         V64 zd, h, hd;
         read_dl<VT>(Trow, g, zd.t);
         hidden_t(zc, zd, h, hd, d1c, ec);
-#ifndef T2_EXP_NO_DUMP
+#ifndef CHG_EXP_T2_NO_DUMP
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
 #endif
         cc = param64(vecs + 0 * D, g);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         V64 zd, h, hd;
         read_dl<VT>(Trow + D, g, zd.t);
         hidden_t(zg, zd, h, hd, d1g, eg);
-#ifndef T2_EXP_NO_DUMP
+#ifndef CHG_EXP_T2_NO_DUMP
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
 #endif
         cg = param64(vecs + 1 * D, g);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
             const float bar_a = d ? in.ba1 : in.ba0, g_a = d ? in.ga1 : in.ga0;
             pair_bw += s.y * bar_a + s.yd * g_a;
             float bar_c, bar_g, g_c, g_g;
-#ifdef T2_EXP_NO_ROWBWD
+#ifdef CHG_EXP_T2_NO_ROWBWD
             bar_c = s.y; bar_g = s.yd; g_c = s.a1; g_g = s.a2;
 #else
             gated_row_bwd(s, in.w * bar_a + in.wd * g_a, in.w * g_a, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
       continue;
     }
     // cc | cg = bar(c | g), cdc | cdg = G(c | g)
-#ifdef T2_EXP_NO_DUMP
+#ifdef CHG_EXP_T2_NO_DUMP
     if (false) {
 #else
     if (j < nvalid) {               // A operands of dW2 (column sums of bar(c|g) = d b2)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     AtomConvArgs sc{};
     __builtin_amdgcn_wave_barrier();
     sc.GP = p.barP; sc.GQ = p.barQ;
-#ifndef T2_EXP_NO_SCATTER
+#ifndef CHG_EXP_T2_NO_SCATTER
     acbwd_scatter(T, c, nvalid, k0, sc, lane);
 #endif
     __builtin_amdgcn_wave_barrier();
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           } else {
             acc_bw += s.y * in.w2 * bar_a + (s.yd * in.w2 + s.y * in.w2d) * g_a;
             const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane;
-#ifndef T2_EXP_NO_ROWATOM
+#ifndef CHG_EXP_T2_NO_ROWATOM
             atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
 #endif
             bar_y = w1 * in.w2 * bar_a + (w1d * in.w2 + w1 * in.w2d) * g_a;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         }
         if (REVERSE) {
           float bar_c, bar_g, g_c, g_g;
-#ifdef T2_EXP_NO_ROWBWD
+#ifdef CHG_EXP_T2_NO_ROWBWD
           bar_c = s.y + bar_y; bar_g = s.yd + g_y; g_c = s.a1; g_g = s.a2;
 #else
           gated_row_bwd(s, bar_y, g_y, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
     }
     // cc | cg = bar(z), cdc | cdg = G(z)
-#ifdef T2_EXP_NO_DUMP
+#ifdef CHG_EXP_T2_NO_DUMP
     if (false) {
 #else
     if (j < nvalid) {                 // A operands of the W_ang gradient
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     write_dl<VT>(Trow + D, g, cg.t);
     __builtin_amdgcn_wave_barrier();
     seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane);
-#ifndef T2_EXP_NO_ROWATOM
+#ifndef CHG_EXP_T2_NO_ROWATOM
     row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane);
 #endif
     seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane);

@@ -30,7 +30,8 @@
 #if !defined(CHG_EXPERIMENTS) &&                                                                                  \
     (defined(CHG_EXP_ATOMIC_AS_STORE) || defined(CHG_EXP_GEMM_T_PLAIN) || defined(CHG_EXP_HALF_ROW_ATOMICS) ||     \
      defined(CHG_EXP_NO_GATHER) || defined(CHG_EXP_NO_ROW_ATOMICS) || defined(CHG_EXP_NO_SEG_ATOMICS) ||           \
-     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_EXP_QUARTER_MFMA) || defined(CHG_PHASE_TIMING))
+     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_EXP_QUARTER_MFMA) || defined(CHG_PHASE_TIMING) ||   \
+     defined(CHG_EXP_T2_NO_DUMP) || defined(CHG_EXP_T2_NO_SCATTER) || defined(CHG_EXP_T2_NO_ROWBWD) || defined(CHG_EXP_T2_NO_ROWATOM))
 #error "CHG_EXP_* / CHG_PHASE_TIMING are timing experiments: define CHG_EXPERIMENTS as well (never in a product build)"
 #endif
 
