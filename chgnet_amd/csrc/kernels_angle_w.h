@@ -156,9 +156,9 @@ __device__ __forceinline__ void gather64_issue(Gather64& gr, const float* __rest
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
-    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
+    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
   }
 }
 __device__ __forceinline__ void gather64_commit(const Gather64& gr, float* tile, int lane) {
@@ -322,10 +322,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       V64 gy;
       if (HIDDEN) {
         V64 g1, g2;
-        CHG_EW(ft, r) {
-          g1.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w2.t[ft][r];      // dE/d wbgc[b1]
-          g2.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w1.t[ft][r];      // dE/d wbgc[b2]
-          gy.t[ft][r] = gu.t[ft][r] * w1.t[ft][r] * w2.t[ft][r];
+        CHG_EV(ft) {
+          const f32x4 gyu = gu.t[ft] * y.t[ft];
+          g1.t[ft] = gyu * w2.t[ft];      // dE/d wbgc[b1]
+          g2.t[ft] = gyu * w1.t[ft];      // dE/d wbgc[b2]
+          gy.t[ft] = gu.t[ft] * w1.t[ft] * w2.t[ft];
         }
         // the bond-weight gradients leave now (two vectors less to carry through the adjoint of the gated MLP):
         // first bond as a run sum, second bond one atomic row per angle

@@ -80,12 +80,15 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
                                               int j, int g, GatedState& s, V64& y, TrainTile* tt = nullptr) {
   if (HIDDEN) {
     V64 hc, hg;
-    CHG_EW(ft, r) {
-      const float sc = sigmoidf_(zc.t[ft][r]), sg = sigmoidf_(zg.t[ft][r]);
-      hc.t[ft][r] = zc.t[ft][r] * sc;
-      hg.t[ft][r] = zg.t[ft][r] * sg;
-      zc.t[ft][r] = sc * (1.0f + zc.t[ft][r] * (1.0f - sc));
-      zg.t[ft][r] = sg * (1.0f + zg.t[ft][r] * (1.0f - sg));
+    CHG_EV(ft) {
+      const f32x4 sc = sigmoid4(zc.t[ft]);
+      hc.t[ft] = zc.t[ft] * sc;
+      zc.t[ft] = sc * (1.0f + zc.t[ft] * (1.0f - sc));
+    }
+    CHG_EV(ft) {
+      const f32x4 sg = sigmoid4(zg.t[ft]);
+      hg.t[ft] = zg.t[ft] * sg;
+      zg.t[ft] = sg * (1.0f + zg.t[ft] * (1.0f - sg));
     }
     if (TRAIN && tt->hrow) {   // hidden activations: the B operand of dW2 = gn'^T . h
       write_dl<VT>(tt->hrow, g, hc.t);
@@ -111,15 +114,15 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
   s.rstd2 = ln_normalize(s.xh2);
   {
     const V64 gam = param64(vecs + 4 * D, g), bet = param64(vecs + 5 * D, g);
-    CHG_EW(ft, r) s.a2.t[ft][r] = sigmoidf_(s.xh2.t[ft][r] * gam.t[ft][r] + bet.t[ft][r]);
+    CHG_EV(ft) s.a2.t[ft] = sigmoid4(s.xh2.t[ft] * gam.t[ft] + bet.t[ft]);
   }
   {
     const V64 gam = param64(vecs + 2 * D, g), bet = param64(vecs + 3 * D, g);
-    CHG_EW(ft, r) {
-      const float n1 = s.xh1.t[ft][r] * gam.t[ft][r] + bet.t[ft][r];
-      const float sg = sigmoidf_(n1);
-      if (!SLIM) s.sg1.t[ft][r] = sg;
-      y.t[ft][r] = n1 * sg * s.a2.t[ft][r];
+    CHG_EV(ft) {
+      const f32x4 n1 = s.xh1.t[ft] * gam.t[ft] + bet.t[ft];
+      const f32x4 sg = sigmoid4(n1);
+      if (!SLIM) s.sg1.t[ft] = sg;
+      y.t[ft] = n1 * sg * s.a2.t[ft];
     }
   }
 }
@@ -150,18 +153,19 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
   const V64 gam1 = param64(vecs + 2 * D, g);
   {
     const V64 bet1 = param64(vecs + 3 * D, g);
-    CHG_EW(ft, r) {
-      const float n1 = s.xh1.t[ft][r] * gam1.t[ft][r] + bet1.t[ft][r];
-      const float sg = SLIM ? sigmoidf_(n1) : s.sg1.t[ft][r], a2 = s.a2.t[ft][r];
-      gn1.t[ft][r] = gy.t[ft][r] * a2 * sg * (1.0f + n1 * (1.0f - sg));     // d silu
-      gn2.t[ft][r] = gy.t[ft][r] * n1 * sg * a2 * (1.0f - a2);
+    CHG_EV(ft) {
+      const f32x4 n1 = s.xh1.t[ft] * gam1.t[ft] + bet1.t[ft];
+      const f32x4 sg = SLIM ? sigmoid4(n1) : s.sg1.t[ft], a2 = s.a2.t[ft];
+      const f32x4 ga = gy.t[ft] * a2 * sg;
+      gn1.t[ft] = ga * (1.0f + n1 * (1.0f - sg));     // d silu
+      gn2.t[ft] = ga * n1 * (1.0f - a2);
     }
   }
   if (TRAIN) {   // LayerNorm affine: d gamma = sum_rows gn * xhat, d beta = sum_rows gn  (gn = adjoint of the LayerNorm output)
     V64 t;
-    CHG_EW(ft, r) t.t[ft][r] = gn1.t[ft][r] * s.xh1.t[ft][r];
+    CHG_EV(ft) t.t[ft] = gn1.t[ft] * s.xh1.t[ft];
     tile_colsum2(tt, j, g, t, gn1, tt->ln[0], tt->ln[1]);
-    CHG_EW(ft, r) t.t[ft][r] = gn2.t[ft][r] * s.xh2.t[ft][r];
+    CHG_EV(ft) t.t[ft] = gn2.t[ft] * s.xh2.t[ft];
     tile_colsum2(tt, j, g, t, gn2, tt->ln[2], tt->ln[3]);
   }
   ln_backward(gn1, gam1, s.xh1, s.rstd1);
@@ -183,9 +187,9 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
       gemm_dl_t<VT, VT>(gzc.t, W2c, WS, gn1.t, j, g);
       gemm_dl_t<VT, VT>(gzg.t, W2g, WS, gn2.t, j, g);
     }
-    CHG_EW(ft, r) {
-      gzc.t[ft][r] *= dzc.t[ft][r];
-      gzg.t[ft][r] *= dzg.t[ft][r];
+    CHG_EV(ft) {
+      gzc.t[ft] = gzc.t[ft] * dzc.t[ft];
+      gzg.t[ft] = gzg.t[ft] * dzg.t[ft];
     }
   } else {
     gzc = gn1;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     gated_forward<true, false, false, 1>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 m;
-    CHG_EW(ft, r) m.t[ft][r] = y.t[ft][r] * wv.t[ft][r];
+    CHG_EV(ft) m.t[ft] = y.t[ft] * wv.t[ft];
     write_dl<VT>(Trow, g, m.t);
     __builtin_amdgcn_wave_barrier();
     {  // even rows: centre c1 is nondecreasing in k; odd rows: c2 is nondecreasing within one c1 (images of
@@ -657,9 +661,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     gated_forward<true, false, TRAIN, true>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
-    CHG_EW(ft, r) {
-      gw.t[ft][r] = gm.t[ft][r] * y.t[ft][r];   // dE/d wag[k], this direction
-      gy.t[ft][r] = gm.t[ft][r] * wv.t[ft][r];
+    CHG_EV(ft) {
+      gw.t[ft] = gm.t[ft] * y.t[ft];   // dE/d wag[k], this direction
+      gy.t[ft] = gm.t[ft] * wv.t[ft];
     }
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gw.t);
@@ -875,9 +879,9 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
     }
     if (!BWD) {
-      CHG_EW(ft, r) {
-        if (HIDDEN) y.t[ft][r] *= w1.t[ft][r] * w2.t[ft][r];
-        else y.t[ft][r] += x.t[ft][r];
+      CHG_EV(ft) {
+        if (HIDDEN) y.t[ft] = y.t[ft] * (w1.t[ft] * w2.t[ft]);
+        else y.t[ft] = y.t[ft] + x.t[ft];
       }
       write_dl<VT>(Trow, g, y.t);
       __builtin_amdgcn_wave_barrier();
@@ -889,10 +893,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       if (HIDDEN) {
         V64 g1, g2, gu;
         read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
-        CHG_EW(ft, r) {
-          g1.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w2.t[ft][r];      // dE/d wbgc[b1]
-          g2.t[ft][r] = gu.t[ft][r] * y.t[ft][r] * w1.t[ft][r];      // dE/d wbgc[b2]
-          gy.t[ft][r] = gu.t[ft][r] * w1.t[ft][r] * w2.t[ft][r];
+        CHG_EV(ft) {
+          const f32x4 gyu = gu.t[ft] * y.t[ft];
+          g1.t[ft] = gyu * w2.t[ft];      // dE/d wbgc[b1]
+          g2.t[ft] = gyu * w1.t[ft];      // dE/d wbgc[b2]
+          gy.t[ft] = gu.t[ft] * w1.t[ft] * w2.t[ft];
         }
         write_dl<VT>(Trow, g, g1.t);
         write_dl<VT>(Trow + D, g, g2.t);

@@ -78,11 +78,20 @@ __device__ __forceinline__ void stage_split(h16x8* img, const float* __restrict_
 
 // ---- operand split of 32 contraction values held by this lane (feature tiles 2 mk, 2 mk + 1) -------
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h16x8& hi, h16x8& lo) {
-  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  f32x4 ha, hb;      // the high halves back in f32; the residuals on vectors (packed subtract / multiply)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)a[e];
+    hi[4 + e] = (_Float16)b[e];
+    ha[e] = (float)hi[e];
+    hb[e] = (float)hi[4 + e];
+  }
+  const f32x4 la = (a - ha) * LO_SCALE, lb = (b - hb) * LO_SCALE;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * LO_SCALE);
+  for (int e = 0; e < 4; ++e) {
+    lo[e] = (_Float16)la[e];
+    lo[4 + e] = (_Float16)lb[e];
+  }
 }
 
 // max over the four lanes that share a tile row (cf. quad_sum)
@@ -104,7 +113,7 @@ __device__ __forceinline__ int row_exponent(const f32x4 (&x)[KT]) {
   for (int kt = 0; kt < KT; ++kt) m = fmaxf(fmaxf(m, fmaxf(fabsf(x[kt][0]), fabsf(x[kt][1]))), fmaxf(fabsf(x[kt][2]), fabsf(x[kt][3])));
   m = quad_max(m);
   const int e = __builtin_amdgcn_frexp_expf(m) - 1;          // m = f * 2^(e+1), f in [0.5, 1)
-  return (m > 0.f && m < 3.0e38f) ? e : 0;
+  return (m > 0.f && m < 3.0e38f) ? max(-125, min(125, e)) : 0;   // clamped: 2^e and 2^-e are both normal numbers
 }
 
 // ---- the contraction ------------------------------------------------------------------------------
@@ -113,20 +122,22 @@ __device__ __forceinline__ int row_exponent(const f32x4 (&x)[KT]) {
 // power of two before the split, the product scaled back.  Output tiles are produced four at a time so
 // that the operands of one K = 32 step (4 x (hi, lo) weights = 32 registers) and the accumulators stay small.
 template <int MK>
-struct SplitRow { h16x8 hi[MK], lo[MK]; int ex; };
+struct SplitRow { h16x8 hi[MK], lo[MK]; float up; };   // up = 2^e of a SCALED row (the product is multiplied back by it: exact)
 
 template <int KT, bool SCALED>
 __device__ __forceinline__ void split_row(SplitRow<KT / 2>& s, const f32x4 (&x)[KT]) {
   static_assert(KT % 2 == 0, "K must be a multiple of 32");
-  s.ex = 0;
-  if (SCALED) s.ex = row_exponent<KT>(x);
+  s.up = 1.0f;
+  float down = 1.0f;
+  if (SCALED) {
+    const int ex = row_exponent<KT>(x);
+    s.up = __builtin_ldexpf(1.0f, ex);
+    down = __builtin_ldexpf(1.0f, -ex);
+  }
 #pragma unroll
   for (int mk = 0; mk < KT / 2; ++mk) {
     f32x4 a = x[2 * mk], b = x[2 * mk + 1];
-    if (SCALED) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { a[r] = __builtin_ldexpf(a[r], -s.ex); b[r] = __builtin_ldexpf(b[r], -s.ex); }
-    }
+    if (SCALED) { a = a * down; b = b * down; }     // powers of two: exact (two values per v_pk_mul_f32 instead of one v_ldexp_f32 each)
     split8(a, b, s.hi[mk], s.lo[mk]);
   }
 }
@@ -173,8 +184,7 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (SCALED) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] += __builtin_ldexpf(t[q][r], s.ex);
+      acc[q] += t[q] * s.up;
     } else {
       acc[q] = t[q];
     }
@@ -271,8 +281,7 @@ __device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F,
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (SCALED) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] += __builtin_ldexpf(t[q][r], s.ex);
+      acc[q] += t[q] * s.up;
     } else {
       acc[q] = t[q];
     }

@@ -75,6 +75,23 @@ __device__ __forceinline__ float dsiluf_(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// The same on four values: written on vectors so that the multiplies / adds lower to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two
+// floats per VALU issue slot; the transcendentals stay one per slot).  The tile kernels are bound by vector-ALU issue.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
+  f32x2 t = x * -1.4426950408889634f;
+  t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+  t = t + 1.0f;
+  t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+  return t;
+}
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 x) {   // pair by pair: four values at once cost the forward kernels ~10 spilled registers
+  const f32x2 lo = sigmoid2(f32x2{x[0], x[1]}), hi = sigmoid2(f32x2{x[2], x[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+#define CHG_EV(ft) _Pragma("unroll") for (int ft = 0; ft < VT; ++ft)
+
 // elementwise loop over this lane's 16 floats of a 64-wide vector
 #define CHG_EW(ft, r) _Pragma("unroll") for (int ft = 0; ft < VT; ++ft) _Pragma("unroll") for (int r = 0; r < 4; ++r)
 
@@ -180,30 +197,29 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // in: c (pre-norm).  out: c <- xhat, returns rstd.
 __device__ __forceinline__ float ln_normalize(V64& c) {
-  float s = 0.f;
-  CHG_EW(ft, r) s += c.t[ft][r];
-  const float mu = quad_sum(s) * (1.0f / 64.0f);
-  float v = 0.f;
-  CHG_EW(ft, r) {
-    c.t[ft][r] -= mu;
-    v += c.t[ft][r] * c.t[ft][r];
+  f32x4 s4 = (c.t[0] + c.t[1]) + (c.t[2] + c.t[3]);
+  const float mu = quad_sum(hsum4(s4)) * (1.0f / 64.0f);
+  f32x4 v4 = zero4();
+  CHG_EV(ft) {
+    c.t[ft] = c.t[ft] - mu;
+    v4 += c.t[ft] * c.t[ft];
   }
-  const float rstd = __builtin_amdgcn_rsqf(quad_sum(v) * (1.0f / 64.0f) + LN_EPS);
-  CHG_EW(ft, r) c.t[ft][r] *= rstd;
+  const float rstd = __builtin_amdgcn_rsqf(quad_sum(hsum4(v4)) * (1.0f / 64.0f) + LN_EPS);
+  CHG_EV(ft) c.t[ft] = c.t[ft] * rstd;
   return rstd;
 }
 
 // LayerNorm backward: gy <- rstd * (gx - mean(gx) - xhat * mean(gx*xhat)),  gx = gy * gamma
 __device__ __forceinline__ void ln_backward(V64& gy, const V64& gamma, const V64& xhat, float rstd) {
-  float s1 = 0.f, s2 = 0.f;
-  CHG_EW(ft, r) {
-    gy.t[ft][r] *= gamma.t[ft][r];
-    s1 += gy.t[ft][r];
-    s2 += gy.t[ft][r] * xhat.t[ft][r];
+  f32x4 s1 = zero4(), s2 = zero4();
+  CHG_EV(ft) {
+    gy.t[ft] = gy.t[ft] * gamma.t[ft];
+    s1 += gy.t[ft];
+    s2 += gy.t[ft] * xhat.t[ft];
   }
-  const float m1 = quad_sum(s1) * (1.0f / 64.0f);
-  const float m2 = quad_sum(s2) * (1.0f / 64.0f);
-  CHG_EW(ft, r) gy.t[ft][r] = rstd * (gy.t[ft][r] - m1 - xhat.t[ft][r] * m2);
+  const float m1 = quad_sum(hsum4(s1)) * (1.0f / 64.0f);
+  const float m2 = quad_sum(hsum4(s2)) * (1.0f / 64.0f);
+  CHG_EV(ft) gy.t[ft] = (gy.t[ft] - m1 - xhat.t[ft] * m2) * rstd;
 }
 
 // ---- LDS staging of a row-major weight matrix [rows][K] -> [rows][K+PAD] ------------------------
@@ -331,9 +347,9 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
   f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
-    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
-    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
+    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
+    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
+    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
@@ -357,9 +373,9 @@ __device__ __forceinline__ void gather_issue128(GatherRegs& gr, const float* __r
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
-    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)r2[it] * ld2 + 4 * t);
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
+    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
   }
 }
 __device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* tile, int stride, int lane) {
@@ -390,8 +406,8 @@ __device__ __forceinline__ void gather_issue_ph(GatherPH& gr, const float* __res
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)r1[it] * ld1 + 4 * t);
+    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
+    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) gr.h[it] = *reinterpret_cast<const f32x4*>(hbase + ho[it] + 4 * t16);
@@ -416,7 +432,7 @@ __device__ __forceinline__ void rows64_issue(Rows64& rr, const float* __restrict
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r[it] * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)r[it] * D + 4 * t);
 }
 __device__ __forceinline__ void rows64_commit(const Rows64& rr, float* tile, int stride, int lane) {
   const int sub = lane >> 4, t = lane & 15;
@@ -431,7 +447,7 @@ __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride
     const int rr = 4 * it + sub;
     const int r = __shfl(idx, rr);
     if (rr < nvalid)
-      *reinterpret_cast<f32x4*>(dst + (size_t)r * D + 4 * t) = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
+      *reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)r * D + 4 * t) = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
   }
 }
 
@@ -443,7 +459,7 @@ __device__ __forceinline__ void gather_rows64(float* tile, int stride, const flo
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)r[it] * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)r[it] * D + 4 * t);
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = v[it];
 }
@@ -456,7 +472,7 @@ __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, fl
   f32x4* p[TILE_ROWS / 4];
   f32x4 v[TILE_ROWS / 4];
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) p[it] = reinterpret_cast<f32x4*>(dst + (size_t)__shfl(idx, 4 * it + sub) * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) p[it] = reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)__shfl(idx, 4 * it + sub) * D + 4 * t);
   if (ACCUM) {   // all loads first: one memory round trip for the tile, not one per step (idx of rows past nvalid is a valid row)
 #pragma unroll
     for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *p[it];
