@@ -631,7 +631,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     f.is_intensive = eng->desc.is_intensive; f.has_composition = eng->desc.has_composition; f.want_stress = want_s;
     f.site_raw = b->site_raw; f.z = b->z; f.atomref = eng->w.atomref; f.energy_out = b->energy; f.virial = b->virial; f.volume = b->volume;
     LaunchScope ls(eng, "finalize");
-    hipLaunchKernelGGL(k_finalize, g1(b->B), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(k_finalize, g1((int64_t)b->B * 64), dim3(256), 0, st, f);   // one wave per structure
     HIP_TRY(eng, hipGetLastError());
   }
   b->last_task = task;
