@@ -434,12 +434,6 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   const float* W2c = reinterpret_cast<const float*>(I2c);
   const float* W2g = reinterpret_cast<const float*>(I2g);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_split<false>(I2c, p.gw.w2c, D, D, tid, 64 * NW);
-  stage_split<false>(I2g, p.gw.w2g, D, D, tid, 64 * NW);
-  stage_split<false>(Ib, p.w_bond, 2 * D, D, tid, 64 * NW);
-  stage_gated_vecs(vecs, p.gw, true, tid);
-  for (int q = tid; q < 2 * D; q += 64 * NW) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
-  __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
@@ -464,6 +458,14 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
     h_n2 = bond_row_offset(p, r1 >> 1, node_n2);
   }
+  // the first tile's indices and gathers are requested BEFORE the weights are staged: two dependent memory round trips land under
+  // the staging (small batches -- MD -- run one or two tiles per wave, and the prologue was a tenth of the launch)
+  stage_split<false>(I2c, p.gw.w2c, D, D, tid, 64 * NW);
+  stage_split<false>(I2g, p.gw.w2g, D, D, tid, 64 * NW);
+  stage_split<false>(Ib, p.w_bond, 2 * D, D, tid, 64 * NW);
+  stage_gated_vecs(vecs, p.gw, true, tid);
+  for (int q = tid; q < 2 * D; q += 64 * NW) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
+  __syncthreads();
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
@@ -607,27 +609,27 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   const float* W2gT = reinterpret_cast<const float*>(I2gT);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  stage_split<false>(I2c, p.gw.w2c, D, D, tid, BLOCK);
-  stage_split<false>(I2g, p.gw.w2g, D, D, tid, BLOCK);
-  stage_split<true>(I2cT, p.gw.w2c, D, D, tid, BLOCK);
-  stage_split<true>(I2gT, p.gw.w2g, D, D, tid, BLOCK);
-  stage_gated_vecs(vecs, p.gw, true, tid);
-  __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
-  if (tb >= te) return;
+  if (tb >= te) return;                                     // uniform over the workgroup
   const int last_row = p.n_edges - 1;
   int c, n, k;
-  {
+  {   // the first tile's indices and gather land under the staging of the weights (see k_atomconv_fwd)
     const int row = min(tb * BLOCK_ROWS + wave * TILE_ROWS + j, last_row);
     c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+    stage_split<false>(I2c, p.gw.w2c, D, D, tid, BLOCK);
+    stage_split<false>(I2g, p.gw.w2g, D, D, tid, BLOCK);
+    stage_split<true>(I2cT, p.gw.w2c, D, D, tid, BLOCK);
+    stage_split<true>(I2gT, p.gw.w2g, D, D, tid, BLOCK);
+    stage_gated_vecs(vecs, p.gw, true, tid);
     gather_commit128(gr, T, TS, lane);
   }
+  __syncthreads();
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
@@ -765,20 +767,6 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   float* vecs = W2g + (HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0);
   float* tiles = vecs + VEC_SLOTS * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  if (SPLIT == 2) {
-    stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
-    stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
-    stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
-  } else {
-    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
-    if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, 64 * NW);
-    if (HIDDEN) {
-      stage_split<false>(reinterpret_cast<h16x8*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
-      stage_split<false>(reinterpret_cast<h16x8*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
-    }
-  }
-  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
-  __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_angles + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
@@ -808,6 +796,21 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       }
     }
   }
+  // (prologue above: the first tile's indices -- forward: and its gathers -- land under the staging of the weights)
+  if (SPLIT == 2) {
+    stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
+    stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
+    stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
+  } else {
+    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
+    if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, 64 * NW);
+    if (HIDDEN) {
+      stage_split<false>(reinterpret_cast<h16x8*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
+      stage_split<false>(reinterpret_cast<h16x8*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
+    }
+  }
+  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
+  __syncthreads();
   PH_DECL
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
