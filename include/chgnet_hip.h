@@ -159,8 +159,11 @@ int chg_synchronize(chg_engine* eng);
  * units chg_batch_download returns the quantities in: energy_cotangent [B] (null = ones), magmom_cotangent [N] or null,
  * force_cotangent [N,3] or null, stress_cotangent [B,9] or null; grad_blob: host [n_weights].  Synchronous.
  * Without force / stress terms this is a first-order reverse sweep (fused kernels).  With them it is ONE tangent sweep along
- * (ux = -gF, strain direction (160.2 / V) gS) followed by a reverse sweep with two adjoints per activation (kernels_train2.h),
- * currently unfused.  Overwrites the batch's gradient workspace: download forces / stress before calling. */
+ * (ux = -gF, strain direction (160.2 / V) gS) followed by a reverse sweep with two adjoints per activation, one fused tile kernel
+ * per layer and direction (kernels_train2_tile.h; CHGNET_T2_UNFUSED=1 selects the row-array pipeline of kernels_train2.h).  That
+ * sweep reuses the first-order adjoints the force / stress sweep of chg_predict leaves in the batch: if the last prediction on
+ * `batch` was energy-only, chg_backward runs the prediction with forces itself first.  Overwrites the batch's gradient workspace:
+ * download forces / stress before calling. */
 int chg_backward(chg_engine* eng, chg_batch* batch, const float* energy_cotangent, const float* magmom_cotangent,
                  const float* force_cotangent, const float* stress_cotangent, float* grad_blob);
 /* The same, for a data-parallel step: the gradient blob is summed over the ranks of `comm` (ncclAllReduce on the engine's
