@@ -132,6 +132,7 @@ struct chg_batch {
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
+  bool seed1_adjoints = false;   // the first-order adjoints (seed 1) of the last force / stress sweep are still in the batch (GP_l, GR_l, GS_l, Gwag, Gwbgc)
   // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
   // ~170 launches per call make small batches (MD: one structure) launch-bound otherwise
   hipGraphExec_t graph_exec = nullptr;
@@ -635,6 +636,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     HIP_TRY(eng, hipGetLastError());
   }
   b->last_task = task;
+  b->seed1_adjoints = want_grad;
   return CHG_OK;
 }
 
@@ -893,6 +895,7 @@ int gated_tail_grads(chg_engine* eng, chg_batch* b, const GatedW& g, int rows, f
 
 int run_backward(chg_engine* eng, chg_batch* b) {
   const Weights& w = eng->w;
+  b->seed1_adjoints = false;   // this sweep reuses the force sweep's buffers with the loss cotangents as seeds
   const int L = b->L;
   hipStream_t st = eng->stream;
   auto G = [&](const float* wp) { return grad_of(eng, b, wp); };
@@ -2339,6 +2342,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   }
   HIP_TRY(eng, hipGraphLaunch(b->graph_exec, eng->stream));
   b->last_task = task;
+  b->seed1_adjoints = (task & (CHG_TASK_F | CHG_TASK_S)) != 0;
   return CHG_OK;
 }
 
@@ -2374,8 +2378,8 @@ static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cota
   if (second_order) {
     // direction of the one tangent sweep: ux = -dL/dF,  W_b = (160.21766208 / V_b) dL/d sigma_b   (kernels_train2.h)
     // the sweep reuses the first-order adjoints (seed 1) that the force / stress sweep of chg_predict leaves in the batch: run it
-    // if the last prediction was energy-only
-    if (!(b->last_task & (CHG_TASK_F | CHG_TASK_S))) TRY(run_predict(eng, b, b->last_task | CHG_TASK_F));
+    // if the last prediction was energy-only or a first-order chg_backward has overwritten them since
+    if (!b->seed1_adjoints) TRY(run_predict(eng, b, b->last_task | CHG_TASK_F));
     TRY(ensure_train2_buffers(eng, b));
     ux.assign((size_t)3 * b->N, 0.f);
     wst.assign((size_t)9 * b->B, 0.f);

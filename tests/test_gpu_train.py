@@ -487,7 +487,9 @@ eng.predict(b, "e")            # energy-only: chg_backward has to run the force 
 g1 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
 eng.predict(b, "efsm")
 g2 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
-np.save(sys.argv[2], np.stack([g1, g2]))
+eng.backward(b, ce, gm)        # a first-order sweep in between reuses the force sweep's buffers with other seeds
+g3 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
+np.save(sys.argv[2], np.stack([g1, g2, g3]))
 '''
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
@@ -504,4 +506,5 @@ np.save(sys.argv[2], np.stack([g1, g2]))
     assert scale > 0 and np.isfinite(out["fused"]).all()
     # after an energy-only prediction == after a full one (the sweep's first-order inputs are rebuilt)
     assert np.abs(out["fused"][0] - out["fused"][1]).max() <= 1e-5 * scale
+    assert np.abs(out["fused"][2] - out["fused"][1]).max() <= 1e-5 * scale      # ... and after a first-order chg_backward in between
     assert np.abs(out["fused"][1] - out["unfused"][1]).max() <= 1e-4 * scale, float(np.abs(out["fused"][1] - out["unfused"][1]).max() / scale)
