@@ -150,3 +150,56 @@ def test_device_pointer_collectives_on_one_rank(hip_engine, golden_weights):
             batch.free()
     finally:
         comm.close()
+
+
+def test_forces_and_stress_are_the_energy_derivatives_at_the_headline_size(golden_weights):
+    """Size-independent property at BASELINE's batch size (1024 structures x 40 atoms), where no CPU oracle goes: central
+    differences of the ENERGY along a random displacement field and a random symmetric strain reproduce -sum F . dx and
+    V sigma : eps / 160.2 per structure (model.py:517-535).  float32 energies bound the accuracy (~2e-5 eV of rounding on
+    differences of 1e-3..1e-2 eV): a percent-level check of sign, units and completeness of the whole reverse sweep, structure
+    by structure."""
+    import bench
+
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.model import CHGNet
+
+    model = CHGNet(state_dict=golden_weights)
+    structs = bench.workload_structures(1024, 9000)
+    rng = np.random.default_rng(17)
+    n = np.array([len(s) for s in structs])
+    h, hs = 0.01, 0.002                                        # displacement amplitude (Angstrom), strain amplitude
+    disp = [rng.normal(size=(k, 3)) / np.sqrt(k) for k in n]   # unit-length displacement field per structure
+    eps = rng.normal(size=(len(structs), 3, 3))
+    eps = 0.5 * (eps + eps.transpose(0, 2, 1))
+
+    def energies(ss):
+        return np.array([o["e"] for o in model.predict_structure(ss, task="e", batch_size=1024)], np.float64) * n
+
+    def moved(sign):
+        out = []
+        for s, d in zip(structs, disp):
+            L = np.asarray(s.lattice.matrix, np.float64)
+            out.append(Structure(Lattice(L), s.atomic_numbers, np.asarray(s.frac_coords) + sign * h * d @ np.linalg.inv(L)))
+        return out
+
+    def strained(amp):
+        return [Structure(Lattice(np.asarray(s.lattice.matrix, np.float64) @ (np.eye(3) + amp * e)), s.atomic_numbers, s.frac_coords)
+                for s, e in zip(structs, eps)]
+
+    base = model.predict_structure(structs, task="efs", batch_size=1024)
+    want_f = np.array([-(o["f"].astype(np.float64) * d).sum() for o, d in zip(base, disp)])
+    got_f = (energies(moved(+1)) - energies(moved(-1))) / (2 * h)
+    vol = np.array([s.volume for s in structs])
+    want_s = np.array([(o["s"].astype(np.float64) * e).sum() for o, e in zip(base, eps)]) * vol / 160.21766208
+    fd1 = (energies(strained(+hs)) - energies(strained(-hs))) / (2 * hs)
+    fd2 = (energies(strained(+2 * hs)) - energies(strained(-2 * hs))) / (4 * hs)
+    got_s = (4.0 * fd1 - fd2) / 3.0            # Richardson: the h^2 term of the central difference cancels
+    assert np.abs(want_f).mean() > 1e-2 and np.abs(want_s).mean() > 1e-1
+    # absolute floors: float32 energy rounding (~2e-5 eV per structure) over the step (the strain derivative is extrapolated from two
+    # steps: this random-weight model has third derivatives of 1e2..1e4 eV along a strain direction)
+    for label, got, want, floor in (("force", got_f, want_f, 5e-3), ("stress", got_s, want_s, 2e-2)):
+        err = np.abs(got - want)
+        assert (err <= 2e-2 * np.abs(want) + floor).all(), (label, float(err.max()), int(err.argmax()), float(want[err.argmax()]))
+    assert np.corrcoef(got_s, want_s)[0, 1] > 0.999 and np.corrcoef(got_f, want_f)[0, 1] > 0.999
+    model.release_forward_state()
