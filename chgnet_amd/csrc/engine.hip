@@ -1067,6 +1067,12 @@ namespace {
 
 void free_train2(chg_batch* b) { delete b->t2; b->t2 = nullptr; }
 
+// fused tile kernels (kernels_train2_tile.h); CHGNET_T2_UNFUSED=1 keeps the row-array pipeline of kernels_train2.h (A/B, debugging)
+bool t2_fused() {
+  static const bool fused = !std::getenv("CHGNET_T2_UNFUSED");
+  return fused;
+}
+
 void layout_train2(chg_batch* b, Train2& t, Carver& c) {
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb, R = std::max(Ed, A);
   const int L = b->L;
@@ -1079,10 +1085,16 @@ void layout_train2(chg_batch* b, Train2& t, Carver& c) {
   for (int l = 0; l < L; ++l) t.hbcd[l] = c.take<float>(Eb * D);
   for (int l = 0; l < L - 1; ++l) t.angd[l] = c.take<float>(A * D);
   t.Pd = c.take<float>(N * 4 * D); t.Qd = c.take<float>(Eu * 2 * D); t.Rd = c.take<float>(Eb * 4 * D); t.Sd = c.take<float>(N * 2 * D);
-  t.ZA = c.take<float>(A * 2 * D); t.ZAd = c.take<float>(A * 2 * D);
-  for (int q = 0; q < 6; ++q) t.scratch6[q] = c.take<float>(R * 2 * D);
-  float** rows[] = {&t.BCG, &t.GCG, &t.BH, &t.GH, &t.BZ, &t.GZ};
+  // the fused sweep keeps six [rows,128] arrays (the operands of the weight-gradient contractions); the row-array pipeline sixteen
+  // here and, when memory allows, a cache of six per layer
+  const bool fused = t2_fused();
+  t.ZA = t.ZAd = t.BH = t.GH = nullptr;
+  if (!fused) { t.ZA = c.take<float>(A * 2 * D); t.ZAd = c.take<float>(A * 2 * D); }
+  for (int q = 0; q < 6; ++q) t.scratch6[q] = (!fused || q == 2 || q == 3) ? c.take<float>(R * 2 * D) : nullptr;   // fused: H, Hd dumps
+  float** rows[] = {&t.BCG, &t.GCG, &t.BZ, &t.GZ};
   for (float** r : rows) *r = c.take<float>(R * 2 * D);
+  if (!fused) { t.BH = c.take<float>(R * 2 * D); t.GH = c.take<float>(R * 2 * D); }
+  if (fused) t.cached = false;
   for (int id = 0; id < 3 * MAX_CONV; ++id)
     for (int q = 0; q < 6; ++q) t.cache[id][q] = nullptr;
   if (t.cached) {
@@ -1173,10 +1185,9 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     return gemm("t2_gemm_w2", 64, 64, X + D, 2 * D, nullptr, Wg, bg, nullptr, 0, Y + D, 2 * D, nullptr, rows, 0);
   };
   auto check = [&]() -> int { HIP_TRY(eng, hipGetLastError()); return CHG_OK; };
-  // fused tile kernels (kernels_train2_tile.h); CHGNET_T2_UNFUSED=1 keeps the row-array pipeline of kernels_train2.h (A/B, debugging).
-  // The fused sweep does not re-form the G adjoints (seed 1) of quantities that only leave it: those are the first-order adjoints the
+  // The fused sweep (t2_fused) does not re-form the G adjoints (seed 1) of quantities that only leave it: those are the first-order adjoints the
   // force sweep of chg_predict left in the batch (chg_backward makes sure that sweep has run): Gwag, Gwbgc and, per layer, GP / GR / GS.
-  static const bool fused = !std::getenv("CHGNET_T2_UNFUSED");
+  const bool fused = t2_fused();
   const float* g_wag = fused ? b->Gwag : t.g_wag;
   const float* g_wbg = fused ? b->Gwbgc : t.g_wbg;
   auto table_adjoints_of = [&](int atom_layer, int angle_slot) {   // where G(P) / G(R), G(S) of the layer being swept live

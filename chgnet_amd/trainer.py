@@ -198,6 +198,7 @@ class TrainStep:
         if not getattr(model, "model_args", {}).get("learnable_rbf", True):   # buffers in the reference (basis.py:31-40, 87-98): never updated
             frozen += [k for k in state if k.endswith(".frequencies")]
         self.optimizer = Adam(state, lr=learning_rate, frozen=tuple(frozen))
+        self.seconds: dict = {}
         self.task = "".join(k for k in "efsm" if k in targets)
         if self.task not in ("e", "ef", "em", "efs", "efsm"):       # the engine's task strings (chgnet/__init__.py:15 PredTask)
             self.task = "efsm" if "m" in targets else "efs"
@@ -220,9 +221,14 @@ class TrainStep:
         return infos
 
     def __call__(self, graphs, targets: dict) -> dict:
+        import time  # noqa: PLC0415
+
         model = self.model
+        t0 = time.perf_counter()
         pred = model.forward(graphs, task=self.task)
+        t1 = time.perf_counter()
         info, g = self.loss.gradients(targets, pred)
+        t2 = time.perf_counter()
         if self.comm is not None and self.comm.world > 1:
             # RCCL straight from the engine library: the 1.65 MB blob is summed in HBM on the engine's stream
             grads = model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s"), comm=self.comm)
@@ -230,5 +236,11 @@ class TrainStep:
         else:
             grads = model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s"))
             grads = allreduce_gradients(grads, comm=self.comm)
+        t3 = time.perf_counter()
         model.load_state_dict(self.optimizer.step(model.state_dict(), grads))
+        t4 = time.perf_counter()
+        # wall-clock split of the step (seconds), summed over the calls: what bench.py reports next to the epoch time
+        for key, dt in (("forward", t1 - t0), ("loss", t2 - t1), ("backward_allreduce", t3 - t2), ("optimizer_reload", t4 - t3)):
+            self.seconds[key] = self.seconds.get(key, 0.0) + dt
+        self.seconds["calls"] = self.seconds.get("calls", 0) + 1
         return info
