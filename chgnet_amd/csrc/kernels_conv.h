@@ -153,9 +153,14 @@ __device__ __forceinline__ void gated_backward(const V64& gy, const V64& dzc, co
   const V64 gam1 = param64(vecs + 2 * D, g);
   {
     const V64 bet1 = param64(vecs + 3 * D, g);
+    V64 gam2, bet2;
+    if (SLIM) { gam2 = param64(vecs + 4 * D, g); bet2 = param64(vecs + 5 * D, g); }
     CHG_EV(ft) {
       const f32x4 n1 = s.xh1.t[ft] * gam1.t[ft] + bet1.t[ft];
-      const f32x4 sg = SLIM ? sigmoid4(n1) : s.sg1.t[ft], a2 = s.a2.t[ft];
+      // SLIM: both gate activations are recomputed here (32 transcendental pairs for 32 registers over the bond-weight phase: a
+      // spilled register costs the BondConv adjoints more than that)
+      const f32x4 sg = SLIM ? sigmoid4(n1) : s.sg1.t[ft];
+      const f32x4 a2 = SLIM ? sigmoid4(s.xh2.t[ft] * gam2.t[ft] + bet2.t[ft]) : s.a2.t[ft];
       const f32x4 ga = gy.t[ft] * a2 * sg;
       gn1.t[ft] = ga * (1.0f + n1 * (1.0f - sg));     // d silu
       gn2.t[ft] = ga * n1 * (1.0f - a2);
