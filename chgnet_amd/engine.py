@@ -200,10 +200,14 @@ class Engine:
     def backward(self, batch: DeviceBatch, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None) -> np.ndarray:
         """Gradient blob (weight-blob layout) of ``sum e_grad*e + sum m_grad*m + sum f_grad.f + sum s_grad:s`` after
         ``predict`` on ``batch`` (chg_backward); ``pack.unpack_weight_grads`` turns it into state_dict names.
-        ``f_grad`` [N,3] / ``s_grad`` [B,3,3] switch to the second-order sweep.  ``comm`` (an ``RcclComm``): the blob is
-        summed over the ranks in HBM on the engine's stream before it comes to the host (chg_backward_allreduce)."""
+        ``f_grad`` [N,3] / ``s_grad`` [B,3,3] switch to the second-order sweep.  ``e_grad=None`` is "ones" only when it is the
+        ONLY term (``backward(batch)`` = gradient of the summed energies); next to another cotangent it means "no energy
+        term".  ``comm`` (an ``RcclComm``): the blob is summed over the ranks in HBM on the engine's stream before it comes to
+        the host (chg_backward_allreduce)."""
         pb = batch.packed
         grad = np.zeros(self.weights.blob.size, np.float32)
+        if e_grad is None and any(x is not None for x in (m_grad, f_grad, s_grad)):
+            e_grad = np.zeros(pb.n_struct, np.float32)      # the C-ABI reads a null energy cotangent as ones
 
         def arg(x, n, what):
             if x is None:

@@ -208,7 +208,7 @@ class CHGNet:
     def backward(self, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None) -> dict:
         """Parameter gradients of ``sum_b e_grad[b] e[b] + sum_i m_grad[i] m[i] + sum_i f_grad[i].f[i] + sum_b s_grad[b]:s[b]``
         for the batch of the last ``forward`` call -- the cotangents are d loss / d prediction as ``CombinedLoss.gradients``
-        returns them (``e_grad`` defaults to ones, the others to none; ``f_grad`` [N,3] over all atoms of the batch,
+        returns them (``e_grad`` defaults to ones when it is the only term and to none next to another cotangent, the others to none; ``f_grad`` [N,3] over all atoms of the batch,
         ``s_grad`` [B,3,3]).  Returns ``{state_dict key: float32 array}``: what ``loss.backward()`` leaves in ``param.grad``
         in the reference's train step (trainer.py:399-411).  AtomRef is frozen (model.py:179-182): zeros.  Force / stress
         terms run the second-order sweep (one tangent pass + a two-adjoint reverse pass).  ``comm`` (``RcclComm``): the

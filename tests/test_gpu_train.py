@@ -508,3 +508,22 @@ np.save(sys.argv[2], np.stack([g1, g2, g3]))
     assert np.abs(out["fused"][0] - out["fused"][1]).max() <= 1e-5 * scale
     assert np.abs(out["fused"][2] - out["fused"][1]).max() <= 1e-5 * scale      # ... and after a first-order chg_backward in between
     assert np.abs(out["fused"][1] - out["unfused"][1]).max() <= 1e-4 * scale, float(np.abs(out["fused"][1] - out["unfused"][1]).max() / scale)
+
+
+def test_a_missing_energy_cotangent_next_to_other_terms_means_no_energy_term(hip_engine):
+    """``backward(batch)`` is the gradient of the summed energies; ``backward(batch, f_grad=...)`` is the force term alone."""
+    graphs = [load_case(n)[0] for n in ("limno2", "s16tri")]
+    rng = np.random.default_rng(9)
+    batch = hip_engine.upload(graphs)
+    try:
+        gf = rng.normal(size=(batch.packed.n_atoms, 3)).astype(np.float32)
+        hip_engine.predict(batch, "ef")
+        alone = hip_engine.backward(batch, f_grad=gf)
+        zeros = hip_engine.backward(batch, np.zeros(2, np.float32), f_grad=gf)
+        ones = hip_engine.backward(batch, np.ones(2, np.float32), f_grad=gf)
+        energy = hip_engine.backward(batch)
+    finally:
+        batch.free()
+    scale = float(np.abs(ones).max())
+    assert np.abs(alone - zeros).max() <= 1e-6 * scale and np.abs(alone - ones).max() > 1e-3 * scale
+    assert np.abs((alone + energy) - ones).max() <= 1e-4 * scale
