@@ -97,6 +97,12 @@ def random_state_dict(model_args: dict, seed: int = 0) -> dict:
     return sd
 
 
+class ForwardResult(dict):
+    """``CHGNet.forward``'s batch dictionary; ``flat`` holds the same f / s / m values as whole-batch arrays ([N,3], [B,3,3], [N])."""
+
+    flat: dict | None = None
+
+
 class CHGNet:
     """Crystal Hamiltonian Graph neural Network, inference path on MI355X."""
 
@@ -201,6 +207,10 @@ class CHGNet:
             out["s"] = [res["s"][i] for i in range(len(graphs))]
         if "crystal_fea" in res:
             out["crystal_fea"] = res["crystal_fea"]
+        # the batch arrays as downloaded ride along as an attribute (the dictionary itself stays the reference's): CombinedLoss
+        # works on these instead of re-concatenating the per-structure views
+        out = ForwardResult(out)
+        out.flat = {k: res[k] for k in ("f", "s", "m") if k in res}
         return out
 
     __call__ = forward

@@ -70,16 +70,43 @@ class CombinedLoss:
             # trainer.py:783-812: with masking the sizes count label ELEMENTS, without it the rows of the [N,3] / [3B,3] targets
             return g, int(valid.sum()) if self.allow_missing_labels else int(t.shape[0])
 
+        # Flat fast path: CHGNet.forward hands over the engine's batch arrays next to the per-structure views (``.flat``), and the
+        # label lists of a batch are flattened once and kept with the label dictionary -- 1024-element lists re-concatenated every
+        # step were most of this function's time in a training loop.  Same arithmetic, same results (tests/test_trainer_cpu.py).
+        pflat = getattr(prediction, "flat", None)
+        tflat = self._flat_targets(targets, prediction["atoms_per_graph"]) if pflat is not None else None
         if "e" in self.target_str:
             grads["e"], _ = term("e", self.energy_loss_ratio, targets["e"], prediction["e"])
             out["e_MAE_size"] = int(np.asarray(prediction["e"]).shape[0])
         if "f" in self.target_str:
-            g, n = term("f", self.force_loss_ratio, np.concatenate(targets["f"], 0), np.concatenate(prediction["f"], 0))
+            tf = tflat["f"] if tflat is not None else np.concatenate(targets["f"], 0)
+            pf = pflat["f"].reshape(-1, 3) if pflat is not None else np.concatenate(prediction["f"], 0)
+            g, n = term("f", self.force_loss_ratio, tf, pf)
             grads["f"], out["f_MAE_size"] = g, n
         if "s" in self.target_str:
-            g, n = term("s", self.stress_loss_ratio, np.concatenate(targets["s"], 0), np.concatenate(prediction["s"], 0))
+            ts = tflat["s"] if tflat is not None else np.concatenate(targets["s"], 0)
+            ps = pflat["s"].reshape(-1, 3) if pflat is not None else np.concatenate(prediction["s"], 0)
+            g, n = term("s", self.stress_loss_ratio, ts, ps)
             grads["s"], out["s_MAE_size"] = g.reshape(-1, 3, 3), n
-        if "m" in self.target_str:
+        if "m" in self.target_str and tflat is not None and "m" in pflat:
+            # atoms of the structures whose magmom labels count (trainer.py:846: a missing or partly-NaN label drops the structure)
+            keep_atoms, tm = tflat["m_keep_atoms"], tflat["m"]
+            pm = np.asarray(pflat["m"], np.float64).reshape(-1)
+            gm_flat = np.zeros(pm.shape[0], np.float64)
+            if tm.size:
+                sel = pm[keep_atoms] if keep_atoms is not None else pm
+                val, gv = self.criterion(tm, sel)
+                out["loss"] += self.mag_loss_ratio * val
+                out["m_MAE"] = float(np.mean(np.abs(tm - sel)))
+                if keep_atoms is not None:
+                    gm_flat[keep_atoms] = self.mag_loss_ratio * gv
+                else:
+                    gm_flat = self.mag_loss_ratio * gv
+            else:
+                out["m_MAE"] = 0.0
+            out["m_MAE_size"] = int(tflat["m_size"])
+            grads["m"] = gm_flat
+        elif "m" in self.target_str:
             preds, targs, keep, size = [], [], [], 0
             for mp, mt in zip(prediction["m"], targets["m"], strict=True):
                 ok = (mt is not None and not np.isnan(np.asarray(mt, np.float64)).any()) if self.allow_missing_labels else True
@@ -103,6 +130,38 @@ class CombinedLoss:
             out["m_MAE_size"] = size
             grads["m"] = np.concatenate(gm) if gm else np.zeros(0)
         return out, grads
+
+    def _flat_targets(self, targets: dict, atoms_per_graph) -> dict:
+        """Flattened labels of one batch, built once per label dictionary (kept in a small cache on this object, keyed by the
+        dictionary's identity: the label sets of an epoch come back every epoch)."""
+        cache = self.__dict__.setdefault("_flat_cache", {})
+        hit = cache.get(id(targets))
+        if hit is not None and hit[0] is targets:
+            return hit[1]
+        flat = {}
+        if "f" in targets:
+            flat["f"] = np.concatenate([np.asarray(x, np.float64) for x in targets["f"]], 0)
+        if "s" in targets:
+            flat["s"] = np.concatenate([np.asarray(x, np.float64) for x in targets["s"]], 0)
+        if "m" in targets:
+            parts, atoms, pos, size, all_kept = [], [], 0, 0, True
+            for i, mt in enumerate(targets["m"]):
+                n = int(atoms_per_graph[i])
+                ok = (mt is not None and not np.isnan(np.asarray(mt, np.float64)).any()) if self.allow_missing_labels else True
+                if ok:
+                    parts.append(np.asarray(mt, np.float64))
+                    atoms.append(np.arange(pos, pos + n))
+                    size += len(mt)
+                else:
+                    all_kept = False
+                pos += n
+            flat["m"] = np.concatenate(parts) if parts else np.zeros(0)
+            flat["m_keep_atoms"] = None if all_kept else (np.concatenate(atoms) if atoms else np.zeros(0, np.int64))
+            flat["m_size"] = size
+        if len(cache) >= 256:
+            cache.clear()
+        cache[id(targets)] = (targets, flat)
+        return flat
 
     def forward(self, targets: dict, prediction: dict) -> dict:
         return self.gradients(targets, prediction)[0]
@@ -211,12 +270,17 @@ class TrainStep:
 
         from chgnet_amd.pack import pack_batch  # noqa: PLC0415
 
+        def prepare(i):          # data-loader work of step i: pack the graphs, flatten the label lists (CombinedLoss keeps them)
+            packed = pack_batch(batches[i])
+            self.loss._flat_targets(targets[i], np.diff(packed.atom_off))
+            return packed
+
         infos = []
         with ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(pack_batch, batches[0]) if len(batches) else None
+            nxt = pool.submit(prepare, 0) if len(batches) else None
             for i in range(len(batches)):
                 packed = nxt.result()
-                nxt = pool.submit(pack_batch, batches[i + 1]) if i + 1 < len(batches) else None
+                nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
                 infos.append(self(packed, targets[i]))
         return infos
 

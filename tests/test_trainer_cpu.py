@@ -116,3 +116,27 @@ def test_train_step_argument_checks(golden_weights):
     with pytest.raises(ValueError, match="training targets"):
         TrainStep(model, targets="fs")          # the reference's TrainTask always contains the energy
     assert TrainStep(model, targets="efsm").task == "efsm" and TrainStep(model, targets="ef").task == "ef"
+
+
+@pytest.mark.parametrize("criterion", ["MSE", "Huber"])
+@pytest.mark.parametrize(("missing", "allow"), [(False, True), (True, True), (False, False)])
+def test_flat_loss_path_equals_the_list_path(criterion, missing, allow):
+    """``CHGNet.forward`` attaches the whole-batch arrays to its dictionary and ``CombinedLoss`` then works on those and on labels
+    flattened once per label set: same loss, MAEs, sizes and cotangents as the per-structure lists (also with missing labels)."""
+    from chgnet_amd.model import ForwardResult
+
+    rng = np.random.default_rng(11)
+    targ, pred = _batch(rng, missing)
+    kw = dict(target_str="efsm", criterion=criterion, energy_loss_ratio=1.3, force_loss_ratio=0.7, stress_loss_ratio=0.2,
+              mag_loss_ratio=0.4, delta=0.3, allow_missing_labels=allow)
+    want, gwant = CombinedLoss(**kw).gradients(targ, pred)
+    fast = ForwardResult(dict(pred, atoms_per_graph=np.array([len(x) for x in pred["f"]])))
+    fast.flat = {"f": np.concatenate(pred["f"], 0), "s": np.stack(pred["s"]), "m": np.concatenate(pred["m"])}
+    loss = CombinedLoss(**kw)
+    for _ in range(2):            # second call: labels from the cache
+        got, ggot = loss.gradients(targ, fast)
+        assert set(got) == set(want)
+        for k, v in want.items():
+            assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) < 1e-14, k
+        for k in "efsm":
+            assert np.allclose(np.asarray(ggot[k]).reshape(-1), np.asarray(gwant[k]).reshape(-1), atol=1e-15), k

@@ -20,7 +20,9 @@ def labels_for(b_):
             "s": [rng.normal(0, 0.2, (3, 3)).astype(np.float32) for _ in b_],
             "m": [np.abs(rng.normal(0.5, 0.2, len(g_.atomic_number))).astype(np.float32) for g_ in b_]}
 labels = [labels_for(b_) for b_ in batches]
-step = TrainStep(model, targets="efsm", learning_rate=1e-4)
+class _OneRank:          # keeps allreduce_gradients from importing torch (PROBE_NO_TORCH=1)
+    world = 1
+step = TrainStep(model, targets="efsm", learning_rate=1e-4, comm=_OneRank() if os.environ.get("PROBE_NO_TORCH") else None)
 step(batches[0], labels[0]); step(batches[0], labels[0])
 packed = [pack_batch(b) for b in batches[:4]]
 for i in range(4):
@@ -35,4 +37,4 @@ with ThreadPoolExecutor(max_workers=1) as pool:
 t = time.perf_counter(); pack_batch(batches[0]); print(f"pack alone {1e3*(time.perf_counter()-t):.1f} ms")
 step.seconds.clear()
 step.run_epoch(batches, labels)
-print("run_epoch split (ms/step):", {k: round(1e3 * v / step.seconds["calls"], 2) for k, v in step.seconds.items() if k != "calls"})
+print("torch imported:", "torch" in sys.modules); print("run_epoch split (ms/step):", {k: round(1e3 * v / step.seconds["calls"], 2) for k, v in step.seconds.items() if k != "calls"})
