@@ -289,6 +289,14 @@ int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS) {
   return std::max(g, 1);
 }
 
+// grid of a tile kernel: CHGNET_GRID_MULT workgroups per CU -- one per CU when that already gives every workgroup no more than a few
+// tiles (small batches: the second workgroup of a CU would stage the weights again for one or two tiles; MD replay 1.478 -> 1.437 ms)
+int tile_grid(chg_engine* eng, int rows, int block_rows = BLOCK_ROWS) {
+  const int ntiles = (rows + block_rows - 1) / block_rows;
+  const int mult = ntiles <= 4 * eng->num_cus ? 1 : tile_grid_mult();
+  return grid_for(rows, mult * eng->num_cus, block_rows);
+}
+
 template <int K, int NOUT, int PARTS = 1>
 int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
   if (p.rows <= 0) return CHG_OK;
@@ -299,10 +307,26 @@ int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
   return CHG_OK;
 }
 
+// few rows (MD-size batches): every row GEMM as column blocks of a 16-wide instance (RowsGemm::col_blocks)
+constexpr int SMALL_GEMM_ROWS = 32768;
+constexpr int SMALL_GEMM_COLS = 16;
+template <int K, int PARTS>
+int launch_rows_gemm_cols(chg_engine* eng, const char* label, RowsGemm p, int n_out, int n_out_first) {
+  if (p.rows <= 0) return CHG_OK;
+  p.col_blocks = n_out / SMALL_GEMM_COLS; p.blocks1 = n_out_first / SMALL_GEMM_COLS;
+  LaunchScope ls(eng, label);
+  hipLaunchKernelGGL((k_rows_gemm<K, SMALL_GEMM_COLS, PARTS>), dim3(grid_for(p.rows, 4 * eng->num_cus), p.col_blocks), dim3(BLOCK),
+                     (rows_gemm_lds<K, SMALL_GEMM_COLS, PARTS>()), eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
 // Y[out] (+)= X[in] . Wt^T, dispatch on (K, NOUT)
 int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt,
               const float* bias, const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int accumulate) {
-  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate, nullptr, 0, 0};
+  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate, nullptr, 0, 0, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS && K == 64 && (NOUT == 64 || NOUT == 128)) return launch_rows_gemm_cols<64, 1>(eng, label, p, NOUT, NOUT);
+  if (rows <= SMALL_GEMM_ROWS && K == 128 && NOUT == 64) return launch_rows_gemm_cols<128, 1>(eng, label, p, NOUT, NOUT);
   if (K == 64 && NOUT == 64) return launch_rows_gemm<64, 64>(eng, label, p);
   if (K == 64 && NOUT == 128) return launch_rows_gemm<64, 128>(eng, label, p);
   if (K == 128 && NOUT == 64) return launch_rows_gemm<128, 64>(eng, label, p);
@@ -313,13 +337,15 @@ int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* 
 // both halves of a 256-wide table in one launch:  Y[:, 0:128 | 128:256] = X . [Wt ; Wt2]^T  (64 -> 2 x 128)
 int rows_gemm_out2(chg_engine* eng, const char* label, const float* X, const int* in_idx, const float* Wt, const float* Wt2,
                    const float* bias, float* Y, int ldy, int rows) {
-  RowsGemm p{X, D, in_idx, Wt, bias, nullptr, 0, Y, ldy, nullptr, rows, 0, Wt2, 0, 2 * D};
+  RowsGemm p{X, D, in_idx, Wt, bias, nullptr, 0, Y, ldy, nullptr, rows, 0, Wt2, 0, 2 * D, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS) return launch_rows_gemm_cols<64, 1>(eng, label, p, 4 * D, 2 * D);
   return launch_rows_gemm<64, 128, 2>(eng, label, p);
 }
 // ... and its adjoint:  Y (+)= X[:, 0:128] . Wt^T + X[:, 128:256] . Wt2^T   (2 x 128 -> 64)
 int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, const float* Wt, const float* Wt2, float* Y,
                   const int* out_idx, int rows, int accumulate) {
-  RowsGemm p{X, ldx, nullptr, Wt, nullptr, nullptr, 0, Y, D, out_idx, rows, accumulate, Wt2, 2 * D, 0};
+  RowsGemm p{X, ldx, nullptr, Wt, nullptr, nullptr, 0, Y, D, out_idx, rows, accumulate, Wt2, 2 * D, 0, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS) return launch_rows_gemm_cols<128, 2>(eng, label, p, D, D);
   return launch_rows_gemm<128, 64, 2>(eng, label, p);
 }
 
@@ -412,7 +438,7 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
     a.e_center = b->p_center;   // bond-pair order
     a.e_nbr = b->p_nbr;
     a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
-    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
+    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
@@ -428,7 +454,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(grid_for(b->Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
+    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
@@ -480,7 +506,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     plain.skip_flag = nullptr;
   }
   const size_t lds = angle_lds<HIDDEN, NW, BWD>();
-  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(grid_for(b->A, tile_grid_mult() * eng->num_cus, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(tile_grid(eng, b->A, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
@@ -715,7 +741,7 @@ int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;
   b->win_built = false;
-  b->win_grid = std::max(1, std::min({grid_for(b->A, tile_grid_mult() * eng->num_cus), WIN_MAX_WAVES / WAVES}));
+  b->win_grid = std::max(1, std::min({tile_grid(eng, b->A), WIN_MAX_WAVES / WAVES}));
   // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle -- plain adjoints, and nothing to build
   if (b->A == 0 || (long)b->N < (long)WIN_MIN_ATOMS_PER_WAVE * b->win_grid * WAVES) return CHG_OK;
   if ((size_t)b->N / SCAN_CHUNK + 1 > (1u << 16)) return CHG_OK;      // beyond the two-level scan: plain adjoints
@@ -939,7 +965,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       a.e_center = b->p_center; a.e_nbr = b->p_nbr;
       a.dumpG = b->t_dumpG; a.dumpH = b->t_dumpH; a.g_ln = G(aw.g.ln1_g);
       LaunchScope ls(eng, "atomconv_bwd_train");
-      hipLaunchKernelGGL(k_atomconv_bwd<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), st, a);
+      hipLaunchKernelGGL(k_atomconv_bwd<true>, dim3(tile_grid(eng, Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), st, a);
       HIP_TRY(eng, hipGetLastError());
     }
     TRY(gated_tail_grads(eng, b, aw.g, Ed, grad_of));
@@ -981,7 +1007,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
         a.dumpG = b->t_dumpG; a.dumpH = nullptr; a.dumpZ = nullptr; a.g_ln = G(uw.g.ln1_g);
         {
           LaunchScope ls(eng, "angleupd_bwd_train");
-          hipLaunchKernelGGL((k_angle<false, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
+          hipLaunchKernelGGL((k_angle<false, true, WAVES, true>), dim3(tile_grid(eng, A, TILE_ROWS * WAVES)), dim3(BLOCK),
                              (angle_lds<false, WAVES, true>()), st, a);
           HIP_TRY(eng, hipGetLastError());
         }
@@ -996,7 +1022,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       a.dumpG = b->t_dumpG; a.dumpH = b->t_dumpH; a.dumpZ = b->t_dumpZ; a.g_ln = G(bw.g.ln1_g);
       {
         LaunchScope ls(eng, "bondconv_bwd_train");
-        hipLaunchKernelGGL((k_angle<true, true, WAVES, true>), dim3(grid_for(A, tile_grid_mult() * eng->num_cus, TILE_ROWS * WAVES)), dim3(BLOCK),
+        hipLaunchKernelGGL((k_angle<true, true, WAVES, true>), dim3(tile_grid(eng, A, TILE_ROWS * WAVES)), dim3(BLOCK),
                            (angle_lds<true, WAVES, true>()), st, a);
         HIP_TRY(eng, hipGetLastError());
       }
@@ -1302,13 +1328,13 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     a.barR = t.barR; a.barS = t.barS; a.g_ln = G(g.ln1_g);
     return a;
   };
-  const dim3 angle_grid(grid_for(std::max(A, 1), tile_grid_mult() * eng->num_cus));
+  const dim3 angle_grid(tile_grid(eng, std::max(A, 1)));
   auto atomconv_t = [&](int l) -> int {
     const ACW& aw = w.ac[l];
     if (Ed > 0 && fused) {
       TRY(atom_tables_t(l));
       LaunchScope ls(eng, "t2_atom_t");
-      hipLaunchKernelGGL(k2_atom<false>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), t2_atom_lds(), st, atom2_args(l));
+      hipLaunchKernelGGL(k2_atom<false>, dim3(tile_grid(eng, Ed)), dim3(BLOCK), t2_atom_lds(), st, atom2_args(l));
       HIP_TRY(eng, hipGetLastError());
     } else if (Ed > 0) {
       TRY(atom_rows(l));
@@ -1433,7 +1459,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       TRY(zero(eng, t.barP, sizeof(float) * (size_t)N * 4 * D));
       const Atom2Args a = atom2_args(l);
       { LaunchScope ls(eng, "t2_atom_b");
-        hipLaunchKernelGGL(k2_atom<true>, dim3(grid_for(Ed, tile_grid_mult() * eng->num_cus)), dim3(BLOCK), t2_atom_lds(), st, a);
+        hipLaunchKernelGGL(k2_atom<true>, dim3(tile_grid(eng, Ed)), dim3(BLOCK), t2_atom_lds(), st, a);
         HIP_TRY(eng, hipGetLastError()); }
       TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG, 2 * D, nullptr, a.H, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D, G(aw.g.b2c))));
       TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG, 2 * D, nullptr, a.Hd, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D)));
@@ -2131,6 +2157,9 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<64, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 2>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;

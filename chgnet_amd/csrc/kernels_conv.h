@@ -225,11 +225,29 @@ struct RowsGemm {
   // for the two halves of a 256-wide table.
   const float* Wt2;
   int x2_off, y2_off;
+  // small row counts (MD, single structures): the output columns are split over gridDim.y workgroups of a narrow instance
+  // (NOUT = block width) -- block y contracts columns NOUT y .. NOUT y + NOUT - 1.  PARTS = 1: weights from Wt for y < blocks1, then
+  // from Wt2 (the two halves of a 256-wide table; the bias covers the Wt blocks).  PARTS = 2 (two input column blocks): the same
+  // output columns of Wt and Wt2.  A few hundred rows then occupy 4-16x the CUs, each staging and contracting its share only.
+  int col_blocks, blocks1;
 };
 
 template <int K, int NOUT, int PARTS = 1>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (p.col_blocks > 1) {   // column-split form: this workgroup's NOUT output columns
+    const int cb = blockIdx.y;
+    const bool first = PARTS == 2 || cb < p.blocks1;
+    if (PARTS == 2) {
+      p.Wt += (size_t)cb * NOUT * K;
+      p.Wt2 += (size_t)cb * NOUT * K;
+    } else {
+      p.Wt = first ? p.Wt + (size_t)cb * NOUT * K : p.Wt2 + (size_t)(cb - p.blocks1) * NOUT * K;
+    }
+    p.bias = (p.bias && first) ? p.bias + cb * NOUT : nullptr;
+    p.Y += cb * NOUT;
+    if (p.resid) p.resid += cb * NOUT;
+  }
   constexpr int KS = K + PAD, KT = K / 16, NFT = NOUT / 16;
   constexpr int XS = (K > NOUT ? K : NOUT) + PAD;  // tile stride: holds X (K wide) then Y (NOUT wide)
   float* W = smem;                          // [PARTS][NOUT][KS]
