@@ -370,18 +370,18 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
   } while (0)
 
 // scratch ints exclusive_scan_with needs for n elements
-inline size_t scan_scratch_ints(int n) { return n <= (1 << 16) ? 1 : 2 * ((size_t)n / SCAN_CHUNK + 2); }
+inline size_t scan_scratch_ints(int n) { return n <= SCAN_CHUNK ? 1 : 2 * ((size_t)n / SCAN_CHUNK + 2); }
 
 int exclusive_scan_with(chg_engine* eng, int* scratch, const int* in, int* out, int n) {
   if (n <= 0) return CHG_OK;
-  if (n <= (1 << 16)) {   // one workgroup, one launch; beyond this the strided chunks of k_small_scan get slow
+  if (n <= SCAN_CHUNK) {   // one workgroup, one launch; beyond a chunk its strided per-thread runs get slow (28k elements: 29 us)
     hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, in, out, n);
     return CHG_OK;
   }
   const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;          // <= 2^18 for n < 2^31
   int *totals = scratch, *offs = scratch + nchunks + 1;
   hipLaunchKernelGGL(k_scan_totals, dim3(nchunks), dim3(1024), 0, eng->stream, in, totals, n);
-  TRY(exclusive_scan_with(eng, nullptr, totals, offs, nchunks));   // nchunks <= 65536 up to n = 5e8: one level is enough
+  hipLaunchKernelGGL(k_small_scan, dim3(1), dim3(1024), 0, eng->stream, totals, offs, nchunks);   // nchunks <= 65536 up to n = 5e8: one level is enough
   hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, eng->stream, in, out, offs, n);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
@@ -1869,7 +1869,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     hipLaunchKernelGGL(k_undirected, g1(capE), dim3(256), 0, st, e_center, e_nbr, e_rev, is_first, first_scan, nE, e_d2u, u_u2d, p_center, p_nbr,
                        d_flags + 2);
   }
-  hipLaunchKernelGGL(k_short_count, g1(N), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1,
+  hipLaunchKernelGGL(k_short_count, g1((int64_t)N * 64), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1,
                      d_flags + 2);
   int A = 0, Eb = 0;
   if (capU > 0) {
@@ -1890,7 +1890,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   a_ctr = tmp.get<int>(capA); a_b1 = tmp.get<int>(capA); a_d1 = tmp.get<int>(capA); a_b2 = tmp.get<int>(capA); a_d2 = tmp.get<int>(capA);
   if (!a_ctr || !a_b1 || !a_d1 || !a_b2 || !a_d2) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
   if (capA > 0 && capU > 0) {
-    hipLaunchKernelGGL(k_angle_fill, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
+    hipLaunchKernelGGL(k_angle_fill, g1((int64_t)capU * 64), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
                        a_d1, a_b2, a_d2, is_node, capA, d_flags + 2);
     TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1));
   } else {

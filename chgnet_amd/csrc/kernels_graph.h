@@ -281,14 +281,21 @@ __global__ void k_undirected(const int* __restrict__ e_center, const int* __rest
 }
 
 // per centre: number of edges strictly shorter than the bond-graph cutoff (graph.py:313 uses '<')
-__global__ void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
-                              int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per atom (a thread per atom walked ~110 edges of dependent loads: 38 us for a 256-atom cell).
+__global__ __launch_bounds__(256) void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
+                                                     int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n_atoms || *overflow) return;
+  const int b = center_off[i], e = center_off[i + 1];
   int c = 0;
-  for (int e = center_off[i]; e < center_off[i + 1]; ++e) c += e_dist[e] < r_bond ? 1 : 0;
-  short_cnt[i] = c;
-  if (center_off[i + 1] == center_off[i]) atomicAdd(n_isolated, 1);
+  for (int k = b + lane; k < e; k += 64) c += e_dist[k] < r_bond ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+  if (lane == 0) {
+    short_cnt[i] = c;
+    if (e == b) atomicAdd(n_isolated, 1);
+  }
 }
 
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
@@ -306,31 +313,39 @@ __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restri
   ang_cnt[k] = c;
 }
 
-__global__ void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
-                             const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
-                             const int* __restrict__ ang_off, DevCount n_und, double r_bond, int* __restrict__ a_ctr, int* __restrict__ a_b1,
-                             int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2, int* __restrict__ is_node,
-                             int cap_angles, int* __restrict__ overflow) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per undirected bond: the other edges of each end are tested 64 at a time and written in edge order (ballot prefix) --
+// the order the serial loop of the reference produces (graph.py:283-327).  (A thread per bond walked up to 2 x ~110 edges: 72 us for
+// a 256-atom cell.)
+__global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
+                                                    const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
+                                                    const int* __restrict__ ang_off, DevCount n_und, double r_bond, int* __restrict__ a_ctr,
+                                                    int* __restrict__ a_b1, int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2,
+                                                    int* __restrict__ is_node, int cap_angles, int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (k >= n_und.get() || *overflow) return;
   if (ang_off[k + 1] == ang_off[k]) return;
-  if (ang_off[k + 1] > cap_angles) { *overflow = 1; return; }   // speculative capacity exceeded: the build is repeated exactly
+  if (ang_off[k + 1] > cap_angles) { if (lane == 0) *overflow = 1; return; }   // speculative capacity exceeded: the build is repeated exactly
   const int f = u_u2d[k];
   const int des[2] = {f, e_rev[f]};
   int w = ang_off[k];
   for (int end = 0; end < 2; ++end) {
     const int de = des[end], ctr = e_center[de];
-    for (int other = center_off[ctr]; other < center_off[ctr + 1]; ++other) {
-      if (other == de) continue;
-      if (e_dist[other] < r_bond) {
+    const int b = center_off[ctr], e = center_off[ctr + 1];
+    for (int base = b; base < e; base += 64) {
+      const int other = base + lane;
+      const bool take = other < e && other != de && e_dist[other] < r_bond;
+      const unsigned long long m = __ballot(take);
+      if (take) {
+        const int at = w + __popcll(m & ((1ull << lane) - 1ull));
         const int b2 = e_d2u[other];
-        a_ctr[w] = ctr; a_b1[w] = k; a_d1[w] = de; a_b2[w] = b2; a_d2[w] = other;
+        a_ctr[at] = ctr; a_b1[at] = k; a_d1[at] = de; a_b2[at] = b2; a_d2[at] = other;
         is_node[b2] = 1;
-        ++w;
       }
+      w += __popcll(m);
     }
   }
-  is_node[k] = 1;
+  if (lane == 0) is_node[k] = 1;
 }
 
 __global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und, int* __restrict__ u_bnode,
