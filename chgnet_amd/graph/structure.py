@@ -56,9 +56,11 @@ class Structure:
 
     def __init__(self, lattice, species, frac_coords) -> None:
         self.lattice = lattice if isinstance(lattice, Lattice) else Lattice(lattice)
-        zs = [SYMBOL_TO_Z[s] if isinstance(s, str) else int(s) for s in species]
-        self.atomic_numbers = np.array(zs, dtype=np.int32)
-        self.frac_coords = np.array(frac_coords, dtype=np.float64).reshape(len(zs), 3)
+        if isinstance(species, np.ndarray) and species.dtype.kind in "iu":     # atomic numbers already (an MD driver rebuilds the
+            self.atomic_numbers = species.astype(np.int32)                       # structure every step: no per-atom Python work)
+        else:
+            self.atomic_numbers = np.array([SYMBOL_TO_Z[s] if isinstance(s, str) else int(s) for s in species], dtype=np.int32)
+        self.frac_coords = np.array(frac_coords, dtype=np.float64).reshape(len(self.atomic_numbers), 3)
 
     def __len__(self) -> int:
         return len(self.atomic_numbers)

@@ -68,8 +68,10 @@ class BerendsenNVT:
         self.vel *= min(max(lam, 0.9), 1.1)
         self.vel += 0.5 * self.dt * self.forces / self.mass
         cart = self.structure.cart_coords + self.dt * self.vel
-        self.structure = Structure(Lattice(self.structure.lattice.matrix), self.structure.atomic_numbers,
-                                   cart @ np.linalg.inv(self.structure.lattice.matrix))
+        lattice = self.structure.lattice                       # fixed cell: the Lattice object and its inverse are reused
+        if getattr(self, "_inv_of", None) is not lattice:
+            self._inv_of, self._inv = lattice, np.linalg.inv(lattice.matrix)
+        self.structure = Structure(lattice, self.structure.atomic_numbers, cart @ self._inv)
         self._evaluate()
         self.vel += 0.5 * self.dt * self.forces / self.mass
         self.timing["steps"] += 1
