@@ -467,6 +467,17 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
 // tables: S = atom . Wctr^T + b1 (per atom),  R = hbc . [Wi;Wj]^T (per bond-graph node)
 int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
   float *S = b->Sl[slot], *R = b->Rl[slot];
+  if (b->N <= SMALL_GEMM_ROWS && b->Eb <= SMALL_GEMM_ROWS && b->N > 0 && b->Eb > 0) {   // small batch: both tables in one launch
+    RowsGemm2 g{};
+    g.a = RowsGemm{atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0, nullptr, 0, 0, 2 * D / SMALL_GEMM_COLS, 2 * D / SMALL_GEMM_COLS};
+    g.b = RowsGemm{hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0, w_bij + 2 * D * D, 0, 2 * D, 4 * D / SMALL_GEMM_COLS,
+                   2 * D / SMALL_GEMM_COLS};
+    LaunchScope ls(eng, "gemm_SR");
+    hipLaunchKernelGGL((k_rows_gemm_pair<64, SMALL_GEMM_COLS>), dim3(grid_for(std::max(b->N, b->Eb), 4 * eng->num_cus), g.a.col_blocks + g.b.col_blocks),
+                       dim3(BLOCK), (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>()), eng->stream, g);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
   TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0));
   return rows_gemm_out2(eng, "gemm_R", hbc, nullptr, w_bij, w_bij + 2 * D * D, nullptr, R, 4 * D, b->Eb);
 }
@@ -553,6 +564,7 @@ BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
   const double p = eng->desc.cutoff_coeff;   // basis.py:184-186
   a.env = Envelope{(float)(-(p + 1) * (p + 2) / 2), (float)(p * (p + 2)), (float)(-p * (p + 1) / 2), eng->desc.cutoff_coeff};
   a.hb0 = b->hb0; a.wag = b->wag; a.wbgc = b->wbgc;
+  a.hbc0 = b->Eb > 0 ? b->hbc[0] : nullptr;
   a.Gb = b->Gb; a.Gwag = b->Gwag; a.Gwbgc = b->Gwbgc; a.Grk = b->Grk;
   return a;
 }
@@ -590,14 +602,12 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   }
   { LaunchScope ls(eng, "atom_embed");
     hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
-  if (b->Eb > 0) {
-    LaunchScope ls(eng, "gather_hbc0");
-    hipLaunchKernelGGL(k_gather_rows, g1((int64_t)b->Eb * (D / 4)), dim3(256), 0, st, b->hb0, b->bn_und, b->hbc[0], b->Eb);
-  }
-  HIP_TRY(eng, hipGetLastError());
+  HIP_TRY(eng, hipGetLastError());   // (hbc[0], the nodes' copy of their embedding rows, is written by k_bond_embed_t)
 
   // ---- message passing (model.py:442-496) ----
-  TRY(zero(eng, b->zero1, (size_t)((char*)b->zero1_end - (char*)b->zero1)));   // every forward scatter target + crystal_fea
+  // every forward scatter target + crystal_fea -- and, when a reverse sweep follows, its accumulators too (the two ranges are
+  // adjacent in the arena: one memset instead of two)
+  TRY(zero(eng, b->zero1, (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1)));
   for (int l = 0; l < L - 1; ++l) {
     TRY(atomconv_fwd(eng, b, l, want_grad));
     if (b->A > 0) {
@@ -627,7 +637,6 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
 
   // ---- reverse sweep: dE/dv_e ----
   if (want_grad) {
-    TRY(zero(eng, b->zero2, (size_t)((char*)b->zero2_end - (char*)b->zero2)));
     TRY(atomconv_bwd(eng, b, L - 1));
     for (int l = L - 2; l >= 0; --l) {
       if (b->A > 0) {
@@ -2158,6 +2167,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm_pair<64, SMALL_GEMM_COLS>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 1>())))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 2>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;

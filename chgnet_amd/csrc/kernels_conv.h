@@ -233,10 +233,9 @@ struct RowsGemm {
 };
 
 template <int K, int NOUT, int PARTS = 1>
-__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
+__device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.col_blocks > 1) {   // column-split form: this workgroup's NOUT output columns
-    const int cb = blockIdx.y;
     const bool first = PARTS == 2 || cb < p.blocks1;
     if (PARTS == 2) {
       p.Wt += (size_t)cb * NOUT * K;
@@ -392,6 +391,21 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
       }
     }
   }
+}
+
+template <int K, int NOUT, int PARTS = 1>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
+  rows_gemm_body<K, NOUT, PARTS>(p, blockIdx.y);
+}
+
+// two independent column-split products in one launch (small batches: the S and R tables of an angle layer): the first
+// a.col_blocks values of blockIdx.y belong to `a`, the rest to `b`; gridDim.x covers the longer of the two row counts
+struct RowsGemm2 { RowsGemm a, b; };
+template <int K, int NOUT>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm_pair(RowsGemm2 g) {
+  const int y = blockIdx.y;
+  if (y < g.a.col_blocks) rows_gemm_body<K, NOUT, 1>(g.a, y);
+  else rows_gemm_body<K, NOUT, 1>(g.b, y - g.a.col_blocks);
 }
 
 template <int K, int NOUT, int PARTS = 1>

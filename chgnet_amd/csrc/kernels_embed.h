@@ -40,6 +40,7 @@ struct BondEmbedTArgs {
   float rc_ag, rc_bg;
   Envelope env;
   float *hb0, *wag, *wbgc;    // fwd out: [Eu,64], [Eu,64], [Eb,64]
+  float* hbc0;                // fwd out (optional): [Eb,64] the bond-graph nodes' copy of their hb0 rows (else a separate gather kernel)
   const float *Gb, *Gwag, *Gwbgc;   // bwd in
   float* Grk;                 // bwd out [Eu] dE/d r_k
   // training (k_bond_embed_t<true, true>) only
@@ -112,6 +113,16 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
       write_dl<VT>(Trow, g, h.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, ETS, p.hb0, k, nvalid, lane);
+      if (p.hbc0 && __any(valid && node >= 0)) {   // bond-graph nodes keep a compact copy of their embedding rows
+        const int sub = lane >> 4, t = lane & 15;
+#pragma unroll
+        for (int it = 0; it < TILE_ROWS / 4; ++it) {
+          const int rr = 4 * it + sub;
+          const int nd = __shfl(node, rr);
+          if (rr < nvalid && nd >= 0)
+            *reinterpret_cast<f32x4*>(p.hbc0 + (size_t)nd * D + 4 * t) = *reinterpret_cast<const f32x4*>(T + rr * ETS + 4 * t);
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       h = zero64();
       gemm_dl<2, VT>(h.t, Wa, WSB, x6, j, g);

@@ -43,7 +43,7 @@ prof = eng.profile_read()
 eng.profile(False)
 tot = sum(ms for _, ms in prof.values()); n = sum(c for c, _ in prof.values())
 print(f"eager: {n} launches, kernel time {tot:.3f} ms")
-for k, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]:
+for k, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"  {k:18s} launches={cnt:4d} total={ms:7.3f} ms")
 
 # clock-state check: the same replay right after a second of heavy work (a 512-structure batch), and interleaved with it
