@@ -473,13 +473,13 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_edges + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
+  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;     // wave-tiles: this wave's own contiguous range
   int tb, te;
-  tile_range(ntiles, tb, te);
+  wave_tile_range(ntiles, NW, wave, tb, te);
   // Software pipeline over tiles: the row gather of tile t+1 is issued before tile t's MFMA / VALU phase and committed to LDS
   // after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of wave time with the gather issued and awaited in place.)
-  const int tstride = TILE_ROWS * NW;
-  auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_edges - 1); };
+  const int tstride = TILE_ROWS;
+  auto row_of = [&](int tile) { return min(tile * tstride + j, p.n_edges - 1); };
   GatherPH gr;
   V64 wv_nx;
   int c_nx = 0, n_nx = 0, c_n2 = 0, n_n2 = 0;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   for (int q = tid; q < 2 * D; q += 64 * NW) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
   __syncthreads();
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * tstride + wave * TILE_ROWS;
+    const int row0 = tile * tstride;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
     // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): hb[k] and w_ag[k] are fetched once per bond (the second
     // row's copy comes from L1)
@@ -648,14 +648,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own contiguous range
   int tb, te;
-  tile_range(ntiles, tb, te);
-  if (tb >= te) return;                                     // uniform over the workgroup
+  wave_tile_range(ntiles, WAVES, wave, tb, te);
   const int last_row = p.n_edges - 1;
   int c, n, k;
   {   // the first tile's indices and gather land under the staging of the weights (see k_atomconv_fwd)
-    const int row = min(tb * BLOCK_ROWS + wave * TILE_ROWS + j, last_row);
+    const int row = max(0, min(tb * TILE_ROWS + j, last_row));
     c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
@@ -670,9 +669,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int row0 = tile * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
-    if (nvalid <= 0) break;                                 // waves past the end of the last tile
     if (TRAIN) {
       tt.nvalid = nvalid;
       tt.hrow = j < nvalid ? p.dumpH + (size_t)(row0 + j) * 2 * D : nullptr;
@@ -680,7 +678,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     }
     int cn, nn, kn;                                         // the next tile's rows (clamped: harmless reads at the range end)
     {
-      const int row = min(row0 + BLOCK_ROWS + j, last_row);
+      const int row = min(row0 + TILE_ROWS + j, last_row);
       cn = p.e_center[row]; nn = p.e_nbr[row]; kn = row >> 1;
     }
     V64 wv, gm;
@@ -806,12 +804,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_angles + (TILE_ROWS * NW) - 1) / (TILE_ROWS * NW);
+  const int ntiles = (p.n_angles + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own contiguous range
   int tb, te;
-  tile_range(ntiles, tb, te);
-  const int tstride = TILE_ROWS * NW;
-  auto row_of = [&](int tile) { return min(tile * tstride + wave * TILE_ROWS + j, p.n_angles - 1); };
-  if (tb >= te) return;
+  wave_tile_range(ntiles, NW, wave, tb, te);
+  const int tstride = TILE_ROWS;
+  auto row_of = [&](int tile) { return max(0, min(tile * tstride + j, p.n_angles - 1)); };
   // Forward: software-pipelined gathers -- the table rows and angle rows of tile t+1 are in flight
   // (registers) while tile t is computed, its indices were loaded during tile t-1 (angleupd_fwd
   // 0.945 -> 0.871 ms).  Backward: indices one tile ahead only; with the adjoint's register load
@@ -852,7 +849,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * tstride + wave * TILE_ROWS;
+    const int row0 = tile * tstride;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     const int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
     if (TRAIN) {

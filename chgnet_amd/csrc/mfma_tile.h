@@ -235,6 +235,19 @@ __device__ __forceinline__ void stage_vector(float* dst, const float* __restrict
   for (int idx = tid; idx < n; idx += (int)blockDim.x) dst[idx] = src[idx];
 }
 
+// ---- tile scheduling at WAVE granularity: wave w of logical workgroup lb takes a contiguous range of 16-row wave-tiles; the
+// surplus tiles (n mod waves) go one each to different waves.  With workgroup-granular ranges a batch of 4,221 wave-tiles on
+// 2,048 wave slots (a 256-atom MD cell) made 16 workgroups run a third round with all eight waves; now 125 waves do, alone on
+// their SIMDs.  Large batches: every wave a long contiguous row range, neighbouring ranges on one XCD as before.
+__device__ __forceinline__ void wave_tile_range(int n_wave_tiles, int waves_per_block, int wave, int& begin, int& end) {
+  const int G = gridDim.x, b = blockIdx.x;
+  int lb = b;
+  if ((G & 7) == 0) lb = (b & 7) * (G >> 3) + (b >> 3);
+  const long W = (long)G * waves_per_block, lw = (long)lb * waves_per_block + wave;
+  begin = (int)(lw * n_wave_tiles / W);            // evenly spaced boundaries: the surplus tiles land on every (W / surplus)-th wave,
+  end = (int)((lw + 1) * n_wave_tiles / W);        // not on the first workgroups
+}
+
 // ---- tile scheduling: contiguous tile ranges per workgroup, neighbouring ranges on one XCD -------
 // Workgroup b is dispatched to XCD b % 8 (observed, speed only); giving XCD x the logical blocks
 // [x*G/8, (x+1)*G/8) keeps one structure's tables inside one XCD's L2.
