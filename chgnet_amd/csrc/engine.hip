@@ -294,7 +294,9 @@ int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS) {
 int tile_grid(chg_engine* eng, int rows, int block_rows = BLOCK_ROWS) {
   const int ntiles = (rows + block_rows - 1) / block_rows;
   const int mult = ntiles <= 4 * eng->num_cus ? 1 : tile_grid_mult();
-  return grid_for(rows, mult * eng->num_cus, block_rows);
+  // rounded UP to a multiple of 8 (tile_range's XCD mapping): rounding 221 blocks down to 216 left 42 waves of a 256-atom cell's
+  // AtomConv kernels with a second tile, i.e. doubled the kernel's time; a workgroup without tiles costs nothing
+  return std::max(1, std::min((ntiles + 7) & ~7, mult * eng->num_cus));
 }
 
 template <int K, int NOUT, int PARTS = 1>
