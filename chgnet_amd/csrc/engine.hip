@@ -42,6 +42,11 @@ constexpr int MAX_CONV = 8;
 #ifndef CHG_FWD_WAVES
 #define CHG_FWD_WAVES 8
 #endif
+#ifdef CHG_PHASE_TIMING
+constexpr size_t PHASE_FLOATS = (size_t)4 * 2 * 10 * PH_WAVES;   // kernels_conv.h PH_FLUSH
+#else
+constexpr size_t PHASE_FLOATS = 64;
+#endif
 constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
 
 struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
@@ -68,6 +73,11 @@ struct chg_engine {
   chg_model_desc desc{};
   float* d_weights = nullptr;
   Weights w{};
+  // prebuilt LDS weight blocks of the inference tile kernels (kernels_conv.h k_*_image), rebuilt by every weight upload
+  float* d_images = nullptr;
+  const float* img_ac_fwd[2][MAX_CONV] = {};   // [without / with q_bias][layer]
+  const float* img_ac_bwd[MAX_CONV] = {};
+  const float* img_angle[2][2 * MAX_CONV] = {};   // [fwd / bwd][slot: BondConv l | L + AngleUpdate l]
   std::string err;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool profiling = false;
@@ -398,6 +408,50 @@ inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4
 // tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half).  The bond partial Q = h_bond^l . Wb^T is contracted inside
 // k_atomconv_fwd, which leaves it behind as a table when a reverse sweep follows; chg_backward after an energy-only predict builds
 // the tables itself (atomconv_q_table).
+// Prebuilt weight blocks (see stage_image, mfma_tile.h): one per tile kernel and layer, laid out by the kernels' own staging code.
+int build_images(chg_engine* eng) {
+  const int L = eng->desc.n_conv;
+  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats();
+  constexpr size_t BF = AngleLds<true, false>::tiles, BB = AngleLds<true, true>::tiles, UF = AngleLds<false, false>::tiles,
+                   UB = AngleLds<false, true>::tiles;
+  static_assert(AF % 4 == 0 && AB % 4 == 0 && BF % 4 == 0 && BB % 4 == 0 && UF % 4 == 0 && UB % 4 == 0, "images are copied in 16-byte units");
+  const size_t total = (size_t)L * (2 * AF + AB) + (size_t)(L - 1) * (BF + BB + UF + UB);
+  if (!eng->d_images) {
+    HIP_TRY(eng, hipMalloc(&eng->d_images, total * sizeof(float)));
+    HIP_TRY(eng, hipMemsetAsync(eng->d_images, 0, total * sizeof(float), eng->stream));   // slots no staging writes (unused vectors)
+  }
+  float* at = eng->d_images;
+  auto take = [&](size_t n) { float* p = at; at += n; return p; };
+  for (int l = 0; l < L; ++l) {
+    AtomConvArgs a{};
+    a.gw = eng->w.ac[l].g; a.w_bond = eng->w.ac[l].w_bond;
+    for (int qb = 0; qb < 2; ++qb) {
+      a.q_bias = qb ? eng->w.ac[l].q_bias : nullptr;
+      float* img = take(AF);
+      eng->img_ac_fwd[qb][l] = img;
+      hipLaunchKernelGGL(k_atomconv_image<false>, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
+    }
+    float* img = take(AB);
+    eng->img_ac_bwd[l] = img;
+    hipLaunchKernelGGL(k_atomconv_image<true>, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
+  }
+  for (int l = 0; l + 1 < L; ++l) {
+    const BCW& bc = eng->w.bc[l];
+    const AUW& au = eng->w.au[l];
+    float* img;
+    eng->img_angle[0][l] = img = take(BF);
+    hipLaunchKernelGGL((k_angle_image<true, false>), dim3(1), dim3(BLOCK), 0, eng->stream, bc.w_ang, bc.g, img);
+    eng->img_angle[1][l] = img = take(BB);
+    hipLaunchKernelGGL((k_angle_image<true, true>), dim3(1), dim3(BLOCK), 0, eng->stream, bc.w_ang, bc.g, img);
+    eng->img_angle[0][L + l] = img = take(UF);
+    hipLaunchKernelGGL((k_angle_image<false, false>), dim3(1), dim3(BLOCK), 0, eng->stream, au.w_ang, au.g, img);
+    eng->img_angle[1][L + l] = img = take(UB);
+    hipLaunchKernelGGL((k_angle_image<false, true>), dim3(1), dim3(BLOCK), 0, eng->stream, au.w_ang, au.g, img);
+  }
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
 int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
   return rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, b->Pl[l], 4 * D, b->N);
@@ -438,6 +492,7 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
     const size_t lds = atomconv_lds<FWD_WAVES, false, true>();
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;   // bond-pair order
+    a.image = eng->img_ac_fwd[a.q_bias ? 1 : 0][l];
     a.e_nbr = b->p_nbr;
     a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
     hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
@@ -455,6 +510,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
+    a.image = eng->img_ac_bwd[l];
     LaunchScope ls(eng, "atomconv_bwd");
     hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
@@ -488,7 +544,7 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   AngleArgs a{};
   a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.ang = ang; a.wbgc = b->wbgc;
   a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
-  a.w_ang = w_ang; a.gw = g; a.out = out;
+  a.w_ang = w_ang; a.gw = g; a.out = out; a.slot = slot;
   a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
   a.first_gang = slot == b->L - 2;   // slot l < L is BondConv l; the sweep's first angle kernel is BondConv L-2
   a.skip_flag = b->win.flag;
@@ -518,6 +574,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
   } else {
     plain.skip_flag = nullptr;
   }
+  plain.image = eng->img_angle[BWD ? 1 : 0][a.slot];
   const size_t lds = angle_lds<HIDDEN, NW, BWD>();
   hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(tile_grid(eng, b->A, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
   HIP_TRY(eng, hipGetLastError());
@@ -586,7 +643,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   const bool want_grad = want_f || want_s;
   hipStream_t st = eng->stream;
 #ifdef CHG_PHASE_TIMING
-  HIP_TRY(eng, hipMemsetAsync(b->phase, 0, sizeof(float) * 64, st));
+  HIP_TRY(eng, hipMemsetAsync(b->phase, 0, sizeof(float) * PHASE_FLOATS, st));
 #endif
 
   // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
@@ -731,7 +788,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->GQ = c.take<float>(Eu * 2 * D);
   b->Gagg = c.take<float>(Eb * D);
   b->Grk = c.take<float>(Eu);
-  b->phase = c.take<float>(64);
+  b->phase = c.take<float>(PHASE_FLOATS);
   {   // windowed angle adjoints (kernels_angle_w.h)
     WinIndex& w = b->win;
     w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1);
@@ -789,7 +846,7 @@ void register_names(chg_batch* b) {
   m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
   m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP_l[0], N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
   m["GR"] = {b->GR_l[0], Eb * 4 * D}; m["GS"] = {b->GS_l[0], N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
-  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["phase"] = {b->phase, 64};
+  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["phase"] = {b->phase, PHASE_FLOATS};
   m["frac"] = {b->frac, 3 * N}; m["lattice"] = {b->lattice, 9 * B}; m["e_image"] = {b->e_image, 3 * Ed};
   auto& mi = b->named_i32;
   mi.clear();
@@ -2163,6 +2220,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   HIP_TRY(eng, hipMalloc(&eng->d_weights, need * sizeof(float)));
   HIP_TRY(eng, hipMemcpy(eng->d_weights, weights_blob, need * sizeof(float), hipMemcpyHostToDevice));
   layout_weights(eng->d_weights, desc->n_conv, eng->w);
+  { const int si = build_images(eng); if (si) return si; }
   // kernels that need more than the default 64 KiB of dynamic LDS
   int s;
   if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
@@ -2219,6 +2277,7 @@ int chg_engine_destroy(chg_engine* eng) {
   if (eng->scratch) hipFree(eng->scratch);
   if (eng->h_stage) hipHostFree(eng->h_stage);
   if (eng->d_weights) hipFree(eng->d_weights);
+  if (eng->d_images) hipFree(eng->d_images);
   if (eng->stream) hipStreamDestroy(eng->stream);
   delete eng;
   return CHG_OK;
@@ -2402,6 +2461,7 @@ int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
   if (!eng || !weights_blob) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   HIP_TRY(eng, hipMemcpyAsync(eng->d_weights, weights_blob, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyHostToDevice, eng->stream));
+  TRY(build_images(eng));
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));
   return CHG_OK;
 }

@@ -428,6 +428,7 @@ struct AtomConvArgs {
   const int* u_bnode;          // [Eu] compact node index or -1
   const float *w_bond, *q_bias;   // [128][64]; [128] shift of the bonds outside the bond graph (0.2.0 checkpoints) or null
   float* Qout;                 // forward: [Eu,128] the partial stored as a table for the adjoint sweep, or null (energy-only tasks)
+  const float* image;          // prebuilt weight block of the kernel's LDS (k_atomconv_image); the TRAIN adjoint stages from the fp32 weights
   float* agg;          // fwd out: [N,64], zeroed by the caller
   // backward only
   const float* GA;     // [N,64] dE/d agg
@@ -449,6 +450,39 @@ template <int NW = WAVES, bool BWD = false, bool FUSEQ = false>
 constexpr size_t atomconv_lds() {
   if (FUSEQ) return 16 * (size_t)(2 * IMG64 + IMG128) + sizeof(float) * (AC_VEC_SLOTS * D + NW * TILE_FLOATS);
   return 16 * (size_t)(BWD ? 4 : 2) * IMG64 + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
+}
+
+// The weight block at the start of the AtomConv kernels' LDS, as a function of the weights alone: staged in the kernel, or built once
+// per weight upload into global memory (k_atomconv_image) and copied (stage_image).
+constexpr int ac_fwd_image_floats() { return 4 * (2 * IMG64 + IMG128) + AC_VEC_SLOTS * D; }
+constexpr int ac_bwd_image_floats() { return 4 * 4 * IMG64 + VEC_SLOTS * D; }
+__device__ __forceinline__ void atomconv_fwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
+  h16x8* I2c = reinterpret_cast<h16x8*>(base);
+  h16x8* I2g = I2c + IMG64;
+  h16x8* Ib = I2g + IMG64;
+  float* vecs = reinterpret_cast<float*>(Ib + IMG128);
+  stage_split<false>(I2c, p.gw.w2c, D, D, tid, nthreads);
+  stage_split<false>(I2g, p.gw.w2g, D, D, tid, nthreads);
+  stage_split<false>(Ib, p.w_bond, 2 * D, D, tid, nthreads);
+  stage_gated_vecs(vecs, p.gw, true, tid);
+  for (int q = tid; q < 2 * D; q += nthreads) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
+}
+__device__ __forceinline__ void atomconv_bwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
+  h16x8* I2c = reinterpret_cast<h16x8*>(base);
+  h16x8* I2g = I2c + IMG64;
+  h16x8* I2cT = I2g + IMG64;
+  h16x8* I2gT = I2cT + IMG64;
+  float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
+  stage_split<false>(I2c, p.gw.w2c, D, D, tid, nthreads);
+  stage_split<false>(I2g, p.gw.w2g, D, D, tid, nthreads);
+  stage_split<true>(I2cT, p.gw.w2c, D, D, tid, nthreads);
+  stage_split<true>(I2gT, p.gw.w2g, D, D, tid, nthreads);
+  stage_gated_vecs(vecs, p.gw, true, tid);
+}
+template <bool BWD>
+__global__ __launch_bounds__(BLOCK) void k_atomconv_image(AtomConvArgs p, float* out) {
+  if (BWD) atomconv_bwd_stage(out, p, threadIdx.x, BLOCK);
+  else atomconv_fwd_stage(out, p, threadIdx.x, BLOCK);
 }
 
 // row of h_bond that feeds bond k's partial, as an offset from hb0 (floats); node: the row carries layer features (no q_bias)
@@ -497,11 +531,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   }
   // the first tile's indices and gathers are requested BEFORE the weights are staged: two dependent memory round trips land under
   // the staging (small batches -- MD -- run one or two tiles per wave, and the prologue was a tenth of the launch)
-  stage_split<false>(I2c, p.gw.w2c, D, D, tid, 64 * NW);
-  stage_split<false>(I2g, p.gw.w2g, D, D, tid, 64 * NW);
-  stage_split<false>(Ib, p.w_bond, 2 * D, D, tid, 64 * NW);
-  stage_gated_vecs(vecs, p.gw, true, tid);
-  for (int q = tid; q < 2 * D; q += 64 * NW) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
+  stage_image<ac_fwd_image_floats() / 4, 64 * NW>(smem, p.image, tid);
   __syncthreads();
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * tstride;
@@ -658,11 +688,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
-    stage_split<false>(I2c, p.gw.w2c, D, D, tid, BLOCK);
-    stage_split<false>(I2g, p.gw.w2g, D, D, tid, BLOCK);
-    stage_split<true>(I2cT, p.gw.w2c, D, D, tid, BLOCK);
-    stage_split<true>(I2gT, p.gw.w2g, D, D, tid, BLOCK);
-    stage_gated_vecs(vecs, p.gw, true, tid);
+    if (TRAIN) atomconv_bwd_stage(smem, p, tid, BLOCK);   // fine-tuning: the weights change every step
+    else stage_image<ac_bwd_image_floats() / 4, BLOCK>(smem, p.image, tid);
     gather_commit128(gr, T, TS, lane);
   }
   __syncthreads();
@@ -750,6 +777,8 @@ struct AngleArgs {
   int n_angles;
   const float* w_ang;  // [128][64] angle block of the first layer (global)
   GatedW gw;
+  const float* image;  // prebuilt weight block of the kernel's LDS (k_angle_image); the TRAIN adjoints stage from the fp32 weights
+  int slot;            // host side: which layer's image (engine.hip launch_angle)
   float* out;          // BondConv fwd: agg [Eb,64] zeroed;  AngleUpdate fwd: new angle features [A,64]
   // backward only
   const float* Gagg;   // BondConv: [Eb,64] dE/d agg
@@ -777,14 +806,58 @@ constexpr size_t angle_lds() {
 // summed per wave and added to p.phase[base + i] at the end; read back with chg_debug_fetch("phase")
 // (tests/gpu_phase_probe.py).
 #ifdef CHG_PHASE_TIMING
-#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(); float ph_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define PH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += (float)(t_ - ph_t); ph_t = t_; __builtin_amdgcn_sched_barrier(0); }
-#define PH_FLUSH(base) if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(p.phase + (base) + i_, ph_acc[i_]); }
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(); bool ph_first = true; float ph_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_acc1[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define PH_TILE(first) ph_first = (first);
+#define PH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (ph_first) ph_acc1[i] += (float)(t_ - ph_t); else ph_acc[i] += (float)(t_ - ph_t); ph_t = t_; __builtin_amdgcn_sched_barrier(0); }
+// p.phase[kernel 0..3][later / first tile][slot 0..9][wave 0..PH_WAVES): every wave adds to its own floats (plain read-modify-write: the
+// first version met in 20 shared addresses, and 2048 waves' same-address atomics -- ~110 ns each -- cost more than the kernel)
+constexpr int PH_WAVES = 4096;
+#define PH_FLUSH(base) { const int gw_ = blockIdx.x * (blockDim.x >> 6) + wave; if (lane == 0 && gw_ < PH_WAVES) { for (int i_ = 0; i_ < 10; ++i_) { \
+  p.phase[((size_t)((base) / 10 * 2 + 0) * 10 + i_) * PH_WAVES + gw_] += ph_acc[i_]; p.phase[((size_t)((base) / 10 * 2 + 1) * 10 + i_) * PH_WAVES + gw_] += ph_acc1[i_]; } } }
 #else
 #define PH_DECL
+#define PH_TILE(first)
 #define PH(i)
 #define PH_FLUSH(base)
 #endif
+
+// The weight block at the start of the angle kernels' LDS (see atomconv_fwd_stage).
+// mode 1: split images of Wang (and, adjoint, of Wang^T), W2c, W2g.  mode 2 (BondConv adjoint): one row-major image each.
+template <bool HIDDEN, bool BWD>
+struct AngleLds {
+  static constexpr int SPLIT = angle_split(HIDDEN, BWD);
+  static constexpr int wangT = SPLIT == 2 ? 0 : 4 * IMG128;     // 4 floats per 16-byte chunk
+  static constexpr int w2c = SPLIT == 2 ? (int)(rm_image_bytes(2 * D, D) / 4) : wangT + (BWD ? 4 * IMG128 : 0);
+  static constexpr int w2 = HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0;
+  static constexpr int w2g = w2c + w2;
+  static constexpr int vecs = w2g + w2;
+  static constexpr int tiles = vecs + VEC_SLOTS * D;            // = floats of the prebuilt image
+};
+template <bool HIDDEN, bool BWD>
+__device__ __forceinline__ void angle_stage(float* base, const float* __restrict__ w_ang, const GatedW& gw, int tid, int nthreads) {
+  using L = AngleLds<HIDDEN, BWD>;
+  float* Wang = base;
+  float* WangT = base + L::wangT;
+  float* W2c = base + L::w2c;
+  float* W2g = base + L::w2g;
+  if (L::SPLIT == 2) {
+    stage_rm(reinterpret_cast<_Float16*>(Wang), w_ang, 2 * D, D, tid, nthreads);
+    stage_rm(reinterpret_cast<_Float16*>(W2c), gw.w2c, D, D, tid, nthreads);
+    stage_rm(reinterpret_cast<_Float16*>(W2g), gw.w2g, D, D, tid, nthreads);
+  } else {
+    stage_split<false>(reinterpret_cast<h16x8*>(Wang), w_ang, 2 * D, D, tid, nthreads);
+    if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), w_ang, 2 * D, D, tid, nthreads);
+    if (HIDDEN) {
+      stage_split<false>(reinterpret_cast<h16x8*>(W2c), gw.w2c, D, D, tid, nthreads);
+      stage_split<false>(reinterpret_cast<h16x8*>(W2g), gw.w2g, D, D, tid, nthreads);
+    }
+  }
+  stage_gated_vecs(base + L::vecs, gw, HIDDEN, tid);
+}
+template <bool HIDDEN, bool BWD>
+__global__ __launch_bounds__(BLOCK) void k_angle_image(const float* w_ang, GatedW gw, float* out) {
+  angle_stage<HIDDEN, BWD>(out, w_ang, gw, threadIdx.x, BLOCK);
+}
 
 // HIDDEN = true: BondConv (gated MLP with one hidden layer, weighted, aggregated over the owning bond)
 // HIDDEN = false: AngleUpdate (single gated layer, residual on the angle itself)
@@ -793,14 +866,15 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
   if (BWD && !TRAIN && p.skip_flag && *p.skip_flag == 1) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  PH_DECL
   constexpr int SPLIT = angle_split(HIDDEN, BWD);
-  // mode 1: split images of Wang (and, adjoint, of Wang^T), W2c, W2g.  mode 2 (BondConv adjoint): one row-major image each.
+  using L = AngleLds<HIDDEN, BWD>;
   float* Wang = smem;
-  float* WangT = SPLIT == 2 ? Wang : Wang + 4 * IMG128;     // 4 floats per 16-byte chunk
-  float* W2c = SPLIT == 2 ? Wang + rm_image_bytes(2 * D, D) / 4 : WangT + (BWD ? 4 * IMG128 : 0);
-  float* W2g = W2c + (HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0);
-  float* vecs = W2g + (HIDDEN ? (SPLIT == 2 ? (int)(rm_image_bytes(D, D) / 4) : 4 * IMG64) : 0);
-  float* tiles = vecs + VEC_SLOTS * D;
+  float* WangT = smem + L::wangT;
+  float* W2c = smem + L::w2c;
+  float* W2g = smem + L::w2g;
+  float* vecs = smem + L::vecs;
+  float* tiles = smem + L::tiles;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
@@ -831,24 +905,14 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     }
   }
   // (prologue above: the first tile's indices -- forward: and its gathers -- land under the staging of the weights)
-  if (SPLIT == 2) {
-    stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
-    stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
-    stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
-  } else {
-    stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, 64 * NW);
-    if (BWD) stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, 64 * NW);
-    if (HIDDEN) {
-      stage_split<false>(reinterpret_cast<h16x8*>(W2c), p.gw.w2c, D, D, tid, 64 * NW);
-      stage_split<false>(reinterpret_cast<h16x8*>(W2g), p.gw.w2g, D, D, tid, 64 * NW);
-    }
-  }
-  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
+  if (TRAIN) angle_stage<HIDDEN, BWD>(smem, p.w_ang, p.gw, tid, 64 * NW);   // fine-tuning: the weights change every step
+  else stage_image<L::tiles / 4, 64 * NW>(smem, p.image, tid);
   __syncthreads();
-  PH_DECL
+  PH(9)   // prologue: first indices (forward: first gathers issued), weight images, barrier
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
   for (int tile = tb; tile < te; ++tile) {
+    PH_TILE(tile == tb)
     const int row0 = tile * tstride;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     const int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
@@ -875,7 +939,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       if (tile + 1 < te) {
         const int a1 = row_of(tile + 1);
         gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane);
-        read_dl<VT>(p.ang + (size_t)a1 * D, g, x_p.t);
+        // lane group recomputed in place (volatile: not hoisted): the loop-invariant p.ang + lane offset otherwise lives in a register pair
+        // over the whole tile -- at 256 registers it is spilled, and its reload waits (vmcnt, in order) behind the gathers just issued
+        int lane_here;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
+        read_dl<VT>(p.ang + (size_t)a1 * D, lane_here >> 4, x_p.t);
         ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
         if (tile + 2 < te) {
           const int a2 = row_of(tile + 2);

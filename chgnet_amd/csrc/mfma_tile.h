@@ -235,6 +235,29 @@ __device__ __forceinline__ void stage_vector(float* dst, const float* __restrict
   for (int idx = tid; idx < n; idx += (int)blockDim.x) dst[idx] = src[idx];
 }
 
+// ---- prologue from a PREBUILT image: the weight block of a tile kernel's LDS (split / row-major f16 images + parameter vectors) as
+// the kernel lays it out, built once per weight upload by k_*_image (kernels_conv.h) -- the prologue is then N16 16-byte copies, every
+// load of a thread in flight before its first store, instead of strided fp32 reads + the hi / lo split in every workgroup of every
+// launch (measured on a 256-atom MD cell, two wave-tiles per wave: 12-17k of a launch's 50-125k clocks per wave were the prologue).
+template <int N16, int NT, int CHUNK = 16>   // CHUNK: loads of a thread in flight together (registers: 4 each)
+__device__ __forceinline__ void stage_image(float* dst, const float* __restrict__ src, int tid) {
+  constexpr int IT = (N16 + NT - 1) / NT;
+#pragma unroll
+  for (int u0 = 0; u0 < IT; u0 += CHUNK) {
+    f32x4 v[CHUNK];
+#pragma unroll
+    for (int u = 0; u < CHUNK; ++u) {
+      const int idx = tid + (u0 + u) * NT;
+      if (u0 + u < IT && idx < N16) v[u] = reinterpret_cast<const f32x4*>(src)[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < CHUNK; ++u) {
+      const int idx = tid + (u0 + u) * NT;
+      if (u0 + u < IT && idx < N16) reinterpret_cast<f32x4*>(dst)[idx] = v[u];
+    }
+  }
+}
+
 // ---- tile scheduling at WAVE granularity: wave w of logical workgroup lb takes a contiguous range of 16-row wave-tiles; the
 // surplus tiles (n mod waves) go one each to different waves.  With workgroup-granular ranges a batch of 4,221 wave-tiles on
 // 2,048 wave slots (a 256-atom MD cell) made 16 workgroups run a third round with all eight waves; now 125 waves do, alone on

@@ -203,3 +203,43 @@ def test_forces_and_stress_are_the_energy_derivatives_at_the_headline_size(golde
         assert (err <= 2e-2 * np.abs(want) + floor).all(), (label, float(err.max()), int(err.argmax()), float(want[err.argmax()]))
     assert np.corrcoef(got_s, want_s)[0, 1] > 0.999 and np.corrcoef(got_f, want_f)[0, 1] > 0.999
     model.release_forward_state()
+
+
+def test_weight_update_rebuilds_the_prebuilt_kernel_images(golden_weights, trained_like_weights):
+    """chg_engine_update_weights: the tile kernels read their weights from images prebuilt per upload (k_*_image, stage_image) --
+    an engine updated to a second weight set gives what an engine created with that set gives (also through a
+    replayed hipGraph captured before the update), and not what the first set gave."""
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.pack import pack_weights
+    from conftest import load_case
+
+    graphs = [load_case(n)[0] for n in ("limno2", "noangle", "s16tri", "li9co7o16")]
+    w1, w2 = pack_weights(golden_weights), pack_weights(trained_like_weights)
+
+    def run(eng, batch):
+        eng.predict(batch, "efsm")
+        return eng.download(batch, "efsm")
+
+    fresh = Engine(w2, 0)
+    try:
+        b = fresh.upload(graphs)
+        want = run(fresh, b)
+        b.free()
+    finally:
+        fresh.close()
+    eng = Engine(w1, 0)
+    try:
+        b = eng.upload(graphs)
+        first = run(eng, b)
+        run(eng, b)                      # second call: the captured graph replays
+        eng.update_weights(w2)
+        got = run(eng, b)                # replay of the graph captured under the first weights
+        b2 = eng.upload(graphs)
+        got2 = run(eng, b2)
+        b.free(); b2.free()
+    finally:
+        eng.close()
+    assert np.abs(first["f"] - want["f"]).max() > 1e-2
+    for k in ("e", "f", "s", "m"):           # fp32 atomics: two sweeps differ by reassociation, nothing else
+        tol = 2e-5 * float(np.abs(want[k]).max())
+        assert np.abs(got[k] - want[k]).max() <= tol and np.abs(got2[k] - want[k]).max() <= tol, k

@@ -13,7 +13,11 @@ eng = Engine(pack_weights(W), 0)
 os.environ["CHGNET_HIP_GRAPHS"] = "0"
 batch = eng.upload(pb)
 eng.predict(batch, "efs"); eng.synchronize()
-ph = eng.debug_fetch(batch, "phase", 64)
+PH_WAVES = 4096                                   # kernels_conv.h: phase[kernel][later / first tile][slot][wave]
+ph4 = eng.debug_fetch(batch, "phase", 4 * 2 * 10 * PH_WAVES).reshape(4, 2, 10, PH_WAVES).sum(axis=(1, 3))
+ph = np.zeros(40)
+for k in range(4):
+    ph[10 * k:10 * k + 10] = ph4[k]               # slot 9 = prologue (per wave, not per tile)
 names = {0: ["idx+ang rows", "table gather", "W_ang GEMM", "gated fwd", "output scatter"],
          10: ["idx+ang rows", "table gather", "W_ang GEMM", "gated fwd", "rows+dE/dy+Gwbgc", "gated bwd", "W_ang^T GEMM", "Gang update", "GR/GS scatter"]}
 tiles = pb.n_angles / 16
