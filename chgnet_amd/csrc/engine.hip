@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -884,6 +885,16 @@ int xty(chg_engine* eng, const char* label, const float* A, int lda, const int* 
   if (rows <= 0) return CHG_OK;
   LaunchScope ls(eng, label);
   XtyArgs p{A, lda, a_idx, B, ldb, b_idx, rows, alpha, out, ldo, n_cols, a_colsum};
+  // long identity-mapped operands (the angle / edge rows of the fine-tuning sweeps): three-piece bf16 form (kernels_train.h k_xty3);
+  // CHGNET_XTY3=0: the f32-MFMA kernel everywhere (A/B timing)
+  static const bool x3 = [] { const char* e = std::getenv("CHGNET_XTY3"); return !e || std::atoi(e) != 0; }();
+  if (x3 && !a_idx && !b_idx && rows >= 65536 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0) {
+    const int nstages = (rows + X3_ROWS - 1) / X3_ROWS;
+    const int g3 = std::max(8, std::min(nstages / 8, 2 * eng->num_cus) & ~7);   // two workgroups (2 x 78 KB of LDS, <= 128 registers) per CU
+    hipLaunchKernelGGL((k_xty3<MT, NT>), dim3(g3), dim3(BLOCK), (xty3_lds<MT, NT>()), eng->stream, p);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
   // one workgroup per CU is resident (LDS), and every workgroup ends with one global atomic per output element:
   // no more workgroups than CUs, and at least four row tiles each
   const int ntiles = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -892,6 +903,25 @@ int xty(chg_engine* eng, const char* label, const float* A, int lda, const int* 
   hipLaunchKernelGGL((k_xty<MT, NT>), dim3(grid), dim3(BLOCK), (xty_lds<MT, NT>()), eng->stream, p);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
+}
+
+// core^T core and gate^T gate of two [rows,128] = [core | gate] arrays (the second layer of a gated MLP): one pass over full 512-byte
+// rows (k_xty3<8, 8, true>) when the operands are long, else the two half-row contractions
+int xty_halves(chg_engine* eng, const char* label, const float* A, const float* B, int rows, float* out_c, float* out_g,
+               float* colsum_c = nullptr, float* colsum_g = nullptr) {
+  if (rows <= 0) return CHG_OK;
+  static const bool x3 = [] { const char* e = std::getenv("CHGNET_XTY3"); return !e || std::atoi(e) != 0; }();
+  if (x3 && rows >= 65536 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0) {
+    LaunchScope ls(eng, label);
+    XtyArgs p{A, 2 * D, nullptr, B, 2 * D, nullptr, rows, 1.0f, out_c, D, D, colsum_c, out_g, colsum_g};
+    const int nstages = (rows + X3_ROWS - 1) / X3_ROWS;
+    const int g3 = std::max(8, std::min(nstages / 8, 2 * eng->num_cus) & ~7);   // 52 KB of LDS (single buffer): two workgroups per CU
+    hipLaunchKernelGGL((k_xty3<8, 8, true>), dim3(g3), dim3(BLOCK), (xty3_lds<8, 8, true>()), eng->stream, p);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
+  TRY((xty<4, 4>(eng, label, A, 2 * D, nullptr, B, 2 * D, nullptr, rows, 1.0f, out_c, D, D, colsum_c)));
+  return xty<4, 4>(eng, label, A + D, 2 * D, nullptr, B + D, 2 * D, nullptr, rows, 1.0f, out_g, D, D, colsum_g);
 }
 
 int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, int rows, int width, float* out) {
@@ -982,9 +1012,7 @@ float* grad_of(chg_engine* eng, chg_batch* b, const float* w) { return b->t_grad
 
 // gated-MLP internals of one layer: dW2c, dW2g, db2c, db2g from the (adjoint, hidden activation) dumps
 int gated_tail_grads(chg_engine* eng, chg_batch* b, const GatedW& g, int rows, float* (*G)(chg_engine*, chg_batch*, const float*)) {
-  TRY((xty<4, 4>(eng, "wgrad_w2", b->t_dumpG, 2 * D, nullptr, b->t_dumpH, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2c), D, D, G(eng, b, g.b2c))));
-  return xty<4, 4>(eng, "wgrad_w2", b->t_dumpG + D, 2 * D, nullptr, b->t_dumpH + D, 2 * D, nullptr, rows, 1.0f, G(eng, b, g.w2g), D, D,
-                   G(eng, b, g.b2g));
+  return xty_halves(eng, "wgrad_w2", b->t_dumpG, b->t_dumpH, rows, G(eng, b, g.w2c), G(eng, b, g.w2g), G(eng, b, g.b2c), G(eng, b, g.b2g));
 }
 
 int run_backward(chg_engine* eng, chg_batch* b) {
@@ -1502,10 +1530,8 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
   reverse = true;
   // gated-MLP internals common to the three layer kinds: BCG / GCG -> weight gradients of the second layer, BZ / GZ
   auto hidden_back = [&](const GatedW& g, const float* w2c_t, const float* w2g_t, int rows) -> int {
-    TRY((xty<4, 4>(eng, "t2_wgrad", t.BCG, 2 * D, nullptr, t.H, 2 * D, nullptr, rows, 1.0f, G(g.w2c), D, D, G(g.b2c))));
-    TRY((xty<4, 4>(eng, "t2_wgrad", t.GCG, 2 * D, nullptr, t.Hd, 2 * D, nullptr, rows, 1.0f, G(g.w2c), D, D)));
-    TRY((xty<4, 4>(eng, "t2_wgrad", t.BCG + D, 2 * D, nullptr, t.H + D, 2 * D, nullptr, rows, 1.0f, G(g.w2g), D, D, G(g.b2g))));
-    TRY((xty<4, 4>(eng, "t2_wgrad", t.GCG + D, 2 * D, nullptr, t.Hd + D, 2 * D, nullptr, rows, 1.0f, G(g.w2g), D, D)));
+    TRY(xty_halves(eng, "t2_wgrad", t.BCG, t.H, rows, G(g.w2c), G(g.w2g), G(g.b2c), G(g.b2g)));
+    TRY(xty_halves(eng, "t2_wgrad", t.GCG, t.Hd, rows, G(g.w2c), G(g.w2g)));
     TRY(gemm_pair(t.BCG, w2c_t, w2g_t, nullptr, nullptr, t.BH, rows));
     TRY(gemm_pair(t.GCG, w2c_t, w2g_t, nullptr, nullptr, t.GH, rows));
     LaunchScope ls(eng, "t2_hidden_b");
@@ -1529,10 +1555,8 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       { LaunchScope ls(eng, "t2_atom_b");
         hipLaunchKernelGGL(k2_atom<true>, dim3(tile_grid(eng, Ed)), dim3(BLOCK), t2_atom_lds(), st, a);
         HIP_TRY(eng, hipGetLastError()); }
-      TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG, 2 * D, nullptr, a.H, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D, G(aw.g.b2c))));
-      TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG, 2 * D, nullptr, a.Hd, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2c), D, D)));
-      TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG + D, 2 * D, nullptr, a.H + D, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2g), D, D, G(aw.g.b2g))));
-      TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG + D, 2 * D, nullptr, a.Hd + D, 2 * D, nullptr, Ed, 1.0f, G(aw.g.w2g), D, D)));
+      TRY(xty_halves(eng, "t2_wgrad", a.BCG, a.H, Ed, G(aw.g.w2c), G(aw.g.w2g), G(aw.g.b2c), G(aw.g.b2g)));
+      TRY(xty_halves(eng, "t2_wgrad", a.GCG, a.Hd, Ed, G(aw.g.w2c), G(aw.g.w2g)));
     } else {
     TRY(atom_rows(l));
     {
@@ -1660,10 +1684,8 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
                        { LaunchScope ls(eng, "t2_bond_b");
                          hipLaunchKernelGGL((k2_angle<true, true>), angle_grid, dim3(BLOCK), t2_angle_lds<true>(), st, a);
                          HIP_TRY(eng, hipGetLastError()); }
-                       TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG, 2 * D, nullptr, a.H, 2 * D, nullptr, A, 1.0f, G(bw.g.w2c), D, D, G(bw.g.b2c))));
-                       TRY((xty<4, 4>(eng, "t2_wgrad", a.GCG, 2 * D, nullptr, a.Hd, 2 * D, nullptr, A, 1.0f, G(bw.g.w2c), D, D)));
-                       TRY((xty<4, 4>(eng, "t2_wgrad", a.BCG + D, 2 * D, nullptr, a.H + D, 2 * D, nullptr, A, 1.0f, G(bw.g.w2g), D, D, G(bw.g.b2g))));
-                       return xty<4, 4>(eng, "t2_wgrad", a.GCG + D, 2 * D, nullptr, a.Hd + D, 2 * D, nullptr, A, 1.0f, G(bw.g.w2g), D, D);
+                       TRY(xty_halves(eng, "t2_wgrad", a.BCG, a.H, A, G(bw.g.w2c), G(bw.g.w2g), G(bw.g.b2c), G(bw.g.b2g)));
+                       return xty_halves(eng, "t2_wgrad", a.GCG, a.Hd, A, G(bw.g.w2c), G(bw.g.w2g));
                      }));
     }
     TRY(atomconv_b(l));
@@ -2247,6 +2269,10 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   if ((s = set_lds(eng, (k_bond_embed_t<true, true>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, (k_angle_embed_t<true, true>), angle_embed_lds()))) return s;
   if ((s = set_lds(eng, (k_xty<8, 4>), (xty_lds<8, 4>())))) return s;
+  if ((s = set_lds(eng, (k_xty3<8, 4>), (xty3_lds<8, 4>())))) return s;
+  if ((s = set_lds(eng, (k_xty3<4, 4>), (xty3_lds<4, 4>())))) return s;
+  if ((s = set_lds(eng, (k_xty3<4, 2>), (xty3_lds<4, 2>())))) return s;
+  if ((s = set_lds(eng, (k_xty3<8, 8, true>), (xty3_lds<8, 8, true>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 4>), (xty_lds<4, 4>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
   if ((s = set_lds(eng, k2_scatter_z, scatter_z_lds()))) return s;

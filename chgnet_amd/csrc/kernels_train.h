@@ -29,6 +29,9 @@ struct XtyArgs {
   int ldo;
   int n_cols;          // columns of the result that exist (<= 16*NT): the 31-wide embedding weights are padded to 32
   float* a_colsum;     // optional [16*MT]: += alpha * column sums of A (bias gradients ride along with the weight gradient)
+  // k_xty3<8, 8, true> only (block-diagonal pair: A and B are the core | gate halves of 128-wide rows, read once as full 512-byte rows):
+  float* out2;         // [64][ldo] product of the second halves (out takes the first halves)
+  float* a_colsum2;    // optional [64]: column sums of A's second half (a_colsum: first half)
 };
 
 template <int MT, int NT>
@@ -148,6 +151,195 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
 #pragma unroll
     for (int c = 0; c < (M + 63) / 64; ++c)
       if (64 * c + lane < M) atomicAdd(p.a_colsum + 64 * c + lane, p.alpha * asum[c]);
+  }
+}
+
+// ---- the same contraction for the LONG row operands of the second-order sweep (millions of angle / edge rows, no row maps) ----
+// k_xty runs v_mfma_f32_16x16x4_f32: 21 flop per operand byte for the 128 x 64 product, i.e. the f32 matrix pipe saturates at 7.4 TB/s
+// of operand reads -- the kernel sat at 2.8-4.5 TB/s with pipe and HBM each half busy.  Here every fp32 value is cut EXACTLY into three
+// bf16 pieces by truncation (x = hi + mid + lo: 8 + 8 + 8 mantissa bits, bit masks and two exact subtractions; bf16 has fp32's exponent,
+// so no scaling), the pieces go to LDS as three 16-bit planes of a 32-row stage, ds_read_b64_tr_b16 hands each lane the 8 ROW values of
+// its column, and six v_mfma_f32_16x16x32_bf16 (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the dropped terms are 2^-24 relative) do
+// per 32 rows what 8 f32 MFMAs of twice the latency did: 2.7x less matrix-pipe time, f32 accumulation as before.
+// One workgroup works on one 32-row stage at a time (loads three stages ahead in registers, LDS double-buffered, one barrier per stage);
+// its eight waves own DIFFERENT output tiles -- no reduction inside the workgroup, one global atomic per element and workgroup.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X3_ROWS = 32;
+// Stages of loads in flight per workgroup.  Measured: the stage TIME is what is fixed (~1.3 us per workgroup: cut + LDS writes, barrier,
+// 30 transposed reads per wave + 24 MFMAs -- the LDS pipe alone is ~1,400 of its ~3,200 clocks), not the bytes in flight: five stages ahead
+// with one workgroup per CU was slower (128 x 64 form 234 -> 280 us) than three stages with two workgroups per CU, whose phases interleave.
+constexpr int X3_PF = 3;
+// LDS: three 16-bit planes of a stage of A and of B, double-buffered (one barrier per stage); the block-diagonal form keeps ONE buffer
+// (two barriers per stage) so that two of its workgroups fit a CU as well
+template <int MT, int NT, bool DIAG = false>
+constexpr size_t xty3_lds() { return (size_t)(DIAG ? 1 : 2) * 3 * X3_ROWS * ((16 * MT + 8) + (16 * NT + 8)) * 2; }
+
+// four fp32 values -> three planes of four bf16 (truncation: every piece has the sign of x and the pieces add up to x exactly)
+__device__ __forceinline__ void cut3(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned xb = __float_as_uint(x[e]);
+    h[e] = xb & 0xffff0000u;
+    const float r1 = x[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xffff0000u;
+    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));   // at most 8 significant bits are left: its upper half is exact
+  }
+  // upper halves of two dwords -> one dword (element 2 e in the low half)
+  hi = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  mid = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  lo = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+
+// operand of column tile `o` of a [32][S] 16-bit plane: this lane's column 16 o + (lane & 15), rows 4 g ..+3 and 16 + 4 g ..+3
+__device__ __forceinline__ bf16x8 x3_operand(const short* plane, int S, int o, int g, int lane) {
+  const int q = lane & 15;
+  const short* p = plane + (4 * g + (q >> 2)) * S + 16 * o + 4 * (q & 3);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * S));
+  return __builtin_bit_cast(bf16x8, s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+// DIAG (MT = NT = 8): A = [core | gate] adjoint rows, B = [core | gate] input rows of a gated MLP's second layer; out = core^T core,
+// out2 = gate^T gate.  As two k_xty<4, 4> calls every pass read 256 of each row's 512 bytes.
+template <int MT, int NT, bool DIAG = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_xty3(XtyArgs p) {   // two workgroups per CU (LDS)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int M = 16 * MT, N = 16 * NT, SA = M + 8, SB = N + 8;
+  // waves own PM x PN blocks of output tiles (2 x 2 where the shape allows: the fewest operand reads per MFMA)
+  constexpr int WM = DIAG ? 2 : 4, WN = 2, PM = DIAG ? 2 : MT / WM, PN = DIAG ? 2 : NT / WN;
+  static_assert(DIAG || (MT % WM == 0 && NT % WN == 0 && WM * WN == WAVES), "tile blocks per wave");
+  static_assert(!DIAG || (MT == 8 && NT == 8), "block-diagonal form: two 64 x 64 products, four waves each");
+  constexpr int PLANE_A = X3_ROWS * SA, PLANE_B = X3_ROWS * SB, BUF = 3 * (PLANE_A + PLANE_B);   // halves
+  short* lds = reinterpret_cast<short*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;                                   // DIAG: which of the two products
+  const int mt0 = DIAG ? 4 * half + 2 * ((wave >> 1) & 1) : (wave % WM) * PM, nt0 = DIAG ? 4 * half + 2 * (wave & 1) : (wave / WM) * PN;
+  // this thread's share of a stage: NLA float4 of A, NLB of B (a narrow B: the first threads only)
+  constexpr int A4 = M / 4, B4 = N / 4, NLA = X3_ROWS * A4 / BLOCK, NLB = X3_ROWS * B4 >= BLOCK ? X3_ROWS * B4 / BLOCK : 1;
+  static_assert(NLA >= 1, "stage shape");
+  const int a_row = tid / A4, a_c4 = tid % A4;                 // + (BLOCK / A4) rows per further load
+  const bool b_on = tid < X3_ROWS * B4;
+  const int b_row = b_on ? tid / B4 : 0, b_c4 = tid % B4;      // + (BLOCK / B4) rows per further load
+  const int nstages = (p.rows + X3_ROWS - 1) / X3_ROWS;
+  const int sb = (int)((long)blockIdx.x * nstages / gridDim.x), se = (int)((long)(blockIdx.x + 1) * nstages / gridDim.x);
+  f32x4 qa[X3_PF][NLA], qb[X3_PF][NLB];
+  // loads are issued unconditionally from clamped addresses and zeroed by predicate: the number of loads in flight stays static, so the
+  // wait for the oldest stage is an exact vmcnt, not vmcnt(0)
+  auto issue = [&](int stage, f32x4 (&va)[NLA], f32x4 (&vb)[NLB]) {
+    const int row0 = min(stage, nstages - 1) * X3_ROWS;
+    const bool on = stage < se;
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+      const int r = row0 + a_row + u * (BLOCK / A4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + (size_t)min(r, p.rows - 1) * p.lda + 4 * a_c4);
+      va[u] = (on && r < p.rows) ? v : zero4();        // rows past the end add nothing
+    }
+#pragma unroll
+    for (int u = 0; u < NLB; ++u) {
+      const int r = row0 + b_row + u * (BLOCK / B4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (size_t)min(r, p.rows - 1) * p.ldb + 4 * b_c4);
+      vb[u] = (on && b_on && r < p.rows) ? v : zero4();
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < X3_PF; ++d) issue(sb + d, qa[d], qb[d]);
+  f32x4 acc[PM][PN];
+#pragma unroll
+  for (int m = 0; m < PM; ++m)
+#pragma unroll
+    for (int n = 0; n < PN; ++n) acc[m][n] = zero4();
+  f32x4 csum[NLA];
+#pragma unroll
+  for (int u = 0; u < NLA; ++u) csum[u] = zero4();
+  for (int stage = sb; stage < se; ++stage) {
+    short* buf = lds + (DIAG ? 0 : ((stage - sb) & 1) * BUF);
+    short* PA = buf;                    // planes hi, mid, lo of A, then of B
+    short* PB = buf + 3 * PLANE_A;
+    if (DIAG) __syncthreads();          // single buffer: the previous stage's operand reads are done
+    // oldest stage of the queue: cut and store
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+      csum[u] += qa[0][u];
+      u32x2 h, m, l;
+      cut3(qa[0][u], h, m, l);
+      const int off = (a_row + u * (BLOCK / A4)) * SA + 4 * a_c4;
+      *reinterpret_cast<u32x2*>(PA + off) = h;
+      *reinterpret_cast<u32x2*>(PA + PLANE_A + off) = m;
+      *reinterpret_cast<u32x2*>(PA + 2 * PLANE_A + off) = l;
+    }
+    if (b_on) {
+#pragma unroll
+      for (int u = 0; u < NLB; ++u) {
+        u32x2 h, m, l;
+        cut3(qb[0][u], h, m, l);
+        const int off = (b_row + u * (BLOCK / B4)) * SB + 4 * b_c4;
+        *reinterpret_cast<u32x2*>(PB + off) = h;
+        *reinterpret_cast<u32x2*>(PB + PLANE_B + off) = m;
+        *reinterpret_cast<u32x2*>(PB + 2 * PLANE_B + off) = l;
+      }
+    }
+    // shift the queue, request the stage X3_PF ahead
+#pragma unroll
+    for (int d = 0; d + 1 < X3_PF; ++d) {
+#pragma unroll
+      for (int u = 0; u < NLA; ++u) qa[d][u] = qa[d + 1][u];
+#pragma unroll
+      for (int u = 0; u < NLB; ++u) qb[d][u] = qb[d + 1][u];
+    }
+    issue(stage + X3_PF, qa[X3_PF - 1], qb[X3_PF - 1]);
+    __syncthreads();
+    bf16x8 a[PM][3], b[PN][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int m = 0; m < PM; ++m) a[m][pl] = x3_operand(PA + pl * PLANE_A, SA, mt0 + m, g, lane);
+#pragma unroll
+      for (int n = 0; n < PN; ++n) b[n][pl] = x3_operand(PB + pl * PLANE_B, SB, nt0 + n, g, lane);
+    }
+#pragma unroll
+    for (int m = 0; m < PM; ++m)
+#pragma unroll
+      for (int n = 0; n < PN; ++n) {
+        f32x4 c = acc[m][n];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], b[n][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[n][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[n][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[n][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[n][1], c, 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[n][0], c, 0, 0, 0);
+      }
+  }
+  // accumulator element (lane (i, g), r) is out[16 mt + 4 g + r][16 nt + i]; DIAG: tile indices inside the wave's own 64 x 64 product
+  float* dst = (DIAG && half) ? p.out2 : p.out;
+#pragma unroll
+  for (int m = 0; m < PM; ++m)
+#pragma unroll
+    for (int n = 0; n < PN; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (DIAG ? mt0 + m - 4 * half : mt0 + m) + 4 * g + r, c = 16 * (DIAG ? nt0 + n - 4 * half : nt0 + n) + i;
+        if (c < p.n_cols) atomicAdd(dst + (size_t)row * p.ldo + c, p.alpha * acc[m][n][r]);
+      }
+  if (p.a_colsum) {   // bias gradients: column sums of A, first inside the workgroup
+    __syncthreads();
+    float* red = smem;
+    for (int c = tid; c < M; c += BLOCK) red[c] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NLA; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * a_c4 + e], csum[u][e]);
+    __syncthreads();
+    for (int c = tid; c < M; c += BLOCK) {
+      if (DIAG && c >= M / 2) atomicAdd(p.a_colsum2 + c - M / 2, p.alpha * red[c]);
+      else atomicAdd(p.a_colsum + c, p.alpha * red[c]);
+    }
   }
 }
 

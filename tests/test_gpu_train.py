@@ -510,6 +510,51 @@ np.save(sys.argv[2], np.stack([g1, g2, g3]))
     assert np.abs(out["fused"][1] - out["unfused"][1]).max() <= 1e-4 * scale, float(np.abs(out["fused"][1] - out["unfused"][1]).max() / scale)
 
 
+def test_three_piece_bf16_weight_gradient_contraction_equals_the_f32_mfma_one():
+    """k_xty3 (long row operands: fp32 cut exactly into three bf16 pieces, six bf16 MFMAs per product) against k_xty (f32 MFMA,
+    CHGNET_XTY3=0, chosen once per process: a child process each): first- and second-order gradient blobs agree to fp32
+    reassociation on a batch whose angle / edge operands take the new kernel (> 65,536 rows, ragged last stage)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bench
+from chgnet_amd.engine import Engine
+from chgnet_amd.pack import pack_batch, pack_weights
+W = dict(np.load(sys.argv[1] + "/tests/golden/weights_trained_like.npz"))
+pb = pack_batch(bench.build_workload(27, 6100))
+assert pb.n_angles > 65536 and pb.n_directed > 65536 and pb.n_angles % 32 != 0
+rng = np.random.default_rng(13)
+ce = rng.normal(size=27).astype(np.float32); gm = rng.normal(size=pb.n_atoms).astype(np.float32)
+gf = rng.normal(size=(pb.n_atoms, 3)).astype(np.float32); gs = rng.normal(size=(27, 3, 3)).astype(np.float32)
+eng = Engine(pack_weights(W), 0)
+b = eng.upload(pb)
+eng.predict(b, "efsm")
+g1 = eng.backward(b, ce, gm)
+g2 = eng.backward(b, ce, gm, f_grad=gf, s_grad=gs)
+np.save(sys.argv[2], np.stack([g1, g2]))
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("bf16x3", "f32"):
+            env = dict(os.environ)
+            env.pop("CHGNET_XTY3", None)
+            if mode == "f32":
+                env["CHGNET_XTY3"] = "0"
+            path = os.path.join(tmp, mode + ".npy")
+            subprocess.run([sys.executable, "-c", code, repo, path], check=True, env=env, timeout=600)
+            out[mode] = np.load(path).astype(np.float64)
+    for k, label in ((0, "first order"), (1, "second order")):
+        scale = np.abs(out["f32"][k]).max()
+        err = np.abs(out["bf16x3"][k] - out["f32"][k]).max()
+        assert scale > 0 and np.isfinite(out["bf16x3"][k]).all() and err <= 2e-5 * scale, (label, float(err / scale))
+
+
 def test_a_missing_energy_cotangent_next_to_other_terms_means_no_energy_term(hip_engine):
     """``backward(batch)`` is the gradient of the summed energies; ``backward(batch, f_grad=...)`` is the force term alone."""
     graphs = [load_case(n)[0] for n in ("limno2", "s16tri")]
