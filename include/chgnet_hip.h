@@ -177,7 +177,8 @@ int chg_batch_all_gather_energy(chg_engine* eng, chg_batch* batch, struct chg_co
 /* The engine's HIP stream (a hipStream_t) and device ordinal, for callers that enqueue their own device work behind it. */
 void* chg_engine_stream(chg_engine* eng);
 int chg_engine_device(chg_engine* eng);
-/* New parameter values for an existing engine (optimizer step): same blob layout and length as at creation. */
+/* New parameter values for an existing engine (optimizer step): same blob layout and length as at creation.  Also rebuilds the
+ * prebuilt LDS weight images the inference kernels read (captured hipGraphs stay valid: they hold the image buffer, not its contents). */
 int chg_engine_update_weights(chg_engine* eng, const float* weights_blob);
 int chg_batch_download(chg_engine* eng, chg_batch* batch, const chg_out_host* out);
 
