@@ -337,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * a_c4 + e], csum[u][e]);
     __syncthreads();
     for (int c = tid; c < M; c += BLOCK) {
-      if (DIAG && c >= M / 2) atomicAdd(p.a_colsum2 + c - M / 2, p.alpha * red[c]);
+      if (DIAG && c >= M / 2) { if (p.a_colsum2) atomicAdd(p.a_colsum2 + c - M / 2, p.alpha * red[c]); }
       else atomicAdd(p.a_colsum + c, p.alpha * red[c]);
     }
   }
