@@ -133,3 +133,46 @@ def test_row_scale_keeps_small_adjoint_rows_exact_and_is_neutral_otherwise(tl_ca
             assert err_u > 1e-3, (mag, err_u)              # 1e-10 rows: the unscaled f16 halves are all subnormal
         else:
             assert err_u < worst_unscaled, (mag, err_u)
+
+
+# ---- three-piece bf16 products of the long weight-gradient contractions (csrc/kernels_train.h: cut3, k_xty3) ------------------------
+def _cut3(x):
+    """fp32 -> three bf16 pieces by truncation, as cut3 does it: masks and two exact fp32 subtractions."""
+    x = np.ascontiguousarray(x, np.float32)
+    mask = np.uint32(0xFFFF0000)
+    hi = (x.view(np.uint32) & mask).view(np.float32)
+    r1 = x - hi
+    mid = (r1.view(np.uint32) & mask).view(np.float32)
+    r2 = r1 - mid
+    lo = (r2.view(np.uint32) & mask).view(np.float32)
+    return hi, mid, lo
+
+
+def test_three_bf16_pieces_are_exact_and_six_products_reach_fp32_accuracy():
+    """Pins the arithmetic k_xty3 relies on: (i) hi + mid + lo == x bit for bit over 30 decades of magnitude (bf16 keeps fp32's
+    exponent: no scaling anywhere), every piece has at most 8 significant bits (so bf16 x bf16 products are exact in fp32);
+    (ii) the six products the kernel keeps reproduce A^T B over 4,096 rows to ~2^-22 of sum |a||b| -- the accuracy of an fp32
+    dot product -- while the three-product (hi/mid only) form is two orders worse: why the `lo` planes exist."""
+    rng = np.random.default_rng(21)
+    x = (rng.normal(size=200_000) * np.exp(rng.uniform(-35, 35, 200_000))).astype(np.float32)
+    x[:5] = [0.0, -0.0, 1.0, np.float32(2.0) ** -120, -np.float32(3.0e38)]
+    hi, mid, lo = _cut3(x)
+    assert np.array_equal((hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)).astype(np.float32), x)
+    assert np.array_equal(hi + (mid + lo), x)                          # also in fp32: the pieces do not overlap
+    for piece in (hi, mid, lo):                                        # bf16-representable: low 16 bits clear
+        assert not (piece.view(np.uint32) & np.uint32(0xFFFF)).any()
+    assert (np.sign(mid) * np.sign(x) >= 0).all() and (np.sign(lo) * np.sign(x) >= 0).all()   # truncation: pieces share x's sign
+
+    rows, M, N = 4096, 64, 32
+    A = (rng.normal(size=(rows, M)) * np.exp(rng.uniform(-6, 6, (rows, 1)))).astype(np.float32)   # adjoint rows: wide dynamic range
+    B = rng.normal(size=(rows, N)).astype(np.float32)
+    exact = A.astype(np.float64).T @ B.astype(np.float64)
+    bound = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    a, b = _cut3(A), _cut3(B)
+    prod = lambda i, j: a[i].astype(np.float64).T @ b[j].astype(np.float64)   # noqa: E731  (each bf16 product is exact; f64 stands for the f32 accumulator)
+    six = prod(2, 0) + prod(0, 2) + prod(1, 1) + prod(1, 0) + prod(0, 1) + prod(0, 0)
+    three = prod(1, 0) + prod(0, 1) + prod(0, 0)
+    err6 = float((np.abs(six - exact) / bound).max())
+    err3 = float((np.abs(three - exact) / bound).max())
+    assert err6 < 2.0 ** -22, err6                                     # dropped terms: mid lo, lo mid, lo lo ~ 3 x 2^-24
+    assert err3 > 30 * err6 and err3 < 2.0 ** -14, (err3, err6)
