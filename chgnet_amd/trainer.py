@@ -57,6 +57,12 @@ class CombinedLoss:
 
         def term(key, ratio, t, p):
             t, p = np.asarray(t, np.float64), np.asarray(p, np.float64)
+            if t.size and not np.isnan(t.sum()):       # no label missing (one pass; inf - inf lands in the general path below): the
+                tv, pv = t.reshape(-1), p.reshape(-1)  # same 1-D operands as t[valid] / p[valid] without the mask and the copies
+                val, gv = self.criterion(tv, pv)
+                out["loss"] += ratio * val
+                out[f"{key}_MAE"] = float(np.mean(np.abs(tv - pv)))
+                return (ratio * gv).reshape(p.shape), int(t.size) if self.allow_missing_labels else int(t.shape[0])
             valid = ~np.isnan(t) if self.allow_missing_labels else np.ones(t.shape, bool)
             g = np.zeros(p.shape, np.float64)
             if valid.any():
