@@ -63,7 +63,7 @@ Rccl& rccl() {
     x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
     x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
     x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
-    x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+    x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(x.handle, "ncclCommCount"));   // optional: chg_comm_info falls back to the size it was created with
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
     return x;
   }();

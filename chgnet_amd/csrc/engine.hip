@@ -138,8 +138,8 @@ struct chg_batch {
   float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GQ, *Gagg, *Grk, *Gu;
   float* phase = nullptr;   // CHG_PHASE_TIMING builds: per-phase shader-clock totals of the angle kernels
   WinIndex win{};           // centre-major row order + window slots of the angle adjoints (kernels_angle_w.h), built by prepare_windows
-  int *win_tmp = nullptr, *win_scan = nullptr, *win_wave_atom = nullptr;
-  int win_grid = 1;         // workgroups of the per-atom adjoints (fixed when the index is built)
+  int *win_tmp = nullptr, *win_scan = nullptr;
+  int win_grid = 64;        // workgroups of the per-atom kernels (a multiple of 64: the atom schedule is built for it, k_win_schedule)
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
@@ -161,6 +161,7 @@ struct chg_batch {
   size_t t2_bytes = 0;
   struct Train2* t2 = nullptr;
   float* t_mcot = nullptr;   // [N] magmom cotangent
+  float h_g_b3 = 0.f;        // host-side gradient of the readout's last bias (copied into the blob on the device)
   bool t_has_mcot = false;
   float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
         *t_ro = nullptr;
@@ -566,10 +567,10 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
   LaunchScope ls(eng, label);
   AngleArgs plain = a;
   if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
-    // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the plain one: both are
+    // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the row-order one: both are
     // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
     AngleWArgs w{};
-    w.a = a; w.w = b->win; w.wave_atom = b->win_wave_atom;
+    w.a = a; w.w = b->win;
     hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
   } else {
@@ -796,9 +797,9 @@ void carve(chg_batch* b, char* base, size_t& total) {
     w.head = c.take<int>(Ed); w.rank = c.take<int>(Ed); w.list = c.take<int>(A ? N * WIN_LIST : 0);
     w.q_a = c.take<int>(A); w.q_ctr = c.take<int>(A); w.q_b1c = c.take<int>(A); w.q_b2c = c.take<int>(A); w.q_ab1 = c.take<int>(A); w.q_ab2 = c.take<int>(A);
     w.abbond = c.take<int>(2 * Eb);
+    w.wave_head = c.take<int>(A ? WIN_MAX_GRID * WAVES : 0); w.next_atom = c.take<int>(A ? N : 0); w.xatom = c.take<int>(WIN_MAX_GRID / 8 + 1);
     b->win_tmp = c.take<int>(N + 1);
     b->win_scan = c.take<int>(scan_scratch_ints((int)N + 1));
-    b->win_wave_atom = c.take<int>(A ? WIN_MAX_WAVES + 1 : 0);
   }
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
   total = (c.pos + 255) & ~size_t(255);
@@ -810,23 +811,28 @@ int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;
   b->win_built = false;
-  b->win_grid = std::max(1, std::min({tile_grid(eng, b->A), WIN_MAX_WAVES / WAVES}));
+  // one workgroup per CU (their LDS admits no second one), in whole groups of 64 waves = 8 workgroups per XCD (k_win_schedule)
+  b->win_grid = std::max(64, std::min(eng->num_cus / 64 * 64, WIN_MAX_GRID));
   // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle -- plain adjoints, and nothing to build
-  if (b->A == 0 || (long)b->N < (long)WIN_MIN_ATOMS_PER_WAVE * b->win_grid * WAVES) return CHG_OK;
+  // (CHGNET_WIN_MIN_ATOMS_PER_WAVE=0 sends small batches through the per-atom kernels too: parity tests on the golden cases)
+  const char* min_env = std::getenv("CHGNET_WIN_MIN_ATOMS_PER_WAVE");
+  const long min_atoms = min_env ? std::atol(min_env) : WIN_MIN_ATOMS_PER_WAVE;
+  if (b->A == 0 || (long)b->N < min_atoms * b->win_grid * WAVES) return CHG_OK;
   if ((size_t)b->N / SCAN_CHUNK + 1 > (1u << 16)) return CHG_OK;      // beyond the two-level scan: plain adjoints
   b->win_built = true;
   HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
   HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
   HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
   HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
-  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w);
+  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w, b->win_grid);
   hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
   TRY(exclusive_scan_with(eng, b->win_scan, w.na, w.boff, b->N + 1));
   hipLaunchKernelGGL(k_win_counts, g1((int64_t)b->N + 1), dim3(256), 0, st, b->N, w, b->win_tmp);
   TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
   hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
   hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
-  hipLaunchKernelGGL(k_win_partition, g1((int64_t)b->win_grid * WAVES + 1), dim3(256), 0, st, b->N, b->A, b->win_grid * WAVES, w, b->win_wave_atom);
+  hipLaunchKernelGGL(k_win_groups, g1(b->win_grid / 8 + 1), dim3(256), 0, st, b->N, b->A, b->win_grid / 8, w);
+  hipLaunchKernelGGL(k_win_schedule, dim3(b->win_grid / 8), dim3(64), 0, st, b->win_grid, w);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }
@@ -858,6 +864,8 @@ void register_names(chg_batch* b) {
   mi["a_ctr"] = {b->a_ctr, A}; mi["a_b1c"] = {b->a_b1c, A}; mi["a_b2c"] = {b->a_b2c, A}; mi["a_d1"] = {b->a_d1, A}; mi["a_d2"] = {b->a_d2, A};
   mi["win_flag"] = {b->win.flag, 4}; mi["win_q_a"] = {b->win.q_a, A}; mi["win_q_ctr"] = {b->win.q_ctr, A}; mi["win_na"] = {b->win.na, N + 1};
   mi["win_aoff"] = {b->win.aoff, N + 1}; mi["win_q_ab1"] = {b->win.q_ab1, A}; mi["win_q_ab2"] = {b->win.q_ab2, A};
+  mi["win_next_atom"] = {b->win.next_atom, A ? N : 0};
+  mi["win_wave_head"] = {b->win.wave_head, A ? (size_t)WIN_MAX_GRID * WAVES : 0}; mi["win_xatom"] = {b->win.xatom, (size_t)WIN_MAX_GRID / 8 + 1};   // win_flag[3] = workgroups
 }
 
 template <class T>
@@ -2492,10 +2500,9 @@ int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
   return CHG_OK;
 }
 
-static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
-                         const float* force_cotangent, const float* stress_cotangent, chg_comm* comm, float* grad_blob) {
-  if (!eng || !b || !grad_blob) return CHG_EINVAL;
-  HIP_TRY(eng, hipSetDevice(eng->device));
+// the local part of chg_backward: everything up to the gradient blob in HBM (b->t_grad), nothing leaves the device
+static int backward_compute(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                            const float* force_cotangent, const float* stress_cotangent) {
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
   if ((int)b->h_atom_off.size() != b->B + 1) { eng->err = "chg_backward: batch has no host atom offsets"; return CHG_EINVAL; }
   TRY(ensure_train_buffers(eng, b));
@@ -2508,6 +2515,7 @@ static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cota
     cot[i] = (float)(eng->desc.is_intensive ? ce / n : ce);
     g_b3 += (double)cot[i] * n;
   }
+  b->h_g_b3 = (float)g_b3;   // gradient of the readout's last bias: sum_b cot_b n_b, known on the host
   HIP_TRY(eng, hipMemcpyAsync(b->t_cot, cot.data(), sizeof(float) * b->B, hipMemcpyHostToDevice, eng->stream));
   b->t_has_mcot = magmom_cotangent != nullptr;
   if (magmom_cotangent) HIP_TRY(eng, hipMemcpyAsync(b->t_mcot, magmom_cotangent, sizeof(float) * b->N, hipMemcpyHostToDevice, eng->stream));
@@ -2532,16 +2540,50 @@ static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cota
   // the forward kernels contract the bond partials in place (and store them only for force / stress tasks); the training sweeps gather them as tables
   if (b->Ed > 0) for (int l = 0; l < b->L; ++l) TRY(atomconv_q_table(eng, b, l));
   TRY(second_order ? run_backward2(eng, b) : run_backward(eng, b));
-  if (comm) {   // data-parallel step: sum of the blob over the ranks, in HBM, on this stream
-    if (chg_comm_all_reduce_sum_f32_device(comm, b->t_grad, (int64_t)eng->desc.n_weights, eng->stream) != CHG_OK) {
-      eng->err = std::string("chg_backward_allreduce: ") + chg_comm_last_error(comm);
-      return CHG_EHIP;
+  // the b3 slot joins the blob ON THE DEVICE, so that a following all-reduce sums it over the ranks like every other entry (it used
+  // to be written into the host copy after the collective: every rank then applied its LOCAL value / world -- ADVICE r03)
+  HIP_TRY(eng, hipMemcpyAsync(b->t_grad + (eng->w.mlp_b3 - eng->d_weights), &b->h_g_b3, sizeof(float), hipMemcpyHostToDevice, eng->stream));
+  return CHG_OK;
+}
+
+static int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
+                         const float* force_cotangent, const float* stress_cotangent, chg_comm* comm, float* grad_blob) {
+  if (!eng || !b || !grad_blob) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  const int64_t n_w = (int64_t)eng->desc.n_weights;
+  if (comm) {   // the collective is enqueued on the engine's stream: the communicator must live on the engine's device
+    int32_t comm_dev = -1;
+    if (chg_comm_info(comm, nullptr, nullptr, &comm_dev) != CHG_OK || comm_dev != eng->device) {
+      eng->err = "chg_backward_allreduce: the communicator belongs to device " + std::to_string(comm_dev) + ", the engine to device " + std::to_string(eng->device);
+      return CHG_EINVAL;
     }
   }
-  HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyDeviceToHost, eng->stream));
-  TRY(chg_synchronize(eng));
-  grad_blob[eng->w.mlp_b3 - eng->d_weights] = (float)g_b3;
-  return CHG_OK;
+  const int status = backward_compute(eng, b, energy_cotangent, magmom_cotangent, force_cotangent, stress_cotangent);
+  if (!comm) {
+    if (status != CHG_OK) return status;
+    HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)n_w, hipMemcpyDeviceToHost, eng->stream));
+    return chg_synchronize(eng);
+  }
+  // Data-parallel step: sum of the blob over the ranks, in HBM, on this stream.  A rank whose local sweep failed (an arena that did
+  // not fit, a bad argument) STILL enters the collective -- with zeros -- and reports its error afterwards: returning early would
+  // leave the other ranks blocked in ncclAllReduce for ever.
+  float* send = b->t_grad;
+  const std::string local_err = eng->err;
+  if (status != CHG_OK) {
+    if (chg_comm_reserve(comm, n_w, &send) != CHG_OK) { eng->err = local_err + " (and no staging for the collective: " + chg_comm_last_error(comm) + ")"; return status; }
+    if (hipMemsetAsync(send, 0, sizeof(float) * (size_t)n_w, eng->stream) != hipSuccess) return status;
+  }
+  if (chg_comm_all_reduce_sum_f32_device(comm, send, n_w, eng->stream) != CHG_OK) {
+    eng->err = std::string("chg_backward_allreduce: ") + chg_comm_last_error(comm);
+    return status != CHG_OK ? status : CHG_EHIP;
+  }
+  if (status != CHG_OK) {
+    hipStreamSynchronize(eng->stream);
+    eng->err = local_err;
+    return status;
+  }
+  HIP_TRY(eng, hipMemcpyAsync(grad_blob, b->t_grad, sizeof(float) * (size_t)n_w, hipMemcpyDeviceToHost, eng->stream));
+  return chg_synchronize(eng);
 }
 
 int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
@@ -2558,8 +2600,12 @@ int chg_batch_all_gather_energy(chg_engine* eng, chg_batch* b, chg_comm* comm, i
   if (!eng || !b || !comm || !table || width < b->B) return CHG_EINVAL;
   if (b->last_task == 0) { eng->err = "chg_batch_all_gather_energy: run chg_predict on this batch first"; return CHG_EINVAL; }
   HIP_TRY(eng, hipSetDevice(eng->device));
-  int32_t nranks = 1;
+  int32_t nranks = 1, comm_dev = -1;
   float* stage = nullptr;
+  if (chg_comm_info(comm, nullptr, &nranks, &comm_dev) == CHG_OK && comm_dev != eng->device) {
+    eng->err = "chg_batch_all_gather_energy: the communicator belongs to device " + std::to_string(comm_dev) + ", the engine to device " + std::to_string(eng->device);
+    return CHG_EINVAL;
+  }
   if (chg_comm_info(comm, nullptr, &nranks, nullptr) != CHG_OK || chg_comm_reserve(comm, width * (int64_t)(nranks + 1), &stage) != CHG_OK) {
     eng->err = std::string("chg_batch_all_gather_energy: ") + chg_comm_last_error(comm);
     return CHG_EHIP;

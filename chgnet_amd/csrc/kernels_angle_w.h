@@ -35,11 +35,14 @@ namespace chg {
 constexpr int TS64 = D + PAD;                  // row stride of the 64-wide wave tiles of this kernel
 constexpr int TILE64_FLOATS = TILE_ROWS * TS64;
 constexpr int WIN_LIST = 32;                   // short bonds per atom the fast path handles
-constexpr int WIN_MAX_WAVES = 8 * 4096;        // capacity of the wave partition (grid <= 4096 workgroups)
+constexpr int WIN_MAX_GRID = 1024;             // workgroups of the per-atom kernels (one per CU; capacity of the schedule's arrays)
 constexpr int WIN_MIN_ATOMS_PER_WAVE = 3;      // below this the atom-per-wave order leaves most of the chip idle: plain adjoints
 
 struct WinIndex {             // built by k_win_*; all in the batch arena
-  int* flag;                  // [4]  flag[0] = 1: the windowed order is valid for this batch
+  int* flag;                  // [4]  flag[0] = 1: the centre-major order is valid for this batch (the per-atom adjoints run);
+                              //      flag[3] = workgroups the atom schedule was built for
+  int *wave_head, *next_atom; // [win_grid * WAVES], [N]: the atoms of every wave as a linked list (k_win_schedule)
+  int* xatom;                 // [win_grid / 8 + 1] atoms [xatom[i], xatom[i + 1]) are dealt to the 64 waves of group i (k_win_groups)
   int *na, *boff, *aoff;      // [N+1] short bonds per atom, exclusive scans of na and na (na - 1)
   int *head, *rank;           // [Ed] first row of the group whose first bond is this directed edge (-1: none); its rank at the centre
   int* list;                  // [N][WIN_LIST] directed edges of the groups of an atom (unordered)
@@ -48,7 +51,7 @@ struct WinIndex {             // built by k_win_*; all in the batch arena
 };
 
 // ---- index construction ---------------------------------------------------------------------------------
-__global__ void k_win_init(WinIndex w) { w.flag[0] = 1; }
+__global__ void k_win_init(WinIndex w, int grid) { w.flag[0] = 1; w.flag[3] = grid; }
 
 __global__ void k_win_heads(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, int A, int Ed, int N, WinIndex w) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,26 +110,78 @@ __global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __restrict_
   w.q_ab2[row] = r2 >= 0 ? w.boff[c] + r2 : -1;
 }
 
-// wave_atom[i] = first atom of wave i: atom ranges of equal row counts (up to one atom), i = 0 .. nwaves
-__global__ void k_win_partition(int N, int A, int nwaves, WinIndex w, int* __restrict__ wave_atom) {
+// ---- which wave works on which atom: a static schedule with the locality of a dynamic one ----------------------------------
+// With one contiguous atom range per wave (round 3) the 256 waves of an XCD sat in ~128 different structures at any moment and their
+// tables (R: 1 KB per bond node) missed the 4 MiB L2: hit rates of 24-37 %, fabric traffic 1.5-2.3x the compulsory bytes
+// (profiles/r03_l2_counters.csv).  Now the rows are cut into grid / 8 equal ranges and GROUPS of 64 waves -- eight workgroups of one
+// XCD (blockIdx & 7 = XCD is the observed dispatch: speed only), the groups of an XCD on neighbouring ranges -- walk one range
+// TOGETHER: its atoms are dealt, in order, always to the wave of the group with the least work so far (greedy list scheduling on the
+// tile count of an atom: what a shared work queue would do, but decided once per batch topology, deterministic, and without a
+// returning atomic per atom).  Waves advance at the same pace, so at any moment an XCD works inside a handful of neighbouring
+// structures, and the loads of a group differ by at most one atom at the end.  The result is a linked list per wave:
+// wave_head[blockIdx * WAVES + wave] -> next_atom[c] -> ... -> -1, so a wave knows its next atom one atom ahead (index prefetch).
+constexpr int WIN_GROUP_WAVES = 64;
+
+__global__ void k_win_groups(int N, int A, int ngroups, WinIndex w) {   // xatom[i] = first atom c with aoff[c + 1] > A i / ngroups
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && (long)N < (long)WIN_MIN_ATOMS_PER_WAVE * nwaves) w.flag[0] = 0;
-  if (i > nwaves) return;
-  if (i == nwaves) { wave_atom[i] = N; return; }
-  const long target = (long)A * i / nwaves;
-  int lo = 0, hi = N;                      // first atom c with aoff[c + 1] > target
+  if (i > ngroups) return;
+  if (i == ngroups) { w.xatom[i] = N; return; }
+  const long target = (long)A * i / ngroups;
+  int lo = 0, hi = N;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (w.aoff[mid + 1] > target) hi = mid; else lo = mid + 1;
   }
-  wave_atom[i] = lo;
+  w.xatom[i] = lo;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {   // minimum over the 64 lanes, in every lane (cf. quad_sum / wave_sum)
+#define CHG_DPP_MIN(ctrl) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, (ctrl), 0xF, 0xF, false))
+  CHG_DPP_MIN(0xB1);    // quad_perm [1,0,3,2]
+  CHG_DPP_MIN(0x4E);    // quad_perm [2,3,0,1]
+  CHG_DPP_MIN(0x141);   // row_half_mirror
+  CHG_DPP_MIN(0x140);   // row_mirror
+#undef CHG_DPP_MIN
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  const unsigned s = min((unsigned)r[0], (unsigned)r[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(s, s, false, false);
+  return min((unsigned)q[0], (unsigned)q[1]);
+}
+
+// one wave per group; lane = slot of the group = ((blockIdx >> 3) & 7) * WAVES + wave of the kernels that consume the lists
+__global__ __launch_bounds__(64) void k_win_schedule(int grid, WinIndex w) {
+  const int gi = blockIdx.x, lane = threadIdx.x;
+  const int spx = grid >> 6;                   // groups per XCD
+  const int x = gi / spx, sub = gi - x * spx;
+  const int head_slot = ((((sub << 3) + (lane / WAVES)) << 3) + x) * WAVES + (lane % WAVES);
+  if (w.flag[0] != 1) { w.wave_head[head_slot] = -1; return; }
+  const int c0 = w.xatom[gi], c1 = w.xatom[gi + 1];
+  unsigned load = 0;
+  int head = -1, tail = -1;
+  for (int cb = c0; cb < c1; cb += 64) {
+    const int nn = w.na[min(cb + lane, c1 - 1)];
+    const int m = min(64, c1 - cb);
+    for (int i = 0; i < m; ++i) {
+      const int n = __builtin_amdgcn_readlane(nn, i);
+      if (n < 2) continue;                    // no angles around this atom
+      const unsigned cost = (unsigned)(n * (n - 1) + TILE_ROWS - 1) / TILE_ROWS + 1;   // its tiles + the per-atom prologue
+      const unsigned best = wave_min_u32((load << 6) | (unsigned)lane);              // least loaded wave, lowest slot among equals
+      if ((int)(best & 63u) == lane) {
+        const int c = cb + i;
+        load += cost;
+        w.next_atom[c] = -1;
+        if (tail < 0) head = c; else w.next_atom[tail] = c;
+        tail = c;
+      }
+    }
+  }
+  w.wave_head[head_slot] = head;
 }
 
 // ---- the adjoint kernel ---------------------------------------------------------------------------------
 struct AngleWArgs {
   AngleArgs a;                // tables, weights, gradient buffers as for k_angle
-  WinIndex w;
-  const int* wave_atom;       // [gridDim.x * WAVES + 1] first atom of every wave (k_win_partition)
+  WinIndex w;                 // incl. the per-wave atom lists (k_win_schedule); the grid is the one the schedule was built for
 };
 
 // Private second-bond rows per wave: dE/dR_j (128 wide).  AngleUpdate: the angle block as two split images (64 KiB), 14 rows.
@@ -256,16 +311,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
   float* T = tiles + wave * TILE64_FLOATS;
   float* Trow = T + j * TS64;
   float* pacc = paccs + wave * NS * PST;
-  // workgroup b is dispatched to XCD b % 8: neighbouring atom ranges on one XCD (tile_range's mapping)
-  const int G = gridDim.x;
-  int lb = blockIdx.x;
-  if ((G & 7) == 0) lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int c_begin = pw.wave_atom[lb * WAVES + wave], c_end = pw.wave_atom[lb * WAVES + wave + 1];
   PH_DECL
-  for (int c = c_begin; c < c_end; ++c) {
-    const int n = w.na[c];
-    if (n < 2) continue;
-    const int r_begin = w.aoff[c], r_end = r_begin + n * (n - 1), ab0 = w.boff[c];
+  int c_next = w.wave_head[blockIdx.x * WAVES + wave];     // this wave's atoms (k_win_schedule): a list, one atom ahead
+  for (int c = __builtin_amdgcn_readfirstlane(c_next); c >= 0; c = __builtin_amdgcn_readfirstlane(c_next)) {
+    c_next = w.next_atom[c];
+    const int n = __builtin_amdgcn_readfirstlane(w.na[c]);
+    const int r_begin = __builtin_amdgcn_readfirstlane(w.aoff[c]), r_end = r_begin + n * (n - 1), ab0 = __builtin_amdgcn_readfirstlane(w.boff[c]);
     // run sums carried over the tiles of this atom (lane = column): first bond (core | gate halves), centre, bond weights
     float ri0 = 0.f, ri1 = 0.f, rs0 = 0.f, rs1 = 0.f, rg = 0.f;
     int cur0 = -1, cur1 = -1, curg = -1;

@@ -507,25 +507,24 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;     // wave-tiles: this wave's own contiguous range
-  int tb, te;
-  wave_tile_range(ntiles, NW, wave, tb, te);
+  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;     // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
+  const TileSeq ts = wave_tile_seq(ntiles, NW, wave);
   // Software pipeline over tiles: the row gather of tile t+1 is issued before tile t's MFMA / VALU phase and committed to LDS
   // after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of wave time with the gather issued and awaited in place.)
   const int tstride = TILE_ROWS;
-  auto row_of = [&](int tile) { return min(tile * tstride + j, p.n_edges - 1); };
+  auto row_of = [&](int v) { return max(0, min(ts.at(v) * tstride + j, p.n_edges - 1)); };   // v-th tile of this wave (clamped past its end)
   GatherPH gr;
   V64 wv_nx;
   int c_nx = 0, n_nx = 0, c_n2 = 0, n_n2 = 0;
   long h_nx = 0, h_n2 = 0;
   bool node_nx = false, node_n2 = false;
-  if (tb < te) {
-    const int r0 = row_of(tb);
+  if (ts.count > 0) {
+    const int r0 = row_of(0);
     c_nx = p.e_center[r0]; n_nx = p.e_nbr[r0];
     h_nx = bond_row_offset(p, r0 >> 1, node_nx);
     gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
     read_dl<VT>(p.wag + (size_t)(r0 >> 1) * D, g, wv_nx.t);
-    const int r1 = row_of(tb + 1);
+    const int r1 = row_of(1);
     c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
     h_n2 = bond_row_offset(p, r1 >> 1, node_n2);
   }
@@ -533,8 +532,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   // the staging (small batches -- MD -- run one or two tiles per wave, and the prologue was a tenth of the launch)
   stage_image<ac_fwd_image_floats() / 4, 64 * NW>(smem, p.image, tid);
   __syncthreads();
-  for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * tstride;
+  for (int v = 0; v < ts.count; ++v) {
+    const int row0 = ts.at(v) * tstride;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
     // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): hb[k] and w_ag[k] are fetched once per bond (the second
     // row's copy comes from L1)
@@ -549,11 +548,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     gather_commit_p(gr, T, TS, lane);
     __builtin_amdgcn_wave_barrier();
     c_nx = c_n2; n_nx = n_n2; h_nx = h_n2; node_nx = node_n2;
-    if (tile + 1 < te) {
-      const int r1 = row_of(tile + 1);
+    if (v + 1 < ts.count) {
+      const int r1 = row_of(v + 1);
       gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
       read_dl<VT>(p.wag + (size_t)(r1 >> 1) * D, g, wv_nx.t);
-      const int r2 = row_of(tile + 2);
+      const int r2 = row_of(v + 2);
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
       h_n2 = bond_row_offset(p, r2 >> 1, node_n2);
     }
@@ -678,13 +677,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own contiguous range
-  int tb, te;
-  wave_tile_range(ntiles, WAVES, wave, tb, te);
+  const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
+  const TileSeq ts = wave_tile_seq(ntiles, WAVES, wave);
   const int last_row = p.n_edges - 1;
   int c, n, k;
   {   // the first tile's indices and gather land under the staging of the weights (see k_atomconv_fwd)
-    const int row = max(0, min(tb * TILE_ROWS + j, last_row));
+    const int row = max(0, min(ts.at(0) * TILE_ROWS + j, last_row));
     c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
@@ -695,8 +693,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   __syncthreads();
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
-  for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * TILE_ROWS;
+  for (int v = 0; v < ts.count; ++v) {
+    const int row0 = ts.at(v) * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
     if (TRAIN) {
       tt.nvalid = nvalid;
@@ -705,7 +703,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     }
     int cn, nn, kn;                                         // the next tile's rows (clamped: harmless reads at the range end)
     {
-      const int row = min(row0 + TILE_ROWS + j, last_row);
+      const int row = max(0, min(ts.at(v + 1) * TILE_ROWS + j, last_row));
       cn = p.e_center[row]; nn = p.e_nbr[row]; kn = row >> 1;
     }
     V64 wv, gm;
@@ -788,7 +786,7 @@ struct AngleArgs {
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
   int first_gang;      // BondConv adjoint of the last layer: first writer of Gang in the sweep (store, do not read: not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
-  const int* skip_flag; // plain adjoints (BWD, not TRAIN): return at once when *skip_flag == 1 (the windowed kernel of kernels_angle_w.h runs)
+  const int* skip_flag; // row-order adjoints (BWD, not TRAIN): return at once when *skip_flag == 1 (the per-atom kernel of kernels_angle_w.h runs)
   // training (k_angle<.., true, .., true>) only
   float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
   float* dumpH;        // [A,128] hidden activations (BondConv)
@@ -878,11 +876,10 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  const int ntiles = (p.n_angles + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own contiguous range
-  int tb, te;
-  wave_tile_range(ntiles, NW, wave, tb, te);
+  const int ntiles = (p.n_angles + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
+  const TileSeq ts = wave_tile_seq(ntiles, NW, wave);
   const int tstride = TILE_ROWS;
-  auto row_of = [&](int tile) { return max(0, min(tile * tstride + j, p.n_angles - 1)); };
+  auto row_of = [&](int v) { return max(0, min(ts.at(v) * tstride + j, p.n_angles - 1)); };   // v-th tile of this wave (clamped past its end)
   // Forward: software-pipelined gathers -- the table rows and angle rows of tile t+1 are in flight
   // (registers) while tile t is computed, its indices were loaded during tile t-1 (angleupd_fwd
   // 0.945 -> 0.871 ms).  Backward: indices one tile ahead only; with the adjoint's register load
@@ -893,13 +890,13 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   GatherRegs gr_p;
   V64 x_p;
   {
-    const int a0 = row_of(tb);
+    const int a0 = row_of(0);
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
     if (PIPE) {
       gather_issue128(gr_p, p.R, b1_nx, p.R + 2 * D, b2_nx, p.S, ctr_nx, 4 * D, 4 * D, 2 * D, lane);
       read_dl<VT>(p.ang + (size_t)a0 * D, g, x_p.t);
-      if (tb + 1 < te) {
-        const int a1 = row_of(tb + 1);
+      if (1 < ts.count) {
+        const int a1 = row_of(1);
         ctr_n2 = p.a_ctr[a1]; b1_n2 = p.a_b1c[a1]; b2_n2 = p.a_b2c[a1];
       }
     }
@@ -911,9 +908,9 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   PH(9)   // prologue: first indices (forward: first gathers issued), weight images, barrier
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
-  for (int tile = tb; tile < te; ++tile) {
-    PH_TILE(tile == tb)
-    const int row0 = tile * tstride;
+  for (int v = 0; v < ts.count; ++v) {
+    PH_TILE(v == 0)
+    const int row0 = ts.at(v) * tstride;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     const int ctr = ctr_nx, b1 = b1_nx, b2 = b2_nx;
     if (TRAIN) {
@@ -921,8 +918,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       tt.hrow = (HIDDEN && j < nvalid) ? p.dumpH + (size_t)(row0 + j) * 2 * D : nullptr;
       tt.grow = j < nvalid ? p.dumpG + (size_t)(row0 + j) * 2 * D : nullptr;
     }
-    if (!PIPE && tile + 1 < te) {
-      const int a1 = row_of(tile + 1);
+    if (!PIPE && v + 1 < ts.count) {
+      const int a1 = row_of(v + 1);
       ctr_nx = p.a_ctr[a1]; b1_nx = p.a_b1c[a1]; b2_nx = p.a_b2c[a1];
     }
     if (nvalid <= 0) continue;   // only past the end of the last tile
@@ -936,8 +933,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       __builtin_amdgcn_wave_barrier();
       read_dl<2 * VT>(Trow, g, z);
       PH(0)
-      if (tile + 1 < te) {
-        const int a1 = row_of(tile + 1);
+      if (v + 1 < ts.count) {
+        const int a1 = row_of(v + 1);
         gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane);
         // lane group recomputed in place (volatile: not hoisted): the loop-invariant p.ang + lane offset otherwise lives in a register pair
         // over the whole tile -- at 256 registers it is spilled, and its reload waits (vmcnt, in order) behind the gathers just issued
@@ -945,8 +942,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
         read_dl<VT>(p.ang + (size_t)a1 * D, lane_here >> 4, x_p.t);
         ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
-        if (tile + 2 < te) {
-          const int a2 = row_of(tile + 2);
+        if (v + 2 < ts.count) {
+          const int a2 = row_of(v + 2);
           ctr_n2 = p.a_ctr[a2]; b1_n2 = p.a_b1c[a2]; b2_n2 = p.a_b2c[a2];
         }
       }

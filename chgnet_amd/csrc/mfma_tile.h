@@ -271,6 +271,41 @@ __device__ __forceinline__ void wave_tile_range(int n_wave_tiles, int waves_per_
   end = (int)((lw + 1) * n_wave_tiles / W);        // not on the first workgroups
 }
 
+// ---- tile scheduling of the large-batch tile kernels: XCD-local interleaved sweeps ------------------------------------------
+// With contiguous per-wave ranges the 256 waves of an XCD sit in 256 different places of the batch, i.e. in the tables of ~128
+// different structures (30 MB against a 4 MiB L2: hit rates of 24-49 %, fabric traffic 1.5-2.9x the compulsory bytes,
+// profiles/r03_l2_counters.csv).  Here XCD x (= blockIdx & 7, the observed dispatch: speed only) owns the x-th eighth of the tiles and
+// its waves walk it side by side: wave lw takes tiles xb + lw, xb + lw + WX, ... (WX = waves of the XCD), the eight waves of a
+// workgroup on eight consecutive tiles.  At any moment an XCD then works inside one or two structures; every table row is fetched
+// from the fabric once.  Small batches (a few tiles per wave: MD) keep the evenly spaced contiguous ranges of wave_tile_range.
+#ifndef CHG_TILE_INTERLEAVE
+#define CHG_TILE_INTERLEAVE 1
+#endif
+constexpr int INTERLEAVE_MIN_TILES = 6;      // per wave
+struct TileSeq {
+  int first, stride, count;
+  __device__ __forceinline__ int at(int v) const { return first + v * stride; }
+};
+__device__ __forceinline__ TileSeq wave_tile_seq(int n_wave_tiles, int waves_per_block, int wave) {
+  const int G = gridDim.x, b = blockIdx.x;
+  TileSeq s;
+  if (CHG_TILE_INTERLEAVE && (G & 7) == 0 && (long)n_wave_tiles >= (long)INTERLEAVE_MIN_TILES * G * waves_per_block) {
+    const int x = b & 7, WX = (G >> 3) * waves_per_block, lw = (b >> 3) * waves_per_block + wave;
+    const int xb = (int)((long)n_wave_tiles * x / 8), xe = (int)((long)n_wave_tiles * (x + 1) / 8);
+    s.first = xb + lw;
+    s.stride = WX;
+    s.count = xe - xb > lw ? (xe - xb - lw + WX - 1) / WX : 0;
+    return s;
+  }
+  int tb, te;
+  wave_tile_range(n_wave_tiles, waves_per_block, wave, tb, te);
+  s.first = tb; s.stride = 1; s.count = te - tb;
+  return s;
+}
+
+// XCD of the executing wave: hwreg(HW_REG_XCC_ID, 0, 4) (speed only: which of the per-XCD work queues a wave starts with)
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u); }
+
 // ---- tile scheduling: contiguous tile ranges per workgroup, neighbouring ranges on one XCD -------
 // Workgroup b is dispatched to XCD b % 8 (observed, speed only); giving XCD x the logical blocks
 // [x*G/8, (x+1)*G/8) keeps one structure's tables inside one XCD's L2.
