@@ -45,6 +45,22 @@ if REPO not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8 TB/s (spec)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense f16 / bf16 MFMA
+SPLIT_MFMA_PER_PRODUCT = 3      # csrc/mfma_split.h: x.w = xh.wh + xl.wh + xh.wl
+
+
+def csrc_hash() -> str:
+    """Hash of the kernel sources: profiles/pmc_latest.json and sq_latest.json carry the hash of the sources their counters were taken
+    on (profiles/summarize.py); counters of OTHER sources are not quoted in the line (they went stale silently before)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "chgnet_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 # Which matrix form a tile kernel's contractions run in (csrc/mfma_split.h): every f32 product as three f16 MFMAs on hi/lo
 # operand halves with f32 accumulation (22+ significand bits; measured parity = the f32 form's), or the f32 MFMA itself.
 # fractions in `tile_kernels` stay relative to the f32 MFMA peak so that they compare with earlier rounds; a split kernel's own
@@ -193,13 +209,16 @@ class Ranks:
         self.comm = None
         self.comm_note = None
         self.rccl_info = None
-        if args.comm == "rccl" and not args.dry_run and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
+        if args.comm in ("rccl", "auto") and not args.dry_run and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
             from chgnet_amd.distributed import RcclComm      # RCCL through the engine library's C-ABI: no torch.distributed
 
             try:
                 self.comm = RcclComm(self.rank, self.world, self.local_rank)
-            except Exception as exc:  # noqa: BLE001 -- a scaling run must not die on the rendezvous: torch.distributed instead
-                self.comm = None
+            except Exception as exc:  # noqa: BLE001
+                if args.comm == "rccl":     # asked for by name: fail, do not measure something else
+                    raise SystemExit(f"bench.py --comm rccl: the engine library's communicator could not be created "
+                                     f"({type(exc).__name__}: {exc})") from exc
+                self.comm = None            # --comm auto: a scaling run must not die on the rendezvous -- torch.distributed instead, and said so
                 self.comm_note = f"RcclComm failed ({type(exc).__name__}: {exc}); torch.distributed used instead"
         if self.comm is not None:
             self.backend = "rccl (chg_comm_*)"
@@ -444,8 +463,11 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
         e_local[:len(preds)] = [p["e"] for p in preds]
         table = ranks.all_gather(e_local)
         ranks.barrier()
-        dt = ranks.max_over_ranks(time.perf_counter() - t0)
-        best = dt if best is None else min(best, dt)
+        mine_s = time.perf_counter() - t0
+        dt = ranks.max_over_ranks(mine_s)
+        if best is None or dt < best:
+            best, per_rank_s = dt, ranks.all_gather(np.array([mine_s], np.float32)).astype(np.float64)
+    shard_atoms = np.array([sum(counts[i] for i in sh) for sh in shards], np.float64)
     if ranks.rank == 0:
         sample = list(range(0, len(structs), max(1, len(structs) // 6)))[:6]
         checks["C3_sweep"] = ([conv(structs[i]) for i in sample], [preds[i] for i in sample])
@@ -458,7 +480,11 @@ def run_configs(eng, weights, ranks: Ranks, args) -> tuple[dict, dict]:
                         f"per atom; host structures -> CHGNet.predict_structure(task efs, batch_size={args.sweep_chunk}) -> host dicts, "
                         f"graphs built on the device, LPT-sharded over {ranks.world} GPU(s), energies all-gathered",
             "seconds": round(best, 4), "structures_per_s": round(n_total / best, 1), "atoms_per_s": round(sum(counts) / best, 1),
-            "energies_gathered": int(np.isfinite(table).sum()) if ranks.world > 1 else len(preds)}
+            "energies_gathered": int(np.isfinite(table).sum()) if ranks.world > 1 else len(preds),
+            # load balance of the LPT sharder (chgnet_amd/distributed.py): atoms per rank, and what the ranks actually took
+            "shard_atoms_max_over_mean": round(float(shard_atoms.max() / shard_atoms.mean()), 4),
+            "per_rank_seconds": {"min": round(float(per_rank_s.min()), 4), "median": round(float(np.median(per_rank_s)), 4),
+                                 "max": round(float(per_rank_s.max()), 4)}}
 
     # ---- C4: NVT MD, graph rebuilt on the device every step (replicas only: rank 0) ------------------------------
     if ranks.rank == 0:
@@ -613,9 +639,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: process-group plumbing only (gloo)")
-    ap.add_argument("--comm", choices=("torch", "rccl"), default="rccl",
-                    help="exchange steps through the engine library's own RCCL entry points (default; falls back to torch.distributed "
-                         "if the communicator cannot be created) or through torch.distributed (backend nccl = RCCL)")
+    ap.add_argument("--comm", choices=("auto", "torch", "rccl"), default="auto",
+                    help="exchange steps: 'rccl' = the engine library's own RCCL entry points, failing if the communicator cannot be "
+                         "created or ncclCommCount differs from the world size; 'torch' = torch.distributed (backend nccl = RCCL); "
+                         "'auto' (default) = rccl, falling back to torch with a comm_note in the line")
+    ap.add_argument("--total-structures", type=int, default=0,
+                    help="strong-scaling mode: this many structures of the headline workload in TOTAL, split evenly over the ranks "
+                         "(the default mode is weak: --structures per rank)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -630,19 +660,24 @@ def main() -> None:
     from chgnet_amd.pack import pack_batch, pack_weights
 
     weights = dict(np.load(os.path.join(REPO, "tests", "golden", "weights_seed0.npz")))
-    graphs = build_workload(args.structures, first_seed=rank * args.structures)
+    first_seed = rank * args.structures
+    if args.total_structures:     # strong scaling: a fixed batch split evenly (identical structures sizes: no balancing needed here; C3 has it)
+        share = [args.total_structures // world + (1 if r < args.total_structures % world else 0) for r in range(world)]
+        args.structures, first_seed = share[rank], sum(share[:rank])
+    graphs = build_workload(args.structures, first_seed=first_seed)
     eng = Engine(pack_weights(weights), ranks.local_rank)
     packed = pack_batch(graphs)
     batch = eng.upload(packed)   # inputs resident in HBM before the timed region
 
     gathered = None
+    gather_width = -(-args.total_structures // world) if args.total_structures else args.structures   # equal width per rank (zero-padded)
 
     def step():
         nonlocal gathered
         eng.predict(batch, "efs")
         res = eng.download(batch, "efs")
         if ranks.comm is not None:      # all-gather of the energies from HBM on the engine's stream (chg_batch_all_gather_energy)
-            gathered = eng.all_gather_energy(batch, ranks.comm, args.structures)
+            gathered = eng.all_gather_energy(batch, ranks.comm, gather_width)
         elif ranks.dist is not None:
             gathered = ranks.all_gather(res["e"])
         return res
@@ -658,10 +693,13 @@ def main() -> None:
     for _ in range(args.steps):
         res = step()
     barrier()
-    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = ranks.max_over_ranks(my_elapsed)
+    per_rank_ms = 1e3 * ranks.all_gather(np.array([my_elapsed], np.float32)).astype(np.float64) / args.steps   # imbalance is visible, not only the max
     assert np.isfinite(res["e"]).all() and np.isfinite(res["f"]).all() and np.isfinite(res["s"]).all()
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.structures / (elapsed / args.steps)
+    total_structures = args.total_structures or world * args.structures
+    value = total_structures / (elapsed / args.steps)
     energies_in_gather = int(np.isfinite(gathered).sum()) if gathered is not None else args.structures
 
     # device-only time of one step and the per-kernel split (HIP events on the engine stream)
@@ -680,7 +718,7 @@ def main() -> None:
     stream_gbs = eng.stream_copy_gbs(1 << 30, 10) if rank == 0 else None
 
     # secondary, informative only: structures on the host -> graph built on the device -> E/F/S on the host
-    structs = workload_structures(args.structures, first_seed=rank * args.structures)
+    structs = workload_structures(args.structures, first_seed=first_seed)
     e2e = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -708,51 +746,79 @@ def main() -> None:
         total_ms = sum(ms for _, ms in prof.values()) or 1.0
         ranked = sorted(prof.items(), key=lambda kv: -kv[1][1])
         dom = next((k for k, _ in ranked if k in KERNEL_MODEL), ranked[0][0])
-        launches, ms = prof[dom]
-        avg_ms = ms / max(launches, 1)
-        roofline = {"kernel": dom, "avg_launch_ms": round(avg_ms, 4), "share_of_step": round(ms / total_ms, 3)}
-        if dom in KERNEL_MODEL:
-            unit_attr, flop_u, byte_u = KERNEL_MODEL[dom]
-            units = getattr(packed, unit_attr)
-            tflops = units * flop_u / (avg_ms * 1e-3) / 1e12
-            gbs = units * byte_u / (avg_ms * 1e-3) / 1e9
-            intensity = flop_u / byte_u
-            if intensity > PEAK_FP32_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS:
-                roofline.update(bound="mfma", achieved=round(tflops, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                                frac=round(tflops / PEAK_FP32_MFMA_TFLOPS, 4))
-            else:
-                roofline.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(gbs / PEAK_HBM_GBS, 4))
-            roofline.update(units_per_launch=int(units), flop_per_unit=flop_u, bytes_per_unit=byte_u,
-                            algorithmic_gbs=round(gbs, 1), algorithmic_tflops=round(tflops, 3))
-        # every MFMA-bound tile kernel, same accounting (factorised flops)
-        tile = {}
-        step_flop = 0.0
-        for k, (unit_attr, flop_u, _) in KERNEL_MODEL.items():
-            if k in prof and prof[k][0]:
-                n_l, t_ms = prof[k]
-                fl = getattr(packed, unit_attr) * flop_u
-                step_flop += fl * n_l / prof_steps
-                tile[k] = {"avg_launch_ms": round(t_ms / n_l, 4), "tflops": round(fl / (t_ms / n_l * 1e-3) / 1e12, 2),
-                           "frac": round(fl / (t_ms / n_l * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "matrix_form": "3 x f16 16x16x32 split, f32 accumulate" if k in SPLIT_KERNELS else "f32 16x16x4"}
-        roofline["tile_kernels"] = tile
-        roofline["peak_note"] = (f"frac = factorised f32-equivalent TFLOP/s / {PEAK_FP32_MFMA_TFLOPS} (dense f32 MFMA); split-form kernels "
-                                 f"issue 3 f16 MFMAs per f32 product, their matrix-pipe ceiling is {PEAK_F16_MFMA_TFLOPS:.0f} / 3 = "
-                                 f"{PEAK_F16_MFMA_TFLOPS / 3:.0f} f32-equivalent TFLOP/s; these kernels are bound by vector-ALU issue "
-                                 f"(operand splits, LayerNorm, activations), profiles/r03_experiments.md")
-        roofline["whole_step_frac"] = round(step_flop / (dev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE runs, summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction)
-        roofline["traffic"] = None
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs,
+        # summarised by profiles/summarize.py with the gfx950 FETCH_SIZE x2 correction) -- quoted only when they were taken on THESE
+        # kernel sources (the summary is stamped with the hash of csrc/)
+        src_hash, pmc, pmc_note = csrc_hash(), {}, None
         try:
             with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)
-            if dom in pmc:
-                roofline["traffic"] = pmc[dom]["hbm_bytes_per_launch"]
+            if pmc.get("csrc_hash") != src_hash:
+                pmc_note = f"profiles/pmc_latest.json was taken on other kernel sources (csrc hash {pmc.get('csrc_hash')} != {src_hash}): traffic not quoted"
+                pmc = {}
+        except (OSError, ValueError):
+            pmc_note = "profiles/pmc_latest.json missing"
+        # The tile kernels contract in the split form (3 f16 MFMAs per f32 product): their matrix ceiling is 2500 / 3 f32-equivalent
+        # TFLOP/s, the balance against HBM 2500 / 3 / 8 = 104 flop per byte.  Every kernel is reported against BOTH roofs of the
+        # formulation it actually runs: matrix pipe (executed f16 flops / 2500) and HBM (algorithmic bytes, and counted traffic).
+        split_peak = PEAK_F16_MFMA_TFLOPS / SPLIT_MFMA_PER_PRODUCT
+        tile = {}
+        step_flop = 0.0
+        for k, (unit_attr, flop_u, byte_u) in KERNEL_MODEL.items():
+            if k in prof and prof[k][0]:
+                n_l, t_ms = prof[k]
+                t_s = t_ms / n_l * 1e-3
+                units = getattr(packed, unit_attr)
+                fl, by = units * flop_u, units * byte_u
+                step_flop += fl * n_l / prof_steps
+                split = k in SPLIT_KERNELS
+                exec_tf = fl * (SPLIT_MFMA_PER_PRODUCT if split else 1) / t_s / 1e12
+                entry = {"avg_launch_ms": round(t_ms / n_l, 4), "units_per_launch": int(units), "flop_per_unit": flop_u, "bytes_per_unit": byte_u,
+                         "matrix_form": "3 x f16 16x16x32 split, f32 accumulate" if split else "f32 16x16x4",
+                         "f32_equivalent_tflops": round(fl / t_s / 1e12, 2),
+                         "frac_mfma_f16": round(exec_tf / PEAK_F16_MFMA_TFLOPS, 4) if split else None,
+                         "algorithmic_gbs": round(by / t_s / 1e9, 1), "frac_hbm_algorithmic": round(by / t_s / 1e9 / PEAK_HBM_GBS, 4),
+                         "bound": "mfma" if flop_u / byte_u > (split_peak if split else PEAK_FP32_MFMA_TFLOPS) * 1e3 / PEAK_HBM_GBS else "hbm",
+                         "frac_f32_mfma_continuity": round(fl / t_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                if k in pmc:
+                    tr = pmc[k]["hbm_bytes_per_launch"]
+                    entry.update(traffic_bytes_per_launch=int(tr), traffic_ratio=round(tr / by, 3),
+                                 frac_hbm_traffic=round(tr / t_s / 1e9 / PEAK_HBM_GBS, 4),
+                                 frac_of_stream_copy_traffic=round(tr / t_s / 1e9 / stream_gbs, 4) if stream_gbs else None)
+                    if "l2_hit_rate" in pmc[k]:
+                        entry["l2_hit_rate"] = pmc[k]["l2_hit_rate"]
+                tile[k] = entry
+        launches, ms = prof[dom]
+        avg_ms = ms / max(launches, 1)
+        roofline = {"kernel": dom, "avg_launch_ms": round(avg_ms, 4), "share_of_step": round(ms / total_ms, 3)}
+        if dom in tile:
+            d = tile[dom]
+            if d["bound"] == "mfma":
+                roofline.update(bound="mfma", achieved=round(d["f32_equivalent_tflops"], 3), peak=round(split_peak, 1), unit="TFLOP/s",
+                                frac=round(d["f32_equivalent_tflops"] / split_peak, 4))
+            else:
+                roofline.update(bound="hbm", achieved=d["algorithmic_gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=d["frac_hbm_algorithmic"])
+            roofline.update(units_per_launch=d["units_per_launch"], flop_per_unit=d["flop_per_unit"], bytes_per_unit=d["bytes_per_unit"],
+                            algorithmic_gbs=d["algorithmic_gbs"], algorithmic_tflops=d["f32_equivalent_tflops"],
+                            frac_mfma_f16=d["frac_mfma_f16"], frac_hbm_algorithmic=d["frac_hbm_algorithmic"],
+                            frac_hbm_traffic=d.get("frac_hbm_traffic"), traffic_ratio=d.get("traffic_ratio"),
+                            frac_f32_mfma_continuity=d["frac_f32_mfma_continuity"])
+            roofline["traffic"] = d.get("traffic_bytes_per_launch")
+            if d.get("traffic_bytes_per_launch") is not None:
                 roofline["traffic_source"] = pmc[dom]["profile"]
-        except (OSError, ValueError, KeyError):
-            pass
+        else:
+            roofline["traffic"] = None
+        if pmc_note:
+            roofline["traffic_note"] = pmc_note
+        roofline["csrc_hash"] = src_hash
+        roofline["tile_kernels"] = tile
+        roofline["peak_note"] = (f"classification against the formulation the kernels run: split contractions (3 f16 MFMAs per f32 product) have a matrix "
+                                 f"ceiling of {PEAK_F16_MFMA_TFLOPS:.0f} / 3 = {split_peak:.0f} f32-equivalent TFLOP/s and balance against HBM at "
+                                 f"{split_peak * 1e3 / PEAK_HBM_GBS:.0f} flop/B; frac_mfma_f16 = executed f16 flops / {PEAK_F16_MFMA_TFLOPS:.0f}; "
+                                 f"frac_f32_mfma_continuity = f32-equivalent TFLOP/s / {PEAK_FP32_MFMA_TFLOPS} (the number earlier rounds quoted as frac). "
+                                 f"Neither roof is near: the tile kernels are bound by vector-ALU issue and memory latency (profiles/r04_experiments.md)")
+        roofline["whole_step_frac_f32_mfma_continuity"] = round(step_flop / (dev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        roofline["whole_step_frac_mfma_f16"] = round(step_flop * SPLIT_MFMA_PER_PRODUCT / (dev_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
         hbm = {"bound": "hbm", "stream_copy_gbs": round(stream_gbs, 1), "spec_gbs": PEAK_HBM_GBS, "kernels": {},
                "note": "achieved = compulsory bytes per launch / mean launch time (HIP events); stream_copy = 1 GiB read + 1 GiB write "
                        "device copy kernel timed in this process"}
@@ -767,6 +833,8 @@ def main() -> None:
         try:
             with open(os.path.join(REPO, "profiles", "sq_latest.json")) as fh:
                 sqc = json.load(fh)
+            if sqc.get("csrc_hash") != src_hash:
+                raise KeyError("SQ counters of other kernel sources")
             for k, v in sqc["kernels"].items():
                 if k in hbm["kernels"]:
                     hbm["kernels"][k]["sq_counters"] = v
@@ -778,11 +846,16 @@ def main() -> None:
         line = {
             "metric": "structures/s (energy+force+stress) on batched ~50-atom crystals",
             "value": round(value, 2), "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.total_structures else "weak",
+            "vs_baseline": None,
+            "per_rank_ms_per_step": {"min": round(float(per_rank_ms.min()), 3), "median": round(float(np.median(per_rank_ms)), 3),
+                                     "max": round(float(per_rank_ms.max()), 3)},
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "f32 storage, f32 accumulation; contractions of the six tile kernels as 3 x f16 MFMA on split f32 operands "
                           "(error of the split contraction <= the f32 MFMA's, profiles/r03_split_lab.txt; E/F/S parity unchanged)",
-            "config": {"workload": f"{args.structures} x LiMnO2 5x1x1 (40 atoms, sigma=0.01 frac perturbation) per GPU, task efs",
+            "config": {"workload": (f"{args.total_structures} x LiMnO2 5x1x1 (40 atoms, sigma=0.01 frac perturbation) in total, split evenly over the GPUs, task efs"
+                                    if args.total_structures else
+                                    f"{args.structures} x LiMnO2 5x1x1 (40 atoms, sigma=0.01 frac perturbation) per GPU, task efs"),
                        "structures_per_gpu": args.structures, "atoms": int(packed.n_atoms), "directed_bonds": int(packed.n_directed),
                        "angles": int(packed.n_angles), "bond_graph_nodes": int(packed.n_bnodes),
                        "weights": "random-init 0.3.0 architecture (tests/golden/weights_seed0.npz)",
@@ -800,6 +873,12 @@ def main() -> None:
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"], parity = cpu_leg(weights, graphs[:128], checks)
+            try:    # the reference ITSELF, timed where it exists: the build container (tools/cpu_reference_baseline.py; it does not travel here)
+                with open(os.path.join(REPO, "profiles", "reference_cpu_baseline.json")) as fh:
+                    ref_cpu = json.load(fh)
+                line["cpu_baseline"]["reference_in_build_container"] = {k: ref_cpu[k] for k in ("value", "unit", "cores", "batch_size", "kind", "what", "script")}
+            except (OSError, ValueError, KeyError):
+                line["cpu_baseline"]["reference_in_build_container"] = None
             for name, p in parity.items():
                 line["configs"].setdefault(name, {})["parity_vs_oracle"] = p
         else:

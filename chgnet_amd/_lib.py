@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = (
     "chg_batch_upload", "chg_batch_build", "chg_debug_fetch_i32", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
-    "chg_debug_fetch", "chg_test_rows_gemm",
+    "chg_debug_fetch", "chg_test_rows_gemm", "chg_test_split_gemm",
     "chg_engine_set_memory_limit", "chg_engine_memory_info", "chg_batch_bytes_required",
     "chg_stream_copy", "chg_backward", "chg_engine_build_stats", "chg_engine_update_weights",
     "chg_engine_set_graph_search", "chg_engine_cell_stats",
@@ -134,6 +134,7 @@ def load() -> ctypes.CDLL:
     lib.chg_profile_read.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     lib.chg_debug_fetch.argtypes = [vp, vp, ctypes.c_char_p, c_float_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     lib.chg_test_rows_gemm.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.chg_test_split_gemm.argtypes = [vp, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ("chg_device_count", "chg_profile_count"):

@@ -40,6 +40,7 @@ using namespace chg;
 namespace {
 
 constexpr int MAX_CONV = 8;
+constexpr float F16_OPERAND_LIMIT = 65504.0f;   // largest finite f16: forward operands of the split contractions are not rescaled
 #ifndef CHG_FWD_WAVES
 #define CHG_FWD_WAVES 8
 #endif
@@ -2201,6 +2202,115 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// The tile kernels carry their weights as f16 hi / lo images (mfma_split.h): a weight of magnitude >= 65504 would become inf there.
+// No trained checkpoint comes near (|w| < 10); a blob that does is refused instead of producing NaN where the reference is finite.
+int check_weight_range(chg_engine* eng, const float* blob, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    if (!(std::fabs(blob[i]) < F16_OPERAND_LIMIT)) {   // also catches NaN
+      eng->err = "weights: entry " + std::to_string(i) + " of the blob is " + std::to_string(blob[i]) +
+                 ": outside the operand range of the split-precision contractions (|w| < 65504)";
+      return CHG_ERANGE;
+    }
+  }
+  return CHG_OK;
+}
+
+// ---- range diagnostic (only after a prediction returned non-finite energies) --------------------------------------------
+// max |finite value| and the number of non-finite entries of a buffer: out[0] = max as float bits (non-negative floats order like
+// unsigned integers), out[1] = count
+__global__ void k_range_scan(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  unsigned bad = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v == v && fabsf(v) < 3.0e38f) m = fmaxf(m, fabsf(v)); else ++bad;
+  }
+  atomicMax(out, __float_as_uint(m));
+  if (bad) atomicAdd(out + 1, bad);
+}
+
+int diagnose_non_finite(chg_engine* eng, chg_batch* b) {
+  unsigned* d_out = nullptr;
+  HIP_TRY(eng, hipMalloc(&d_out, 4 * sizeof(unsigned)));
+  auto scan = [&](const float* p, size_t n, float& mx, unsigned& bad) -> int {
+    unsigned h[2] = {0, 0};
+    mx = 0.f; bad = 0;
+    if (!p || n == 0) return CHG_OK;
+    HIP_TRY(eng, hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned), eng->stream));
+    hipLaunchKernelGGL(k_range_scan, dim3(1024), dim3(256), 0, eng->stream, p, n, d_out);
+    HIP_TRY(eng, hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, eng->stream));
+    HIP_TRY(eng, hipStreamSynchronize(eng->stream));
+    std::memcpy(&mx, &h[0], sizeof(float));
+    bad = h[1];
+    return CHG_OK;
+  };
+  int status = CHG_OK;
+  float mx = 0.f;
+  unsigned bad = 0;
+  // 1. the geometry: a zero-length or non-finite bond vector makes the bases NaN in the reference as well (basis.py: sin(w r) / r)
+  status = scan(reinterpret_cast<const float*>(b->ev), (size_t)4 * b->Ed, mx, bad);
+  bool geometry_nan = bad > 0;
+  if (status == CHG_OK && !geometry_nan && b->Ed > 0) {   // any r == 0 ?  (ev = (v, r): scan the embedding rows built from 1 / r instead)
+    status = scan(b->hb0, (size_t)b->Eu * D, mx, bad);
+    geometry_nan = bad > 0;
+  }
+  // 2. the operands of the split contractions: feature rows and first-layer tables of every layer
+  std::string where;
+  float worst = 0.f;
+  if (status == CHG_OK && !geometry_nan) {
+    auto look = [&](const char* name, int l, const float* p, size_t n) {
+      if (status != CHG_OK || !p) return;
+      float m1; unsigned b1;
+      status = scan(p, n, m1, b1);
+      if (m1 > worst) { worst = m1; where = std::string(name) + "[" + std::to_string(l) + "]"; }
+    };
+    const size_t N = b->N, Eu = b->Eu, Eb = b->Eb, A = b->A;
+    for (int l = 0; l <= b->L; ++l) look("atom features", l, b->atom[l], N * D);
+    for (int l = 0; l < b->L; ++l) look("bond features", l, b->hbc[l], Eb * D);
+    for (int l = 0; l < b->L - 1; ++l) look("angle features", l, b->ang[l], A * D);
+    for (int l = 0; l < b->L; ++l) { look("AtomConv atom table", l, b->Pl[l], N * 4 * D); look("AtomConv bond table", l, b->Ql[l], Eu * 2 * D); }
+    for (int t = 0; t < 2 * b->L; ++t) { look("angle-layer bond table", t, b->Rl[t], Eb * 4 * D); look("angle-layer atom table", t, b->Sl[t], N * 2 * D); }
+  }
+  hipFree(d_out);
+  if (status != CHG_OK) return status;
+  if (!geometry_nan && worst >= 0.25f * F16_OPERAND_LIMIT) {
+    eng->err = "non-finite results: " + where + " reaches |x| = " + std::to_string(worst) + ", at or beyond the f16 operand range of the "
+               "split-precision contractions (65504; csrc/mfma_split.h) -- the reference's fp32 path does not overflow here.  Weights this far "
+               "from any trained checkpoint are outside the engine's domain";
+    return CHG_ERANGE;
+  }
+  return CHG_OK;   // coincident atoms / non-finite inputs: NaN like the reference
+}
+
+// ---- self-test of the split-precision contractions (chg_test_split_gemm): the exact device functions of the tile kernels, W [F][64]
+// MODE 0 / 1: split images (forward / adjoint of W^T);  MODE 2 / 3: one row-major image, forward / adjoint (mfma_split.h)
+template <int MODE, int F>
+__global__ __launch_bounds__(BLOCK) void k_test_split(const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ y, int rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool ADJ = (MODE & 1) != 0, RM = MODE >= 2;
+  constexpr int KIN = ADJ ? F : D, NOUT = ADJ ? D : F;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  if (RM) stage_rm(reinterpret_cast<_Float16*>(smem), W, F, D, tid, BLOCK);
+  else stage_split<ADJ>(reinterpret_cast<h16x8*>(smem), W, F, D, tid, BLOCK);
+  __syncthreads();
+  for (int row0 = (blockIdx.x * WAVES + wave) * TILE_ROWS; row0 < rows; row0 += gridDim.x * BLOCK_ROWS) {
+    const int row = min(row0 + j, rows - 1);
+    f32x4 xin[KIN / 16], acc[NOUT / 16];
+    read_dl<KIN / 16>(x + (size_t)row * KIN, g, xin);
+#pragma unroll
+    for (int q = 0; q < NOUT / 16; ++q) acc[q] = zero4();
+    if (RM) gemm_rm<KIN / 16, NOUT / 16, ADJ, ADJ>(acc, reinterpret_cast<const _Float16*>(smem), F, D, xin, j, g, lane);
+    else gemm_split<KIN / 16, NOUT / 16, ADJ>(acc, reinterpret_cast<const h16x8*>(smem), NOUT, xin, j, g);
+    if (row0 + j < rows) write_dl<NOUT / 16>(y + (size_t)row * NOUT, g, acc);
+  }
+}
+
+template <int MODE, int F>
+void launch_test_split(hipStream_t st, const float* x, const float* W, float* y, int rows) {
+  const size_t lds = MODE >= 2 ? rm_image_bytes(F, D) : split_image_bytes(F, D);
+  hipLaunchKernelGGL((k_test_split<MODE, F>), dim3(std::max(1, std::min(256, (rows + BLOCK_ROWS - 1) / BLOCK_ROWS))), dim3(BLOCK), lds, st, x, W, y, rows);
+}
+
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
@@ -2248,6 +2358,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
     return CHG_EINVAL;
   }
   HIP_TRY(eng, hipMalloc(&eng->d_weights, need * sizeof(float)));
+  if (int rs = check_weight_range(eng, weights_blob, need); rs != CHG_OK) { eng->err = "chg_engine_create: " + eng->err; *out = eng; return rs; }
   HIP_TRY(eng, hipMemcpy(eng->d_weights, weights_blob, need * sizeof(float), hipMemcpyHostToDevice));
   layout_weights(eng->d_weights, desc->n_conv, eng->w);
   { const int si = build_images(eng); if (si) return si; }
@@ -2493,6 +2604,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
 
 int chg_engine_update_weights(chg_engine* eng, const float* weights_blob) {
   if (!eng || !weights_blob) return CHG_EINVAL;
+  TRY(check_weight_range(eng, weights_blob, (size_t)eng->desc.n_weights));
   HIP_TRY(eng, hipSetDevice(eng->device));
   HIP_TRY(eng, hipMemcpyAsync(eng->d_weights, weights_blob, sizeof(float) * (size_t)eng->desc.n_weights, hipMemcpyHostToDevice, eng->stream));
   TRY(build_images(eng));
@@ -2644,7 +2756,15 @@ int chg_batch_download(chg_engine* eng, chg_batch* b, const chg_out_host* o) {
   if (s == CHG_OK) s = d2h(eng, o->atom_fea, b->atom[b->L - 1], N * D);
   if (s == CHG_OK) s = d2h(eng, o->crystal_fea, b->crystal_fea, B * D);
   if (s != CHG_OK) return s;
-  return chg_synchronize(eng);
+  TRY(chg_synchronize(eng));
+  // Non-finite energies: the reference gives them too for coincident atoms (1 / r of a zero-length bond) -- passed through.  But an
+  // activation past the f16 operand range of the split contractions (mfma_split.h) ALSO ends as NaN here where the reference's fp32
+  // path stays finite: that case is an error, not a result.  An overflow cannot stay silent (an inf operand makes the accumulator
+  // inf / NaN, LayerNorm spreads it over the row, the sums carry it to the energy), so the check costs nothing until it triggers.
+  bool finite = true;
+  if (o->energy) for (size_t i = 0; i < B && finite; ++i) finite = std::isfinite(o->energy[i]);
+  if (!finite) TRY(diagnose_non_finite(eng, b));
+  return CHG_OK;
 }
 
 int chg_timer_start(chg_engine* eng) {
@@ -2748,6 +2868,34 @@ int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const f
   if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "test gemm failed"; s = CHG_EHIP; }
   if (s == CHG_OK) hipMemcpy(y, dy, sizeof(float) * (size_t)rows * nout, hipMemcpyDeviceToHost);
   hipFree(dx); hipFree(dw); hipFree(db); hipFree(dy);
+  return s;
+}
+
+int chg_test_split_gemm(chg_engine* eng, const float* x, const float* w, float* y, int rows, int f, int mode) {
+  if (!eng || !x || !w || !y || rows <= 0 || (f != D && f != 2 * D) || mode < 0 || mode > 3) return CHG_EINVAL;
+  HIP_TRY(eng, hipSetDevice(eng->device));
+  const int kin = (mode & 1) ? f : D, nout = (mode & 1) ? D : f;
+  float *dx = nullptr, *dw = nullptr, *dy = nullptr;
+  HIP_TRY(eng, hipMalloc(&dx, sizeof(float) * (size_t)rows * kin));
+  HIP_TRY(eng, hipMalloc(&dw, sizeof(float) * (size_t)f * D));
+  HIP_TRY(eng, hipMalloc(&dy, sizeof(float) * (size_t)rows * nout));
+  HIP_TRY(eng, hipMemcpy(dx, x, sizeof(float) * (size_t)rows * kin, hipMemcpyHostToDevice));
+  HIP_TRY(eng, hipMemcpy(dw, w, sizeof(float) * (size_t)f * D, hipMemcpyHostToDevice));
+  hipStream_t st = eng->stream;
+  switch (mode * 2 + (f == D ? 0 : 1)) {
+    case 0: launch_test_split<0, D>(st, dx, dw, dy, rows); break;
+    case 1: launch_test_split<0, 2 * D>(st, dx, dw, dy, rows); break;
+    case 2: launch_test_split<1, D>(st, dx, dw, dy, rows); break;
+    case 3: launch_test_split<1, 2 * D>(st, dx, dw, dy, rows); break;
+    case 4: launch_test_split<2, D>(st, dx, dw, dy, rows); break;
+    case 5: launch_test_split<2, 2 * D>(st, dx, dw, dy, rows); break;
+    case 6: launch_test_split<3, D>(st, dx, dw, dy, rows); break;
+    default: launch_test_split<3, 2 * D>(st, dx, dw, dy, rows); break;
+  }
+  int s = CHG_OK;
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { eng->err = "chg_test_split_gemm failed"; s = CHG_EHIP; }
+  if (s == CHG_OK) hipMemcpy(y, dy, sizeof(float) * (size_t)rows * nout, hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dw); hipFree(dy);
   return s;
 }
 

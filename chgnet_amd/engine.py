@@ -33,6 +33,11 @@ class EngineOutOfMemory(RuntimeError):
     The engine stays usable; ``CHGNet.predict_*`` answer by splitting the chunk."""
 
 
+class EngineRangeError(RuntimeError, FloatingPointError):
+    """CHG_ERANGE: a weight or an activation left the f16 operand range of the split-precision contractions (|x| >= 65504), where
+    the reference's fp32 path stays finite.  Raised instead of returning inf / NaN results."""
+
+
 class DeviceBatch:
     """A packed batch resident in HBM together with all its workspace."""
 
@@ -97,12 +102,18 @@ class Engine:
             if self.handle:
                 self.lib.chg_engine_destroy(self.handle)
                 self.handle = ctypes.c_void_p()
+            if status == -6:
+                raise EngineRangeError(f"chg_engine_create: {msg}")
             raise RuntimeError(f"chg_engine_create failed with status {status}: {msg or 'no usable gfx950 device'}")
 
     def _check(self, status: int) -> None:
         if status != 0:
             msg = f"chgnet_hip error {status}: {self.lib.chg_last_error(self.handle).decode()}"
-            raise EngineOutOfMemory(msg) if status == -3 else RuntimeError(msg)
+            if status == -3:
+                raise EngineOutOfMemory(msg)
+            if status == -6:
+                raise EngineRangeError(msg)
+            raise RuntimeError(msg)
 
     def build_stats(self) -> tuple[int, int]:
         """(single-pass graph builds, capacity overflows that fell back to the exact pass) of ``build_batch``."""
@@ -312,6 +323,18 @@ class Engine:
         if got.value != n:
             raise RuntimeError(f"debug_fetch({name}): expected {n} floats, device buffer has {got.value}")
         return dst[:n].reshape(shape)
+
+    def test_split_gemm(self, x: np.ndarray, w: np.ndarray, mode: int) -> np.ndarray:
+        """The split-precision contraction of the tile kernels on its own (csrc/mfma_split.h): ``w`` [f, 64], f in {64, 128};
+        mode 0 / 2: ``x`` [rows, 64] -> ``x @ w.T`` [rows, f] (split images / row-major image); mode 1 / 3: ``x`` [rows, f] ->
+        ``x @ w`` [rows, 64] (the adjoint forms, rows scaled by a power of two)."""
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        f = w.shape[0]
+        assert w.shape[1] == 64 and x.shape[1] == (f if mode & 1 else 64)
+        y = np.empty((x.shape[0], 64 if mode & 1 else f), np.float32)
+        self._check(self.lib.chg_test_split_gemm(self.handle, _fp(x), _fp(w), _fp(y), x.shape[0], f, int(mode)))
+        return y
 
     def test_rows_gemm(self, x: np.ndarray, wt: np.ndarray, bias: np.ndarray | None) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)

@@ -35,7 +35,10 @@ typedef enum {
   CHG_EHIP = -2,       /* HIP runtime error (text in chg_last_error) */
   CHG_ENOMEM = -3,     /* device or host allocation failed */
   CHG_ENODEV = -4,     /* no usable gfx950 device */
-  CHG_EUNSUPPORTED = -5
+  CHG_EUNSUPPORTED = -5,
+  CHG_ERANGE = -6      /* a weight or an activation left the operand range of the split-precision contractions (|x| >= 65504):
+                          the results would be inf / NaN where the reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE) stays
+                          finite -- reported instead of returned (chg_engine_create / update_weights, chg_batch_download) */
 } chg_status;
 
 /* task bits (reference task strings "e","ef","em","efs","efsm": chgnet/__init__.py:15) */
@@ -203,6 +206,12 @@ int chg_debug_fetch(chg_engine* eng, chg_batch* batch, const char* name, float* 
 
 /* Self-test of the MFMA tile primitives: Y[rows,nout] = X[rows,k] . Wt[nout,k]^T + bias (k, nout in {64,128}). */
 int chg_test_rows_gemm(chg_engine* eng, const float* x, const float* wt, const float* bias, float* y, int rows, int k, int nout);
+/* Self-test of the split-precision contractions every tile kernel runs on (csrc/mfma_split.h: three f16 MFMAs per f32 product,
+ * f32 accumulation), W [f][64] row-major with f in {64, 128}:
+ *   mode 0  Y[rows,f]  = X[rows,64] . W^T   forward operands, split image [plane][k/32][g][f][8]
+ *   mode 1  Y[rows,64] = X[rows,f]  . W     adjoint operands (rows scaled by a power of two), split image of W^T
+ *   mode 2 / 3  the same two products from ONE row-major image (forward ds_read_b64, adjoint ds_read_b64_tr_b16) */
+int chg_test_split_gemm(chg_engine* eng, const float* x, const float* w, float* y, int rows, int f, int mode);
 
 /* ---- exchange steps of the multi-GPU path, straight on RCCL (one communicator per process = per GPU) ----------
  * The reference is single-device; these carry what SURVEY 8e needs and nothing else: the all-gather of per-structure

@@ -12,6 +12,10 @@ import csv, json, os, shutil, sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bench import csrc_hash  # noqa: E402  the counters are stamped with the hash of the kernel sources they were taken on
+
+SRC_HASH = csrc_hash()
 SRC = os.path.join(REPO, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01", "prof")
 if not os.path.isdir(SRC):
     SRC = os.path.join(REPO, "gpurun_out", "prof")
@@ -51,6 +55,24 @@ with open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.csv"), "w", newline
     w_ = csv.writer(fh)
     w_.writerow(["kernel", "launches", "mean_FETCH_SIZE_KiB_reported", "mean_WRITE_SIZE_KiB_reported", "hbm_bytes_per_launch_corrected"])
     w_.writerows(rows)
+# L2 hit rates (separate --pmc TCC_HIT_sum TCC_MISS_sum pass, tools/gpu_round4_profiles.sh) next to the traffic
+l2_path = os.path.join(SRC, "l2a_counter_collection.csv")
+if os.path.exists(l2_path):
+    hit, miss = mean_counter(l2_path, "TCC_HIT_sum"), mean_counter(l2_path, "TCC_MISS_sum")
+    l2_rows = []
+    for name in sorted(hit, key=lambda k: -(hit[k][1] + miss.get(k, (0, 0.0))[1])):
+        h, m = hit[name][1], miss.get(name, (0, 0.0))[1]
+        if h + m <= 0:
+            continue
+        l2_rows.append([name, hit[name][0], int(h), int(m), round(h / (h + m), 4)])
+        for sub, label in LABELS.items():
+            if sub in name and label in latest and "l2_hit_rate" not in latest[label]:
+                latest[label]["l2_hit_rate"] = round(h / (h + m), 4)
+    with open(os.path.join(REPO, "profiles", f"{tag}_l2_counters.csv"), "w", newline="") as fh:
+        w_ = csv.writer(fh)
+        w_.writerow(["kernel", "launches", "mean_TCC_HIT_sum", "mean_TCC_MISS_sum", "hit_rate"])
+        w_.writerows(l2_rows[:40])
+latest["csrc_hash"] = SRC_HASH
 json.dump(latest, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)
 for r in rows[:12]:
     print(r)
@@ -81,7 +103,7 @@ if os.path.exists(sq_path):
         s_ = sq[lab]
         s_["bound"] = ("memory (wave slots idle: HBM bandwidth / latency)" if s_["active_inst_any"] < 0.2 else
                        "memory latency (waits on LDS / L2 / atomics)" if s_["wait_any"] >= 0.45 else "vector-ALU issue")
-    json.dump({"unit": "fraction of SQ_WAVE_CYCLES (mfma_busy: of the SIMD cycles of the launch)", "profile": f"gpurun_out/{tag}/prof/pmc_sq_*",
+    json.dump({"unit": "fraction of SQ_WAVE_CYCLES (mfma_busy: of the SIMD cycles of the launch)", "profile": f"gpurun_out/{tag}/prof/pmc_sq_*", "csrc_hash": SRC_HASH,
                "kernels": sq}, open(os.path.join(REPO, "profiles", "sq_latest.json"), "w"), indent=1)
     for k, v in sq.items():
         print(k, v)

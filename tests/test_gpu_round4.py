@@ -240,3 +240,133 @@ def test_all_reduced_gradient_carries_the_last_bias_and_survives_a_weight_update
         fresh.close()
     assert np.abs(want - plain).max() > 1e-3 * scale                        # the two weight sets do give different gradients
     assert np.abs(after - want).max() <= 1e-4 * float(np.abs(want).max())
+
+
+# ---- the split-precision contraction on its own (csrc/mfma_split.h): every tile kernel's arithmetic --------------------------
+@pytest.mark.parametrize("f", [64, 128])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_split_contraction_against_float64(hip_engine, mode, f):
+    """chg_test_split_gemm runs the device functions of the tile kernels (gemm_split / gemm_rm) on their own: forward operands from
+    the split images (mode 0) and the row-major image (2), adjoint operands -- rows scaled by a power of two -- from the image of
+    W^T (1) and through the transposing LDS reads of the row-major image (3).  Against float64 the error of every output stays
+    below 3e-7 of sum |w| |x| of its row (measured maxima over 64k outputs: 1.2e-7 .. 2.3e-7; f32 MFMA: 1.8e-7, tools/split_lab.hip;
+    5e-7 for a row with ONE non-zero entry), 99.9 % of them below 1.5e-7, over the magnitudes the operands have in the
+    model: adjoint rows 1e-7 .. 1e4 (gradients), forward rows 1e-4 .. 1e4 (features, activations: unscaled, so the low plane of
+    a value below ~1e-4 falls into f16 subnormals -- documented domain, mfma_split.h)."""
+    rng = np.random.default_rng(100 * mode + f)
+    rows = 1000
+    adjoint = bool(mode & 1)
+    kin = f if adjoint else 64
+    mags = 10.0 ** rng.uniform(-7 if adjoint else -4, 4, size=(rows, 1))
+    x = (mags * rng.normal(size=(rows, kin))).astype(np.float32)
+    x[5] = 0.0                                            # a row of zeros (exponent 0 in the scaled form)
+    x[6, 1:] = 0.0                                        # one non-zero entry
+    w = (rng.normal(size=(f, 64)) * 10.0 ** rng.uniform(-2, 0.5, size=(f, 1))).astype(np.float32)
+    y = hip_engine.test_split_gemm(x, w, mode)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    ref = x64 @ w64 if adjoint else x64 @ w64.T
+    bound = np.abs(x64) @ np.abs(w64) if adjoint else np.abs(x64) @ np.abs(w64).T
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    rel = np.abs(y - ref) / np.maximum(bound, 1e-300)
+    dense = np.ones(rows, bool)
+    dense[6] = False
+    assert rel[dense].max() <= 3e-7, (mode, f, float(rel[dense].max()), np.unravel_index(rel.argmax(), rel.shape))
+    assert np.quantile(rel[dense], 0.999) <= 1.5e-7 and rel[dense].mean() <= 3e-8
+    assert rel[6].max() <= 5e-7       # a single product: both operands carry 22 bits (2^-22 = 2.4e-7 each), nothing averages out
+    assert np.array_equal(y[5], np.zeros_like(y[5]))
+
+
+def test_split_contraction_is_asymmetric_safe(hip_engine):
+    """A transposed or permuted operand fragment cannot pass: one-hot rows pick single weights, exactly (hi + lo planes carry 22
+    bits: a weight with an 11-bit significand comes back bit for bit)."""
+    w = (np.arange(128 * 64, dtype=np.float32).reshape(128, 64) % 1021) / 8.0           # exact in 11 bits + 3 fraction bits
+    for mode in (0, 2):
+        x = np.eye(64, dtype=np.float32)[[0, 1, 17, 33, 63]]
+        assert np.array_equal(hip_engine.test_split_gemm(x, w, mode), w[:, [0, 1, 17, 33, 63]].T)
+    for mode in (1, 3):
+        x = np.eye(128, dtype=np.float32)[[0, 1, 17, 64, 127]]
+        assert np.array_equal(hip_engine.test_split_gemm(x, w, mode), w[[0, 1, 17, 64, 127]])
+
+
+def test_operands_beyond_the_f16_range_are_reported_not_returned(golden_weights):
+    """VERDICT r03 missing 4: the forward operands of the split contractions go to f16 unscaled, so an activation of magnitude
+    >= 65504 ends as NaN where the reference's fp32 path (crystalgraph.py:12) is finite.  (i) Linear weights x 4: still inside the
+    range, results match the fp32 oracle; (ii) x 100: the oracle is finite, the engine raises EngineRangeError at download instead
+    of returning NaN; (iii) a weight >= 65504 is refused at upload.  (Coincident atoms still give NaN like the reference:
+    tests/test_gpu_parity.py, zero-length bond.)"""
+    import torch
+
+    from chgnet_amd.engine import Engine, EngineRangeError
+    from chgnet_amd.pack import pack_weights
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    torch.set_num_threads(8)
+    graphs = [load_case(n)[0] for n in ("limno2", "s16tri")]
+
+    def scaled(k):
+        out = {}
+        for name, v in golden_weights.items():
+            lin = name.endswith(".weight") and v.ndim == 2 and "embedding" not in name and "composition" not in name
+            out[name] = (v * k).astype(v.dtype) if lin else v
+        return out
+
+    def run(weights):
+        eng = Engine(pack_weights(weights), 0)
+        try:
+            batch = eng.upload(graphs)
+            try:
+                eng.predict(batch, "efs")
+                return eng.download(batch, "efs")
+            finally:
+                batch.free()
+        finally:
+            eng.close()
+
+    w4 = scaled(4.0)
+    got = run(w4)
+    ref = OracleCHGNet(w4).predict_graph(graphs, "efs", batch_size=8)
+    off = np.concatenate([[0], np.cumsum([len(g.atomic_number) for g in graphs])])
+    for i, r in enumerate(ref):
+        fs = max(1.0, float(np.abs(r["f"]).max()))
+        assert abs(got["e"][i] - r["e"]) < 2e-5 * max(1.0, abs(r["e"])), (got["e"][i], r["e"])
+        assert np.abs(got["f"][off[i]:off[i + 1]] - r["f"]).max() < 2e-5 * fs
+    w100 = scaled(100.0)
+    ref100 = OracleCHGNet(w100).predict_graph(graphs, "efs", batch_size=8)
+    assert all(np.isfinite(r["e"]) and np.isfinite(r["f"]).all() for r in ref100), "the fp32 reference path does not overflow here"
+    with pytest.raises(EngineRangeError, match="f16 operand range"):
+        run(w100)
+    huge = dict(golden_weights)
+    k = next(n for n in huge if "mlp_out" in n and n.endswith(".weight"))
+    huge[k] = huge[k].copy()
+    huge[k].flat[3] = 7.0e4
+    with pytest.raises(EngineRangeError, match="operand range"):
+        Engine(pack_weights(huge), 0)
+
+
+def test_calculator_under_an_atoms_shaped_object(golden_weights):
+    """CHGNetCalculator.calculate on an ``ase.Atoms`` stand-in (non-orthogonal cell, unwrapped positions; tests/test_calculator_cpu.py)
+    == predict_structure on the same structure with the reference's unit conventions (dynamics.py:166-181): extensive energy, stress
+    in eV/A^3 (x ase.units.GPa), magmoms, free_energy, crystal_fea; and the get_* accessors."""
+    from test_calculator_cpu import AtomsDuck, triclinic_case
+
+    from chgnet_amd.calculator import GPA_TO_EV_A3, CHGNetCalculator
+    from chgnet_amd.graph.structure import Lattice, Structure
+    from chgnet_amd.model import CHGNet
+
+    cell, z, frac = triclinic_case()
+    model = CHGNet(state_dict=golden_weights)
+    model.graph_converter.set_isolated_atom_response("ignore")
+    calc = CHGNetCalculator(model, on_isolated_atoms="ignore", return_site_energies=True)
+    atoms = AtomsDuck(cell, z, frac @ cell)
+    calc.calculate(atoms)
+    want = model.predict_structure(Structure(Lattice(cell), z, frac), task="efsm", return_site_energies=True, return_crystal_feas=True)
+    r = calc.results
+    assert abs(r["energy"] - want["e"] * len(z)) < 1e-5 and r["free_energy"] == r["energy"]
+    assert np.abs(r["forces"] - want["f"]).max() < 1e-6 and r["forces"].shape == (len(z), 3)
+    assert np.abs(r["stress"] - want["s"] * GPA_TO_EV_A3).max() < 1e-7 and r["stress"].shape == (3, 3)
+    assert np.abs(r["magmoms"] - want["m"]).max() < 1e-6
+    assert np.abs(r["energies"] - want["site_energies"]).max() < 1e-5 and np.abs(r["crystal_fea"] - want["crystal_fea"]).max() < 1e-5
+    moved = AtomsDuck(cell, z, frac @ cell + 0.05)
+    e2 = calc.get_potential_energy(moved)            # a rigid shift: same energy, the accessor recomputes for the new object
+    assert abs(e2 - r["energy"]) < 1e-4 and np.abs(calc.get_forces(moved) - want["f"]).max() < 1e-5
+    model.release_forward_state()
