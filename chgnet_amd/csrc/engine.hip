@@ -472,6 +472,14 @@ int atomconv_q_table(chg_engine* eng, chg_batch* b, int l) {
   return CHG_OK;
 }
 
+// Tile order per kernel: bit k of CHGNET_TILE_INTERLEAVE (default 31 = every kernel; A/B switch) -- 1 atomconv_fwd, 2 atomconv_bwd,
+// 4 bondconv_fwd, 8 angleupd_fwd, 16 row-order angle adjoints.  Same-box A/B (profiles/r04_experiments.md): the interleaved sweep cuts
+// the fabric traffic of every kernel by 20-30 %; their times move by 0-3 % (they are bound by vector-ALU issue, not by bytes).
+static int interleave_mask() {
+  static const int m = [] { const char* e = std::getenv("CHGNET_TILE_INTERLEAVE"); return e ? std::atoi(e) : 31; }();
+  return m;
+}
+
 AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   AtomConvArgs a{};
   a.P = b->Pl[l]; a.Q = b->Ql[l]; a.wag = b->wag;
@@ -498,6 +506,7 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
     a.image = eng->img_ac_fwd[a.q_bias ? 1 : 0][l];
     a.e_nbr = b->p_nbr;
     a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
+    a.interleave = interleave_mask() & 1;
     hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
@@ -514,6 +523,7 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     a.image = eng->img_ac_bwd[l];
+    a.interleave = (interleave_mask() >> 1) & 1;
     LaunchScope ls(eng, "atomconv_bwd");
     hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
@@ -578,6 +588,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     plain.skip_flag = nullptr;
   }
   plain.image = eng->img_angle[BWD ? 1 : 0][a.slot];
+  plain.interleave = (interleave_mask() >> (BWD ? 4 : HIDDEN ? 2 : 3)) & 1;
   const size_t lds = angle_lds<HIDDEN, NW, BWD>();
   hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(tile_grid(eng, b->A, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
   HIP_TRY(eng, hipGetLastError());

@@ -422,6 +422,7 @@ struct AtomConvArgs {
   const float* wag;    // [Eu,64]  smooth bond weights (atom graph)
   const int *e_center, *e_nbr, *e_d2u;
   int n_edges;
+  int interleave;      // XCD-local interleaved tile sequence (mfma_tile.h wave_tile_seq) or contiguous per-wave ranges
   GatedW gw;
   // forward: bond partial contracted in the kernel (no gemm_Q / gemm_Qnode launches):  Q[k] = hb[k] . W_bond^T (+ q_bias)
   const float *hb0, *hbc;      // [Eu,64] embedding rows; [Eb,64] layer features of the bond-graph nodes (null: every bond uses hb0)
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;     // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
-  const TileSeq ts = wave_tile_seq(ntiles, NW, wave);
+  const TileSeq ts = wave_tile_seq(ntiles, NW, wave, p.interleave);
   // Software pipeline over tiles: the row gather of tile t+1 is issued before tile t's MFMA / VALU phase and committed to LDS
   // after it; the indices run two tiles ahead.  (SQ_WAIT_ANY was 37 % of wave time with the gather issued and awaited in place.)
   const int tstride = TILE_ROWS;
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
-  const TileSeq ts = wave_tile_seq(ntiles, WAVES, wave);
+  const TileSeq ts = wave_tile_seq(ntiles, WAVES, wave, p.interleave);
   const int last_row = p.n_edges - 1;
   int c, n, k;
   {   // the first tile's indices and gather land under the staging of the weights (see k_atomconv_fwd)
@@ -773,6 +774,7 @@ struct AngleArgs {
   const float* wbgc;   // [Eb,64]  smooth bond weights (bond graph), compact rows (BondConv only)
   const int *a_ctr, *a_b1c, *a_b2c;
   int n_angles;
+  int interleave;      // XCD-local interleaved tile sequence (mfma_tile.h wave_tile_seq) or contiguous per-wave ranges
   const float* w_ang;  // [128][64] angle block of the first layer (global)
   GatedW gw;
   const float* image;  // prebuilt weight block of the kernel's LDS (k_angle_image); the TRAIN adjoints stage from the fp32 weights
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_angles + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
-  const TileSeq ts = wave_tile_seq(ntiles, NW, wave);
+  const TileSeq ts = wave_tile_seq(ntiles, NW, wave, p.interleave);
   const int tstride = TILE_ROWS;
   auto row_of = [&](int v) { return max(0, min(ts.at(v) * tstride + j, p.n_angles - 1)); };   // v-th tile of this wave (clamped past its end)
   // Forward: software-pipelined gathers -- the table rows and angle rows of tile t+1 are in flight

@@ -286,10 +286,10 @@ struct TileSeq {
   int first, stride, count;
   __device__ __forceinline__ int at(int v) const { return first + v * stride; }
 };
-__device__ __forceinline__ TileSeq wave_tile_seq(int n_wave_tiles, int waves_per_block, int wave) {
+__device__ __forceinline__ TileSeq wave_tile_seq(int n_wave_tiles, int waves_per_block, int wave, int interleave = 1) {
   const int G = gridDim.x, b = blockIdx.x;
   TileSeq s;
-  if (CHG_TILE_INTERLEAVE && (G & 7) == 0 && (long)n_wave_tiles >= (long)INTERLEAVE_MIN_TILES * G * waves_per_block) {
+  if (CHG_TILE_INTERLEAVE && interleave && (G & 7) == 0 && (long)n_wave_tiles >= (long)INTERLEAVE_MIN_TILES * G * waves_per_block) {
     const int x = b & 7, WX = (G >> 3) * waves_per_block, lw = (b >> 3) * waves_per_block + wave;
     const int xb = (int)((long)n_wave_tiles * x / 8), xe = (int)((long)n_wave_tiles * (x + 1) / 8);
     s.first = xb + lw;

@@ -141,8 +141,16 @@ class CombinedLoss:
         """Flattened labels of one batch, built once per label dictionary (kept in a small cache on this object, keyed by the
         dictionary's identity: the label sets of an epoch come back every epoch)."""
         cache = self.__dict__.setdefault("_flat_cache", {})
+        # a hit must be the same dictionary holding the same label OBJECTS for the same graph sizes: a loader that refills one
+        # dictionary (or its lists) in place gets fresh labels, not the previous batch's
+        def probe(x):   # identity + first / last value: an array refilled in place changes the stamp as well (O(1) per array)
+            a = np.asarray(x) if x is not None else np.zeros(0)
+            return (id(x), float(a.flat[0]) if a.size else 0.0, float(a.flat[-1]) if a.size else 0.0)
+
+        stamp = (tuple(id(targets.get(k)) for k in ("f", "s", "m")), tuple(probe(x) for k in ("f", "s", "m") for x in (targets.get(k) or ())),
+                 tuple(int(n) for n in atoms_per_graph), bool(self.allow_missing_labels))
         hit = cache.get(id(targets))
-        if hit is not None and hit[0] is targets:
+        if hit is not None and hit[0] is targets and hit[2] == stamp:
             return hit[1]
         flat = {}
         if "f" in targets:
@@ -166,7 +174,7 @@ class CombinedLoss:
             flat["m_size"] = size
         if len(cache) >= 256:
             cache.clear()
-        cache[id(targets)] = (targets, flat)
+        cache[id(targets)] = (targets, flat, stamp)
         return flat
 
     def forward(self, targets: dict, prediction: dict) -> dict:

@@ -103,13 +103,20 @@ def build_cygraph(scratch: str | None = None) -> str:
                      "setup(name='cygraph_build', ext_modules=cythonize([Extension('chgnet.graph.cygraph', ['chgnet/graph/cygraph.pyx'],"
                      " include_dirs=[np.get_include()])], language_level=3), script_args=['build_ext', '--inplace'])\n")
         subprocess.run([sys.executable, setup_py], cwd=work, check=True, capture_output=True)
+        def built(root: str) -> bool:
+            graph_dir = os.path.join(root, "chgnet", "graph")
+            return os.path.isdir(graph_dir) and any(f.startswith("cygraph") and f.endswith(".so") for f in os.listdir(graph_dir))
+
         try:
-            if os.path.isdir(scratch):
-                shutil.rmtree(scratch)            # carries the marker (checked above)
-            os.rename(work, scratch)
-        except OSError:                           # another process won the race: use its build
+            if built(scratch):                    # another process finished while this one compiled: its build stays, ours goes
+                shutil.rmtree(work, ignore_errors=True)
+            else:
+                if os.path.isdir(scratch):        # a marked directory WITHOUT a finished build (an interrupted earlier run): replace it
+                    shutil.rmtree(scratch)
+                os.rename(work, scratch)
+        except OSError:                           # lost the rename race: use the winner's build
             shutil.rmtree(work, ignore_errors=True)
-            if not os.path.isdir(os.path.join(scratch, "chgnet", "graph")):
+            if not built(scratch):
                 raise
     return scratch
 

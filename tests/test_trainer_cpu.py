@@ -140,3 +140,26 @@ def test_flat_loss_path_equals_the_list_path(criterion, missing, allow):
             assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) < 1e-14, k
         for k in "efsm":
             assert np.allclose(np.asarray(ggot[k]).reshape(-1), np.asarray(gwant[k]).reshape(-1), atol=1e-15), k
+
+
+def test_flat_label_cache_sees_a_refilled_dictionary():
+    """the flattened-label cache is keyed on the label dictionary's identity.  A loader that reuses ONE dictionary --
+    replacing its lists, or refilling the arrays in place -- must get the new labels, not the previous batch's."""
+    from chgnet_amd.model import ForwardResult
+
+    rng = np.random.default_rng(5)
+    targ, pred = _batch(rng, False)
+    fast = ForwardResult(dict(pred, atoms_per_graph=np.array([len(x) for x in pred["f"]])))
+    fast.flat = {"f": np.concatenate(pred["f"], 0), "s": np.stack(pred["s"]), "m": np.concatenate(pred["m"])}
+    loss = CombinedLoss(target_str="efsm", criterion="MSE")
+    first = loss.gradients(targ, fast)[0]["loss"]
+    assert loss.gradients(targ, fast)[0]["loss"] == first                    # cache hit: same labels
+    targ["f"] = [x + 1.0 for x in targ["f"]]                                  # same dictionary, new list of new arrays
+    second = loss.gradients(targ, fast)[0]["loss"]
+    want = CombinedLoss(target_str="efsm", criterion="MSE").gradients(targ, pred)[0]["loss"]
+    assert abs(second - want) < 1e-12 and abs(second - first) > 0.1
+    for x in targ["f"]:
+        x += 2.0                                                              # same arrays refilled in place
+    third = loss.gradients(targ, fast)[0]["loss"]
+    want = CombinedLoss(target_str="efsm", criterion="MSE").gradients(targ, pred)[0]["loss"]
+    assert abs(third - want) < 1e-12 and abs(third - second) > 0.1
