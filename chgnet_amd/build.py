@@ -23,9 +23,10 @@ INCLUDE = os.path.join(REPO_DIR, "include")
 GRAPH_LIB = os.path.join(LIB_DIR, "libchgnet_graph.so")
 HIP_LIB = os.path.join(LIB_DIR, "libchgnet_hip.so")
 
-HIP_SOURCES = ["engine.hip", "comm.hip"]
+# one translation unit per subsystem (csrc/engine_internal.h): a kernel edit recompiles the unit that launches it
+HIP_SOURCES = ["engine.hip", "engine_predict.hip", "engine_train.hip", "engine_graph.hip", "comm.hip"]
 HIP_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-munsafe-fp-atomics",      # native global_atomic_add_f32, no CAS loops
     "-ffp-contract=fast",
     "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
@@ -60,30 +61,55 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+def _compile_units(out: str, extra: list[str], obj_dir: str, force: bool) -> None:
+    """Compile every unit to an object (in parallel; only those older than a source they depend on), then link."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(INCLUDE, "chgnet_hip.h")]
+    objs, todo = [], []
+    for name in HIP_SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not _newer(obj, [src, *headers]):
+            todo.append([hipcc_path(), *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj])
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        list(pool.map(_run, todo))
+    if todo or not os.path.exists(out):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+
+
 def build_hip(force: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".hip"))]
-    deps.append(os.path.join(INCLUDE, "chgnet_hip.h"))
-    if force or not _newer(HIP_LIB, deps):
-        _run([hipcc_path(), *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", HIP_LIB])
+    _compile_units(HIP_LIB, [], os.path.join(LIB_DIR, "obj"), force)
     return HIP_LIB
 
 
 def build_variant(name: str, defines: list[str], extra_flags: list[str] | None = None) -> str:
     """Experiment build (timing studies only): libchgnet_hip_<name>.so with extra -D / compiler flags."""
     out = os.path.join(LIB_DIR, f"libchgnet_hip_{name}.so")
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if any(d.startswith(("CHG_EXP_", "CHG_PHASE_TIMING")) for d in defines) and "CHG_EXPERIMENTS" not in defines:
         defines = [*defines, "CHG_EXPERIMENTS"]   # mfma_tile.h refuses experiment switches without it
-    _run([hipcc_path(), *HIP_FLAGS, *(extra_flags or []), *[f"-D{d}" for d in defines], f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", out])
+    _compile_units(out, [*(extra_flags or []), *[f"-D{d}" for d in defines]], os.path.join(LIB_DIR, f"obj_{name}"), True)
     return out
 
 
-def build_all(force: bool = False) -> None:
+def clean_variants() -> None:
+    """Remove experiment libraries and their objects from chgnet_amd/lib: a snapshot pushed to the GPU box carries the product only."""
+    for f in os.listdir(LIB_DIR):
+        p = os.path.join(LIB_DIR, f)
+        if (f.startswith("libchgnet_hip_") and f.endswith(".so")) or f == "split_lab":
+            os.remove(p)
+        elif f.startswith("obj_") and os.path.isdir(p):
+            shutil.rmtree(p)
+
+
+def build_all(force: bool = False, keep_variants: bool = False) -> None:
     build_graph(force)
     build_hip(force)
+    if not keep_variants:
+        clean_variants()
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    build_all(force="--force" in sys.argv, keep_variants="--keep-variants" in sys.argv)

@@ -1,0 +1,280 @@
+// engine_internal.h -- host-side types and helpers shared by the translation units of libchgnet_hip.so (not an API):
+//   engine.hip          C-ABI: engine / batch lifetime, upload / download, timers, profiling, debug fetch, self-tests
+//   engine_predict.hip  launch schedule of chg_predict (forward + force / stress sweep), arena layout, per-atom schedule
+//   engine_train.hip    fine-tuning backward: first- and second-order sweeps (chg_backward*)
+//   engine_graph.hip    device-side graph construction (chg_batch_build)
+// A kernel edit recompiles the unit that launches it, not 150 KB of host code; every kernel instantiation is launched from ONE unit.
+#pragma once
+
+#include "chgnet_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mfma_tile.h"
+#include "mfma_split.h"
+#include "kernels_conv.h"     // argument structs (GatedW, AtomConvArgs, AngleArgs, RowsGemm) and the tile constants
+#include "kernels_angle_w.h"  // WinIndex
+#include "kernels_embed.h"    // BondEmbedTArgs / AngleEmbedTArgs
+
+using namespace chg;
+
+constexpr int MAX_CONV = 8;
+constexpr float F16_OPERAND_LIMIT = 65504.0f;   // largest finite f16: forward operands of the split contractions are not rescaled
+#ifndef CHG_FWD_WAVES
+#define CHG_FWD_WAVES 8
+#endif
+#ifdef CHG_PHASE_TIMING
+constexpr size_t PHASE_FLOATS = (size_t)4 * 2 * 10 * PH_WAVES;   // kernels_conv.h PH_FLUSH
+#else
+constexpr size_t PHASE_FLOATS = 64;
+#endif
+constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
+
+struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
+struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
+struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };
+
+struct Weights {
+  const float *atomref, *emb, *freq_ag, *freq_bg, *freq_ang, *w_bond_emb, *w_wag, *w_wbg, *w_ang_emb;
+  ACW ac[MAX_CONV];
+  BCW bc[MAX_CONV];
+  AUW au[MAX_CONV];
+  const float *site_w, *site_b, *ro_ln_g, *ro_ln_b, *mlp_w0, *mlp_b0, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2, *mlp_w3, *mlp_b3;
+  const float *mlp_w0_t, *mlp_w1_t, *mlp_w2_t;
+};
+
+struct ProfEntry { std::string label; int64_t launches = 0; double ms = 0.0; };
+struct PendingEvent { int entry; hipEvent_t start, stop; };
+
+struct chg_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  chg_model_desc desc{};
+  float* d_weights = nullptr;
+  Weights w{};
+  // prebuilt LDS weight blocks of the inference tile kernels (kernels_conv.h k_*_image), rebuilt by every weight upload
+  float* d_images = nullptr;
+  const float* img_ac_fwd[2][MAX_CONV] = {};   // [without / with q_bias][layer]
+  const float* img_ac_bwd[MAX_CONV] = {};
+  const float* img_angle[2][2 * MAX_CONV] = {};   // [fwd / bwd][slot: BondConv l | L + AngleUpdate l]
+  std::string err;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  std::map<std::string, int> prof_index;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
+  std::vector<std::pair<char*, size_t>> work_pool;    // released training workspaces (tens of GB: a hipMalloc per step would dominate it)
+  std::vector<int> work_kind;                         // 0: first-order workspace, 1: second-order workspace
+  bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
+  char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
+  size_t scratch_bytes = 0, scratch_wanted = 0;
+  char* h_stage = nullptr;   // pinned staging for the inputs of chg_batch_build
+  size_t h_stage_bytes = 0;
+  int num_cus = 256;
+  // single-pass graph builds (chg_batch_build): counts of the previous build size the next one's scratch speculatively
+  bool spec_builds = true;    // CHGNET_SPEC_BUILD=0 forces the exact three-round-trip pass
+  int last_N = 0, last_Ed = 0, last_A = 0, last_Eb = 0;
+  double last_r_atom = 0.0, last_r_bond = 0.0;
+  long n_spec_builds = 0, n_spec_overflows = 0, n_cell_builds = 0, n_cell_fallbacks = 0;
+  int graph_search = 0;       // chg_engine_set_graph_search: 0 by size, 1 all pairs, 2 cell list
+  int cell_min_atoms = 512;   // structures at least this large are binned (by size)
+  size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
+};
+
+struct Train2;   // stage-B buffers (defined with run_backward2)
+
+struct chg_batch {
+  int B = 0, N = 0, Ed = 0, Eu = 0, A = 0, Eb = 0, L = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  // inputs
+  int *z, *atom_owner, *atom_off, *e_center, *e_nbr, *e_d2u, *e_owner, *e_rev, *p_center, *p_nbr, *u_u2d, *u_bnode, *bn_und, *a_ctr, *a_b1c, *a_b2c, *a_d1, *a_d2;
+  float *frac, *lattice, *e_image;
+  // geometry / features
+  float* cart;
+  f32x4 *ev, *eu;
+  float *hb0, *wag, *wbgc;
+  float* atom[MAX_CONV + 1];
+  float* hbc[MAX_CONV + 1];
+  float* ang[MAX_CONV];
+  // first-layer partial-product tables, one set per layer so the reverse sweep reuses the forward's
+  float* Pl[MAX_CONV];          // AtomConv l: [N,256]
+  float* Ql[MAX_CONV];          // AtomConv l: [Eu,128]
+  float* Rl[2 * MAX_CONV];      // BondConv l (slot l) / AngleUpdate l (slot L+l): [Eb,256]
+  float* Sl[2 * MAX_CONV];      // same slots: [N,128]
+  // scatter targets, one per layer so that each direction of the sweep needs ONE memset (not one per layer)
+  float* agg_l[MAX_CONV];       // AtomConv l: [N,64]
+  float* aggB_l[MAX_CONV];      // BondConv l: [Eb,64]
+  float* GP_l[MAX_CONV];        // AtomConv l adjoint: [N,256]
+  float* GR_l[2 * MAX_CONV];    // BondConv / AngleUpdate adjoint (slots like Rl): [Eb,256]
+  float* GS_l[2 * MAX_CONV];    // same slots: [N,128]
+  // outputs
+  float *energy, *site_energy, *site_raw, *magmom, *crystal_fea, *force, *virial, *volume;
+  // reverse sweep
+  float *Ga, *GA, *Gb, *Gwag, *Gwbgc, *Gang, *GQ, *Gagg, *Grk, *Gu;
+  float* phase = nullptr;   // CHG_PHASE_TIMING builds: per-phase shader-clock totals of the angle kernels
+  WinIndex win{};           // centre-major row order + window slots of the angle adjoints (kernels_angle_w.h), built by prepare_windows
+  int *win_tmp = nullptr, *win_scan = nullptr;
+  int win_grid = 64;        // workgroups of the per-atom kernels (a multiple of 64: the atom schedule is built for it, k_win_schedule)
+  bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
+  float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
+  uint32_t last_task = 0;
+  bool seed1_adjoints = false;   // the first-order adjoints (seed 1) of the last force / stress sweep are still in the batch (GP_l, GR_l, GS_l, Gwag, Gwbgc)
+  // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:
+  // ~170 launches per call make small batches (MD: one structure) launch-bound otherwise
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_task = 0;
+  int eager_calls = 0;        // the first call of a (batch, task) runs eagerly: one-shot batches never pay a capture
+  std::map<std::string, std::pair<const float*, size_t>> named;
+  std::map<std::string, std::pair<const int*, size_t>> named_i32;
+  // fine-tuning backward (chg_backward): allocated on first use, freed with the batch
+  char* train_arena = nullptr;
+  size_t train_bytes = 0;
+  std::vector<int> h_atom_off;   // host copy (chg_backward: atoms per structure)
+  std::vector<double> h_volume;  // host copy of the cell volumes (chg_backward: stress cotangent -> strain direction)
+  // stage B (second-order) workspace: one more arena, carved by layout_train2
+  char* t2_arena = nullptr;
+  size_t t2_bytes = 0;
+  struct Train2* t2 = nullptr;
+  float* t_mcot = nullptr;   // [N] magmom cotangent
+  float h_g_b3 = 0.f;        // host-side gradient of the readout's last bias (copied into the blob on the device)
+  bool t_has_mcot = false;
+  float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
+        *t_ro = nullptr;
+};
+
+#define HIP_TRY(eng, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      (eng)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                               \
+      return CHG_EHIP;                                                                              \
+    }                                                                                               \
+  } while (0)
+
+#define TRY(x)                   \
+  do {                           \
+    int _s = (x);                \
+    if (_s != CHG_OK) return _s; \
+  } while (0)
+
+namespace chgh {   // host-side internals (one namespace: the library exports only the chg_* C symbols by name)
+
+int prof_entry(chg_engine* eng, const char* label);
+hipEvent_t get_event(chg_engine* eng);
+int collect_profile(chg_engine* eng);
+
+struct LaunchScope {
+  chg_engine* eng;
+  PendingEvent pe{};
+  bool on;
+  LaunchScope(chg_engine* e, const char* label) : eng(e), on(e->profiling) {
+    if (on) {
+      pe.entry = prof_entry(eng, label);
+      pe.start = get_event(eng);
+      pe.stop = get_event(eng);
+      hipEventRecord(pe.start, eng->stream);
+    }
+  }
+  ~LaunchScope() {
+    if (on) {
+      hipEventRecord(pe.stop, eng->stream);
+      eng->pending.push_back(pe);
+    }
+  }
+};
+
+
+struct Carver {
+  char* base;
+  size_t pos = 0;
+  template <class T>
+  T* take(size_t n) {
+    pos = (pos + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + pos) : nullptr;
+    pos += std::max<size_t>(n, 1) * sizeof(T);
+    return p;
+  }
+};
+
+inline dim3 g1(int64_t n, int b = 256) { return dim3((unsigned)std::max<int64_t>(1, (n + b - 1) / b)); }
+inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4 waves per block, grid-stride
+  return (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 16 * (int64_t)eng->num_cus));
+}
+
+template <class T>
+int h2d(chg_engine* eng, T* dst, const T* src, size_t n) {
+  if (n == 0) return CHG_OK;
+  if (!src) { eng->err = "chg_batch_upload: null host array"; return CHG_EINVAL; }
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, eng->stream));
+  return CHG_OK;
+}
+template <class T>
+int d2h(chg_engine* eng, T* dst, const T* src, size_t n) {
+  if (n == 0 || !dst) return CHG_OK;
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, eng->stream));
+  return CHG_OK;
+}
+
+template <class K>
+int set_lds(chg_engine* eng, K kernel, size_t bytes) {
+  HIP_TRY(eng, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CHG_OK;
+}
+
+// ---- engine_predict.hip
+size_t layout_weights(const float* base, int L, Weights& w);
+int grid_for(int rows, int max_blocks, int block_rows = BLOCK_ROWS);
+int tile_grid(chg_engine* eng, int rows, int block_rows = BLOCK_ROWS);
+int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt,
+              const float* bias, const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int accumulate);
+int rows_gemm_out2(chg_engine* eng, const char* label, const float* X, const int* in_idx, const float* Wt, const float* Wt2,
+                   const float* bias, float* Y, int ldy, int rows);
+int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, const float* Wt, const float* Wt2, float* Y,
+                  const int* out_idx, int rows, int accumulate);
+int zero(chg_engine* eng, void* p, size_t bytes);
+int build_images(chg_engine* eng);
+int predict_set_lds(chg_engine* eng);      // dynamic-LDS attributes of the kernels this unit launches
+int atomconv_tables(chg_engine* eng, chg_batch* b, int l);
+int atomconv_q_table(chg_engine* eng, chg_batch* b, int l);
+AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l);
+int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1);
+AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_ang, const GatedW& g, float* out);
+int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t);
+BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b);
+AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b);
+int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
+void carve(chg_batch* b, char* base, size_t& total);
+int prepare_windows(chg_engine* eng, chg_batch* b);
+void register_names(chg_batch* b);
+
+// ---- engine_train.hip
+int train_set_lds(chg_engine* eng);
+void free_train2(chg_batch* b);
+void release_workspace(chg_engine* eng, char* p, size_t bytes, int kind);
+int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent, const float* force_cotangent,
+                  const float* stress_cotangent, chg_comm* comm, float* grad_blob);
+
+// ---- engine_graph.hip
+size_t scan_scratch_ints(int n);           // scratch ints exclusive_scan_with needs for n elements
+int exclusive_scan_with(chg_engine* eng, int* scratch, const int* in, int* out, int n);
+int acquire_arena(chg_engine* eng, chg_batch* b, size_t total);
+int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double numerical_tol, chg_batch** out);
+
+}  // namespace chgh
+
+using namespace chgh;
+

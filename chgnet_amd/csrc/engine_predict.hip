@@ -1,0 +1,679 @@
+// engine_predict.hip -- launch schedule of chg_predict: weight layout, launch helpers, the forward sweep and the force / stress
+// sweep (order of layers: CHGNet._compute, reference chgnet/model/model.py:442-503; the reverse sweep is its hand-derived adjoint,
+// SURVEY Appendix B), the batch arena, the centre-major atom schedule of the per-atom adjoints.
+#include "engine_internal.h"
+
+#include "kernels_geom.h"
+
+namespace chgh {
+
+
+// ---- weight blob layout: MUST mirror chgnet_amd/pack.py:weight_layout -------------------------------
+struct Cursor {
+  const float* base;
+  size_t pos = 0;
+  const float* take(size_t n) {
+    pos += (4 - pos % 4) % 4;  // 16-byte alignment of every tensor
+    const float* p = base + pos;
+    pos += n;
+    return p;
+  }
+};
+
+void take_gated_tail(Cursor& c, GatedW& g, const float*& w2c_t, const float*& w2g_t) {
+  g.w2c = c.take(D * D); g.b2c = c.take(D); g.w2g = c.take(D * D); g.b2g = c.take(D);
+  w2c_t = c.take(D * D); w2g_t = c.take(D * D);
+}
+void take_ln(Cursor& c, GatedW& g) {
+  g.ln1_g = c.take(D); g.ln1_b = c.take(D); g.ln2_g = c.take(D); g.ln2_b = c.take(D);
+}
+
+size_t layout_weights(const float* base, int L, Weights& w) {
+  Cursor c{base};
+  w.atomref = c.take(94); w.emb = c.take(94 * D);
+  w.freq_ag = c.take(NRAD); w.freq_bg = c.take(NRAD); w.freq_ang = c.take(NFREQ);
+  w.w_bond_emb = c.take(D * NRAD); w.w_wag = c.take(D * NRAD); w.w_wbg = c.take(D * NRAD); w.w_ang_emb = c.take(D * NANG);
+  for (int l = 0; l < L; ++l) {
+    ACW& a = w.ac[l];
+    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D); a.q_bias = c.take(2 * D);
+    take_gated_tail(c, a.g, a.w2c_t, a.w2g_t);
+    take_ln(c, a.g);
+    a.w_out = c.take(D * D); a.b_out = c.take(D); a.w_out_t = c.take(D * D);
+    a.w_cn_t = c.take(4 * D * D); a.w_bond_t = c.take(2 * D * D);
+  }
+  for (int l = 0; l < L - 1; ++l) {
+    BCW& b = w.bc[l];
+    b.w_bij = c.take(4 * D * D); b.w_ang = c.take(2 * D * D); b.w_ctr = c.take(2 * D * D); b.b1 = c.take(2 * D);
+    take_gated_tail(c, b.g, b.w2c_t, b.w2g_t);
+    take_ln(c, b.g);
+    b.w_out = c.take(D * D); b.b_out = c.take(D); b.w_out_t = c.take(D * D);
+    b.w_bij_t = c.take(4 * D * D); b.w_ang_t = c.take(2 * D * D); b.w_ctr_t = c.take(2 * D * D);
+  }
+  for (int l = 0; l < L - 1; ++l) {
+    AUW& u = w.au[l];
+    u.w_bij = c.take(4 * D * D); u.w_ang = c.take(2 * D * D); u.w_ctr = c.take(2 * D * D); u.b1 = c.take(2 * D);
+    u.g = GatedW{};
+    take_ln(c, u.g);
+    u.w_bij_t = c.take(4 * D * D); u.w_ang_t = c.take(2 * D * D); u.w_ctr_t = c.take(2 * D * D);
+  }
+  w.site_w = c.take(D); w.site_b = c.take(1); w.ro_ln_g = c.take(D); w.ro_ln_b = c.take(D);
+  w.mlp_w0 = c.take(D * D); w.mlp_b0 = c.take(D); w.mlp_w1 = c.take(D * D); w.mlp_b1 = c.take(D);
+  w.mlp_w2 = c.take(D * D); w.mlp_b2 = c.take(D); w.mlp_w3 = c.take(D); w.mlp_b3 = c.take(1);
+  w.mlp_w0_t = c.take(D * D); w.mlp_w1_t = c.take(D * D); w.mlp_w2_t = c.take(D * D);
+  return c.pos;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------
+int prof_entry(chg_engine* eng, const char* label) {
+  auto it = eng->prof_index.find(label);
+  if (it != eng->prof_index.end()) return it->second;
+  eng->prof.push_back(ProfEntry{label});
+  const int idx = (int)eng->prof.size() - 1;
+  eng->prof_index[label] = idx;
+  return idx;
+}
+
+hipEvent_t get_event(chg_engine* eng) {
+  if (!eng->event_pool.empty()) {
+    hipEvent_t e = eng->event_pool.back();
+    eng->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+int collect_profile(chg_engine* eng) {
+  for (auto& pe : eng->pending) {
+    float ms = 0.f;
+    HIP_TRY(eng, hipEventSynchronize(pe.stop));
+    HIP_TRY(eng, hipEventElapsedTime(&ms, pe.start, pe.stop));
+    eng->prof[pe.entry].launches += 1;
+    eng->prof[pe.entry].ms += ms;
+    eng->event_pool.push_back(pe.start);
+    eng->event_pool.push_back(pe.stop);
+  }
+  eng->pending.clear();
+  return CHG_OK;
+}
+
+// workgroups per CU launched for the tile kernels (CHGNET_GRID_MULT, timing experiments; default 2)
+static int tile_grid_mult() {
+  static const int m = [] { const char* e = std::getenv("CHGNET_GRID_MULT"); const int v = e ? std::atoi(e) : 2; return v > 0 ? v : 2; }();
+  return m;
+}
+
+int grid_for(int rows, int max_blocks, int block_rows) {
+  int ntiles = (rows + block_rows - 1) / block_rows;
+  int g = std::min(ntiles, max_blocks);
+  if (g >= 8) g &= ~7;  // multiple of 8: tile_range keeps neighbouring ranges on one XCD
+  return std::max(g, 1);
+}
+
+// grid of a tile kernel: CHGNET_GRID_MULT workgroups per CU -- one per CU when that already gives every workgroup no more than a few
+// tiles (small batches: the second workgroup of a CU would stage the weights again for one or two tiles; MD replay 1.478 -> 1.437 ms)
+int tile_grid(chg_engine* eng, int rows, int block_rows) {
+  const int ntiles = (rows + block_rows - 1) / block_rows;
+  const int mult = ntiles <= 4 * eng->num_cus ? 1 : tile_grid_mult();
+  // rounded UP to a multiple of 8 (tile_range's XCD mapping): rounding 221 blocks down to 216 left 42 waves of a 256-atom cell's
+  // AtomConv kernels with a second tile, i.e. doubled the kernel's time; a workgroup without tiles costs nothing
+  return std::max(1, std::min((ntiles + 7) & ~7, mult * eng->num_cus));
+}
+
+template <int K, int NOUT, int PARTS = 1>
+int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
+  if (p.rows <= 0) return CHG_OK;
+  LaunchScope ls(eng, label);
+  const size_t lds = rows_gemm_lds<K, NOUT, PARTS>();
+  hipLaunchKernelGGL((k_rows_gemm<K, NOUT, PARTS>), dim3(grid_for(p.rows, 4 * eng->num_cus)), dim3(BLOCK), lds, eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+// few rows (MD-size batches): every row GEMM as column blocks of a 16-wide instance (RowsGemm::col_blocks)
+constexpr int SMALL_GEMM_ROWS = 32768;
+constexpr int SMALL_GEMM_COLS = 16;
+template <int K, int PARTS>
+int launch_rows_gemm_cols(chg_engine* eng, const char* label, RowsGemm p, int n_out, int n_out_first) {
+  if (p.rows <= 0) return CHG_OK;
+  p.col_blocks = n_out / SMALL_GEMM_COLS; p.blocks1 = n_out_first / SMALL_GEMM_COLS;
+  LaunchScope ls(eng, label);
+  hipLaunchKernelGGL((k_rows_gemm<K, SMALL_GEMM_COLS, PARTS>), dim3(grid_for(p.rows, 4 * eng->num_cus), p.col_blocks), dim3(BLOCK),
+                     (rows_gemm_lds<K, SMALL_GEMM_COLS, PARTS>()), eng->stream, p);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+// Y[out] (+)= X[in] . Wt^T, dispatch on (K, NOUT)
+int rows_gemm(chg_engine* eng, const char* label, int K, int NOUT, const float* X, int ldx, const int* in_idx, const float* Wt,
+              const float* bias, const float* resid, int ldr, float* Y, int ldy, const int* out_idx, int rows, int accumulate) {
+  RowsGemm p{X, ldx, in_idx, Wt, bias, resid, ldr, Y, ldy, out_idx, rows, accumulate, nullptr, 0, 0, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS && K == 64 && (NOUT == 64 || NOUT == 128)) return launch_rows_gemm_cols<64, 1>(eng, label, p, NOUT, NOUT);
+  if (rows <= SMALL_GEMM_ROWS && K == 128 && NOUT == 64) return launch_rows_gemm_cols<128, 1>(eng, label, p, NOUT, NOUT);
+  if (K == 64 && NOUT == 64) return launch_rows_gemm<64, 64>(eng, label, p);
+  if (K == 64 && NOUT == 128) return launch_rows_gemm<64, 128>(eng, label, p);
+  if (K == 128 && NOUT == 64) return launch_rows_gemm<128, 64>(eng, label, p);
+  eng->err = "rows_gemm: unsupported shape";
+  return CHG_EINVAL;
+}
+
+// both halves of a 256-wide table in one launch:  Y[:, 0:128 | 128:256] = X . [Wt ; Wt2]^T  (64 -> 2 x 128)
+int rows_gemm_out2(chg_engine* eng, const char* label, const float* X, const int* in_idx, const float* Wt, const float* Wt2,
+                   const float* bias, float* Y, int ldy, int rows) {
+  RowsGemm p{X, D, in_idx, Wt, bias, nullptr, 0, Y, ldy, nullptr, rows, 0, Wt2, 0, 2 * D, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS) return launch_rows_gemm_cols<64, 1>(eng, label, p, 4 * D, 2 * D);
+  return launch_rows_gemm<64, 128, 2>(eng, label, p);
+}
+// ... and its adjoint:  Y (+)= X[:, 0:128] . Wt^T + X[:, 128:256] . Wt2^T   (2 x 128 -> 64)
+int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, const float* Wt, const float* Wt2, float* Y,
+                  const int* out_idx, int rows, int accumulate) {
+  RowsGemm p{X, ldx, nullptr, Wt, nullptr, nullptr, 0, Y, D, out_idx, rows, accumulate, Wt2, 2 * D, 0, 0, 0};
+  if (rows <= SMALL_GEMM_ROWS) return launch_rows_gemm_cols<128, 2>(eng, label, p, D, D);
+  return launch_rows_gemm<128, 64, 2>(eng, label, p);
+}
+
+int zero(chg_engine* eng, void* p, size_t bytes) {
+  if (bytes == 0) return CHG_OK;
+  LaunchScope ls(eng, "memset");
+  HIP_TRY(eng, hipMemsetAsync(p, 0, bytes, eng->stream));
+  return CHG_OK;
+}
+
+
+
+
+
+// ---- AtomConv ----------------------------------------------------------------------------------------
+// tables of layer l:  P = atom[l] . [Wc;Wn]^T (+b1 on the centre half).  The bond partial Q = h_bond^l . Wb^T is contracted inside
+// k_atomconv_fwd, which leaves it behind as a table when a reverse sweep follows; chg_backward after an energy-only predict builds
+// the tables itself (atomconv_q_table).
+// Prebuilt weight blocks (see stage_image, mfma_tile.h): one per tile kernel and layer, laid out by the kernels' own staging code.
+int build_images(chg_engine* eng) {
+  const int L = eng->desc.n_conv;
+  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats();
+  constexpr size_t BF = AngleLds<true, false>::tiles, BB = AngleLds<true, true>::tiles, UF = AngleLds<false, false>::tiles,
+                   UB = AngleLds<false, true>::tiles;
+  static_assert(AF % 4 == 0 && AB % 4 == 0 && BF % 4 == 0 && BB % 4 == 0 && UF % 4 == 0 && UB % 4 == 0, "images are copied in 16-byte units");
+  const size_t total = (size_t)L * (2 * AF + AB) + (size_t)(L - 1) * (BF + BB + UF + UB);
+  if (!eng->d_images) {
+    HIP_TRY(eng, hipMalloc(&eng->d_images, total * sizeof(float)));
+    HIP_TRY(eng, hipMemsetAsync(eng->d_images, 0, total * sizeof(float), eng->stream));   // slots no staging writes (unused vectors)
+  }
+  float* at = eng->d_images;
+  auto take = [&](size_t n) { float* p = at; at += n; return p; };
+  for (int l = 0; l < L; ++l) {
+    AtomConvArgs a{};
+    a.gw = eng->w.ac[l].g; a.w_bond = eng->w.ac[l].w_bond;
+    for (int qb = 0; qb < 2; ++qb) {
+      a.q_bias = qb ? eng->w.ac[l].q_bias : nullptr;
+      float* img = take(AF);
+      eng->img_ac_fwd[qb][l] = img;
+      hipLaunchKernelGGL(k_atomconv_image<false>, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
+    }
+    float* img = take(AB);
+    eng->img_ac_bwd[l] = img;
+    hipLaunchKernelGGL(k_atomconv_image<true>, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
+  }
+  for (int l = 0; l + 1 < L; ++l) {
+    const BCW& bc = eng->w.bc[l];
+    const AUW& au = eng->w.au[l];
+    float* img;
+    eng->img_angle[0][l] = img = take(BF);
+    hipLaunchKernelGGL((k_angle_image<true, false>), dim3(1), dim3(BLOCK), 0, eng->stream, bc.w_ang, bc.g, img);
+    eng->img_angle[1][l] = img = take(BB);
+    hipLaunchKernelGGL((k_angle_image<true, true>), dim3(1), dim3(BLOCK), 0, eng->stream, bc.w_ang, bc.g, img);
+    eng->img_angle[0][L + l] = img = take(UF);
+    hipLaunchKernelGGL((k_angle_image<false, false>), dim3(1), dim3(BLOCK), 0, eng->stream, au.w_ang, au.g, img);
+    eng->img_angle[1][L + l] = img = take(UB);
+    hipLaunchKernelGGL((k_angle_image<false, true>), dim3(1), dim3(BLOCK), 0, eng->stream, au.w_ang, au.g, img);
+  }
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  return rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, b->Pl[l], 4 * D, b->N);
+}
+
+int atomconv_q_table(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  float* Q = b->Ql[l];
+  if (b->Eu == 0) return CHG_OK;
+  // q_bias: constant shift of the bonds outside the bond graph when mlp_out has a bias (0.2.0 only; zero otherwise);
+  // the reference runs BondConv only when the batch has angles (model.py:460)
+  TRY(rows_gemm(eng, "gemm_Q", 64, 128, b->hb0, D, nullptr, w.w_bond, b->A > 0 ? w.q_bias : nullptr, nullptr, 0, Q, 2 * D, nullptr, b->Eu, 0));
+  if (b->Eb > 0 && b->hbc[l] != b->hbc[0])   // bond-graph nodes carry layer-l features
+    TRY(rows_gemm(eng, "gemm_Qnode", 64, 128, b->hbc[l], D, nullptr, w.w_bond, nullptr, nullptr, 0, Q, 2 * D, b->bn_und, b->Eb, 0));
+  return CHG_OK;
+}
+
+// Tile order per kernel: bit k of CHGNET_TILE_INTERLEAVE (default 31 = every kernel; A/B switch) -- 1 atomconv_fwd, 2 atomconv_bwd,
+// 4 bondconv_fwd, 8 angleupd_fwd, 16 row-order angle adjoints.  Same-box A/B (profiles/r04_experiments.md): the interleaved sweep cuts
+// the fabric traffic of every kernel by 20-30 %; their times move by 0-3 % (they are bound by vector-ALU issue, not by bytes).
+static int interleave_mask() {
+  static const int m = [] { const char* e = std::getenv("CHGNET_TILE_INTERLEAVE"); return e ? std::atoi(e) : 31; }();
+  return m;
+}
+
+AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
+  AtomConvArgs a{};
+  a.P = b->Pl[l]; a.Q = b->Ql[l]; a.wag = b->wag;
+  a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_d2u = b->e_d2u; a.n_edges = b->Ed;
+  a.gw = eng->w.ac[l].g;
+  a.agg = b->agg_l[l]; a.GA = b->GA; a.GP = b->GP_l[l]; a.GQ = b->GQ; a.Gwag = b->Gwag;
+  a.first_wag = l == b->L - 1;   // the reverse sweep starts with the last AtomConv
+  a.hb0 = b->hb0;
+  a.hbc = (b->Eb > 0 && b->hbc[l] != b->hbc[0]) ? b->hbc[l] : nullptr;   // bond-graph nodes carry layer-l features
+  a.u_bnode = b->u_bnode;
+  a.w_bond = eng->w.ac[l].w_bond;
+  a.q_bias = b->A > 0 ? eng->w.ac[l].q_bias : nullptr;
+  return a;
+}
+
+int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
+  const ACW& w = eng->w.ac[l];
+  if (b->Ed > 0) {
+    TRY(atomconv_tables(eng, b, l));
+    LaunchScope ls(eng, "atomconv_fwd");
+    const size_t lds = atomconv_lds<FWD_WAVES, false, true>();
+    AtomConvArgs a = atomconv_args(eng, b, l);
+    a.e_center = b->p_center;   // bond-pair order
+    a.image = eng->img_ac_fwd[a.q_bias ? 1 : 0][l];
+    a.e_nbr = b->p_nbr;
+    a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
+    a.interleave = interleave_mask() & 1;
+    hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
+    HIP_TRY(eng, hipGetLastError());
+  }
+  // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
+  return rows_gemm(eng, "gemm_out", 64, 64, b->agg_l[l], D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
+}
+
+int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
+  {  // pair-ordered edge list: GQ and Gwag rows are owned by one tile each (no zeroing, no atomics)
+    AtomConvArgs a = atomconv_args(eng, b, l);
+    a.e_center = b->p_center;
+    a.e_nbr = b->p_nbr;
+    a.image = eng->img_ac_bwd[l];
+    a.interleave = (interleave_mask() >> 1) & 1;
+    LaunchScope ls(eng, "atomconv_bwd");
+    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
+    HIP_TRY(eng, hipGetLastError());
+  }
+  if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
+    TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
+  }
+  return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, l == b->L - 1 ? 0 : 1);
+}
+
+// ---- BondConv / AngleUpdate ----------------------------------------------------------------------------
+// tables: S = atom . Wctr^T + b1 (per atom),  R = hbc . [Wi;Wj]^T (per bond-graph node)
+int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
+  float *S = b->Sl[slot], *R = b->Rl[slot];
+  if (b->N <= SMALL_GEMM_ROWS && b->Eb <= SMALL_GEMM_ROWS && b->N > 0 && b->Eb > 0) {   // small batch: both tables in one launch
+    RowsGemm2 g{};
+    g.a = RowsGemm{atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0, nullptr, 0, 0, 2 * D / SMALL_GEMM_COLS, 2 * D / SMALL_GEMM_COLS};
+    g.b = RowsGemm{hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0, w_bij + 2 * D * D, 0, 2 * D, 4 * D / SMALL_GEMM_COLS,
+                   2 * D / SMALL_GEMM_COLS};
+    LaunchScope ls(eng, "gemm_SR");
+    hipLaunchKernelGGL((k_rows_gemm_pair<64, SMALL_GEMM_COLS>), dim3(grid_for(std::max(b->N, b->Eb), 4 * eng->num_cus), g.a.col_blocks + g.b.col_blocks),
+                       dim3(BLOCK), (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>()), eng->stream, g);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
+  TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0));
+  return rows_gemm_out2(eng, "gemm_R", hbc, nullptr, w_bij, w_bij + 2 * D * D, nullptr, R, 4 * D, b->Eb);
+}
+
+AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_ang, const GatedW& g, float* out) {
+  AngleArgs a{};
+  a.R = b->Rl[slot]; a.S = b->Sl[slot]; a.ang = ang; a.wbgc = b->wbgc;
+  a.a_ctr = b->a_ctr; a.a_b1c = b->a_b1c; a.a_b2c = b->a_b2c; a.n_angles = b->A;
+  a.w_ang = w_ang; a.gw = g; a.out = out; a.slot = slot;
+  a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
+  a.first_gang = slot == b->L - 2;   // slot l < L is BondConv l; the sweep's first angle kernel is BondConv L-2
+  a.skip_flag = b->win.flag;
+  return a;
+}
+
+// Which adjoints run per atom (kernels_angle_w.h): both.  AngleUpdate 2.23 -> 1.60 ms; BondConv 3.44 -> 3.03 ms once all of its
+// contractions run in split precision from row-major images.  CHGNET_PER_ATOM_BONDCONV=0 / CHGNET_PER_ATOM_ANGLEUPD=0 switch back to
+// the plain kernels for A/B timing.
+static bool per_atom_adjoint(bool hidden) {
+  static const bool bc = [] { const char* e = std::getenv("CHGNET_PER_ATOM_BONDCONV"); return !e || std::atoi(e) != 0; }();
+  static const bool au = [] { const char* e = std::getenv("CHGNET_PER_ATOM_ANGLEUPD"); return !e || std::atoi(e) != 0; }();
+  return hidden ? bc : au;
+}
+
+template <bool HIDDEN, bool BWD, int NW = WAVES>
+int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
+  LaunchScope ls(eng, label);
+  AngleArgs plain = a;
+  if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
+    // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the row-order one: both are
+    // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
+    AngleWArgs w{};
+    w.a = a; w.w = b->win;
+    hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
+    HIP_TRY(eng, hipGetLastError());
+  } else {
+    plain.skip_flag = nullptr;
+  }
+  plain.image = eng->img_angle[BWD ? 1 : 0][a.slot];
+  plain.interleave = (interleave_mask() >> (BWD ? 4 : HIDDEN ? 2 : 3)) & 1;
+  const size_t lds = angle_lds<HIDDEN, NW, BWD>();
+  hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(tile_grid(eng, b->A, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
+  const BCW& w = eng->w.bc[l];
+  TRY(angle_tables(eng, b, l, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
+  TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, b->aggB_l[l]))));
+  // hbc[l+1] = agg . Wout^T + b_out + hbc[l]          (layers.py:255-260)
+  return rows_gemm(eng, "gemm_out", 64, 64, b->aggB_l[l], D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
+}
+
+int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
+  const AUW& w = eng->w.au[l];
+  TRY(angle_tables(eng, b, b->L + l, b->atom[l + 1], b->hbc[l + 1], w.w_bij, w.w_ctr, w.b1));
+  return launch_angle<false, false, FWD_WAVES>(eng, "angleupd_fwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, b->ang[l + 1]));
+}
+
+// scatter of the table gradients back to atoms / bond nodes
+int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t) {
+  TRY(rows_gemm_in2(eng, "gemm_GR", b->GR_l[slot], 4 * D, w_bij_t, w_bij_t + 2 * D * D, b->Gb, b->bn_und, b->Eb, 1));
+  return rows_gemm(eng, "gemm_GS", 128, 64, b->GS_l[slot], 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
+}
+
+int bondconv_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const BCW& w = eng->w.bc[l];
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, w.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, b->Eb, 0));
+  TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, nullptr))));
+  return angle_table_grads(eng, b, l, w.w_bij_t, w.w_ctr_t);
+}
+
+int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const AUW& w = eng->w.au[l];
+  TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, b->L + l, b->ang[l], w.w_ang, w.g, nullptr))));
+  return angle_table_grads(eng, b, b->L + l, w.w_bij_t, w.w_ctr_t);
+}
+
+BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
+  const Weights& w = eng->w;
+  BondEmbedTArgs a{};
+  a.ev = b->ev; a.u_u2d = b->u_u2d; a.u_bnode = b->u_bnode; a.n_und = b->Eu;
+  a.freq_ag = w.freq_ag; a.freq_bg = w.freq_bg; a.w_emb = w.w_bond_emb; a.w_ag = w.w_wag; a.w_bg = w.w_wbg;
+  a.rc_ag = eng->desc.atom_graph_cutoff; a.rc_bg = eng->desc.bond_graph_cutoff;
+  const double p = eng->desc.cutoff_coeff;   // basis.py:184-186
+  a.env = Envelope{(float)(-(p + 1) * (p + 2) / 2), (float)(p * (p + 2)), (float)(-p * (p + 1) / 2), eng->desc.cutoff_coeff};
+  a.hb0 = b->hb0; a.wag = b->wag; a.wbgc = b->wbgc;
+  a.hbc0 = b->Eb > 0 ? b->hbc[0] : nullptr;
+  a.Gb = b->Gb; a.Gwag = b->Gwag; a.Gwbgc = b->Gwbgc; a.Grk = b->Grk;
+  return a;
+}
+
+AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b) {
+  AngleEmbedTArgs a{};
+  a.eu = b->eu; a.a_d1 = b->a_d1; a.a_d2 = b->a_d2; a.n_angles = b->A;
+  a.freq = eng->w.freq_ang; a.w_emb = eng->w.w_ang_emb;
+  a.ang0 = b->ang[0]; a.Gang = b->Gang; a.Gu = b->Gu;
+  return a;
+}
+
+int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
+  const Weights& w = eng->w;
+  const int L = b->L;
+  const bool want_f = task & CHG_TASK_F, want_s = task & CHG_TASK_S, want_m = task & CHG_TASK_M;
+  const bool want_grad = want_f || want_s;
+  hipStream_t st = eng->stream;
+#ifdef CHG_PHASE_TIMING
+  HIP_TRY(eng, hipMemsetAsync(b->phase, 0, sizeof(float) * PHASE_FLOATS, st));
+#endif
+
+  // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
+  { LaunchScope ls(eng, "cart");
+    hipLaunchKernelGGL(k_cart, g1(b->N), dim3(256), 0, st, b->frac, b->lattice, b->atom_owner, b->cart, b->N); }
+  if (b->Ed > 0) {
+    { LaunchScope ls(eng, "edge_geom");
+      hipLaunchKernelGGL(k_edge_geom, g1(b->Ed), dim3(256), 0, st, b->cart, b->lattice, b->e_center, b->e_nbr, b->e_image, b->e_owner, b->ev, b->eu, b->Ed); }
+    { LaunchScope ls(eng, "bond_embed_fwd");
+      hipLaunchKernelGGL((k_bond_embed_t<false>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
+  }
+  if (b->A > 0) {
+    LaunchScope ls(eng, "angle_embed_fwd");
+    hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
+  }
+  { LaunchScope ls(eng, "atom_embed");
+    hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
+  HIP_TRY(eng, hipGetLastError());   // (hbc[0], the nodes' copy of their embedding rows, is written by k_bond_embed_t)
+
+  // ---- message passing (model.py:442-496) ----
+  // every forward scatter target + crystal_fea -- and, when a reverse sweep follows, its accumulators too (the two ranges are
+  // adjacent in the arena: one memset instead of two)
+  TRY(zero(eng, b->zero1, (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1)));
+  for (int l = 0; l < L - 1; ++l) {
+    TRY(atomconv_fwd(eng, b, l, want_grad));
+    if (b->A > 0) {
+      TRY(bondconv_fwd(eng, b, l));
+      if (l < L - 2) TRY(angleupd_fwd(eng, b, l));   // the last AngleUpdate's output is never consumed
+    }
+  }
+  if (want_m) {
+    LaunchScope ls(eng, "magmom");
+    hipLaunchKernelGGL(k_magmom, dim3(wave_grid(eng, b->N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->magmom, b->N);
+  }
+  TRY(atomconv_fwd(eng, b, L - 1, want_grad));
+
+  // ---- readout (model.py:497-509) and its adjoint ----
+  {
+    ReadoutArgs r{};
+    r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = b->N;
+    r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
+    r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
+    r.has_composition = eng->desc.has_composition;
+    r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
+    r.Ga = want_grad ? b->Ga : nullptr;
+    LaunchScope ls(eng, "readout");
+    hipLaunchKernelGGL(k_readout<false>, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
+    HIP_TRY(eng, hipGetLastError());
+  }
+
+  // ---- reverse sweep: dE/dv_e ----
+  if (want_grad) {
+    TRY(atomconv_bwd(eng, b, L - 1));
+    for (int l = L - 2; l >= 0; --l) {
+      if (b->A > 0) {
+        if (l < L - 2) TRY(angleupd_bwd(eng, b, l));
+        TRY(bondconv_bwd(eng, b, l));
+      }
+      TRY(atomconv_bwd(eng, b, l));
+    }
+    if (b->Ed > 0) {
+      { LaunchScope ls(eng, "bond_embed_bwd");
+        hipLaunchKernelGGL((k_bond_embed_t<true>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
+      if (b->A > 0) {
+        LaunchScope ls(eng, "angle_embed_bwd");
+        hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
+      }
+      ForceArgs f{};
+      f.ev = b->ev; f.eu = b->eu; f.Gu = b->Gu; f.Grk = b->Grk;
+      f.e_center = b->e_center; f.e_d2u = b->e_d2u; f.e_owner = b->e_owner; f.e_rev = b->e_rev; f.u_u2d = b->u_u2d;
+      f.n_edges = b->Ed; f.force = b->force; f.virial = b->virial;
+      LaunchScope ls(eng, "edge_force");
+      hipLaunchKernelGGL(k_edge_force, g1(b->Ed, EF_EDGES_PER_BLOCK), dim3(256), 0, st, f);
+    }
+    HIP_TRY(eng, hipGetLastError());
+  }
+  {
+    FinalizeArgs f{};
+    f.lattice = b->lattice; f.atom_off = b->atom_off; f.n_struct = b->B;
+    f.is_intensive = eng->desc.is_intensive; f.has_composition = eng->desc.has_composition; f.want_stress = want_s;
+    f.site_raw = b->site_raw; f.z = b->z; f.atomref = eng->w.atomref; f.energy_out = b->energy; f.virial = b->virial; f.volume = b->volume;
+    LaunchScope ls(eng, "finalize");
+    hipLaunchKernelGGL(k_finalize, g1((int64_t)b->B * 64), dim3(256), 0, st, f);   // one wave per structure
+    HIP_TRY(eng, hipGetLastError());
+  }
+  b->last_task = task;
+  b->seed1_adjoints = want_grad;
+  return CHG_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------------------------
+
+void carve(chg_batch* b, char* base, size_t& total) {
+  Carver c{base};
+  const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+  const int L = b->L;
+  b->z = c.take<int>(N); b->atom_owner = c.take<int>(N); b->atom_off = c.take<int>(B + 1);
+  b->e_center = c.take<int>(Ed); b->e_nbr = c.take<int>(Ed); b->e_d2u = c.take<int>(Ed); b->e_owner = c.take<int>(Ed);
+  b->e_rev = c.take<int>(Ed); b->p_center = c.take<int>(Ed); b->p_nbr = c.take<int>(Ed);
+  b->u_u2d = c.take<int>(Eu); b->u_bnode = c.take<int>(Eu); b->bn_und = c.take<int>(Eb);
+  b->a_ctr = c.take<int>(A); b->a_b1c = c.take<int>(A); b->a_b2c = c.take<int>(A); b->a_d1 = c.take<int>(A); b->a_d2 = c.take<int>(A);
+  b->frac = c.take<float>(3 * N); b->lattice = c.take<float>(9 * B); b->e_image = c.take<float>(3 * Ed);
+  b->cart = c.take<float>(3 * N); b->ev = c.take<f32x4>(Ed); b->eu = c.take<f32x4>(Ed);
+  b->hb0 = c.take<float>(Eu * D); b->wag = c.take<float>(Eu * D); b->wbgc = c.take<float>(Eb * D);
+  for (int l = 0; l <= L; ++l) b->atom[l] = c.take<float>(N * D);
+  for (int l = 0; l < L; ++l) b->hbc[l] = (A > 0 || l == 0) ? c.take<float>(Eb * D) : nullptr;
+  for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
+  for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
+  for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
+  b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
+  // zero group 1 (cleared with one memset before the readout)
+  b->zero1 = c.take<float>(0);
+  b->crystal_fea = c.take<float>(B * D);
+  for (int l = 0; l < L; ++l) b->agg_l[l] = c.take<float>(N * D);
+  for (int l = 0; l < L - 1; ++l) b->aggB_l[l] = c.take<float>(Eb * D);
+  b->zero1_end = c.take<float>(0);
+  // zero group 2 (cleared with one memset before the reverse sweep)
+  b->zero2 = c.take<float>(0);
+  b->Gwbgc = c.take<float>(Eb * D);
+  b->Gu = c.take<float>(4 * Ed); b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B);
+  for (int l = 0; l < L; ++l) b->GP_l[l] = c.take<float>(N * 4 * D);
+  for (int t = 0; t < 2 * L; ++t) {
+    const bool used = (t < L - 1) || (t >= L && t < 2 * L - 2);   // BondConv 0..L-2, AngleUpdate L..2L-3
+    b->GR_l[t] = used ? c.take<float>(Eb * 4 * D) : nullptr;
+    b->GS_l[t] = used ? c.take<float>(N * 2 * D) : nullptr;
+  }
+  b->zero2_end = c.take<float>(0);
+  // first written by a plain store in every sweep (AtomConv L-1: Gwag, its gemm_GQ: Gb; BondConv L-2: Gang): never zeroed
+  b->Gb = c.take<float>(Eu * D); b->Gwag = c.take<float>(Eu * D); b->Gang = c.take<float>(A * D);
+  b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D);
+  b->GQ = c.take<float>(Eu * 2 * D);
+  b->Gagg = c.take<float>(Eb * D);
+  b->Grk = c.take<float>(Eu);
+  b->phase = c.take<float>(PHASE_FLOATS);
+  {   // windowed angle adjoints (kernels_angle_w.h)
+    WinIndex& w = b->win;
+    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1);
+    w.head = c.take<int>(Ed); w.rank = c.take<int>(Ed); w.list = c.take<int>(A ? N * WIN_LIST : 0);
+    w.q_a = c.take<int>(A); w.q_ctr = c.take<int>(A); w.q_b1c = c.take<int>(A); w.q_b2c = c.take<int>(A); w.q_ab1 = c.take<int>(A); w.q_ab2 = c.take<int>(A);
+    w.abbond = c.take<int>(2 * Eb);
+    w.wave_head = c.take<int>(A ? WIN_MAX_GRID * WAVES : 0); w.next_atom = c.take<int>(A ? N : 0); w.xatom = c.take<int>(WIN_MAX_GRID / 8 + 1);
+    b->win_tmp = c.take<int>(N + 1);
+    b->win_scan = c.take<int>(scan_scratch_ints((int)N + 1));
+  }
+  if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
+  total = (c.pos + 255) & ~size_t(255);
+}
+
+// Centre-major row order and (atom, bond) pair indices of the angle adjoints (kernels_angle_w.h): once per batch topology,
+// stream-ordered, no host round trip; a graph without the canonical structure leaves win.flag[0] = 0.
+int prepare_windows(chg_engine* eng, chg_batch* b) {
+  hipStream_t st = eng->stream;
+  WinIndex& w = b->win;
+  b->win_built = false;
+  // one workgroup per CU (their LDS admits no second one), in whole groups of 64 waves = 8 workgroups per XCD (k_win_schedule)
+  b->win_grid = std::max(64, std::min(eng->num_cus / 64 * 64, WIN_MAX_GRID));
+  // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle -- plain adjoints, and nothing to build
+  // (CHGNET_WIN_MIN_ATOMS_PER_WAVE=0 sends small batches through the per-atom kernels too: parity tests on the golden cases)
+  const char* min_env = std::getenv("CHGNET_WIN_MIN_ATOMS_PER_WAVE");
+  const long min_atoms = min_env ? std::atol(min_env) : WIN_MIN_ATOMS_PER_WAVE;
+  if (b->A == 0 || (long)b->N < min_atoms * b->win_grid * WAVES) return CHG_OK;
+  if (scan_scratch_ints(b->N + 1) > (size_t)(1u << 17)) return CHG_OK;      // beyond the two-level scan (65,536 chunks): plain adjoints
+  b->win_built = true;
+  HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
+  HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
+  HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+  HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w, b->win_grid);
+  hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
+  TRY(exclusive_scan_with(eng, b->win_scan, w.na, w.boff, b->N + 1));
+  hipLaunchKernelGGL(k_win_counts, g1((int64_t)b->N + 1), dim3(256), 0, st, b->N, w, b->win_tmp);
+  TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
+  hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
+  hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+  hipLaunchKernelGGL(k_win_groups, g1(b->win_grid / 8 + 1), dim3(256), 0, st, b->N, b->A, b->win_grid / 8, w);
+  hipLaunchKernelGGL(k_win_schedule, dim3(b->win_grid / 8), dim3(64), 0, st, b->win_grid, w);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+void register_names(chg_batch* b) {
+  auto& m = b->named;
+  m.clear();
+  const size_t N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb, B = b->B;
+  m["cart"] = {b->cart, 3 * N};
+  m["ev"] = {reinterpret_cast<const float*>(b->ev), 4 * Ed};
+  m["eu"] = {reinterpret_cast<const float*>(b->eu), 4 * Ed};
+  m["hb0"] = {b->hb0, Eu * D}; m["wag"] = {b->wag, Eu * D}; m["wbgc"] = {b->wbgc, Eb * D};
+  for (int l = 0; l <= b->L; ++l) m["atom" + std::to_string(l)] = {b->atom[l], N * D};
+  for (int l = 0; l < b->L; ++l) m["hbc" + std::to_string(l)] = {b->hbc[l], Eb * D};
+  for (int l = 0; l < b->L - 1; ++l) m["ang" + std::to_string(l)] = {b->ang[l], A * D};
+  for (int l = 0; l < b->L; ++l) { m["P" + std::to_string(l)] = {b->Pl[l], N * 4 * D}; m["Q" + std::to_string(l)] = {b->Ql[l], Eu * 2 * D}; }
+  m["agg"] = {b->agg_l[b->L - 1], N * D}; m["aggB"] = {b->aggB_l[0], Eb * D};
+  m["Ga"] = {b->Ga, N * D}; m["GA"] = {b->GA, N * D}; m["Gb"] = {b->Gb, Eu * D}; m["Gwag"] = {b->Gwag, Eu * D};
+  m["Gwbgc"] = {b->Gwbgc, Eb * D}; m["Gang"] = {b->Gang, A * D}; m["GP"] = {b->GP_l[0], N * 4 * D}; m["GQ"] = {b->GQ, Eu * 2 * D};
+  m["GR"] = {b->GR_l[0], Eb * 4 * D}; m["GS"] = {b->GS_l[0], N * 2 * D}; m["Grk"] = {b->Grk, Eu}; m["Gu"] = {b->Gu, 4 * Ed};
+  m["virial"] = {b->virial, 9 * B}; m["volume"] = {b->volume, B}; m["phase"] = {b->phase, PHASE_FLOATS};
+  m["frac"] = {b->frac, 3 * N}; m["lattice"] = {b->lattice, 9 * B}; m["e_image"] = {b->e_image, 3 * Ed};
+  auto& mi = b->named_i32;
+  mi.clear();
+  mi["z"] = {b->z, N}; mi["atom_owner"] = {b->atom_owner, N}; mi["atom_off"] = {b->atom_off, B + 1};
+  mi["e_center"] = {b->e_center, Ed}; mi["e_nbr"] = {b->e_nbr, Ed}; mi["e_d2u"] = {b->e_d2u, Ed}; mi["e_owner"] = {b->e_owner, Ed};
+  mi["e_rev"] = {b->e_rev, Ed}; mi["p_center"] = {b->p_center, Ed}; mi["p_nbr"] = {b->p_nbr, Ed};
+  mi["u_u2d"] = {b->u_u2d, Eu}; mi["u_bnode"] = {b->u_bnode, Eu}; mi["bn_und"] = {b->bn_und, Eb};
+  mi["a_ctr"] = {b->a_ctr, A}; mi["a_b1c"] = {b->a_b1c, A}; mi["a_b2c"] = {b->a_b2c, A}; mi["a_d1"] = {b->a_d1, A}; mi["a_d2"] = {b->a_d2, A};
+  mi["win_flag"] = {b->win.flag, 4}; mi["win_q_a"] = {b->win.q_a, A}; mi["win_q_ctr"] = {b->win.q_ctr, A}; mi["win_na"] = {b->win.na, N + 1};
+  mi["win_aoff"] = {b->win.aoff, N + 1}; mi["win_q_ab1"] = {b->win.q_ab1, A}; mi["win_q_ab2"] = {b->win.q_ab2, A};
+  mi["win_next_atom"] = {b->win.next_atom, A ? N : 0};
+  mi["win_wave_head"] = {b->win.wave_head, A ? (size_t)WIN_MAX_GRID * WAVES : 0}; mi["win_xatom"] = {b->win.xatom, (size_t)WIN_MAX_GRID / 8 + 1};   // win_flag[3] = workgroups
+}
+
+
+// dynamic-LDS attributes (more than the default 64 KiB) of the kernels this unit launches
+int predict_set_lds(chg_engine* eng) {
+  int s;
+  if ((s = set_lds(eng, k_rows_gemm<64, 64>, rows_gemm_lds<64, 64>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<64, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm_pair<64, SMALL_GEMM_COLS>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 2>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 2>())))) return s;
+  if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;
+  if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
+  if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
+  if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
+  if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_angle<false, true>, (angle_lds<false, WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
+  if ((s = set_lds(eng, k_readout<false>, readout_lds()))) return s;
+  if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_embed_t<true>, angle_embed_lds()))) return s;
+  return CHG_OK;
+}
+
+
+}  // namespace chgh

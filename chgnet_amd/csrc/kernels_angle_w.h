@@ -51,9 +51,9 @@ struct WinIndex {             // built by k_win_*; all in the batch arena
 };
 
 // ---- index construction ---------------------------------------------------------------------------------
-__global__ void k_win_init(WinIndex w, int grid) { w.flag[0] = 1; w.flag[3] = grid; }
+static __global__ void k_win_init(WinIndex w, int grid) { w.flag[0] = 1; w.flag[3] = grid; }
 
-__global__ void k_win_heads(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, int A, int Ed, int N, WinIndex w) {
+static __global__ void k_win_heads(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, int A, int Ed, int N, WinIndex w) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= A) return;
   const int d1 = a_d1[a];
@@ -66,14 +66,14 @@ __global__ void k_win_heads(const int* __restrict__ a_d1, const int* __restrict_
   else w.flag[0] = 0;
 }
 
-__global__ void k_win_counts(int N, WinIndex w, int* __restrict__ nang) {   // nang[c] = na (na - 1): rows of atom c
+static __global__ void k_win_counts(int N, WinIndex w, int* __restrict__ nang) {   // nang[c] = na (na - 1): rows of atom c
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > N) return;
   const int n = c < N ? w.na[c] : 0;
   nang[c] = n * (n - 1);
 }
 
-__global__ void k_win_ranks(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, int A, int N,
+static __global__ void k_win_ranks(const int* __restrict__ a_d1, const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, int A, int N,
                             WinIndex w) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= A || w.flag[0] == 0) return;
@@ -89,7 +89,7 @@ __global__ void k_win_ranks(const int* __restrict__ a_d1, const int* __restrict_
   if (n < 2 || last >= A || a_d1[last] != d1 || (last + 1 < A && a_d1[last + 1] == d1)) w.flag[0] = 0;
 }
 
-__global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, const int* __restrict__ a_b2c,
+static __global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __restrict__ a_b1c, const int* __restrict__ a_b2c,
                            const int* __restrict__ a_d1, const int* __restrict__ a_d2, int A, int N, int Ed, WinIndex w) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a == 0 && w.aoff[N] != A) w.flag[0] = 0;     // every atom's angle set must be the complete n (n - 1) block
@@ -122,7 +122,7 @@ __global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __restrict_
 // wave_head[blockIdx * WAVES + wave] -> next_atom[c] -> ... -> -1, so a wave knows its next atom one atom ahead (index prefetch).
 constexpr int WIN_GROUP_WAVES = 64;
 
-__global__ void k_win_groups(int N, int A, int ngroups, WinIndex w) {   // xatom[i] = first atom c with aoff[c + 1] > A i / ngroups
+static __global__ void k_win_groups(int N, int A, int ngroups, WinIndex w) {   // xatom[i] = first atom c with aoff[c + 1] > A i / ngroups
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > ngroups) return;
   if (i == ngroups) { w.xatom[i] = N; return; }
@@ -149,7 +149,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {   // minimum over
 }
 
 // one wave per group; lane = slot of the group = ((blockIdx >> 3) & 7) * WAVES + wave of the kernels that consume the lists
-__global__ __launch_bounds__(64) void k_win_schedule(int grid, WinIndex w) {
+static __global__ __launch_bounds__(64) void k_win_schedule(int grid, WinIndex w) {
   const int gi = blockIdx.x, lane = threadIdx.x;
   const int spx = grid >> 6;                   // groups per XCD
   const int x = gi / spx, sub = gi - x * spx;

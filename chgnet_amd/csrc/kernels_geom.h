@@ -41,7 +41,7 @@ __device__ __forceinline__ float bcast(float v, int src) {
 }
 
 // ---- cartesian coordinates: x = frac @ lattice ------------------------------------------------
-__global__ void k_cart(const float* __restrict__ frac, const float* __restrict__ lattice, const int* __restrict__ owner,
+static __global__ void k_cart(const float* __restrict__ frac, const float* __restrict__ lattice, const int* __restrict__ owner,
                        float* __restrict__ cart, int n_atoms) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
@@ -53,7 +53,7 @@ __global__ void k_cart(const float* __restrict__ frac, const float* __restrict__
 
 // ---- directed bond vectors, lengths and unit vectors ---------------------------------------------
 // ev[e] = (vx, vy, vz, r),  eu[e] = (ux, uy, uz, 0)
-__global__ void k_edge_geom(const float* __restrict__ cart, const float* __restrict__ lattice, const int* __restrict__ e_center,
+static __global__ void k_edge_geom(const float* __restrict__ cart, const float* __restrict__ lattice, const int* __restrict__ e_center,
                             const int* __restrict__ e_nbr, const float* __restrict__ e_image, const int* __restrict__ e_owner,
                             f32x4* __restrict__ ev, f32x4* __restrict__ eu, int n_edges) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void rbf_eval(float r, float rc, float freq, Envelope
 }
 
 // ---- atom embedding ------------------------------------------------------------------------------
-__global__ void k_atom_embed(const int* __restrict__ z, const float* __restrict__ emb, float* __restrict__ out, int n_atoms) {
+static __global__ void k_atom_embed(const int* __restrict__ z, const float* __restrict__ emb, float* __restrict__ out, int n_atoms) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_atoms * (D / 4)) return;
   const int i = idx / (D / 4), q = idx % (D / 4);
@@ -122,7 +122,7 @@ __global__ void k_atom_embed(const int* __restrict__ z, const float* __restrict_
 }
 
 // ---- magmom head: |h . w + b| ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_magmom(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
+static __global__ __launch_bounds__(256) void k_magmom(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
                                                 float* __restrict__ out, int n_atoms) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -162,7 +162,7 @@ struct ForceArgs {
 // sums are formed once per wave over the chunks when they belong to one structure.
 constexpr int EF_IT = 4;    // measured: 2 -> 0.157 ms, 4 -> 0.145, 8 -> 0.190 (one edge per thread: 0.180)
 constexpr int EF_EDGES_PER_BLOCK = 4 * 64 * EF_IT;
-__global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
+static __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
   __shared__ float vir[4][9];
   __shared__ int vown[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,7 +299,7 @@ struct FinalizeArgs {
 // One wave per structure: lane l sums atoms l, l + 64, ... in that order, the lanes meet in a fixed butterfly -- fp64, and the
 // same operation order wherever the structure sits in the batch (one THREAD per structure walked a 256-atom MD cell in 41 us:
 // 256 dependent loads).
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs p) {
+static __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs p) {
   const int lane = threadIdx.x & 63;
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (b >= p.n_struct) return;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_neighbors(NlArgs p) {
 }
 
 // reverse edge of every directed edge by binary search in the neighbour's (nbr, image)-sorted range
-__global__ void k_reverse(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_img,
+static __global__ void k_reverse(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_img,
                           const int* __restrict__ center_off, DevCount n_edges, int* __restrict__ e_rev, int* __restrict__ is_first,
                           int* __restrict__ err) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,7 +267,7 @@ __global__ void k_reverse(const int* __restrict__ e_center, const int* __restric
   is_first[e] = e < found ? 1 : 0;   // undirected index = order of first appearance (create_graph.c:152-189)
 }
 
-__global__ void k_undirected(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_rev,
+static __global__ void k_undirected(const int* __restrict__ e_center, const int* __restrict__ e_nbr, const int* __restrict__ e_rev,
                              const int* __restrict__ is_first, const int* __restrict__ first_scan, DevCount n_edges, int* __restrict__ e_d2u,
                              int* __restrict__ u_u2d, int* __restrict__ p_center, int* __restrict__ p_nbr, const int* __restrict__ overflow) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,7 +282,7 @@ __global__ void k_undirected(const int* __restrict__ e_center, const int* __rest
 
 // per centre: number of edges strictly shorter than the bond-graph cutoff (graph.py:313 uses '<')
 // One wave per atom (a thread per atom walked ~110 edges of dependent loads: 38 us for a 256-atom cell).
-__global__ __launch_bounds__(256) void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
+static __global__ __launch_bounds__(256) void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
                                                      int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow) {
   const int lane = threadIdx.x & 63;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_short_count(const double* __restrict__ 
 }
 
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
-__global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
+static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
                               int* __restrict__ ang_cnt, const int* __restrict__ overflow) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,7 +316,7 @@ __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restri
 // One wave per undirected bond: the other edges of each end are tested 64 at a time and written in edge order (ballot prefix) --
 // the order the serial loop of the reference produces (graph.py:283-327).  (A thread per bond walked up to 2 x ~110 edges: 72 us for
 // a 256-atom cell.)
-__global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
+static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                                                     const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
                                                     const int* __restrict__ ang_off, DevCount n_und, double r_bond, int* __restrict__ a_ctr,
                                                     int* __restrict__ a_b1, int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2,
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict__ u_u2
   if (lane == 0) is_node[k] = 1;
 }
 
-__global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und, int* __restrict__ u_bnode,
+static __global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und, int* __restrict__ u_bnode,
                              int* __restrict__ bn_und, int cap_nodes, int* __restrict__ overflow) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_und.get() || *overflow) return;
@@ -361,7 +361,7 @@ __global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restr
   }
 }
 
-__global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restrict__ a_b2, const int* __restrict__ u_bnode, int n_ang,
+static __global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restrict__ a_b2, const int* __restrict__ u_bnode, int n_ang,
                                 int* __restrict__ a_b1c, int* __restrict__ a_b2c) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_ang) return;
@@ -371,7 +371,7 @@ __global__ void k_angle_compact(const int* __restrict__ a_b1, const int* __restr
 
 // counts of a single-pass build, gathered for one device-to-host copy:
 // {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow, cell-sort overflow}
-__global__ void k_collect_counts(const int* ed, const int* a, const int* eb, const int* flags, int* __restrict__ out) {
+static __global__ void k_collect_counts(const int* ed, const int* a, const int* eb, const int* flags, int* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2]; out[6] = flags[3];
   }
@@ -380,7 +380,7 @@ __global__ void k_collect_counts(const int* ed, const int* a, const int* eb, con
 // Exclusive prefix sum of up to a few hundred thousand ints by ONE workgroup (one launch instead of the three of a
 // device-wide scan, which is what counts for the ~1e4-element arrays of a single-structure build): each thread sums a
 // contiguous chunk, the 1024 chunk sums are scanned through LDS, each thread writes its chunk.
-__global__ __launch_bounds__(1024) void k_small_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
+static __global__ __launch_bounds__(1024) void k_small_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
   __shared__ int wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n + 1023) / 1024;
@@ -415,7 +415,7 @@ __device__ __forceinline__ int block_sum_1024(int v, int* wave_tot) {
   for (int w = 0; w < 16; ++w) t += wave_tot[w];
   return t;
 }
-__global__ __launch_bounds__(1024) void k_scan_totals(const int* __restrict__ in, int* __restrict__ totals, int n) {
+static __global__ __launch_bounds__(1024) void k_scan_totals(const int* __restrict__ in, int* __restrict__ totals, int n) {
   __shared__ int wave_tot[16];
   const int b0 = blockIdx.x * SCAN_CHUNK;
   int s = 0;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_scan_totals(const int* __restrict__ in
   const int t = block_sum_1024(s, wave_tot);
   if (threadIdx.x == 0) totals[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(1024) void k_scan_apply(const int* __restrict__ in, int* __restrict__ out, const int* __restrict__ chunk_off, int n) {
+static __global__ __launch_bounds__(1024) void k_scan_apply(const int* __restrict__ in, int* __restrict__ out, const int* __restrict__ chunk_off, int n) {
   __shared__ int wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int PER = SCAN_CHUNK / 1024;
@@ -452,7 +452,7 @@ struct MultiCopy {
   const void* src[MULTI_COPY_MAX];
   unsigned long long words[MULTI_COPY_MAX];
 };
-__global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
+static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
   const int seg = blockIdx.y;
   const unsigned long long n = m.words[seg];
   const unsigned* __restrict__ src = static_cast<const unsigned*>(m.src[seg]);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
   }
 }
 
-__global__ void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int n) {
+static __global__ void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) dst[t] = (float)src[t];
 }

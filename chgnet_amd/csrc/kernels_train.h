@@ -354,7 +354,7 @@ struct ColsumArgs {
   float* out;
 };
 
-__global__ __launch_bounds__(256) void k_colsum(ColsumArgs p) {
+static __global__ __launch_bounds__(256) void k_colsum(ColsumArgs p) {
   __shared__ float part[256];
   const int tid = threadIdx.x;
   const int c = tid % p.width, grp = tid / p.width, ngrp = 256 / p.width;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_colsum(ColsumArgs p) {
 }
 
 // d emb[z-1] += dE/d atom[0]   (embedding lookup, model.py:432-434)
-__global__ void k_embed_grad(const float* __restrict__ Ga, const int* __restrict__ z, float* __restrict__ gemb, int n_atoms) {
+static __global__ void k_embed_grad(const float* __restrict__ Ga, const int* __restrict__ z, float* __restrict__ gemb, int n_atoms) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_atoms * D) return;
   const int i = idx / D, c = idx - i * D;
@@ -382,7 +382,7 @@ __global__ void k_embed_grad(const float* __restrict__ Ga, const int* __restrict
 // magmom head m_i = |h_i . w + b| (model.py:484-487): given gm_i = d loss / d m_i,
 //   dE/d h_i += gm_i sign(h_i . w + b) w,   d w += sum_i gm_i sign h_i,   d b += sum_i gm_i sign
 // one wave per atom (grid-stride), lane = feature; the weight sums stay in registers until the end.
-__global__ __launch_bounds__(256) void k_magmom_bwd(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
+static __global__ __launch_bounds__(256) void k_magmom_bwd(const float* __restrict__ atom, const float* __restrict__ w, const float* __restrict__ b,
                                                     const float* __restrict__ gm, float* __restrict__ Ga, float* __restrict__ g_w,
                                                     float* __restrict__ g_b, int n_atoms) {
   const int lane = threadIdx.x & 63;

@@ -58,7 +58,7 @@ struct GatherZArgs {
   float *Z, *Zd, *H, *Hd;        // [rows,128]
 };
 
-__global__ __launch_bounds__(256) void k2_gather_z(GatherZArgs p) {
+static __global__ __launch_bounds__(256) void k2_gather_z(GatherZArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int r = wave; r < p.rows; r += nwaves) {
@@ -163,7 +163,7 @@ struct GatedTArgs {
 // Rows are centre-major (edges) / sorted by owning bond (angles): each wave takes a CONTIGUOUS block of rows, keeps what
 // depends only on the run's key in registers (weights of the owning bond) and sends one atomic row per run instead of one
 // per row.
-__global__ __launch_bounds__(256) void k2_gated_t(GatedTArgs p) {
+static __global__ __launch_bounds__(256) void k2_gated_t(GatedTArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const float g1 = p.ln[lane], b1 = p.ln[D + lane], g2 = p.ln[2 * D + lane], b2 = p.ln[3 * D + lane];
@@ -214,7 +214,7 @@ struct GatedBArgs {
   float* g_ln;                           // [4][64] LayerNorm-affine gradients (atomics)
 };
 
-__global__ __launch_bounds__(256) void k2_gated_b(GatedBArgs p) {
+static __global__ __launch_bounds__(256) void k2_gated_b(GatedBArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const float g1 = p.ln[lane], b1 = p.ln[D + lane], g2 = p.ln[2 * D + lane], b2 = p.ln[3 * D + lane];
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k2_gated_b(GatedBArgs p) {
 }
 
 // hidden layer:  bar(z) = silu'(z) bar(H) + silu''(z) zd G(H),   G(z) = silu'(z) G(H)      (elementwise over [rows,128])
-__global__ void k2_hidden_b(const float* __restrict__ Z, const float* __restrict__ Zd, const float* __restrict__ BH,
+static __global__ void k2_hidden_b(const float* __restrict__ Z, const float* __restrict__ Zd, const float* __restrict__ BH,
                             const float* __restrict__ GH, float* __restrict__ BZ, float* __restrict__ GZ, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -310,7 +310,7 @@ struct ScatterZArgs {
 constexpr int SZ_TS = 2 * D + PAD;
 constexpr size_t scatter_z_lds() { return sizeof(float) * 4 * 2 * TILE_ROWS * SZ_TS; }
 
-__global__ __launch_bounds__(256) void k2_scatter_z(ScatterZArgs p) {
+static __global__ __launch_bounds__(256) void k2_scatter_z(ScatterZArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* TB = smem + wv * 2 * TILE_ROWS * SZ_TS;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k2_scatter_z(ScatterZArgs p) {
 // geometry: tangent of the bond vectors
 // ---------------------------------------------------------------------------------------------------------
 // vd_e = ux[c] - ux[n] + v_e W_b;  rd = u . vd;  ud = (vd - u rd) / r          out: vd4 = (vd, rd), ud4 = (ud, 0)
-__global__ void k2_geom_t(const f32x4* __restrict__ ev, const f32x4* __restrict__ eu, const int* __restrict__ e_center,
+static __global__ void k2_geom_t(const f32x4* __restrict__ ev, const f32x4* __restrict__ eu, const int* __restrict__ e_center,
                           const int* __restrict__ e_nbr, const int* __restrict__ e_owner, const float* __restrict__ ux,
                           const float* __restrict__ Wst, f32x4* __restrict__ vd4, f32x4* __restrict__ ud4, int n_edges) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,7 +396,7 @@ struct BondBasisArgs {
   float *X6, *X6d, *X3, *X3d;     // [Eu,32]: basis and tangent (column 31 = 0)
 };
 
-__global__ void k2_bond_basis(BondBasisArgs p) {
+static __global__ void k2_bond_basis(BondBasisArgs p) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = t / KB2, j = t % KB2;
   if (k >= p.n_und) return;
@@ -411,7 +411,7 @@ __global__ void k2_bond_basis(BondBasisArgs p) {
 }
 
 // out[row][f] = sum_j W[f][j] X[row][j]  (W [64][31] row-major, X [rows][32]); optional output row map
-__global__ __launch_bounds__(256) void k2_embed_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void k2_embed_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ out,
                                                     const int* __restrict__ in_rows, int rows) {
   __shared__ float Ws[D * NRAD];
   for (int i = threadIdx.x; i < D * NRAD; i += blockDim.x) Ws[i] = W[i];
@@ -443,7 +443,7 @@ struct FreqGradArgs {
   float* g_freq;                  // [31]
 };
 
-__global__ __launch_bounds__(256) void k2_freq_grad(FreqGradArgs p) {
+static __global__ __launch_bounds__(256) void k2_freq_grad(FreqGradArgs p) {
   __shared__ float WAs[D * NRAD], WBs[D * NRAD];
   for (int i = threadIdx.x; i < D * NRAD; i += blockDim.x) {
     WAs[i] = p.WA[i];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k2_freq_grad(FreqGradArgs p) {
 }
 
 // Fourier basis of every angle with tangent:  X [A,32], Xd [A,32];  also theta and thetadot (for the frequency gradient)
-__global__ void k2_angle_basis(const f32x4* __restrict__ eu, const f32x4* __restrict__ ud4, const int* __restrict__ a_d1,
+static __global__ void k2_angle_basis(const f32x4* __restrict__ eu, const f32x4* __restrict__ ud4, const int* __restrict__ a_d1,
                                const int* __restrict__ a_d2, const float* __restrict__ freq, float* __restrict__ X, float* __restrict__ Xd,
                                float* __restrict__ th2, int n_angles) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -505,7 +505,7 @@ __global__ void k2_angle_basis(const f32x4* __restrict__ eu, const f32x4* __rest
 }
 
 // d g_q += sum_a [ bar(four) d four/dg + G(four) d2 four/(d theta dg) thetadot ],  bar(four) = bar(ang0) Wae
-__global__ __launch_bounds__(256) void k2_angle_freq_grad(const float* __restrict__ bar_ang, const float* __restrict__ g_ang,
+static __global__ __launch_bounds__(256) void k2_angle_freq_grad(const float* __restrict__ bar_ang, const float* __restrict__ g_ang,
                                                           const float* __restrict__ Wae, const float* __restrict__ th2,
                                                           const float* __restrict__ freq, float* __restrict__ g_freq, int n_angles) {
   __shared__ float Ws[D * NANG];
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k2_angle_freq_grad(const float* __restric
 // readout: LayerNorm and the three silu layers, tangent forward and two-adjoint backward (rows = atoms, width 64)
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm forward with tangent:  y = gamma xhat + beta,  yd = gamma xhatd;  keeps xhat, xhatd, rstd (per row in R[3*row..])
-__global__ __launch_bounds__(256) void k2_ln_t(const float* __restrict__ x, const float* __restrict__ xd, const float* __restrict__ gamma,
+static __global__ __launch_bounds__(256) void k2_ln_t(const float* __restrict__ x, const float* __restrict__ xd, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ yd,
                                                float* __restrict__ xh, float* __restrict__ xhd, int rows) {
   const int lane = threadIdx.x & 63;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k2_ln_t(const float* __restrict__ x, cons
 }
 
 // bar(y), G(y) -> bar(x), G(x) through the LayerNorm; dgam / dbet rows are written for a later column sum
-__global__ __launch_bounds__(256) void k2_ln_b(const float* __restrict__ x, const float* __restrict__ xd, const float* __restrict__ gamma,
+static __global__ __launch_bounds__(256) void k2_ln_b(const float* __restrict__ x, const float* __restrict__ xd, const float* __restrict__ gamma,
                                                const float* __restrict__ bar_y, const float* __restrict__ g_y, float* __restrict__ bar_x,
                                                float* __restrict__ g_x, float* __restrict__ dgam, float* __restrict__ dbet, int rows) {
   const int lane = threadIdx.x & 63;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void k2_ln_b(const float* __restrict__ x, cons
 }
 
 // s = silu(l), sd = silu'(l) ld
-__global__ void k2_silu_t(const float* __restrict__ l, const float* __restrict__ ld, float* __restrict__ s, float* __restrict__ sd, size_t n) {
+static __global__ void k2_silu_t(const float* __restrict__ l, const float* __restrict__ ld, float* __restrict__ s, float* __restrict__ sd, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   s[i] = siluf_(l[i]);
@@ -588,7 +588,7 @@ __global__ void k2_silu_t(const float* __restrict__ l, const float* __restrict__
 }
 
 // seeds of the reverse sweep at the site energies:  bar(s3) = cot[owner] w3,  G(s3) = w3;  also d w3 rows = cot s3 + s3d
-__global__ void k2_readout_seed(const float* __restrict__ w3, const float* __restrict__ cot, const int* __restrict__ owner,
+static __global__ void k2_readout_seed(const float* __restrict__ w3, const float* __restrict__ cot, const int* __restrict__ owner,
                                 const float* __restrict__ s3, const float* __restrict__ s3d, float* __restrict__ bar_s,
                                 float* __restrict__ g_s, float* __restrict__ dw3_rows, int n_atoms) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,7 +601,7 @@ __global__ void k2_readout_seed(const float* __restrict__ w3, const float* __res
 }
 
 // out[i] = a[i] + b[i]   /   magmom head handled by k_magmom_bwd (kernels_train.h)
-__global__ void k2_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+static __global__ void k2_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
 }
