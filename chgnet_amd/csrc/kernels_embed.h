@@ -88,17 +88,18 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
     const float rlen = p.ev[p.u_u2d[k]][3];
     const int node = p.u_bnode[k];
     f32x4 x6[2], x3[2], d6[2], d3[2], q6[2], q3[2];
+    const EnvAt e6 = env_at(rlen, p.rc_ag, p.env), e3 = env_at(rlen, p.rc_bg, p.env);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool pad = 16 * kt + 4 * g + r >= NRAD;
         float v, dv, df;
-        rbf_eval(rlen, p.rc_ag, f6[kt][r], p.env, v, dv, df);
+        rbf_eval(rlen, p.rc_ag, f6[kt][r], e6, v, dv, df);
         x6[kt][r] = pad ? 0.f : v;
         d6[kt][r] = pad ? 0.f : dv;
         q6[kt][r] = pad ? 0.f : df;
-        rbf_eval(rlen, p.rc_bg, f3[kt][r], p.env, v, dv, df);
+        rbf_eval(rlen, p.rc_bg, f3[kt][r], e3, v, dv, df);
         x3[kt][r] = pad ? 0.f : v;
         d3[kt][r] = pad ? 0.f : dv;
         q3[kt][r] = pad ? 0.f : df;
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
     for (int r = 0; r < 4; ++r) {
       const int ks = 4 * g + r;
       float sn, cs;
-      sincosf(fs[r] * theta, &sn, &cs);
+      sincos_cw(fs[r] * theta, sn, cs);
       x[0][r] = ks == 0 ? INV_SQRT_2 * INV_SQRT_PI : sn * INV_SQRT_PI;
       dx[0][r] = ks == 0 ? 0.f : fs[r] * cs * INV_SQRT_PI;
-      sincosf(fc[r] * theta, &sn, &cs);
+      sincos_cw(fc[r] * theta, sn, cs);
       x[1][r] = ks < NFREQ ? cs * INV_SQRT_PI : 0.f;
       dx[1][r] = ks < NFREQ ? -fc[r] * sn * INV_SQRT_PI : 0.f;
     }

@@ -370,7 +370,7 @@ static __global__ void k2_geom_t(const f32x4* __restrict__ ev, const f32x4* __re
 __device__ __forceinline__ void rbf_all(float r, float rc, float freq, Envelope env, float& val, float& dr, float& df, float& drdf) {
   const float inv_rc = 1.0f / rc, w = freq * inv_rc, cn = sqrtf(2.0f * inv_rc);
   float sn, cs;
-  sincosf(w * r, &sn, &cs);
+  sincos_cw(w * r, sn, cs);
   const float s = r * inv_rc;
   float e = 0.f, de = 0.f;
   if (s < 1.0f) {
@@ -492,11 +492,11 @@ static __global__ void k2_angle_basis(const f32x4* __restrict__ eu, const f32x4*
     x = INV_SQRT_2 * INV_SQRT_PI;
   } else if (j <= NFREQ) {
     float sn, cs;
-    sincosf(freq[j - 1] * theta, &sn, &cs);
+    sincos_cw(freq[j - 1] * theta, sn, cs);
     x = sn * INV_SQRT_PI; dx = freq[j - 1] * cs * INV_SQRT_PI;
   } else if (j < NANG) {
     float sn, cs;
-    sincosf(freq[j - 1 - NFREQ] * theta, &sn, &cs);
+    sincos_cw(freq[j - 1 - NFREQ] * theta, sn, cs);
     x = cs * INV_SQRT_PI; dx = -freq[j - 1 - NFREQ] * sn * INV_SQRT_PI;
   }
   X[t] = x;
@@ -529,7 +529,7 @@ static __global__ __launch_bounds__(256) void k2_angle_freq_grad(const float* __
     }
     const float theta = th2[2 * a], thd = th2[2 * a + 1];
     float sn, cs;
-    sincosf(gq * theta, &sn, &cs);
+    sincos_cw(gq * theta, sn, cs);
     if (is_sin) acc += (bar_x * theta * cs + g_x * (cs - gq * theta * sn) * thd) * INV_SQRT_PI;
     if (is_cos) acc += (-bar_x * theta * sn + g_x * (-sn - gq * theta * cs) * thd) * INV_SQRT_PI;
   }
