@@ -249,12 +249,26 @@ __device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
   }
   constexpr int KS = K + PAD, KT = K / 16, NFT = NOUT / 16;
   constexpr int XS = (K > NOUT ? K : NOUT) + PAD;  // tile stride: holds X (K wide) then Y (NOUT wide)
-  float* W = smem;                          // [PARTS][NOUT][KS]
+  // Full-width instances (NOUT a multiple of 64) contract in the split form of the tile kernels (mfma_split.h: 3 f16 MFMAs per f32
+  // product on hi / lo halves, every row scaled by a power of two first -- exact, any magnitude, so gradient rows of 1e-7 and feature
+  // rows of 1e3 alike keep 22 bits): the f32 MFMA kept the matrix pipe of these HBM-streaming GEMMs 45 % busy (gemm_GQ: 29 GFLOP per
+  // launch = 0.18 of its 0.41 ms).  The 16-column instances of the small-batch form keep the f32 MFMA.
+  constexpr bool SPLIT = NOUT % 64 == 0;
+  float* W = smem;                          // [PARTS][NOUT][KS]  (SPLIT: [PARTS] split images at the same offsets)
   float* bias = W + PARTS * NOUT * KS;      // [NOUT]
   float* tiles = bias + NOUT;               // [WAVES][16][XS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_weights(W, p.Wt, NOUT, K, tid);
-  if (PARTS == 2) stage_weights(W + NOUT * KS, p.Wt2, NOUT, K, tid);
+  if constexpr (SPLIT) {
+    stage_split<false>(reinterpret_cast<h16x8*>(W), p.Wt, NOUT, K, tid, BLOCK);
+    if (PARTS == 2) stage_split<false>(reinterpret_cast<h16x8*>(W + NOUT * KS), p.Wt2, NOUT, K, tid, BLOCK);
+  } else {
+    stage_weights(W, p.Wt, NOUT, K, tid);
+    if (PARTS == 2) stage_weights(W + NOUT * KS, p.Wt2, NOUT, K, tid);
+  }
+  auto contract = [&](f32x4 (&acc)[NFT], int part, const f32x4 (&x)[KT]) {
+    if constexpr (SPLIT) gemm_split<KT, NFT, true>(acc, reinterpret_cast<const h16x8*>(W + part * NOUT * KS), NOUT, x, j, g);
+    else gemm_dl<KT, NFT>(acc, W + part * NOUT * KS, KS, x, j, g);
+  };
   for (int idx = tid; idx < NOUT; idx += BLOCK) bias[idx] = p.bias ? p.bias[idx] : 0.f;
   __syncthreads();
   float* T = tiles + wave * TILE_ROWS * XS;
@@ -319,7 +333,7 @@ __device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
       }
       f32x4 acc[NFT];
       read_dl<NFT>(bias, g, acc);
-      gemm_dl<KT, NFT>(acc, W, KS, x, j, g);
+      contract(acc, 0, x);
       write_dl<NFT>(T + j * XS, g, acc);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -369,7 +383,7 @@ __device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) acc[ft] = zero4();
       }
-      gemm_dl<KT, NFT>(acc, W + part * NOUT * KS, KS, x, j, g);
+      contract(acc, part, x);
       if (part == PARTS - 1 || !split_in) {
         write_dl<NFT>(T + j * XS, g, acc);
         __builtin_amdgcn_wave_barrier();

@@ -104,9 +104,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         V64 zd, h, hd;
         read_dl<VT>(Trow, g, zd.t);
         hidden_t(zc, zd, h, hd, d1c, ec);
-#ifndef CHG_EXP_T2_NO_DUMP
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
-#endif
         cc = param64(vecs + 0 * D, g);
         cdc = zero64();
         gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane);
@@ -116,9 +114,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         V64 zd, h, hd;
         read_dl<VT>(Trow + D, g, zd.t);
         hidden_t(zg, zd, h, hd, d1g, eg);
-#ifndef CHG_EXP_T2_NO_DUMP
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
-#endif
         cg = param64(vecs + 1 * D, g);
         cdg = zero64();
         gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane);
@@ -180,11 +176,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
             const float bar_a = d ? in.ba1 : in.ba0, g_a = d ? in.ga1 : in.ga0;
             pair_bw += s.y * bar_a + s.yd * g_a;
             float bar_c, bar_g, g_c, g_g;
-#ifdef CHG_EXP_T2_NO_ROWBWD
-            bar_c = s.y; bar_g = s.yd; g_c = s.a1; g_g = s.a2;
-#else
             gated_row_bwd(s, in.w * bar_a + in.wd * g_a, in.w * g_a, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
-#endif
             a[0] = bar_c; a[D] = bar_g; a[2 * D] = g_c; a[3 * D] = g_g;
           }
         }
@@ -208,11 +200,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
       continue;
     }
     // cc | cg = bar(c | g), cdc | cdg = G(c | g)
-#ifdef CHG_EXP_T2_NO_DUMP
-    if (false) {
-#else
     if (j < nvalid) {               // A operands of dW2 (column sums of bar(c|g) = d b2)
-#endif
       float* brow = p.BCG + (size_t)(row0 + j) * 2 * D;
       float* grow = p.GCG + (size_t)(row0 + j) * 2 * D;
       write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
@@ -245,9 +233,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     AtomConvArgs sc{};
     __builtin_amdgcn_wave_barrier();
     sc.GP = p.barP; sc.GQ = p.barQ;
-#ifndef CHG_EXP_T2_NO_SCATTER
     acbwd_scatter(T, c, nvalid, k0, sc, lane);
-#endif
     __builtin_amdgcn_wave_barrier();
     // G side: G(P) is the first-order adjoint the force sweep of chg_predict left in GP_l[l] -- only the Q rows are formed here
     write_dl<VT>(Trow, g, cdc.t);
@@ -441,9 +427,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           } else {
             acc_bw += s.y * in.w2 * bar_a + (s.yd * in.w2 + s.y * in.w2d) * g_a;
             const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane;
-#ifndef CHG_EXP_T2_NO_ROWATOM
             atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
-#endif
             bar_y = w1 * in.w2 * bar_a + (w1d * in.w2 + w1 * in.w2d) * g_a;
             g_y = w1 * in.w2 * g_a;
           }
@@ -455,11 +439,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         }
         if (REVERSE) {
           float bar_c, bar_g, g_c, g_g;
-#ifdef CHG_EXP_T2_NO_ROWBWD
-          bar_c = s.y + bar_y; bar_g = s.yd + g_y; g_c = s.a1; g_g = s.a2;
-#else
           gated_row_bwd(s, bar_y, g_y, ln_g1, ln_g2, lnacc, bar_c, bar_g, g_c, g_g);
-#endif
           a[0] = bar_c; a[D] = bar_g; a[2 * D] = g_c; a[3 * D] = g_g;
         }
       }
@@ -511,11 +491,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
     }
     // cc | cg = bar(z), cdc | cdg = G(z)
-#ifdef CHG_EXP_T2_NO_DUMP
-    if (false) {
-#else
     if (j < nvalid) {                 // A operands of the W_ang gradient
-#endif
       float* brow = p.BZ + (size_t)(row0 + j) * 2 * D;
       float* grow = p.GZ + (size_t)(row0 + j) * 2 * D;
       write_dl<VT>(brow, g, cc.t); write_dl<VT>(brow + D, g, cg.t);
@@ -539,9 +515,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     write_dl<VT>(Trow + D, g, cg.t);
     __builtin_amdgcn_wave_barrier();
     seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane);
-#ifndef CHG_EXP_T2_NO_ROWATOM
     row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane);
-#endif
     seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane);
     __builtin_amdgcn_wave_barrier();
     // ---- G: only the angle features (an input of the earlier layers); G(R), G(S) are the first-order table adjoints ----

@@ -24,15 +24,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Timing-experiment switches (several of them compute WRONG results on purpose: dropped atomics, stores
-// instead of adds).  None may be set in a product build: every one requires -DCHG_EXPERIMENTS next to
-// it (chgnet_amd/build.py:build_variant adds it; tests/test_abi.py checks that HIP_FLAGS define none).
-#if !defined(CHG_EXPERIMENTS) &&                                                                                  \
-    (defined(CHG_EXP_ATOMIC_AS_STORE) || defined(CHG_EXP_GEMM_T_PLAIN) || defined(CHG_EXP_HALF_ROW_ATOMICS) ||     \
-     defined(CHG_EXP_NO_GATHER) || defined(CHG_EXP_NO_ROW_ATOMICS) || defined(CHG_EXP_NO_SEG_ATOMICS) ||           \
-     defined(CHG_EXP_NO_WAVES_ATTR) || defined(CHG_EXP_QUAD_SHFL) || defined(CHG_EXP_QUARTER_MFMA) || defined(CHG_PHASE_TIMING) ||   \
-     defined(CHG_EXP_T2_NO_DUMP) || defined(CHG_EXP_T2_NO_SCATTER) || defined(CHG_EXP_T2_NO_ROWBWD) || defined(CHG_EXP_T2_NO_ROWATOM))
-#error "CHG_EXP_* / CHG_PHASE_TIMING are timing experiments: define CHG_EXPERIMENTS as well (never in a product build)"
+// The one diagnostic build switch left: -DCHG_PHASE_TIMING (s_memtime stamps between the phases of the angle kernels, right results,
+// slower).  It needs -DCHG_EXPERIMENTS next to it (chgnet_amd/build.py:build_variant adds it; tests/test_abi.py checks that the product
+// flags define neither).  The wrong-result timing switches of rounds 1-3 (dropped atomics, a quarter of the MFMAs, ...) are gone from the
+// sources; what they measured is in profiles/r01_sq_counters.md, r02_experiments.md, r03_experiments.md.
+#if defined(CHG_PHASE_TIMING) && !defined(CHG_EXPERIMENTS)
+#error "CHG_PHASE_TIMING is a diagnostic build: define CHG_EXPERIMENTS as well (never in a product build)"
 #endif
 
 namespace chg {
@@ -48,11 +45,7 @@ constexpr int PAD = 4;           // floats of padding per LDS row: keeps 16-B al
                                  // ds_read_b128 of consecutive rows over the banks (row stride = 4 mod 64)
 constexpr int VT = 4;            // 16-feature tiles per 64 features
 constexpr float LN_EPS = 1e-5f;
-#ifdef CHG_EXP_QUARTER_MFMA     // timing experiment only (wrong results): one MFMA of four, what a 4x faster matrix pipe would leave
-constexpr int MFMA_R = 1;
-#else
 constexpr int MFMA_R = 4;
-#endif
 
 struct V64 { f32x4 t[VT]; };     // 64 features of one row, this lane's share (16 floats)
 
@@ -151,16 +144,6 @@ __device__ __forceinline__ void gemm_t_touch(float (&a)[4][NFT]) {
 }
 template <int KT, int NFT>
 __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int ws, const f32x4 (&x)[KT], int i, int g) {
-#ifdef CHG_EXP_GEMM_T_PLAIN
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* wrow = W + dfeat(kt, r, g) * ws + i;
-#pragma unroll
-      for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * fo], x[kt][r], acc[fo], 0, 0, 0);
-    }
-#else
   float a[2][4][NFT];
   gemm_t_load<NFT>(a[0], W, ws, 0, i, g);
 #pragma unroll
@@ -172,7 +155,6 @@ __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int
 #pragma unroll
       for (int fo = 0; fo < NFT; ++fo) acc[fo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt & 1][r][fo], x[kt][r], acc[fo], 0, 0, 0);
   }
-#endif
 }
 
 // ---- LayerNorm over the 64 features of a row (spread over 4 lanes) ------------------------------
@@ -180,19 +162,14 @@ __device__ __forceinline__ void gemm_dl_t(f32x4 (&acc)[NFT], const float* W, int
 // them.  gfx950's row swaps do it in the VALU: v_permlane16_swap exchanges the odd rows of one operand
 // with the even rows of the other (both copies of v: a + b = row0+row1 | row2+row3), v_permlane32_swap
 // the upper half of one with the lower half of the other.  Two ds_bpermute round trips through the LDS
-// crossbar before (CHG_EXP_QUAD_SHFL keeps that form for A/B).
+// crossbar before.
 __device__ __forceinline__ float quad_sum(float v) {
-#ifdef CHG_EXP_QUAD_SHFL
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
-#else
   const unsigned u = __float_as_uint(v);
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   const unsigned w = __float_as_uint(s);
   const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-#endif
 }
 
 // in: c (pre-norm).  out: c <- xhat, returns rstd.
@@ -321,20 +298,11 @@ __device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) {
 // The tile kernels run 8 waves per CU (LDS-limited), i.e. two per SIMD, whatever their register count:
 // telling the compiler lets its scheduler spend the 256-register budget on overlap instead of
 // trading instruction-level parallelism for an occupancy it cannot have.
-#ifdef CHG_EXP_NO_WAVES_ATTR
-#define CHG_TWO_WAVES
-#else
 #define CHG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
 
-// fp32 add to global memory (global_atomic_add_f32, no return).  CHG_EXP_ATOMIC_AS_STORE: timing
-// experiment only (same addresses and instruction count as plain stores; wrong results).
+// fp32 add to global memory (global_atomic_add_f32, no return: -munsafe-fp-atomics, no CAS loop)
 __device__ __forceinline__ void tile_atomic_add(float* p, float v) {
-#ifdef CHG_EXP_ATOMIC_AS_STORE
-  *p = v;
-#else
   atomicAdd(p, v);
-#endif
 }
 
 // ---- segmented reductions over the rows of a wave tile -----------------------------------------
@@ -344,9 +312,6 @@ __device__ __forceinline__ void tile_atomic_add(float* p, float v) {
 template <int W>
 __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride, int key, int nvalid, float* __restrict__ dst,
                                                   int ldd, int lane) {
-#ifdef CHG_EXP_NO_SEG_ATOMICS   // timing experiment only: wrong results
-  return;
-#endif
   constexpr int NC = W / 64;
   float acc[NC];
 #pragma unroll
@@ -377,17 +342,10 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
 template <int W>
 __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, int key, int nvalid, float* __restrict__ dst,
                                                int ldd, int lane) {
-#ifdef CHG_EXP_NO_ROW_ATOMICS   // timing experiment only: wrong results
-  return;
-#endif
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr) {
     const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
-#ifdef CHG_EXP_HALF_ROW_ATOMICS   // timing experiment only (wrong results): every other row is dropped
-    if (kk >= 0 && (rr & 1) == 0) {
-#else
     if (kk >= 0) {
-#endif
 #pragma unroll
       for (int c = 0; c < W / 64; ++c) tile_atomic_add(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
     }
@@ -409,11 +367,7 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
     const int rr = 2 * it + hw;
-#ifdef CHG_EXP_NO_GATHER        // timing experiment only: every row reads table row 0 (cache-resident)
-    r0[it] = r1[it] = r2[it] = 0;
-#else
     r0[it] = __shfl(i0, rr); r1[it] = __shfl(i1, rr); r2[it] = __shfl(i2, rr);
-#endif
   }
   f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
 #pragma unroll

@@ -6,6 +6,6 @@ for rep in 1 2; do
 for v in ${AB_VARIANTS:-_prev cur}; do
   [ "$v" = "cur" ] && v=""
   echo "=== lib$v (rep $rep)" | tee -a $O/ab.log
-  CHGNET_HIP_LIB=$R/chgnet_amd/lib/libchgnet_hip$v.so timeout 200 python tools/gpu_kernel_probe.py 1024 2>&1 | grep -E "conv_|angleupd_|embed|steady" | tee -a $O/ab.log
+  CHGNET_HIP_LIB=$R/chgnet_amd/lib/libchgnet_hip$v.so timeout 200 python tools/gpu_kernel_probe.py 1024 2>&1 | grep -E "conv_|angleupd_|embed|gemm|steady" | tee -a $O/ab.log
 done
 done
