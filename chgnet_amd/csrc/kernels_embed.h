@@ -15,6 +15,7 @@
 
 #include "kernels_geom.h"
 #include "mfma_tile.h"
+#include "mfma_split.h"
 
 namespace chg {
 
@@ -27,6 +28,26 @@ __device__ __forceinline__ void stage_embed_weight(float* dst, const float* __re
   for (int idx = tid; idx < D * KB; idx += BLOCK) {
     const int f = idx / KB, k = idx - f * KB;
     dst[f * WSB + k] = k < NRAD ? src[f * NRAD + k] : 0.f;
+  }
+}
+
+// the same matrix as a split-precision image (mfma_split.h, K = 32 = one k-step): the forward kernels contract the 31 -> 64 embeddings
+// as three f16 MFMAs per product (rows scaled by a power of two) instead of f32 MFMAs at the vector rate -- 96 x 32 matrix-pipe cycles
+// per tile of 16 bonds were a third of the bond embedding kernel once its sin / cos were cheap
+__device__ __forceinline__ void stage_embed_split(h16x8* img, const float* __restrict__ src, int tid) {
+  constexpr int NCH = 4 * D;                        // chunks per plane: [g][f]
+  for (int c = tid; c < NCH; c += BLOCK) {
+    const int f = c % D, g = c / D;
+    h16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * (e >> 2) + 4 * g + (e & 3);
+      const float w = k < NRAD ? src[f * NRAD + k] : 0.f;
+      hi[e] = (_Float16)w;
+      lo[e] = (_Float16)((w - (float)hi[e]) * LO_SCALE);
+    }
+    img[c] = hi;
+    img[NCH + c] = lo;
   }
 }
 
@@ -59,9 +80,15 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   float* Wb = Wa + D * WSB;
   float* tiles = Wb + D * WSB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_embed_weight(We, p.w_emb, tid);
-  stage_embed_weight(Wa, p.w_ag, tid);
-  stage_embed_weight(Wb, p.w_bg, tid);
+  if (BWD) {
+    stage_embed_weight(We, p.w_emb, tid);
+    stage_embed_weight(Wa, p.w_ag, tid);
+    stage_embed_weight(Wb, p.w_bg, tid);
+  } else {   // forward: split images in the same slots (2,048 of the 2,304 floats)
+    stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
+    stage_embed_split(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
+    stage_embed_split(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
+  }
   // this lane's 8 basis indices k = 16*kt + 4*g + r and their frequencies (k = 31 is padding)
   float f6[2][4], f3[2][4];
 #pragma unroll
@@ -110,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
     }
     if (!BWD) {
       V64 h = zero64();
-      gemm_dl<2, VT>(h.t, We, WSB, x6, j, g);
+      gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(We), D, x6, j, g);
       write_dl<VT>(Trow, g, h.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, ETS, p.hb0, k, nvalid, lane);
@@ -126,14 +153,14 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
       }
       __builtin_amdgcn_wave_barrier();
       h = zero64();
-      gemm_dl<2, VT>(h.t, Wa, WSB, x6, j, g);
+      gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(Wa), D, x6, j, g);
       write_dl<VT>(Trow, g, h.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, ETS, p.wag, k, nvalid, lane);
       __builtin_amdgcn_wave_barrier();
       if (__any(valid && node >= 0)) {
         h = zero64();
-        gemm_dl<2, VT>(h.t, Wb, WSB, x3, j, g);
+        gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(Wb), D, x3, j, g);
         write_dl<VT>(Trow, g, h.t);
         __builtin_amdgcn_wave_barrier();
         // rows that are bond-graph nodes go to their compact slot; others are dropped
@@ -227,7 +254,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
   float* We = smem;
   float* tiles = We + D * WSB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  stage_embed_weight(We, p.w_emb, tid);
+  if (BWD) stage_embed_weight(We, p.w_emb, tid);
+  else stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
   // basis index k = 16*kt + 4*g + r:  k = 0 const, 1..15 sin(f_{k-1} t), 16..30 cos(f_{k-16} t), 31 padding
   float fs[4], fc[4];
 #pragma unroll
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
     }
     if (!BWD) {
       V64 h = zero64();
-      gemm_dl<2, VT>(h.t, We, WSB, x, j, g);
+      gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(We), D, x, j, g);
       write_dl<VT>(Trow, g, h.t);
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, ETS, p.ang0, a, nvalid, lane);
