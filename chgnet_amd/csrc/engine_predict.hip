@@ -427,6 +427,11 @@ AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b) {
   return a;
 }
 
+static int embed_grid_mult() {
+  static const int m = [] { const char* e = std::getenv("CHGNET_EMBED_GRID_MULT"); return e ? std::atoi(e) : 2; }();
+  return m;
+}
+
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   const Weights& w = eng->w;
   const int L = b->L;
@@ -448,7 +453,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   }
   if (b->A > 0) {
     LaunchScope ls(eng, "angle_embed_fwd");
-    hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
+    hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
   }
   { LaunchScope ls(eng, "atom_embed");
     hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
@@ -500,7 +505,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
         hipLaunchKernelGGL((k_bond_embed_t<true>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
       if (b->A > 0) {
         LaunchScope ls(eng, "angle_embed_bwd");
-        hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, 2 * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
+        hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
       }
       ForceArgs f{};
       f.ev = b->ev; f.eu = b->eu; f.Gu = b->Gu; f.Grk = b->Grk;

@@ -19,6 +19,10 @@
 
 namespace chg {
 
+#ifndef CHG_EMBED_WAVES
+#define CHG_EMBED_WAVES CHG_TWO_WAVES
+#endif
+
 constexpr int KB = 32;            // basis count padded to a multiple of 16
 constexpr int WSB = KB + PAD;     // LDS row stride of a [64][32] embedding weight
 constexpr int ETS = D + PAD;      // LDS tile row stride (64-wide rows)
@@ -248,7 +252,7 @@ struct AngleEmbedTArgs {
 constexpr size_t angle_embed_lds() { return sizeof(float) * (D * WSB + WAVES * TILE_ROWS * ETS); }
 
 template <bool BWD, bool TRAIN = false>
-__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
+__global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
@@ -345,10 +349,24 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_embed_t(AngleEmbe
         for (int r = 0; r < 4; ++r) gtheta += t[kt][r] * dx[kt][r];
       gtheta = quad_sum(gtheta);
       const float gcos = -gtheta / sqrtf(1.0f - cosv * cosv) * KAPPA;
-      if (valid && g < 3) {   // lane g handles cartesian component g of this row
-        atomicAdd(p.Gu + 4 * (size_t)d1 + g, gcos * u2[g]);
+      // lane g handles cartesian component g of this row.  The rows arrive sorted by their first bond (graph.py:283-327: runs of
+      // n - 1 angles share d1): the first-bond terms leave as ONE atomic per run and tile, not one per angle -- these scattered
+      // 4-byte atomics execute at the memory side (~19 G requests/s chip-wide) and were what bounded this kernel (12.8 M requests in
+      // 0.79 ms); the second bonds of a run are all different and keep their per-angle atomics.
+      __builtin_amdgcn_wave_barrier();
+      if (g < 3) T[4 * j + g] = valid ? gcos * u2[g] : 0.f;
+      if (g == 3) reinterpret_cast<int*>(T)[4 * j + 3] = valid ? d1 : -1;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && g < 3) {
+        const int* keys = reinterpret_cast<const int*>(T);
+        if (j == 0 || keys[4 * (j - 1) + 3] != d1) {        // head of a run: sum it
+          float run = 0.f;
+          for (int r = j; r < nvalid && keys[4 * r + 3] == d1; ++r) run += T[4 * r + g];
+          atomicAdd(p.Gu + 4 * (size_t)d1 + g, run);
+        }
         atomicAdd(p.Gu + 4 * (size_t)d2 + g, gcos * u1[g]);
       }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (TRAIN) {
