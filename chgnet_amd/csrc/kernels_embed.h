@@ -27,15 +27,7 @@ constexpr int KB = 32;            // basis count padded to a multiple of 16
 constexpr int WSB = KB + PAD;     // LDS row stride of a [64][32] embedding weight
 constexpr int ETS = D + PAD;      // LDS tile row stride (64-wide rows)
 
-// [64][31] global -> [64][WSB] LDS, column 31 zero
-__device__ __forceinline__ void stage_embed_weight(float* dst, const float* __restrict__ src, int tid) {
-  for (int idx = tid; idx < D * KB; idx += BLOCK) {
-    const int f = idx / KB, k = idx - f * KB;
-    dst[f * WSB + k] = k < NRAD ? src[f * NRAD + k] : 0.f;
-  }
-}
-
-// the same matrix as a split-precision image (mfma_split.h, K = 32 = one k-step): the forward kernels contract the 31 -> 64 embeddings
+// a [64][31] embedding weight as a split-precision image (mfma_split.h, K = 32 = one k-step, column 31 zero): the forward kernels contract the 31 -> 64 embeddings
 // as three f16 MFMAs per product (rows scaled by a power of two) instead of f32 MFMAs at the vector rate -- 96 x 32 matrix-pipe cycles
 // per tile of 16 bonds were a third of the bond embedding kernel once its sin / cos were cheap
 __device__ __forceinline__ void stage_embed_split(h16x8* img, const float* __restrict__ src, int tid) {
@@ -53,6 +45,31 @@ __device__ __forceinline__ void stage_embed_split(h16x8* img, const float* __res
     img[c] = hi;
     img[NCH + c] = lo;
   }
+}
+
+// ... and its transpose [32 outputs k][64 contraction f] as a split image (K = 64: two k-steps) for the adjoint kernels:
+// t[k] = sum_f W[f][k] g[f], the adjoint rows g scaled per row by a power of two (gradients of any magnitude)
+constexpr int EMB_T_CHUNKS = 2 * 4 * KB;            // chunks per plane
+__device__ __forceinline__ void stage_embed_split_t(h16x8* img, const float* __restrict__ src, int tid) {
+  for (int c = tid; c < EMB_T_CHUNKS; c += BLOCK) {
+    const int k = c % KB, g = (c / KB) & 3, mk = c / (4 * KB);
+    h16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = 32 * mk + 16 * (e >> 2) + 4 * g + (e & 3);
+      const float w = k < NRAD ? src[f * NRAD + k] : 0.f;
+      hi[e] = (_Float16)w;
+      lo[e] = (_Float16)((w - (float)hi[e]) * LO_SCALE);
+    }
+    img[c] = hi;
+    img[EMB_T_CHUNKS + c] = lo;
+  }
+}
+// t (2 tiles = 32 values per row) += W^T g
+__device__ __forceinline__ void embed_adjoint(f32x4 (&t)[2], const float* img, const V64& gin, int j, int g) {
+  SplitRow<2> sr;
+  split_row<VT, true>(sr, gin.t);
+  gemm_split2<2, true>(t, reinterpret_cast<const h16x8*>(img), KB, sr, j, g);
 }
 
 struct BondEmbedTArgs {
@@ -84,10 +101,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   float* Wb = Wa + D * WSB;
   float* tiles = Wb + D * WSB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  if (BWD) {
-    stage_embed_weight(We, p.w_emb, tid);
-    stage_embed_weight(Wa, p.w_ag, tid);
-    stage_embed_weight(Wb, p.w_bg, tid);
+  if (BWD) {   // adjoint: split images of the transposes (2,048 of the 2,304 floats of a slot)
+    stage_embed_split_t(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
+    stage_embed_split_t(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
+    stage_embed_split_t(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
   } else {   // forward: split images in the same slots (2,048 of the 2,304 floats)
     stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
     stage_embed_split(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
@@ -185,17 +202,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
       gather_rows64(T, ETS, p.Gb, k, lane);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, gin.t);
-      gemm_dl_t<VT, 2>(t6, We, WSB, gin.t, j, g);
+      embed_adjoint(t6, We, gin, j, g);
       __builtin_amdgcn_wave_barrier();
       gather_rows64(T, ETS, p.Gwag, k, lane);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, gin.t);
-      gemm_dl_t<VT, 2>(t6, Wa, WSB, gin.t, j, g);
+      embed_adjoint(t6, Wa, gin, j, g);
       __builtin_amdgcn_wave_barrier();
       if (__any(valid && node >= 0)) {
         read_dl<VT>(p.Gwbgc + (size_t)(node >= 0 ? node : 0) * D, g, gin.t);
         if (node < 0) gin = zero64();
-        gemm_dl_t<VT, 2>(t3, Wb, WSB, gin.t, j, g);
+        embed_adjoint(t3, Wb, gin, j, g);
       }
       float acc = 0.f;
 #pragma unroll
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEm
   float* We = smem;
   float* tiles = We + D * WSB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  if (BWD) stage_embed_weight(We, p.w_emb, tid);
+  if (BWD) stage_embed_split_t(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
   else stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
   // basis index k = 16*kt + 4*g + r:  k = 0 const, 1..15 sin(f_{k-1} t), 16..30 cos(f_{k-16} t), 31 padding
   float fs[4], fc[4];
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEm
       rows64_commit(gin_rows, T, ETS, lane);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, gin.t);
-      gemm_dl_t<VT, 2>(t, We, WSB, gin.t, j, g);
+      embed_adjoint(t, We, gin, j, g);
       __builtin_amdgcn_wave_barrier();
       if (TRAIN && valid) {
         write_dl<2>(p.Xa + (size_t)a * KB, g, x);

@@ -191,6 +191,40 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
   }
 }
 
+// two output tiles (32 outputs): the adjoint of the 31 -> 64 embedding contractions (kernels_embed.h).  Same arithmetic as gemm_split4.
+template <int MK, bool SCALED>
+__device__ __forceinline__ void gemm_split2(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int i, int g) {
+  const int nchunks = MK * 4 * F;
+  const h16x8* base0 = img + g * F + i;
+  f32x4 t[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
+#pragma unroll
+  for (int mk = 0; mk < MK; ++mk) {
+    const h16x8* base = base0 + mk * 4 * F;
+    h16x8 wh[2], wl[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) t[q] *= LO_UNSCALE;
+#pragma unroll
+  for (int mk = 0; mk < MK; ++mk) {
+    const h16x8* base = base0 + mk * 4 * F;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(base[16 * q], s.hi[mk], t[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (SCALED) acc[q] += t[q] * s.up;
+    else acc[q] = t[q];
+  }
+}
+
 template <int KT, int NFT, bool SCALED>
 __device__ __forceinline__ void gemm_split(f32x4 (&acc)[NFT], const h16x8* img, int F, const f32x4 (&x)[KT], int i, int g) {
   static_assert(NFT % 4 == 0, "output width must be a multiple of 64");
