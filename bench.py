@@ -840,6 +840,14 @@ def main() -> None:
                     hbm["kernels"][k]["sq_counters"] = v
                 elif k in roofline.get("tile_kernels", {}):
                     roofline["tile_kernels"][k]["sq_counters"] = v
+                    # the roof these kernels are actually under: vector-ALU issue.  A wave issues vector instructions `active_inst_valu`
+                    # of its resident cycles; the tile kernels run two waves per SIMD (256 registers each), so the SIMD's vector port is
+                    # busy about twice that -- the third "frac" next to frac_mfma_f16 and frac_hbm_*
+                    roofline["tile_kernels"][k]["frac_valu_issue"] = round(2.0 * v["active_inst_valu"], 3)
+            if dom in roofline.get("tile_kernels", {}) and "frac_valu_issue" in roofline["tile_kernels"][dom]:
+                roofline["frac_valu_issue"] = roofline["tile_kernels"][dom]["frac_valu_issue"]
+                roofline["binding_resource"] = ("vector-ALU issue (2 waves per SIMD x active_inst_valu; the matrix pipe and HBM fractions above are "
+                                                "both far from their roofs)")
             hbm["sq_counters_unit"] = sqc["unit"]
         except (OSError, ValueError, KeyError):
             pass
