@@ -4,6 +4,7 @@
 #include "engine_internal.h"
 
 #include "kernels_geom.h"
+#include "kernels_angle_fa.h"
 
 namespace chgh {
 
@@ -350,11 +351,23 @@ static bool per_atom_adjoint(bool hidden) {
   return hidden ? bc : au;
 }
 
+// AngleUpdate forward per atom, table rows in LDS (kernels_angle_fa.h).  CHGNET_PER_ATOM_FWD=0 switches back to the row-order kernel.
+static bool per_atom_forward() {
+  static const bool on = [] { const char* e = std::getenv("CHGNET_PER_ATOM_FWD"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+
 template <bool HIDDEN, bool BWD, int NW = WAVES>
 int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleArgs& a) {
   LaunchScope ls(eng, label);
   AngleArgs plain = a;
-  if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
+  if (!BWD && !HIDDEN && b->win_built && per_atom_forward()) {
+    AngleWArgs w{};
+    w.a = a; w.w = b->win;
+    w.a.image = eng->img_angle[0][a.slot];
+    hipLaunchKernelGGL(k_angleupd_fwd_a, dim3(b->win_grid), dim3(BLOCK), angle_fa_lds(), eng->stream, w);
+    HIP_TRY(eng, hipGetLastError());
+  } else if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
     // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the row-order one: both are
     // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
     AngleWArgs w{};
@@ -666,6 +679,7 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, k_angleupd_fwd_a, angle_fa_lds()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;

@@ -802,7 +802,7 @@ struct AngleArgs {
   float* Gwbgc;        // [Eb,64] accumulated over layers (BondConv only)
   int first_gang;      // BondConv adjoint of the last layer: first writer of Gang in the sweep (store, do not read: not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
-  const int* skip_flag; // row-order adjoints (BWD, not TRAIN): return at once when *skip_flag == 1 (the per-atom kernel of kernels_angle_w.h runs)
+  const int* skip_flag; // row-order kernels (not TRAIN): return at once when *skip_flag == 1 (a per-atom kernel of kernels_angle_w.h / _fa.h runs)
   // training (k_angle<.., true, .., true>) only
   float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
   float* dumpH;        // [A,128] hidden activations (BondConv)
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle_image(const float* w_ang, Gated
 template <bool HIDDEN, bool BWD, int NW = WAVES, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
-  if (BWD && !TRAIN && p.skip_flag && *p.skip_flag == 1) return;
+  if (!TRAIN && p.skip_flag && *p.skip_flag == 1) return;   // a per-atom kernel does this launch's work (kernels_angle_w.h / kernels_angle_fa.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PH_DECL
   constexpr int SPLIT = angle_split(HIDDEN, BWD);

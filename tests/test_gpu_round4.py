@@ -161,8 +161,9 @@ def test_per_atom_adjoint_intermediates_match_the_pipeline_model(hip_engine, pac
 
 def test_atoms_with_more_bonds_than_private_rows(hip_engine, golden_weights, force_per_atom):
     """Dense cells: 14 short bonds per atom (bcc-like, 3 A) and 26 (bond-graph cutoff raised to 4.2 A) -- more than the 13 / 14
-    private second-bond rows of the per-atom adjoints: the ranks past them leave as direct row atomics.  Both against the CPU oracle
-    on the same graphs."""
+    private second-bond rows of the per-atom adjoints (the ranks past them leave as direct row atomics) and, at 26, than the 15
+    table rows per wave of the per-atom AngleUpdate forward (kernels_angle_fa.h: those tiles gather from the tables).  Both
+    against the CPU oracle on the same graphs."""
     import torch
 
     from chgnet_amd import CrystalGraphConverter, Structure
