@@ -130,6 +130,7 @@ struct chg_batch {
   int *win_tmp = nullptr, *win_scan = nullptr;
   int win_grid = 64;        // workgroups of the per-atom kernels (a multiple of 64: the atom schedule is built for it, k_win_schedule)
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
+  int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
   bool seed1_adjoints = false;   // the first-order adjoints (seed 1) of the last force / stress sweep are still in the batch (GP_l, GR_l, GS_l, Gwag, Gwbgc)
@@ -248,10 +249,8 @@ int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, c
 int zero(chg_engine* eng, void* p, size_t bytes);
 int build_images(chg_engine* eng);
 int predict_set_lds(chg_engine* eng);      // dynamic-LDS attributes of the kernels this unit launches
-int atomconv_tables(chg_engine* eng, chg_batch* b, int l);
 int atomconv_q_table(chg_engine* eng, chg_batch* b, int l);
 AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l);
-int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1);
 AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_ang, const GatedW& g, float* out);
 int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t);
 BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b);

@@ -174,6 +174,29 @@ int rows_gemm_in2(chg_engine* eng, const char* label, const float* X, int ldx, c
   return launch_rows_gemm<128, 64, 2>(eng, label, p);
 }
 
+// small batches: several independent row GEMMs of one K in a single launch (k_rows_gemm_multi); n_out / n_out_first as in
+// launch_rows_gemm_cols.  The caller has checked that every row count is in (0, SMALL_GEMM_ROWS].
+struct MultiGemm {
+  RowsGemmN g{};
+  int max_rows = 0;
+  void add(RowsGemm p, int n_out, int n_out_first) {
+    p.col_blocks = n_out / SMALL_GEMM_COLS; p.blocks1 = n_out_first / SMALL_GEMM_COLS;
+    g.p[g.n++] = p;
+    max_rows = std::max(max_rows, p.rows);
+  }
+};
+template <int K>
+int launch_rows_gemm_multi(chg_engine* eng, const char* label, const MultiGemm& m) {
+  int blocks = 0;
+  for (int i = 0; i < m.g.n; ++i) blocks += m.g.p[i].col_blocks;
+  LaunchScope ls(eng, label);
+  hipLaunchKernelGGL((k_rows_gemm_multi<K, SMALL_GEMM_COLS>), dim3(grid_for(m.max_rows, 4 * eng->num_cus), blocks), dim3(BLOCK),
+                     (rows_gemm_lds<K, SMALL_GEMM_COLS, (K == 128 ? 2 : 1)>()), eng->stream, m.g);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+static bool small_rows(int rows) { return rows > 0 && rows <= SMALL_GEMM_ROWS; }
+
 int zero(chg_engine* eng, void* p, size_t bytes) {
   if (bytes == 0) return CHG_OK;
   LaunchScope ls(eng, "memset");
@@ -233,8 +256,14 @@ int build_images(chg_engine* eng) {
   return CHG_OK;
 }
 
+static RowsGemm atomconv_p_problem(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  return RowsGemm{b->atom[l], D, nullptr, w.w_cn, w.b1, nullptr, 0, b->Pl[l], 4 * D, nullptr, b->N, 0, w.w_cn + 2 * D * D, 0, 2 * D, 0, 0};
+}
+
 int atomconv_tables(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
+  if (b->p_table_done == l) return CHG_OK;   // contracted next to the S and R tables of BondConv l - 1 (angle_tables, small batches)
   return rows_gemm_out2(eng, "gemm_P", b->atom[l], nullptr, w.w_cn, w.w_cn + 2 * D * D, w.b1, b->Pl[l], 4 * D, b->N);
 }
 
@@ -306,6 +335,12 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
+  if (l > 0 && small_rows(b->N) && small_rows(b->Eu)) {   // small batch: both in one launch (targets: atom rows, bond rows)
+    MultiGemm m;
+    m.add(RowsGemm{b->GP_l[l], 4 * D, nullptr, w.w_cn_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1, w.w_cn_t + 2 * D * D, 2 * D, 0, 0, 0}, D, D);
+    m.add(RowsGemm{b->GQ, 2 * D, nullptr, w.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, b->Eu, l == b->L - 1 ? 0 : 1, nullptr, 0, 0, 0, 0}, D, D);
+    return launch_rows_gemm_multi<128>(eng, "gemm_GPQ", m);
+  }
   if (l > 0) {  // dE/d atom[l] += GPc . Wc + GPn . Wn   (atom[0] is an embedding: no position dependence)
     TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
   }
@@ -314,18 +349,20 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
 
 // ---- BondConv / AngleUpdate ----------------------------------------------------------------------------
 // tables: S = atom . Wctr^T + b1 (per atom),  R = hbc . [Wi;Wj]^T (per bond-graph node)
-int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1) {
+// p_layer >= 0 (BondConv l: atom = atom[l + 1]): the P table of AtomConv p_layer = l + 1, which reads the same atom rows, joins a
+// small batch's launch
+int angle_tables(chg_engine* eng, chg_batch* b, int slot, const float* atom, const float* hbc, const float* w_bij, const float* w_ctr, const float* b1,
+                 int p_layer = -1) {
   float *S = b->Sl[slot], *R = b->Rl[slot];
-  if (b->N <= SMALL_GEMM_ROWS && b->Eb <= SMALL_GEMM_ROWS && b->N > 0 && b->Eb > 0) {   // small batch: both tables in one launch
-    RowsGemm2 g{};
-    g.a = RowsGemm{atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0, nullptr, 0, 0, 2 * D / SMALL_GEMM_COLS, 2 * D / SMALL_GEMM_COLS};
-    g.b = RowsGemm{hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0, w_bij + 2 * D * D, 0, 2 * D, 4 * D / SMALL_GEMM_COLS,
-                   2 * D / SMALL_GEMM_COLS};
-    LaunchScope ls(eng, "gemm_SR");
-    hipLaunchKernelGGL((k_rows_gemm_pair<64, SMALL_GEMM_COLS>), dim3(grid_for(std::max(b->N, b->Eb), 4 * eng->num_cus), g.a.col_blocks + g.b.col_blocks),
-                       dim3(BLOCK), (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>()), eng->stream, g);
-    HIP_TRY(eng, hipGetLastError());
-    return CHG_OK;
+  if (small_rows(b->N) && small_rows(b->Eb)) {   // small batch: the tables in one launch
+    MultiGemm m;
+    m.add(RowsGemm{atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0, nullptr, 0, 0, 0, 0}, 2 * D, 2 * D);
+    m.add(RowsGemm{hbc, D, nullptr, w_bij, nullptr, nullptr, 0, R, 4 * D, nullptr, b->Eb, 0, w_bij + 2 * D * D, 0, 2 * D, 0, 0}, 4 * D, 2 * D);
+    if (p_layer >= 0 && b->Ed > 0) {
+      m.add(atomconv_p_problem(eng, b, p_layer), 4 * D, 2 * D);
+      b->p_table_done = p_layer;
+    }
+    return launch_rows_gemm_multi<64>(eng, m.g.n == 3 ? "gemm_SRP" : "gemm_SR", m);
   }
   TRY(rows_gemm(eng, "gemm_S", 64, 128, atom, D, nullptr, w_ctr, b1, nullptr, 0, S, 2 * D, nullptr, b->N, 0));
   return rows_gemm_out2(eng, "gemm_R", hbc, nullptr, w_bij, w_bij + 2 * D * D, nullptr, R, 4 * D, b->Eb);
@@ -387,7 +424,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
 
 int bondconv_fwd(chg_engine* eng, chg_batch* b, int l) {
   const BCW& w = eng->w.bc[l];
-  TRY(angle_tables(eng, b, l, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1));
+  TRY(angle_tables(eng, b, l, b->atom[l + 1], b->hbc[l], w.w_bij, w.w_ctr, w.b1, l + 1));
   TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.w_ang, w.g, b->aggB_l[l]))));
   // hbc[l+1] = agg . Wout^T + b_out + hbc[l]          (layers.py:255-260)
   return rows_gemm(eng, "gemm_out", 64, 64, b->aggB_l[l], D, nullptr, w.w_out, w.b_out, b->hbc[l], D, b->hbc[l + 1], D, nullptr, b->Eb, 0);
@@ -401,6 +438,12 @@ int angleupd_fwd(chg_engine* eng, chg_batch* b, int l) {
 
 // scatter of the table gradients back to atoms / bond nodes
 int angle_table_grads(chg_engine* eng, chg_batch* b, int slot, const float* w_bij_t, const float* w_ctr_t) {
+  if (small_rows(b->N) && small_rows(b->Eb)) {   // small batch: both in one launch (different targets: bond rows, atom rows)
+    MultiGemm m;
+    m.add(RowsGemm{b->GR_l[slot], 4 * D, nullptr, w_bij_t, nullptr, nullptr, 0, b->Gb, D, b->bn_und, b->Eb, 1, w_bij_t + 2 * D * D, 2 * D, 0, 0, 0}, D, D);
+    m.add(RowsGemm{b->GS_l[slot], 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1, nullptr, 0, 0, 0, 0}, D, D);
+    return launch_rows_gemm_multi<128>(eng, "gemm_GRS", m);
+  }
   TRY(rows_gemm_in2(eng, "gemm_GR", b->GR_l[slot], 4 * D, w_bij_t, w_bij_t + 2 * D * D, b->Gb, b->bn_und, b->Eb, 1));
   return rows_gemm(eng, "gemm_GS", 128, 64, b->GS_l[slot], 2 * D, nullptr, w_ctr_t, nullptr, nullptr, 0, b->Ga, D, nullptr, b->N, 1);
 }
@@ -476,6 +519,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   // every forward scatter target + crystal_fea -- and, when a reverse sweep follows, its accumulators too (the two ranges are
   // adjacent in the arena: one memset instead of two)
   TRY(zero(eng, b->zero1, (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1)));
+  b->p_table_done = -1;
   for (int l = 0; l < L - 1; ++l) {
     TRY(atomconv_fwd(eng, b, l, want_grad));
     if (b->A > 0) {
@@ -672,7 +716,8 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_rows_gemm<64, 128>, rows_gemm_lds<64, 128>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, 64>, rows_gemm_lds<128, 64>()))) return s;
   if ((s = set_lds(eng, k_rows_gemm<64, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
-  if ((s = set_lds(eng, k_rows_gemm_pair<64, SMALL_GEMM_COLS>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm_multi<64, SMALL_GEMM_COLS>, (rows_gemm_lds<64, SMALL_GEMM_COLS, 1>())))) return s;
+  if ((s = set_lds(eng, k_rows_gemm_multi<128, SMALL_GEMM_COLS>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 2>())))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 1>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 1>())))) return s;
   if ((s = set_lds(eng, k_rows_gemm<128, SMALL_GEMM_COLS, 2>, (rows_gemm_lds<128, SMALL_GEMM_COLS, 2>())))) return s;
   if ((s = set_lds(eng, (k_rows_gemm<64, 128, 2>), (rows_gemm_lds<64, 128, 2>())))) return s;

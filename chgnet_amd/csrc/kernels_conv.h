@@ -412,14 +412,24 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm(RowsGemm p) {
   rows_gemm_body<K, NOUT, PARTS>(p, blockIdx.y);
 }
 
-// two independent column-split products in one launch (small batches: the S and R tables of an angle layer): the first
-// a.col_blocks values of blockIdx.y belong to `a`, the rest to `b`; gridDim.x covers the longer of the two row counts
-struct RowsGemm2 { RowsGemm a, b; };
+// Several independent column-split products in one launch (small batches): block y of the grid belongs to the problem whose
+// col_blocks range holds it; gridDim.x covers the longest row count.  Each in the one- or the two-input-block form (K = 128:
+// x2_off > 0 picks PARTS = 2): the S and R tables of an angle layer with the next AtomConv's P table, the table gradients of an
+// angle layer (GR | GS) and of an AtomConv (GP | GQ).
+struct RowsGemmN { RowsGemm p[3]; int n; };
 template <int K, int NOUT>
-__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm_pair(RowsGemm2 g) {
-  const int y = blockIdx.y;
-  if (y < g.a.col_blocks) rows_gemm_body<K, NOUT, 1>(g.a, y);
-  else rows_gemm_body<K, NOUT, 1>(g.b, y - g.a.col_blocks);
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_gemm_multi(RowsGemmN g) {
+  int y = blockIdx.y;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= g.n) return;
+    if (y < g.p[i].col_blocks) {
+      if (K == 128 && g.p[i].x2_off > 0) rows_gemm_body<K, NOUT, (K == 128 ? 2 : 1)>(g.p[i], y);
+      else rows_gemm_body<K, NOUT, 1>(g.p[i], y);
+      return;
+    }
+    y -= g.p[i].col_blocks;
+  }
 }
 
 template <int K, int NOUT, int PARTS = 1>
