@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angleupd_fwd_a(AngleWAr
       f32x4 z[2 * VT];
 #pragma unroll
       for (int fo = 0; fo < 2 * VT; ++fo) z[fo] = zero4();
-      gemm_split<VT, 2 * VT, false>(z, Wang, 2 * D, x.t, j, g);
+      gemm_split<VT, 2 * VT, false, true>(z, Wang, 2 * D, x.t, j, g);
       // the previous tile's rows leave now: behind this tile's requests, so that no wait for those covers the stores
       asm volatile("" ::: "memory");
       if (j < nvalid_prev) write_dl<VT>(p.out + (size_t)a_prev * D, g, y_prev.t);

@@ -75,7 +75,8 @@ struct TrainTile {
 };
 
 // SPLIT: 0 = W2c / W2g are padded f32 rows, 1 = split-precision images, 2 = row-major split images (mfma_split.h)
-template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, int SPLIT = 0>
+// LEAN: the hidden layer's split contractions in the two-sweep form (mfma_split.h gemm_split4: the forward kernels)
+template <bool HIDDEN, bool SLIM = false, bool TRAIN = false, int SPLIT = 0, bool LEAN = false>
 __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c, const float* W2g, const float* vecs,
                                               int j, int g, GatedState& s, V64& y, TrainTile* tt = nullptr) {
   if (HIDDEN) {
@@ -100,8 +101,8 @@ __device__ __forceinline__ void gated_forward(V64& zc, V64& zg, const float* W2c
       gemm_rm<VT, VT, false, false>(s.xh1.t, reinterpret_cast<const _Float16*>(W2c), D, D, hc.t, j, g, j + 16 * g);
       gemm_rm<VT, VT, false, false>(s.xh2.t, reinterpret_cast<const _Float16*>(W2g), D, D, hg.t, j, g, j + 16 * g);
     } else if (SPLIT == 1) {
-      gemm_split<VT, VT, false>(s.xh1.t, reinterpret_cast<const h16x8*>(W2c), D, hc.t, j, g);
-      gemm_split<VT, VT, false>(s.xh2.t, reinterpret_cast<const h16x8*>(W2g), D, hg.t, j, g);
+      gemm_split<VT, VT, false, LEAN>(s.xh1.t, reinterpret_cast<const h16x8*>(W2c), D, hc.t, j, g);
+      gemm_split<VT, VT, false, LEAN>(s.xh2.t, reinterpret_cast<const h16x8*>(W2g), D, hg.t, j, g);
     } else {
       gemm_dl<VT, VT>(s.xh1.t, W2c, WS, hc.t, j, g);
       gemm_dl<VT, VT>(s.xh2.t, W2g, WS, hg.t, j, g);
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
 #pragma unroll
       for (int ft = 0; ft < 2 * VT; ++ft) z[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    gemm_split<VT, 2 * VT, false>(z, Ib, 2 * D, x.t, j, g);
+    gemm_split<VT, 2 * VT, false, true>(z, Ib, 2 * D, x.t, j, g);
     if (p.Qout && !(j & 1) && j < nvalid) {   // the adjoint sweep gathers the partial as a table: one row per bond, from the even rows
       float* q = p.Qout + (size_t)((row0 + j) >> 1) * 2 * D + 4 * g;
 #pragma unroll
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     GatedState s;
     V64 y;
-    gated_forward<true, false, false, 1>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    gated_forward<true, false, false, 1, true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
     __builtin_amdgcn_wave_barrier();
     V64 m;
     CHG_EV(ft) m.t[ft] = y.t[ft] * wv.t[ft];
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     Rows64 gy_rows;
     if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
     if (SPLIT == 2) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
-    else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
+    else gemm_split<VT, 2 * VT, false, !BWD>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
     if (BWD && !HIDDEN) {
       __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     GatedState s;
     V64 y;
     constexpr bool SLIM = HIDDEN && BWD;   // the BondConv adjoint is the one kernel that spills otherwise (3.41 -> 3.36 ms)
-    gated_forward<HIDDEN, SLIM, TRAIN, SPLIT>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
+    gated_forward<HIDDEN, SLIM, TRAIN, SPLIT, !BWD>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     __builtin_amdgcn_wave_barrier();
     PH(3)   // gated forward
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low

@@ -146,29 +146,31 @@ __device__ __forceinline__ void split_row(SplitRow<KT / 2>& s, const f32x4 (&x)[
 // are accumulated first, the sum is scaled back -- powers of two, exact -- and the high-order products follow into the SAME
 // accumulators: separate scaled accumulators without a second register set (the forward kernels carry the next tile's
 // gathered rows in registers and spilled ~100 dwords with one).
-template <int MK, bool SCALED>
+// LEAN: the two-sweep form (one accumulator set; the high plane is read again for the main product): 16 registers fewer, a third
+// more LDS reads -- the forward kernels, which spill otherwise (same-box A/B: atomconv_fwd +8 %, bondconv_fwd +11 % single-sweep;
+// the adjoint kernels -1 .. -5 %).
+template <int MK, bool SCALED, bool LEAN = false>
 __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int fo0, int i, int g) {
   const int nchunks = MK * 4 * F;
   const h16x8* base0 = img + g * F + 16 * fo0 + i;
-  f32x4 t[4];
+  // LO_SEPARATE: the cross products (hi x lo, lo x hi, carried at 2^11) and the main product in separate accumulators, so that
+  // every operand is read from LDS ONCE (a second sweep over the high plane cost a third more LDS reads than the contraction needs;
+  // the tile kernels' weight reads are a large share of their LDS traffic)
+  if constexpr (LEAN && LO_SEPARATE) {
+    f32x4 t[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : (LO_SEPARATE ? acc[q] * LO_SCALE : acc[q]);
+    for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
 #pragma unroll
-  for (int mk = 0; mk < MK; ++mk) {
-    const h16x8* base = base0 + mk * 4 * F;
-    h16x8 wh[4], wl[4];
+    for (int mk = 0; mk < MK; ++mk) {
+      const h16x8* base = base0 + mk * 4 * F;
+      h16x8 wh[4], wl[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+      for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
-    if (!LO_SEPARATE) {   // the matrix pipe keeps f16 subnormals (tools/split_lab.hip T2): one pass for all three products
-#pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
     }
-  }
-  if (LO_SEPARATE) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] *= LO_UNSCALE;
 #pragma unroll
@@ -180,13 +182,42 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
 #pragma unroll
       for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (SCALED) acc[q] += t[q] * s.up;
+      else acc[q] = t[q];
+    }
+    return;
+  }
+  f32x4 t[4], u[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { t[q] = (SCALED || LO_SEPARATE) ? zero4() : acc[q]; u[q] = SCALED ? zero4() : acc[q]; }
+#pragma unroll
+  for (int mk = 0; mk < MK; ++mk) {
+    const h16x8* base = base0 + mk * 4 * F;
+    h16x8 wh[4], wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
+    if (LO_SEPARATE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], u[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
+    if (!LO_SEPARATE) {   // the matrix pipe keeps f16 subnormals (tools/split_lab.hip T2): one pass for all three products
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    const f32x4 r = LO_SEPARATE ? u[q] + t[q] * LO_UNSCALE : t[q];
     if (SCALED) {
-      acc[q] += t[q] * s.up;
+      acc[q] += r * s.up;
     } else {
-      acc[q] = t[q];
+      acc[q] = r;
     }
   }
 }
@@ -196,9 +227,9 @@ template <int MK, bool SCALED>
 __device__ __forceinline__ void gemm_split2(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int i, int g) {
   const int nchunks = MK * 4 * F;
   const h16x8* base0 = img + g * F + i;
-  f32x4 t[2];
+  f32x4 t[2], u[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
+  for (int q = 0; q < 2; ++q) { t[q] = zero4(); u[q] = SCALED ? zero4() : acc[q]; }
 #pragma unroll
   for (int mk = 0; mk < MK; ++mk) {
     const h16x8* base = base0 + mk * 4 * F;
@@ -208,30 +239,25 @@ __device__ __forceinline__ void gemm_split2(f32x4* acc, const h16x8* img, int F,
 #pragma unroll
     for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
 #pragma unroll
+    for (int q = 0; q < 2; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], u[q], 0, 0, 0);
+#pragma unroll
     for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) t[q] *= LO_UNSCALE;
-#pragma unroll
-  for (int mk = 0; mk < MK; ++mk) {
-    const h16x8* base = base0 + mk * 4 * F;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(base[16 * q], s.hi[mk], t[q], 0, 0, 0);
-  }
-#pragma unroll
   for (int q = 0; q < 2; ++q) {
-    if (SCALED) acc[q] += t[q] * s.up;
-    else acc[q] = t[q];
+    const f32x4 r = u[q] + t[q] * LO_UNSCALE;
+    if (SCALED) acc[q] += r * s.up;
+    else acc[q] = r;
   }
 }
 
-template <int KT, int NFT, bool SCALED>
+template <int KT, int NFT, bool SCALED, bool LEAN = false>
 __device__ __forceinline__ void gemm_split(f32x4 (&acc)[NFT], const h16x8* img, int F, const f32x4 (&x)[KT], int i, int g) {
   static_assert(NFT % 4 == 0, "output width must be a multiple of 64");
   SplitRow<KT / 2> s;
   split_row<KT, SCALED>(s, x);
 #pragma unroll
-  for (int fo0 = 0; fo0 < NFT; fo0 += 4) gemm_split4<KT / 2, SCALED>(acc + fo0, img, F, s, fo0, i, g);
+  for (int fo0 = 0; fo0 < NFT; fo0 += 4) gemm_split4<KT / 2, SCALED, LEAN>(acc + fo0, img, F, s, fo0, i, g);
 }
 
 // ---- row-major images: ONE LDS copy for both contraction directions -------------------------------------------------
@@ -289,9 +315,11 @@ __device__ __forceinline__ h16x8 rm_operand(const _Float16* img, int F, int K, i
 // four output tiles o0 .. o0 + 3 from an already split row; contraction over MS steps of 32
 template <int MS, bool SCALED, bool ADJOINT>
 __device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F, int K, const SplitRow<MS>& s, int o0, int i, int g, int lane) {
-  f32x4 t[4];
+  // the cross products (hi x lo, lo x hi: carried at 2^11) and the main product in separate accumulators: every operand is read
+  // from LDS once (re-reading the high plane for a second sweep cost a third more LDS reads than the contraction needs)
+  f32x4 t[4], u[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
+  for (int q = 0; q < 4; ++q) { t[q] = zero4(); u[q] = SCALED ? zero4() : acc[q]; }
 #pragma unroll
   for (int m = 0; m < MS; ++m) {
     h16x8 wh[4], wl[4];
@@ -300,24 +328,17 @@ __device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F,
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[m], t[q], 0, 0, 0);
 #pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[m], u[q], 0, 0, 0);
+#pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[m], t[q], 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) t[q] *= LO_UNSCALE;
-#pragma unroll
-  for (int m = 0; m < MS; ++m) {
-    h16x8 wh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wh[q] = rm_operand<ADJOINT>(img, F, K, 0, o0 + q, m, i, g, lane);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[m], t[q], 0, 0, 0);
-  }
-#pragma unroll
   for (int q = 0; q < 4; ++q) {
+    const f32x4 r = u[q] + t[q] * LO_UNSCALE;
     if (SCALED) {
-      acc[q] += t[q] * s.up;
+      acc[q] += r * s.up;
     } else {
-      acc[q] = t[q];
+      acc[q] = r;
     }
   }
 }

@@ -27,3 +27,16 @@ for base, label, launches in ((0, "bondconv_fwd", 3), (10, "bondconv_bwd", 3), (
     print(f"{label}: {tot / (tiles * launches):8.0f} cycles per wave-tile")
     for i, nm in enumerate(names[10 if base % 20 else 0]):
         print(f"   {nm:20s} {v[i] / (tiles * launches):8.0f}  {100 * v[i] / tot:5.1f} %")
+
+# per-atom adjoints (kernels_angle_w.h): kernel slots 4 (BondConv) and 5 (AngleUpdate); tiles padded per atom
+try:
+    ph6 = eng.debug_fetch(batch, "phase", 6 * 2 * 10 * PH_WAVES).reshape(6, 2, 10, PH_WAVES).sum(axis=(1, 3))
+    wn = ["indices + gathers", "GEMMs + gated fwd/bwd", "W_ang^T + Gang update", "scatter (runs, private rows)", "per-atom flush", "-", "bond-weight grads"]
+    for k, label, launches in ((4, "bondconv_bwd per atom", 3), (5, "angleupd_bwd per atom", 2)):
+        v = ph6[k]; tot = v.sum()
+        if tot <= 0: continue
+        print(f"{label}: {tot / (tiles * launches):8.0f} cycles per (unpadded) wave-tile")
+        for i, nm in enumerate(wn):
+            if v[i] > 0: print(f"   {nm:30s} {v[i] / (tiles * launches):8.0f}  {100 * v[i] / tot:5.1f} %")
+except Exception as e:
+    print("per-atom phases unavailable:", e)
