@@ -370,6 +370,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       V64 y;
       constexpr bool SLIM = HIDDEN;
       gated_forward<HIDDEN, SLIM, false, MODE>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+      PH(7)   // forward recomputation
       V64 gy;
       if (HIDDEN) {
         V64 g1, g2;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         }
         if (HIDDEN) gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane);
         else gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
+        PH(5)   // W_ang^T contraction
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         scatter_rows64_add(T, TS64, p.Gang, a, nvalid, lane, gang_old);

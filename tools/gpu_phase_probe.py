@@ -31,7 +31,8 @@ for base, label, launches in ((0, "bondconv_fwd", 3), (10, "bondconv_bwd", 3), (
 # per-atom adjoints (kernels_angle_w.h): kernel slots 4 (BondConv) and 5 (AngleUpdate); tiles padded per atom
 try:
     ph6 = eng.debug_fetch(batch, "phase", 6 * 2 * 10 * PH_WAVES).reshape(6, 2, 10, PH_WAVES).sum(axis=(1, 3))
-    wn = ["indices + gathers", "GEMMs + gated fwd/bwd", "W_ang^T + Gang update", "scatter (runs, private rows)", "per-atom flush", "-", "bond-weight grads"]
+    wn = ["indices + gathers", "dE/dy rows + gated bwd (+W2^T)", "Gang update", "scatter (runs, private rows)", "per-atom flush", "W_ang^T contraction",
+          "bond-weight grads", "forward recomputation"]
     for k, label, launches in ((4, "bondconv_bwd per atom", 3), (5, "angleupd_bwd per atom", 2)):
         v = ph6[k]; tot = v.sum()
         if tot <= 0: continue
