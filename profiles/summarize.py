@@ -23,7 +23,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 LABELS = {  # kernel-name substring -> bench.py label
     "k_angle_bwd_w<true": "bondconv_bwd", "k_angle<true, false": "bondconv_fwd",     # per-atom adjoints (kernels_angle_w.h); the plain
-    "k_angle_bwd_w<false": "angleupd_bwd", "k_angle<false, false": "angleupd_fwd",   # k_angle<*, true> launches return at once
+    "k_angle_bwd_w<false": "angleupd_bwd", "k_angleupd_fwd_a": "angleupd_fwd",       # k_angle<*, true> / <false, false> launches return
+                                                                                      # at once (per-atom forward: kernels_angle_fa.h)
     "k_atomconv_bwd": "atomconv_bwd", "k_atomconv_fwd": "atomconv_fwd",
 }
 
