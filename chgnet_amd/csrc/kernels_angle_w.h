@@ -326,6 +326,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
     }
     for (int row0 = r_begin; row0 < r_end; row0 += TILE_ROWS) {
+      // lane index made opaque once per tile: everything derived from it (64-bit row pointers base + 4 lane for every buffer, row
+      // constants) is recomputed where it is used instead of living -- and being spilled -- across the whole kernel; a spilled
+      // value reloaded between stores or atomics costs their full round trip (the reload's wait is in order behind them)
+      // (BondConv only: the AngleUpdate adjoint does not spill, and recomputing cost it 3 %)
+      int lane_t = lane;
+      if (HIDDEN) asm volatile("" : "+v"(lane_t));
       const int nvalid = min(TILE_ROWS, r_end - row0);
       const int a = a_n, b1 = b1_n, b2 = b2_n, ab2 = ab2_n;
       if (row0 + TILE_ROWS < r_end) {
@@ -338,32 +344,32 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       // phase -- was tried: 112 loop-carried registers for the table rows cost 225 spills (2x slower), 16 for the angle rows alone 51
       // spills (+14 %): this kernel has no registers left to pipeline with.) ----
       Gather64 gc, gg;
-      gather64_issue(gc, p.R, b1, 4 * D, p.R + 2 * D, b2, 4 * D, p.S, c, 2 * D, lane);
-      gather64_issue(gg, p.R + D, b1, 4 * D, p.R + 3 * D, b2, 4 * D, p.S + D, c, 2 * D, lane);
-      gather_rows64(T, TS64, p.ang, a, lane);
+      gather64_issue(gc, p.R, b1, 4 * D, p.R + 2 * D, b2, 4 * D, p.S, c, 2 * D, lane_t);
+      gather64_issue(gg, p.R + D, b1, 4 * D, p.R + 3 * D, b2, 4 * D, p.S + D, c, 2 * D, lane_t);
+      gather_rows64(T, TS64, p.ang, a, lane_t);
       __builtin_amdgcn_wave_barrier();
       V64 x;
       read_dl<VT>(Trow, g, x.t);
       __builtin_amdgcn_wave_barrier();
       f32x4 z[2 * VT];
-      gather64_commit(gc, T, lane);
+      gather64_commit(gc, T, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[0]));
       __builtin_amdgcn_wave_barrier();
-      gather64_commit(gg, T, lane);
+      gather64_commit(gg, T, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[VT]));
       __builtin_amdgcn_wave_barrier();
       PH(0)   // indices + gathers
       Rows64 gy_rows;
-      if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);
+      if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);
       V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
       if (HIDDEN) {
         read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
         read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
         read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
       }
-      if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
+      if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane_t);
       else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
       V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
       GatedState s;
@@ -384,14 +390,14 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
         // first bond as a run sum, second bond one atomic row per angle
         {
           Cols64 c1, c2[1];
-          to_columns(g1, T, Trow, g, lane, c1);
-          to_columns(g2, T, Trow, g, lane, c2[0]);
-          run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane);
-          row_add64(c2[0], nvalid, p.Gwbgc, b2, D, lane);
+          to_columns(g1, T, Trow, g, lane_t, c1);
+          to_columns(g2, T, Trow, g, lane_t, c2[0]);
+          run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane_t);
+          row_add64(c2[0], nvalid, p.Gwbgc, b2, D, lane_t);
         }
         PH(6)   // bond-weight gradient scatter
       } else {
-        rows64_commit(gy_rows, T, TS64, lane);
+        rows64_commit(gy_rows, T, TS64, lane_t);
         __builtin_amdgcn_wave_barrier();
         read_dl<VT>(Trow, g, gy.t);
         __builtin_amdgcn_wave_barrier();
@@ -409,33 +415,33 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
 #pragma unroll
           for (int it = 0; it < TILE_ROWS / 4; ++it) gang_old.v[it] = zero4();
         } else {
-          rows64_issue(gang_old, p.Gang, a, lane);
+          rows64_issue(gang_old, p.Gang, a, lane_t);
         }
-        if (HIDDEN) gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane);
+        if (HIDDEN) gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane_t);
         else gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
         PH(5)   // W_ang^T contraction
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
-        scatter_rows64_add(T, TS64, p.Gang, a, nvalid, lane, gang_old);
+        scatter_rows64_add<HIDDEN>(T, TS64, p.Gang, a, nvalid, lane_t, gang_old);
         __builtin_amdgcn_wave_barrier();
       }
       PH(2)   // W_ang^T contraction + Gang update
       // ---- scatter: first bond and centre as carried run sums, second bond into the private rows ----
       {
         Cols64 cc[2];
-        to_columns(gzc, T, Trow, g, lane, cc[0]);
-        to_columns(gzg, T, Trow, g, lane, cc[1]);
+        to_columns(gzc, T, Trow, g, lane_t, cc[0]);
+        to_columns(gzg, T, Trow, g, lane_t, cc[1]);
 #pragma unroll
         for (int rr = 0; rr < TILE_ROWS; ++rr)
           if (rr < nvalid) { rs0 += cc[0].v[rr]; rs1 += cc[1].v[rr]; }
-        run_sum64(cc[0], nvalid, b1, ri0, cur0, p.GR, 4 * D, lane);
-        run_sum64(cc[1], nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane);
-        private_add<2>(cc, nvalid, s2, pacc, T, lane);
-        if (__builtin_amdgcn_ballot_w64(j < nvalid && lane < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
+        run_sum64(cc[0], nvalid, b1, ri0, cur0, p.GR, 4 * D, lane_t);
+        run_sum64(cc[1], nvalid, b1, ri1, cur1, p.GR + D, 4 * D, lane_t);
+        private_add<2>(cc, nvalid, s2, pacc, T, lane_t);
+        if (__builtin_amdgcn_ballot_w64(j < nvalid && lane_t < TILE_ROWS && s2 < 0)) {   // rare: no private row for this second bond
 #pragma unroll
           for (int rr = 0; rr < TILE_ROWS; ++rr)
             if (rr < nvalid && __builtin_amdgcn_readlane(s2, rr) < 0) {
-              float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane;
+              float* d = p.GR + (size_t)__builtin_amdgcn_readlane(b2, rr) * 4 * D + 2 * D + lane_t;
               atomicAdd(d, cc[0].v[rr]);
               atomicAdd(d + D, cc[1].v[rr]);
             }
@@ -445,20 +451,22 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       PH(3)   // scatter
     }
     // ---- the atom is done: runs, centre sum, private second-bond rows ----
-    run_flush64(ri0, cur0, p.GR, 4 * D, lane);
-    run_flush64(ri1, cur1, p.GR + D, 4 * D, lane);
-    if (HIDDEN) run_flush64(rg, curg, p.Gwbgc, D, lane);
-    atomicAdd(p.GS + (size_t)c * 2 * D + lane, rs0);
-    atomicAdd(p.GS + (size_t)c * 2 * D + D + lane, rs1);
+    int lane_f = lane;
+    if (HIDDEN) asm volatile("" : "+v"(lane_f));   // as lane_t above
+    run_flush64(ri0, cur0, p.GR, 4 * D, lane_f);
+    run_flush64(ri1, cur1, p.GR + D, 4 * D, lane_f);
+    if (HIDDEN) run_flush64(rg, curg, p.Gwbgc, D, lane_f);
+    atomicAdd(p.GS + (size_t)c * 2 * D + lane_f, rs0);
+    atomicAdd(p.GS + (size_t)c * 2 * D + D + lane_f, rs1);
     const int nrows = min(n, NS);
-    const int bond_of = w.abbond[ab0 + min(lane, nrows - 1)];
+    const int bond_of = w.abbond[ab0 + min(lane_f, nrows - 1)];
     for (int sl = 0; sl < nrows; ++sl) {
       const int bond = __builtin_amdgcn_readlane(bond_of, sl);
       float* src = pacc + sl * PST;
-      const float v0 = src[lane], v1 = src[D + lane];
-      src[lane] = 0.f; src[D + lane] = 0.f;
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane, v0);
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane, v1);
+      const float v0 = src[lane_f], v1 = src[D + lane_f];
+      src[lane_f] = 0.f; src[D + lane_f] = 0.f;
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane_f, v0);
+      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane_f, v1);
     }
     PH(4)   // per-atom flush
   }

@@ -969,8 +969,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
         read_dl<VT>(p.ang + (size_t)a1 * D, lane_here >> 4, x_p.t);
         ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
-        if (v + 2 < ts.count) {
-          const int a2 = row_of(v + 2);
+        if (v + 2 < ts.count) {   // (row index from the recomputed lane as well: the strength-reduced constant 2 stride + j was spilled too)
+          const int a2 = max(0, min(ts.at(v + 2) * tstride + (lane_here & 15), p.n_angles - 1));
           ctr_n2 = p.a_ctr[a2]; b1_n2 = p.a_b1c[a2]; b2_n2 = p.a_b2c[a2];
         }
       }

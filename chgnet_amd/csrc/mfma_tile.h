@@ -464,6 +464,7 @@ __device__ __forceinline__ void rows64_commit(const Rows64& rr, float* tile, int
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = rr.v[it];
 }
+template <bool OPAQUE = false>
 __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid, int lane,
                                                    const Rows64& old) {
   const int sub = lane >> 4, t = lane & 15;
@@ -471,7 +472,12 @@ __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
     const int rr = 4 * it + sub;
     const int r = __shfl(idx, rr);
-    if (rr < nvalid)
+    // OPAQUE (per-atom BondConv adjoint): compared as sub < nvalid - 4 it with the right side hidden from the optimiser.  Written as
+    // rr < nvalid the compiler kept 4 it + sub for every `it` in registers across the kernel, spilled them and reloaded each BETWEEN
+    // these stores: the wait for a scratch reload is a wait for every store before it -- 3 store round trips per tile
+    int lim = nvalid - 4 * it;
+    if (OPAQUE) asm volatile("" : "+v"(lim));
+    if (sub < lim)
       *reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)r * D + 4 * t) = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
   }
 }
@@ -509,7 +515,7 @@ __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, fl
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it)
-    if (4 * it + sub < nvalid) *p[it] = v[it];
+    if (sub < nvalid - 4 * it) *p[it] = v[it];
 }
 
 }  // namespace chg
