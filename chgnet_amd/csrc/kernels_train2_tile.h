@@ -75,6 +75,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
   tile_range(ntiles, tb, te);
   const int last_row = p.n_edges - 1;
   for (int tile = tb; tile < te; ++tile) {
+    // lane index opaque per tile: the 64-bit row pointers (base + 4 lane, one pair per buffer: a dozen of them) and row constants
+    // derived from it are recomputed where used instead of living -- spilled -- across the kernel; a spilled value reloaded behind
+    // stores or atomics waits for their round trip (kernels_angle_w.h, same measure)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even (pair order)
     if (nvalid <= 0) break;
@@ -86,17 +91,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     V64 cc, cg, cdc, cdg, d1c, d1g, ec, eg;
     {
       GatherRegs gr;
-      gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
+      gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane_t);
       GatherRegs gd;
-      gather_issue128(gd, p.Pd, c, p.Pd + 2 * D, n, p.Qd, k, 4 * D, 4 * D, 2 * D, lane);
+      gather_issue128(gd, p.Pd, c, p.Pd + 2 * D, n, p.Qd, k, 4 * D, 4 * D, 2 * D, lane_t);
       __builtin_amdgcn_wave_barrier();
-      gather_commit128(gr, T, TS, lane);
+      gather_commit128(gr, T, TS, lane_t);
       __builtin_amdgcn_wave_barrier();
       V64 zc, zg;
       read_dl<VT>(Trow, g, zc.t);
       read_dl<VT>(Trow + D, g, zg.t);
       __builtin_amdgcn_wave_barrier();
-      gather_commit128(gd, T, TS, lane);
+      gather_commit128(gd, T, TS, lane_t);
       __builtin_amdgcn_wave_barrier();
       float* hrow = p.H + (size_t)(row0 + j) * 2 * D;      // B operands of dW2 = bar(c|g)^T H + G(c|g)^T Hd
       float* hdrow = p.Hd + (size_t)(row0 + j) * 2 * D;
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
         cc = param64(vecs + 0 * D, g);
         cdc = zero64();
-        gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane);
-        gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane);
+        gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
+        gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane_t);
       }
       {
         V64 zd, h, hd;
@@ -117,11 +122,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
         cg = param64(vecs + 1 * D, g);
         cdg = zero64();
-        gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane);
-        gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane);
+        gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
+        gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane_t);
       }
     }
-    // ---- row-local part, eight rows at a time through the tile (lane = feature) ----
+    // ---- row-local part, eight rows at a time through the tile (lane_t = feature) ----
     // Rolled loops: unrolled, the sixteen copies of the row math cost 175 spilled registers.  One bond (two rows) per step; what the
     // next bond needs from memory (adjoints of its two atoms' aggregates, its weight row, the old rows of the weight adjoints) is
     // requested a step ahead.
@@ -132,12 +137,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     auto fetch = [&](int b) {                                        // b: bond of the tile (clamped: harmless reads past the end)
       BondIn v{};
       const int bb = min(b, nb - 1);
-      const size_t kb = (size_t)(k0 + bb) * D + lane;
+      const size_t kb = (size_t)(k0 + bb) * D + lane_t;
       v.w = p.wag[kb]; v.wd = p.wagd[kb];
       if (REVERSE) {
         const int c0 = __builtin_amdgcn_readlane(c, 2 * bb), c1 = __builtin_amdgcn_readlane(c, 2 * bb + 1);
-        v.ba0 = p.bar_agg[(size_t)c0 * D + lane]; v.ga0 = p.g_agg[(size_t)c0 * D + lane];
-        v.ba1 = p.bar_agg[(size_t)c1 * D + lane]; v.ga1 = p.g_agg[(size_t)c1 * D + lane];
+        v.ba0 = p.bar_agg[(size_t)c0 * D + lane_t]; v.ga0 = p.g_agg[(size_t)c0 * D + lane_t];
+        v.ba1 = p.bar_agg[(size_t)c1 * D + lane_t]; v.ga1 = p.g_agg[(size_t)c1 * D + lane_t];
         v.obw = p.bar_w[kb];
       }
       return v;
@@ -160,16 +165,16 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         float pair_bw = 0.f;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {                    // the two directions
-          float* a = T + (2 * pb + d) * T2_AS + lane;
+          float* a = T + (2 * pb + d) * T2_AS + lane_t;
           const GatedRow s = gated_row_fwd(a[0], a[D], a[2 * D], a[3 * D], ln_g1, ln_b1, ln_g2, ln_b2);
           if (!REVERSE) {
             const float m = s.yd * in.w + s.y * in.wd;
             const int ci = __builtin_amdgcn_readlane(c, 2 * b + d);
             if (d) {
-              if (ci != cur2) { tile_atomic_add(p.aggd + (size_t)cur2 * D + lane, acc2); acc2 = 0.f; cur2 = ci; }
+              if (ci != cur2) { tile_atomic_add(p.aggd + (size_t)cur2 * D + lane_t, acc2); acc2 = 0.f; cur2 = ci; }
               acc2 += m;
             } else {
-              if (ci != cur1) { tile_atomic_add(p.aggd + (size_t)cur1 * D + lane, acc1); acc1 = 0.f; cur1 = ci; }
+              if (ci != cur1) { tile_atomic_add(p.aggd + (size_t)cur1 * D + lane_t, acc1); acc1 = 0.f; cur1 = ci; }
               acc1 += m;
             }
           } else {
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
           }
         }
         if (REVERSE) {                                   // the tile owns bond k0 + b: plain update of the weight adjoints
-          const size_t kb = (size_t)(k0 + b) * D + lane;
+          const size_t kb = (size_t)(k0 + b) * D + lane_t;
           p.bar_w[kb] = in.obw + pair_bw;
         }
       }
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
       }
     }
     if (!REVERSE) {
-      tile_atomic_add(p.aggd + (size_t)cur1 * D + lane, acc1);
-      tile_atomic_add(p.aggd + (size_t)cur2 * D + lane, acc2);
+      tile_atomic_add(p.aggd + (size_t)cur1 * D + lane_t, acc1);
+      tile_atomic_add(p.aggd + (size_t)cur2 * D + lane_t, acc2);
       __builtin_amdgcn_wave_barrier();
       continue;
     }
@@ -211,8 +216,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     __builtin_amdgcn_wave_barrier();
     {
       V64 bh = zero64(), gh = zero64();
-      gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane);
-      gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane);
+      gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane_t);
+      gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane_t);
       CHG_EW(ft, r) {
         bh.t[ft][r] = d1c.t[ft][r] * bh.t[ft][r] + ec.t[ft][r] * gh.t[ft][r];
         cdc.t[ft][r] = d1c.t[ft][r] * gh.t[ft][r];
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     }
     {
       V64 bh = zero64(), gh = zero64();
-      gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane);
-      gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane);
+      gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane_t);
+      gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane_t);
       CHG_EW(ft, r) {
         bh.t[ft][r] = d1g.t[ft][r] * bh.t[ft][r] + eg.t[ft][r] * gh.t[ft][r];
         cdg.t[ft][r] = d1g.t[ft][r] * gh.t[ft][r];
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     AtomConvArgs sc{};
     __builtin_amdgcn_wave_barrier();
     sc.GP = p.barP; sc.GQ = p.barQ;
-    acbwd_scatter(T, c, nvalid, k0, sc, lane);
+    acbwd_scatter(T, c, nvalid, k0, sc, lane_t);
     __builtin_amdgcn_wave_barrier();
     // G side: G(P) is the first-order adjoint the force sweep of chg_predict left in GP_l[l] -- only the Q rows are formed here
     write_dl<VT>(Trow, g, cdc.t);
@@ -242,9 +247,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
 #pragma unroll
     for (int b = 0; b < TILE_ROWS / 2; ++b)
       if (2 * b < nvalid) {
-        float* q = p.gQ + (size_t)(k0 + b) * 2 * D + lane;
-        q[0] = T[(2 * b) * TS + lane] + T[(2 * b + 1) * TS + lane];
-        q[64] = T[(2 * b) * TS + 64 + lane] + T[(2 * b + 1) * TS + 64 + lane];
+        float* q = p.gQ + (size_t)(k0 + b) * 2 * D + lane_t;
+        q[0] = T[(2 * b) * TS + lane_t] + T[(2 * b + 1) * TS + lane_t];
+        q[64] = T[(2 * b) * TS + 64 + lane_t] + T[(2 * b + 1) * TS + 64 + lane_t];
       }
     __builtin_amdgcn_wave_barrier();
   }
@@ -313,6 +318,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
   tile_range(ntiles, tb, te);
   const int last_row = p.n_angles - 1;
   for (int tile = tb; tile < te; ++tile) {
+    // lane index opaque per tile: the 64-bit row pointers (base + 4 lane, one pair per buffer: a dozen of them) and row constants
+    // derived from it are recomputed where used instead of living -- spilled -- across the kernel; a spilled value reloaded behind
+    // stores or atomics waits for their round trip (kernels_angle_w.h, same measure)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
     if (nvalid <= 0) break;
@@ -322,24 +332,24 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     V64 cc, cg, cdc, cdg, d1c, d1g, ec, eg;
     {
       GatherRegs gr;
-      gather_issue128(gr, p.R, b1, p.R + 2 * D, b2, p.S, ct, 4 * D, 4 * D, 2 * D, lane);
+      gather_issue128(gr, p.R, b1, p.R + 2 * D, b2, p.S, ct, 4 * D, 4 * D, 2 * D, lane_t);
       GatherRegs gd;
-      gather_issue128(gd, p.Rd, b1, p.Rd + 2 * D, b2, p.Sd, ct, 4 * D, 4 * D, 2 * D, lane);
+      gather_issue128(gd, p.Rd, b1, p.Rd + 2 * D, b2, p.Sd, ct, 4 * D, 4 * D, 2 * D, lane_t);
       V64 x, xd;
       read_dl<VT>(p.ang + (size_t)row * D, g, x.t);
       read_dl<VT>(p.angd + (size_t)row * D, g, xd.t);
       __builtin_amdgcn_wave_barrier();
-      gather_commit128(gr, T, TS, lane);
+      gather_commit128(gr, T, TS, lane_t);
       __builtin_amdgcn_wave_barrier();
       f32x4 z[2 * VT], zd[2 * VT];
       read_dl<2 * VT>(Trow, g, z);
       __builtin_amdgcn_wave_barrier();
-      gather_commit128(gd, T, TS, lane);
+      gather_commit128(gd, T, TS, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<2 * VT>(Trow, g, zd);
       __builtin_amdgcn_wave_barrier();
-      gemm_rm<VT, 2 * VT, false, false>(z, Iang, 2 * D, D, x.t, j, g, lane);
-      gemm_rm<VT, 2 * VT, true, false>(zd, Iang, 2 * D, D, xd.t, j, g, lane);
+      gemm_rm<VT, 2 * VT, false, false>(z, Iang, 2 * D, D, x.t, j, g, lane_t);
+      gemm_rm<VT, 2 * VT, true, false>(zd, Iang, 2 * D, D, xd.t, j, g, lane_t);
 #pragma unroll
       for (int ft = 0; ft < VT; ++ft) { cc.t[ft] = z[ft]; cg.t[ft] = z[VT + ft]; cdc.t[ft] = zd[ft]; cdg.t[ft] = zd[VT + ft]; }
       if (HIDDEN) {
@@ -351,8 +361,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
           cc = param64(vecs + 0 * D, g);
           cdc = zero64();
-          gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane);
-          gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane);
+          gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
+          gemm_rm<VT, VT, true, false>(cdc.t, I2c, D, D, hd.t, j, g, lane_t);
         }
         {
           V64 h, hd;
@@ -360,12 +370,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
           cg = param64(vecs + 1 * D, g);
           cdg = zero64();
-          gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane);
-          gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane);
+          gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
+          gemm_rm<VT, VT, true, false>(cdg.t, I2g, D, D, hd.t, j, g, lane_t);
         }
       }
     }
-    // ---- row-local part, eight rows at a time through the tile (lane = feature); what the next row needs from memory is
+    // ---- row-local part, eight rows at a time through the tile (lane_t = feature); what the next row needs from memory is
     //      requested a row ahead ----
     float acc = 0.f, acc_bw = 0.f;                    // BondConv: run sums over the owning bond
     float w1 = 0.f, w1d = 0.f, bar_a = 0.f, g_a = 0.f;
@@ -375,13 +385,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       RowIn v{};
       const int rc = min(rt, nvalid - 1);
       if (HIDDEN) {
-        const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rc) * D + lane;
+        const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rc) * D + lane_t;
         v.w2 = p.w[k2]; v.w2d = p.wd[k2];
       } else if (REVERSE) {
-        const size_t o = (size_t)(row0 + rc) * D + lane;
+        const size_t o = (size_t)(row0 + rc) * D + lane_t;
         v.by = p.bar_ang[o]; v.gy = p.g_ang[o];
       } else {
-        v.by = p.angd[(size_t)(row0 + rc) * D + lane];
+        v.by = p.angd[(size_t)(row0 + rc) * D + lane_t];
       }
       return v;
     };
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         if (rt >= nvalid) break;
         const RowIn in = nx;
         nx = fetch(rt + 1);
-        float* a = T + rr * T2_AS + lane;
+        float* a = T + rr * T2_AS + lane_t;
         const GatedRow s = gated_row_fwd(a[0], a[D], a[2 * D], a[3 * D], ln_g1, ln_b1, ln_g2, ln_b2);
         float bar_y = 0.f, g_y = 0.f;
         if (HIDDEN) {
@@ -408,31 +418,31 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           if (dst != cur) {                              // a new owning bond: flush the run, fetch its rows
             if (cur >= 0) {
               if (!REVERSE) {
-                tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
+                tile_atomic_add(p.aggd + (size_t)cur * D + lane_t, acc);
               } else {
-                atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+                atomicAdd(p.bar_w + (size_t)cur * D + lane_t, acc_bw);
               }
             }
             cur = dst;
             acc = acc_bw = 0.f;
-            w1 = p.w[(size_t)dst * D + lane];
-            w1d = p.wd[(size_t)dst * D + lane];
+            w1 = p.w[(size_t)dst * D + lane_t];
+            w1d = p.wd[(size_t)dst * D + lane_t];
             if (REVERSE) {
-              bar_a = p.bar_agg[(size_t)dst * D + lane];
-              g_a = p.g_agg[(size_t)dst * D + lane];
+              bar_a = p.bar_agg[(size_t)dst * D + lane_t];
+              g_a = p.g_agg[(size_t)dst * D + lane_t];
             }
           }
           if (!REVERSE) {
             acc += s.yd * w1 * in.w2 + s.y * (w1d * in.w2 + w1 * in.w2d);
           } else {
             acc_bw += s.y * in.w2 * bar_a + (s.yd * in.w2 + s.y * in.w2d) * g_a;
-            const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane;
+            const size_t k2 = (size_t)__builtin_amdgcn_readlane(b2, rt) * D + lane_t;
             atomicAdd(p.bar_w + k2, s.y * w1 * bar_a + (s.yd * w1 + s.y * w1d) * g_a);
             bar_y = w1 * in.w2 * bar_a + (w1d * in.w2 + w1 * in.w2d) * g_a;
             g_y = w1 * in.w2 * g_a;
           }
         } else if (!REVERSE) {
-          p.angd_out[(size_t)(row0 + rt) * D + lane] = in.by + s.yd;
+          p.angd_out[(size_t)(row0 + rt) * D + lane_t] = in.by + s.yd;
         } else {
           bar_y = in.by;
           g_y = in.gy;
@@ -453,9 +463,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     }
     if (HIDDEN && cur >= 0) {
       if (!REVERSE) {
-        tile_atomic_add(p.aggd + (size_t)cur * D + lane, acc);
+        tile_atomic_add(p.aggd + (size_t)cur * D + lane_t, acc);
       } else {
-        atomicAdd(p.bar_w + (size_t)cur * D + lane, acc_bw);
+        atomicAdd(p.bar_w + (size_t)cur * D + lane_t, acc_bw);
       }
     }
     if (!REVERSE) {
@@ -473,8 +483,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       // back through the second layer and the hidden activation, branch by branch
       {
         V64 bh = zero64(), gh = zero64();
-        gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane);
-        gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane);
+        gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane_t);
+        gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane_t);
         CHG_EW(ft, r) {
           cc.t[ft][r] = d1c.t[ft][r] * bh.t[ft][r] + ec.t[ft][r] * gh.t[ft][r];
           cdc.t[ft][r] = d1c.t[ft][r] * gh.t[ft][r];
@@ -482,8 +492,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
       {
         V64 bh = zero64(), gh = zero64();
-        gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane);
-        gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane);
+        gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane_t);
+        gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane_t);
         CHG_EW(ft, r) {
           cg.t[ft][r] = d1g.t[ft][r] * bh.t[ft][r] + eg.t[ft][r] * gh.t[ft][r];
           cdg.t[ft][r] = d1g.t[ft][r] * gh.t[ft][r];
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       f32x4 bz[2 * VT];
 #pragma unroll
       for (int ft = 0; ft < VT; ++ft) { bz[ft] = cc.t[ft]; bz[VT + ft] = cg.t[ft]; }
-      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, bz, j, g, lane);
+      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, bz, j, g, lane_t);
       CHG_EW(ft, r) up.t[ft][r] += old.t[ft][r];
       if (j < nvalid) write_dl<VT>(arow, g, up.t);
     }
@@ -514,9 +524,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     write_dl<VT>(Trow, g, cc.t);
     write_dl<VT>(Trow + D, g, cg.t);
     __builtin_amdgcn_wave_barrier();
-    seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane);
-    row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane);
-    seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane);
+    seg_colsum_atomic<2 * D>(T, TS, k1, nvalid, p.barR, 4 * D, lane_t);
+    row_atomic_add<2 * D>(T, TS, k2, nvalid, p.barR + 2 * D, 4 * D, lane_t);
+    seg_colsum_atomic<2 * D>(T, TS, k3, nvalid, p.barS, 2 * D, lane_t);
     __builtin_amdgcn_wave_barrier();
     // ---- G: only the angle features (an input of the earlier layers); G(R), G(S) are the first-order table adjoints ----
     {
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       f32x4 gz[2 * VT];
 #pragma unroll
       for (int ft = 0; ft < VT; ++ft) { gz[ft] = cdc.t[ft]; gz[VT + ft] = cdg.t[ft]; }
-      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, gz, j, g, lane);
+      gemm_rm<2 * VT, VT, true, true>(up.t, Iang, 2 * D, D, gz, j, g, lane_t);
       CHG_EW(ft, r) up.t[ft][r] += old.t[ft][r];
       if (j < nvalid) write_dl<VT>(arow, g, up.t);
     }
