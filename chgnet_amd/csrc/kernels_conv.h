@@ -936,6 +936,11 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
   for (int v = 0; v < ts.count; ++v) {
+    // BondConv adjoint (the kernel of MD-size batches, and with TRAIN of the first-order fine-tuning sweep): lane index opaque per
+    // tile, so that the row pointers derived from it are formed where they are used instead of being spilled and reloaded
+    // behind the tile's atomics (kernels_angle_w.h, same measure)
+    int lane_t = lane;
+    if (BWD && HIDDEN) asm volatile("" : "+v"(lane_t));
     PH_TILE(v == 0)
     const int row0 = ts.at(v) * tstride;
     const int nvalid = min(TILE_ROWS, p.n_angles - row0);
@@ -955,40 +960,40 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     V64 x;
     f32x4 z[2 * VT];
     if (PIPE) {
-      gather_commit128(gr_p, T, TS, lane);
+      gather_commit128(gr_p, T, TS, lane_t);
       x = x_p;
       __builtin_amdgcn_wave_barrier();
       read_dl<2 * VT>(Trow, g, z);
       PH(0)
       if (v + 1 < ts.count) {
         const int a1 = row_of(v + 1);
-        gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane);
-        // lane group recomputed in place (volatile: not hoisted): the loop-invariant p.ang + lane offset otherwise lives in a register pair
+        gather_issue128(gr_p, p.R, b1_n2, p.R + 2 * D, b2_n2, p.S, ctr_n2, 4 * D, 4 * D, 2 * D, lane_t);
+        // lane_t group recomputed in place (volatile: not hoisted): the loop-invariant p.ang + lane_t offset otherwise lives in a register pair
         // over the whole tile -- at 256 registers it is spilled, and its reload waits (vmcnt, in order) behind the gathers just issued
         int lane_here;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
         read_dl<VT>(p.ang + (size_t)a1 * D, lane_here >> 4, x_p.t);
         ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
-        if (v + 2 < ts.count) {   // (row index from the recomputed lane as well: the strength-reduced constant 2 stride + j was spilled too)
+        if (v + 2 < ts.count) {   // (row index from the recomputed lane_t as well: the strength-reduced constant 2 stride + j was spilled too)
           const int a2 = max(0, min(ts.at(v + 2) * tstride + (lane_here & 15), p.n_angles - 1));
           ctr_n2 = p.a_ctr[a2]; b1_n2 = p.a_b1c[a2]; b2_n2 = p.a_b2c[a2];
         }
       }
     } else {
       // the angle rows are consumed (B operand of the first contraction) before the table sum is written
-      gather_rows64(T, TS, p.ang, a, lane);
+      gather_rows64(T, TS, p.ang, a, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, x.t);
       __builtin_amdgcn_wave_barrier();
       PH(0)   // indices + angle rows
-      gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane);
+      gather_sum128(T, TS, p.R, b1, p.R + 2 * D, b2, p.S, ctr, 4 * D, 4 * D, 2 * D, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<2 * VT>(Trow, g, z);
     }
     PH(1)   // table gather
     Rows64 gy_rows;
-    if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
-    if (SPLIT == 2) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane);
+    if (BWD && !HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);   // AngleUpdate adjoint: dE/d(new angle), read under the first contraction
+    if (SPLIT == 2) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane_t);
     else gemm_split<VT, 2 * VT, false, !BWD>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
     if (BWD && !HIDDEN) {
       __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
@@ -1014,8 +1019,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       }
       write_dl<VT>(Trow, g, y.t);
       __builtin_amdgcn_wave_barrier();
-      if (HIDDEN) seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.out, D, lane);
-      else scatter_rows64<false>(T, TS, p.out, a, nvalid, lane);
+      if (HIDDEN) seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.out, D, lane_t);
+      else scatter_rows64<false>(T, TS, p.out, a, nvalid, lane_t);
       PH(4)   // forward output
     } else {
       V64 gy, gzc, gzg;
@@ -1031,10 +1036,10 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         write_dl<VT>(Trow, g, g1.t);
         write_dl<VT>(Trow + D, g, g2.t);
         __builtin_amdgcn_wave_barrier();
-        seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.Gwbgc, D, lane);
-        row_atomic_add<D>(T + D, TS, valid ? b2 : -1, nvalid, p.Gwbgc, D, lane);
+        seg_colsum_atomic<D>(T, TS, valid ? b1 : -1, nvalid, p.Gwbgc, D, lane_t);
+        row_atomic_add<D>(T + D, TS, valid ? b2 : -1, nvalid, p.Gwbgc, D, lane_t);
       } else {
-        rows64_commit(gy_rows, T, TS, lane);             // dE/d(new angle) of this tile, issued above
+        rows64_commit(gy_rows, T, TS, lane_t);             // dE/d(new angle) of this tile, issued above
         __builtin_amdgcn_wave_barrier();
         read_dl<VT>(Trow, g, gy.t);
       }
@@ -1055,27 +1060,27 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
 #pragma unroll
           for (int it = 0; it < TILE_ROWS / 4; ++it) gang_old.v[it] = zero4();
         } else {
-          rows64_issue(gang_old, p.Gang, a, lane);
+          rows64_issue(gang_old, p.Gang, a, lane_t);
         }
-        gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane);
+        gemm_rm<2 * VT, VT, true, true>(ga.t, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, gz, j, g, lane_t);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         PH(6)   // W_ang^T contraction
-        scatter_rows64_add(T, TS, p.Gang, a, nvalid, lane, gang_old);
+        scatter_rows64_add(T, TS, p.Gang, a, nvalid, lane_t, gang_old);
       } else {
         gemm_split<2 * VT, VT, true>(ga.t, reinterpret_cast<const h16x8*>(WangT), D, gz, j, g);
         write_dl<VT>(Trow, g, ga.t);
         __builtin_amdgcn_wave_barrier();
         PH(6)   // W_ang^T contraction
-        scatter_rows64<true>(T, TS, p.Gang, a, nvalid, lane);
+        scatter_rows64<true>(T, TS, p.Gang, a, nvalid, lane_t);
       }
       __builtin_amdgcn_wave_barrier();
       PH(7)   // Gang update
       write_dl<2 * VT>(Trow, g, gz);
       __builtin_amdgcn_wave_barrier();
-      seg_colsum_atomic<2 * D>(T, TS, valid ? b1 : -1, nvalid, p.GR, 4 * D, lane);
-      row_atomic_add<2 * D>(T, TS, valid ? b2 : -1, nvalid, p.GR + 2 * D, 4 * D, lane);
-      seg_colsum_atomic<2 * D>(T, TS, valid ? ctr : -1, nvalid, p.GS, 2 * D, lane);
+      seg_colsum_atomic<2 * D>(T, TS, valid ? b1 : -1, nvalid, p.GR, 4 * D, lane_t);
+      row_atomic_add<2 * D>(T, TS, valid ? b2 : -1, nvalid, p.GR + 2 * D, 4 * D, lane_t);
+      seg_colsum_atomic<2 * D>(T, TS, valid ? ctr : -1, nvalid, p.GS, 2 * D, lane_t);
       PH(8)   // GR / GS scatter
     }
     __builtin_amdgcn_wave_barrier();
