@@ -511,11 +511,13 @@ __global__ __launch_bounds__(BLOCK) void k_atomconv_image(AtomConvArgs p, float*
   else atomconv_fwd_stage(out, p, threadIdx.x, BLOCK);
 }
 
-// row of h_bond that feeds bond k's partial, as an offset from hb0 (floats); node: the row carries layer features (no q_bias)
-__device__ __forceinline__ long bond_row_offset(const AtomConvArgs& p, int k, bool& node) {
-  const int bn = p.hbc ? p.u_bnode[k] : -1;
-  node = bn >= 0;
-  return node ? (p.hbc - p.hb0) + (long)bn * D : (long)k * D;
+// Row of h_bond that feeds bond k's partial, as an offset from hb0 (floats).  bn = bond_node(k) >= 0: the row carries layer features
+// (no q_bias).  In two steps: the node index is REQUESTED two tiles ahead and only turned into an offset when the gather is issued --
+// consumed at the load (compare + select) it made every tile wait for it and, the memory counter being in order, for the gathers of
+// the next tile issued just before.
+__device__ __forceinline__ int bond_node(const AtomConvArgs& p, int k) { return p.hbc ? p.u_bnode[k] : -1; }
+__device__ __forceinline__ long bond_row_offset(const AtomConvArgs& p, int k, int bn) {
+  return bn >= 0 ? (p.hbc - p.hb0) + (long)bn * D : (long)k * D;
 }
 
 // NW waves per workgroup.  The bond partial Q[k] = hb[k] . W_bond^T is contracted here (one more split contraction per tile)
@@ -542,17 +544,16 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
   GatherPH gr;
   V64 wv_nx;
   int c_nx = 0, n_nx = 0, c_n2 = 0, n_n2 = 0;
-  long h_nx = 0, h_n2 = 0;
-  bool node_nx = false, node_n2 = false;
+  int bn_nx = -1, bn_n2 = -1;          // bond-graph node (or -1) of the rows gathered next / after that
   if (ts.count > 0) {
     const int r0 = row_of(0);
     c_nx = p.e_center[r0]; n_nx = p.e_nbr[r0];
-    h_nx = bond_row_offset(p, r0 >> 1, node_nx);
-    gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
+    bn_nx = bond_node(p, r0 >> 1);
+    gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, bond_row_offset(p, r0 >> 1, bn_nx), lane);
     read_dl<VT>(p.wag + (size_t)(r0 >> 1) * D, g, wv_nx.t);
     const int r1 = row_of(1);
     c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
-    h_n2 = bond_row_offset(p, r1 >> 1, node_n2);
+    bn_n2 = bond_node(p, r1 >> 1);
   }
   // the first tile's indices and gathers are requested BEFORE the weights are staged: two dependent memory round trips land under
   // the staging (small batches -- MD -- run one or two tiles per wave, and the prologue was a tenth of the launch)
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     // bond-pair order (rows 2k, 2k+1 = the two directions of bond k): hb[k] and w_ag[k] are fetched once per bond (the second
     // row's copy comes from L1)
     const int c = c_nx;
-    const bool node = node_nx;
+    const bool node = bn_nx >= 0;
     const V64 wv = wv_nx;
     gather_commit_h(gr, T, TS, lane);      // hb rows first: the tile's left half is reused by the table sums below
     __builtin_amdgcn_wave_barrier();
@@ -573,14 +574,14 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     __builtin_amdgcn_wave_barrier();
     gather_commit_p(gr, T, TS, lane);
     __builtin_amdgcn_wave_barrier();
-    c_nx = c_n2; n_nx = n_n2; h_nx = h_n2; node_nx = node_n2;
+    c_nx = c_n2; n_nx = n_n2; bn_nx = bn_n2;
     if (v + 1 < ts.count) {
       const int r1 = row_of(v + 1);
-      gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, h_nx, lane);
+      gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, bond_row_offset(p, r1 >> 1, bn_nx), lane);
       read_dl<VT>(p.wag + (size_t)(r1 >> 1) * D, g, wv_nx.t);
       const int r2 = row_of(v + 2);
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
-      h_n2 = bond_row_offset(p, r2 >> 1, node_n2);
+      bn_n2 = bond_node(p, r2 >> 1);
     }
     if (nvalid <= 0) continue;
     f32x4 z[2 * VT];
