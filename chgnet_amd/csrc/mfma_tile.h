@@ -468,17 +468,26 @@ template <bool OPAQUE = false>
 __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid, int lane,
                                                    const Rows64& old) {
   const int sub = lane >> 4, t = lane & 15;
+  // all sums first, then the stores: a wait for an old row placed between the (conditional, hence uncounted) stores is a wait for the
+  // stores before it
+  f32x4 v[TILE_ROWS / 4];
+  int r[TILE_ROWS / 4];
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
     const int rr = 4 * it + sub;
-    const int r = __shfl(idx, rr);
+    r[it] = __shfl(idx, rr);
+    v[it] = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) asm volatile("" : "+v"(v[it]));   // (the scheduler re-interleaves the two loops otherwise)
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) {
     // OPAQUE (per-atom BondConv adjoint): compared as sub < nvalid - 4 it with the right side hidden from the optimiser.  Written as
     // rr < nvalid the compiler kept 4 it + sub for every `it` in registers across the kernel, spilled them and reloaded each BETWEEN
     // these stores: the wait for a scratch reload is a wait for every store before it -- 3 store round trips per tile
     int lim = nvalid - 4 * it;
     if (OPAQUE) asm volatile("" : "+v"(lim));
-    if (sub < lim)
-      *reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)r * D + 4 * t) = old.v[it] + *reinterpret_cast<const f32x4*>(tile + rr * stride + 4 * t);
+    if (sub < lim) *reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)r[it] * D + 4 * t) = v[it];
   }
 }
 
