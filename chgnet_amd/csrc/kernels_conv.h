@@ -337,16 +337,21 @@ __device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
       contract(acc, 0, x);
       write_dl<NFT>(T + j * XS, g, acc);
       __builtin_amdgcn_wave_barrier();
+      // all sums, then the stores: a wait for an old row between the conditional (uncounted) stores is a wait for those stores
+      f32x4 ov[NO];
+      int orow[NO];
 #pragma unroll
       for (int it = 0; it < NO; ++it) {
         const int rr = RPO * it + suby;
-        const int r = __shfl(out_row, rr);
-        if (rr < nvalid) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * ty);
-          if (rmw) v += old[it];
-          *reinterpret_cast<f32x4*>(p.Y + (size_t)r * p.ldy + 4 * ty) = v;
-        }
+        orow[it] = __shfl(out_row, rr);
+        ov[it] = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * ty);
+        if (rmw) ov[it] += old[it];
       }
+#pragma unroll
+      for (int it = 0; it < NO; ++it) asm volatile("" : "+v"(ov[it]));
+#pragma unroll
+      for (int it = 0; it < NO; ++it)
+        if (RPO * it + suby < nvalid) *reinterpret_cast<f32x4*>(p.Y + (size_t)orow[it] * p.ldy + 4 * ty) = ov[it];
       __builtin_amdgcn_wave_barrier();
     }
     return;
@@ -390,18 +395,27 @@ __device__ __forceinline__ void rows_gemm_body(RowsGemm p, int cb) {
         __builtin_amdgcn_wave_barrier();
         float* Y = p.Y + (part ? p.y2_off : 0);
         const int sub = lane / LPO, t = lane % LPO;
+        // every old / residual row of the tile is requested first (rows past nvalid index a valid row: harmless reads), summed, and
+        // only then stored: row by row, each load was waited for in place -- behind the previous row's store
+        constexpr int NOI = TILE_ROWS / RPO;
+        f32x4 ov[NOI];
+        f32x4* odst[NOI];
 #pragma unroll
-        for (int it = 0; it < TILE_ROWS / RPO; ++it) {
-          const int rr = RPO * it + sub;
-          const int r = __shfl(out_row, rr);
-          if (rr < nvalid) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * XS + 4 * t);
-            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)r * p.ldr + 4 * t);
-            f32x4* dst = reinterpret_cast<f32x4*>(Y + (size_t)r * p.ldy + 4 * t);
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
+        for (int it = 0; it < NOI; ++it) {
+          const int r = __shfl(out_row, RPO * it + sub);
+          odst[it] = reinterpret_cast<f32x4*>(Y + (size_t)r * p.ldy + 4 * t);
+          ov[it] = zero4();
+          if (p.resid) ov[it] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)r * p.ldr + 4 * t);
+          if (p.accumulate) ov[it] += *odst[it];
         }
+#pragma unroll
+        for (int it = 0; it < NOI; ++it) {
+          ov[it] += *reinterpret_cast<const f32x4*>(T + (RPO * it + sub) * XS + 4 * t);
+          asm volatile("" : "+v"(ov[it]));
+        }
+#pragma unroll
+        for (int it = 0; it < NOI; ++it)
+          if (RPO * it + sub < nvalid) *odst[it] = ov[it];
         __builtin_amdgcn_wave_barrier();
       }
     }
