@@ -83,6 +83,8 @@ struct chg_engine {
   size_t scratch_bytes = 0, scratch_wanted = 0;
   char* h_stage = nullptr;   // pinned staging for the inputs of chg_batch_build
   size_t h_stage_bytes = 0;
+  char* h_out = nullptr;     // pinned staging for the outputs of chg_batch_download (small batches: one queue of async copies, one sync)
+  size_t h_out_bytes = 0;
   int num_cus = 256;
   // single-pass graph builds (chg_batch_build): counts of the previous build size the next one's scratch speculatively
   bool spec_builds = true;    // CHGNET_SPEC_BUILD=0 forces the exact three-round-trip pass
