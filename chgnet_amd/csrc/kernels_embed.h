@@ -127,14 +127,33 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   int tb, te;
   tile_range(ntiles, tb, te);
   float fa6[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, fa3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // TRAIN: d freq, this lane's rows
+  // Inputs run ahead of the tiles: the bond length of tile t+1 (a load through the index requested during tile t-1) and the indices of
+  // tile t+2 are requested at the top of tile t and taken (an empty asm: a wait placed by hand) after the basis functions, BEFORE the
+  // tile's stores.  Read in place, every tile began with two dependent round trips, waited for behind the previous tile's stores
+  // (conditional, so the compiler's wait covered them all): SQ_WAIT_ANY 61 % of the wave cycles of the forward kernel.
+  auto row_k = [&](int tile) { return max(0, min(tile * BLOCK_ROWS + wave * TILE_ROWS + j, p.n_und - 1)); };
+  int d_n = 0, node_n = -1, d_n2 = 0, node_n2 = -1;
+  float rlen_n = 1.f;
+  if (tb < te) {
+    const int k0 = row_k(tb), k1 = row_k(tb + 1);
+    d_n = p.u_u2d[k0]; node_n = p.u_bnode[k0];
+    d_n2 = p.u_u2d[k1]; node_n2 = p.u_bnode[k1];
+    rlen_n = p.ev[d_n][3];
+  }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_und - row0);
+    const float rlen = rlen_n;
+    const int node = node_n;
+    {   // requests for the next two tiles (clamped rows: harmless reads past the end)
+      node_n = node_n2;
+      rlen_n = p.ev[d_n2][3];
+      const int k2 = row_k(tile + 2);
+      d_n2 = p.u_u2d[k2]; node_n2 = p.u_bnode[k2];
+    }
     if (nvalid <= 0) continue;
     const bool valid = j < nvalid;
     const int k = row0 + (valid ? j : 0);
-    const float rlen = p.ev[p.u_u2d[k]][3];
-    const int node = p.u_bnode[k];
     f32x4 x6[2], x3[2], d6[2], d3[2], q6[2], q3[2];
     const EnvAt e6 = env_at(rlen, p.rc_ag, p.env), e3 = env_at(rlen, p.rc_bg, p.env);
 #pragma unroll
@@ -152,6 +171,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
         d3[kt][r] = pad ? 0.f : dv;
         q3[kt][r] = pad ? 0.f : df;
       }
+    asm volatile("" : "+v"(rlen_n), "+v"(d_n2), "+v"(node_n2));   // the requests above have landed by now; nothing is stored before here
     if (TRAIN && valid) {   // bases of this bond: B operand of the embedding-weight gradients (kernels_train.h)
       write_dl<2>(p.Xb + (size_t)k * D, g, x6);
       write_dl<2>(p.Xb + (size_t)k * D + KB, g, x3);
