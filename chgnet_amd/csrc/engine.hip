@@ -178,6 +178,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   }
   eng->num_cus = prop.multiProcessorCount;
   HIP_TRY(eng, hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+  HIP_TRY(eng, hipStreamCreateWithFlags(&eng->copy_stream, hipStreamNonBlocking));
   HIP_TRY(eng, hipEventCreate(&eng->t0));
   HIP_TRY(eng, hipEventCreate(&eng->t1));
   Weights probe{};
@@ -211,6 +212,7 @@ int chg_engine_destroy(chg_engine* eng) {
   if (eng->h_out) hipHostFree(eng->h_out);
   if (eng->d_weights) hipFree(eng->d_weights);
   if (eng->d_images) hipFree(eng->d_images);
+  if (eng->copy_stream) hipStreamDestroy(eng->copy_stream);
   if (eng->stream) hipStreamDestroy(eng->stream);
   delete eng;
   return CHG_OK;
@@ -250,6 +252,7 @@ int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_
   HIP_TRY(eng, hipSetDevice(eng->device));
   size_t f = 0, t = 0;
   HIP_TRY(eng, hipMemGetInfo(&f, &t));
+  std::lock_guard<std::mutex> lk(eng->pool_mu);
   for (auto& a : eng->arena_pool) f += a.second;   // pooled arenas are reusable
   for (auto& a : eng->work_pool) f += a.second;
   if (free_bytes) *free_bytes = (int64_t)f;
@@ -294,14 +297,15 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   }
   int s = CHG_OK;
   const size_t B = b->B, N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
-#define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n))
+#define UP(field, n) if (s == CHG_OK) s = h2d(eng, b->field, h->field, (n), eng->copy_stream)
   UP(z, N); UP(atom_owner, N); UP(atom_off, B + 1); UP(frac, 3 * N); UP(lattice, 9 * B);
   UP(e_center, Ed); UP(e_nbr, Ed); UP(e_d2u, Ed); UP(e_owner, Ed); UP(e_image, 3 * Ed); UP(e_rev, Ed); UP(p_center, Ed); UP(p_nbr, Ed);
   UP(u_u2d, Eu); UP(u_bnode, Eu); UP(bn_und, Eb);
   UP(a_ctr, A); UP(a_b1c, A); UP(a_b2c, A); UP(a_d1, A); UP(a_d2, A);
 #undef UP
-  if (s == CHG_OK) s = prepare_windows(eng, b);
-  if (s == CHG_OK && hipStreamSynchronize(eng->stream) != hipSuccess) { eng->err = "chg_batch_upload: sync failed"; s = CHG_EHIP; }
+  // (copy stream only: the caller may be a loader thread next to a running sweep -- nothing is launched on the compute stream here)
+  b->win_pending = true;
+  if (s == CHG_OK && hipStreamSynchronize(eng->copy_stream) != hipSuccess) { eng->err = "chg_batch_upload: sync failed"; s = CHG_EHIP; }
   if (s != CHG_OK) { hipFree(b->arena); delete b; return s; }
   *out = b;
   return CHG_OK;
@@ -312,6 +316,7 @@ int chg_debug_fetch_i32(chg_engine* eng, chg_batch* b, const char* name, int32_t
   auto it = b->named_i32.find(name);
   if (it == b->named_i32.end()) { eng->err = std::string("chg_debug_fetch_i32: unknown buffer ") + name; return CHG_EINVAL; }
   const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));
+  TRY(ensure_windows(eng, b));
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));
   if (n) HIP_TRY(eng, hipMemcpy(dst, it->second.first, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (n_written) *n_written = (int64_t)n;
@@ -343,8 +348,12 @@ int chg_batch_free(chg_engine* eng, chg_batch* b) {
   release_workspace(eng, b->t2_arena, b->t2_bytes, 1);
   free_train2(b);
   if (b->arena) {
-    if (eng && eng->arena_pool.size() < 2) eng->arena_pool.emplace_back(b->arena, b->arena_bytes);
-    else hipFree(b->arena);
+    bool pooled = false;
+    if (eng) {
+      std::lock_guard<std::mutex> lk(eng->pool_mu);
+      if (eng->arena_pool.size() < 2) { eng->arena_pool.emplace_back(b->arena, b->arena_bytes); pooled = true; }
+    }
+    if (!pooled) hipFree(b->arena);
   }
   delete b;
   return CHG_OK;
@@ -356,6 +365,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   if (!eng || !b) return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   const uint32_t task = task_mask | CHG_TASK_E;
+  TRY(ensure_windows(eng, b));
   if (eng->profiling || !eng->use_graphs) return run_predict(eng, b, task);   // per-kernel events need eager launches
   if (b->graph_task != task) {
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);

@@ -74,6 +74,7 @@ int acquire_arena(chg_engine* eng, chg_batch* b, size_t total) {
     eng->err = "batch needs " + std::to_string(total) + " bytes of device memory, the engine's limit is " + std::to_string(eng->memory_limit);
     return CHG_ENOMEM;
   }
+  std::lock_guard<std::mutex> lk(eng->pool_mu);
   int best = -1;
   for (int i = 0; i < (int)eng->arena_pool.size(); ++i)
     if (eng->arena_pool[i].second >= total && (best < 0 || eng->arena_pool[i].second < eng->arena_pool[best].second)) best = i;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,11 @@ struct chg_engine {
   std::map<std::string, int> prof_index;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
+  // chg_batch_upload may run on a second host thread while this engine computes (a data loader uploading the next batch under the
+  // current step's sweeps): its copies go through copy_stream, the arena pools are guarded, and everything it would launch on the
+  // compute stream (the per-atom index, prepare_windows) waits for the batch's first use (chg_batch::win_pending)
+  hipStream_t copy_stream = nullptr;
+  std::mutex pool_mu;
   std::vector<std::pair<char*, size_t>> arena_pool;   // released batch arenas, reused by later uploads
   std::vector<std::pair<char*, size_t>> work_pool;    // released training workspaces (tens of GB: a hipMalloc per step would dominate it)
   std::vector<int> work_kind;                         // 0: first-order workspace, 1: second-order workspace
@@ -132,6 +138,7 @@ struct chg_batch {
   int *win_tmp = nullptr, *win_scan = nullptr;
   int win_grid = 64;        // workgroups of the per-atom kernels (a multiple of 64: the atom schedule is built for it, k_win_schedule)
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
+  bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
   int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   uint32_t last_task = 0;
@@ -219,10 +226,10 @@ inline int wave_grid(chg_engine* eng, int64_t items) {   // one wave per item, 4
 }
 
 template <class T>
-int h2d(chg_engine* eng, T* dst, const T* src, size_t n) {
+int h2d(chg_engine* eng, T* dst, const T* src, size_t n, hipStream_t stream = nullptr) {
   if (n == 0) return CHG_OK;
   if (!src) { eng->err = "chg_batch_upload: null host array"; return CHG_EINVAL; }
-  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, eng->stream));
+  HIP_TRY(eng, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, stream ? stream : eng->stream));
   return CHG_OK;
 }
 template <class T>
@@ -260,6 +267,7 @@ AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b);
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
 void carve(chg_batch* b, char* base, size_t& total);
 int prepare_windows(chg_engine* eng, chg_batch* b);
+int ensure_windows(chg_engine* eng, chg_batch* b);   // launches a pending prepare_windows (compute stream)
 void register_names(chg_batch* b);
 
 // ---- engine_train.hip

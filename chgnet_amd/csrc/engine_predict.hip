@@ -647,6 +647,12 @@ void carve(chg_batch* b, char* base, size_t& total) {
 
 // Centre-major row order and (atom, bond) pair indices of the angle adjoints (kernels_angle_w.h): once per batch topology,
 // stream-ordered, no host round trip; a graph without the canonical structure leaves win.flag[0] = 0.
+int ensure_windows(chg_engine* eng, chg_batch* b) {
+  if (!b->win_pending) return CHG_OK;
+  b->win_pending = false;
+  return prepare_windows(eng, b);
+}
+
 int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;

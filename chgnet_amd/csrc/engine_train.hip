@@ -123,8 +123,11 @@ char* acquire_workspace(chg_engine* eng, size_t total, size_t& got, int kind) {
   for (auto& a : eng->work_pool) hipFree(a.first);   // make room (both pools) and ask for the exact size
   eng->work_pool.clear();
   eng->work_kind.clear();
-  for (auto& a : eng->arena_pool) hipFree(a.first);
-  eng->arena_pool.clear();
+  {
+    std::lock_guard<std::mutex> lk(eng->pool_mu);
+    for (auto& a : eng->arena_pool) hipFree(a.first);
+    eng->arena_pool.clear();
+  }
   if (hipMalloc(&p, total) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   got = total;
   return p;

@@ -86,7 +86,8 @@ class DeviceBatch:
 
 
 class Engine:
-    """One engine per GPU; not thread-safe (serialise calls per engine)."""
+    """One engine per GPU; not thread-safe (serialise calls per engine) -- except ``upload``, which may run on a second thread
+    while the engine computes (its copies use their own stream; TrainStep.run_epoch uploads the next batch that way)."""
 
     def __init__(self, weights: PackedWeights, device: int = 0) -> None:
         self.lib = _lib.load()

@@ -172,7 +172,7 @@ class CHGNet:
 
     # ---- batched forward (model.py:330-387) -----------------------------------------------------------
     def forward(self, graphs: Sequence, *, task: str = "e", return_site_energies: bool = False,
-                return_atom_feas: bool = False, return_crystal_feas: bool = False) -> dict:
+                return_atom_feas: bool = False, return_crystal_feas: bool = False, device_batch=None) -> dict:
         """One device batch from ``graphs`` -> the reference's batch dictionary (model.py:330-387, 427-542):
         ``atoms_per_graph`` int64 [B], ``e`` float32 [B] (eV/atom when ``is_intensive``), and -- by task --
         ``f`` list of [n,3] (eV/A), ``s`` list of [3,3] (GPa), ``m`` list of [n] (mu_B); optional
@@ -192,7 +192,8 @@ class CHGNet:
             packed = pack_batch(graphs)
         eng = self.engine
         self.release_forward_state()
-        batch = eng.upload(packed)
+        # device_batch: ``packed`` already uploaded (Engine.upload may run on a loader thread while the previous step computes)
+        batch = device_batch if device_batch is not None else eng.upload(packed)
         self._fwd_batch, self._fwd_task = batch, task
         eng.predict(batch, task)
         res = eng.download(batch, task, site_energies=return_site_energies, atom_feas=return_atom_feas,

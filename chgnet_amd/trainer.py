@@ -287,26 +287,26 @@ class TrainStep:
 
         from chgnet_amd.pack import pack_batch  # noqa: PLC0415
 
-        def prepare(i):          # data-loader work of step i: pack the graphs, flatten the label lists (CombinedLoss keeps them)
-            packed = pack_batch(batches[i])
+        def prepare(i):          # data-loader work of step i: pack the graphs, flatten the label lists (CombinedLoss keeps them),
+            packed = pack_batch(batches[i])      # and put the batch on the device (copy stream: under the current step's sweeps)
             self.loss._flat_targets(targets[i], np.diff(packed.atom_off))
-            return packed
+            return packed, self.model.engine.upload(packed)
 
         infos = []
         with ThreadPoolExecutor(max_workers=1) as pool:
             nxt = pool.submit(prepare, 0) if len(batches) else None
             for i in range(len(batches)):
-                packed = nxt.result()
+                packed, device_batch = nxt.result()
                 nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
-                infos.append(self(packed, targets[i]))
+                infos.append(self(packed, targets[i], device_batch=device_batch))
         return infos
 
-    def __call__(self, graphs, targets: dict) -> dict:
+    def __call__(self, graphs, targets: dict, device_batch=None) -> dict:
         import time  # noqa: PLC0415
 
         model = self.model
         t0 = time.perf_counter()
-        pred = model.forward(graphs, task=self.task)
+        pred = model.forward(graphs, task=self.task, device_batch=device_batch)
         t1 = time.perf_counter()
         info, g = self.loss.gradients(targets, pred)
         t2 = time.perf_counter()
