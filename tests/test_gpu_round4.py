@@ -371,3 +371,37 @@ def test_calculator_under_an_atoms_shaped_object(golden_weights):
     e2 = calc.get_potential_energy(moved)            # a rigid shift: same energy, the accessor recomputes for the new object
     assert abs(e2 - r["energy"]) < 1e-4 and np.abs(calc.get_forces(moved) - want["f"]).max() < 1e-5
     model.release_forward_state()
+
+
+@pytest.mark.gpu
+def test_upload_on_a_loader_thread_next_to_a_running_sweep(hip_engine, big_batch):
+    """chg_batch_upload is the one call that may run on a second host thread while the engine computes (copy stream, guarded arena
+    pools, per-atom index built at the batch's first use): the trainer uploads the next batch that way.  The batch uploaded under
+    running sweeps gives the same results as one uploaded on its own."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    ref_batch = hip_engine.upload(big_batch)
+    try:
+        hip_engine.predict(ref_batch, "efs")
+        ref = hip_engine.download(ref_batch, "efs")
+    finally:
+        ref_batch.free()
+    a = hip_engine.upload(big_batch)
+    b = None
+    try:
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(hip_engine.upload, big_batch)
+            for _ in range(6):
+                hip_engine.predict(a, "efs")
+            b = fut.result()
+        res_a = hip_engine.download(a, "efs")
+        hip_engine.predict(b, "efs")
+        res_b = hip_engine.download(b, "efs")
+    finally:
+        a.free()
+        if b is not None:
+            b.free()
+    for res in (res_a, res_b):
+        assert np.abs(res["e"] - ref["e"]).max() < 2e-6
+        assert np.abs(res["f"] - ref["f"]).max() < 2e-6
+        assert np.abs(res["s"] - ref["s"]).max() < 2e-5
