@@ -36,7 +36,7 @@ constexpr float F16_OPERAND_LIMIT = 65504.0f;   // largest finite f16: forward o
 #define CHG_FWD_WAVES 8
 #endif
 #ifdef CHG_PHASE_TIMING
-constexpr size_t PHASE_FLOATS = (size_t)6 * 2 * 10 * PH_WAVES;   // kernels_conv.h PH_FLUSH
+constexpr size_t PHASE_FLOATS = (size_t)8 * 2 * 10 * PH_WAVES;   // kernels_conv.h PH_FLUSH
 #else
 constexpr size_t PHASE_FLOATS = 64;
 #endif

@@ -294,6 +294,7 @@ AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   a.gw = eng->w.ac[l].g;
   a.agg = b->agg_l[l]; a.GA = b->GA; a.GP = b->GP_l[l]; a.GQ = b->GQ; a.Gwag = b->Gwag;
   a.first_wag = l == b->L - 1;   // the reverse sweep starts with the last AtomConv
+  a.phase = b->phase;
   a.hb0 = b->hb0;
   a.hbc = (b->Eb > 0 && b->hbc[l] != b->hbc[0]) ? b->hbc[l] : nullptr;   // bond-graph nodes carry layer-l features
   a.u_bnode = b->u_bnode;

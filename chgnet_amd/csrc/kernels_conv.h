@@ -452,6 +452,25 @@ constexpr size_t rows_gemm_lds() {
   return sizeof(float) * (PARTS * NOUT * (K + PAD) + NOUT + WAVES * TILE_ROWS * ((K > NOUT ? K : NOUT) + PAD));
 }
 
+// Phase timing (diagnostic builds, -DCHG_PHASE_TIMING): s_memtime deltas between the phases of a tile,
+// summed per wave and added to p.phase[base + i] at the end; read back with chg_debug_fetch("phase")
+// (tests/gpu_phase_probe.py).
+#ifdef CHG_PHASE_TIMING
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(); bool ph_first = true; float ph_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_acc1[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define PH_TILE(first) ph_first = (first);
+#define PH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (ph_first) ph_acc1[i] += (float)(t_ - ph_t); else ph_acc[i] += (float)(t_ - ph_t); ph_t = t_; __builtin_amdgcn_sched_barrier(0); }
+// p.phase[kernel 0..3][later / first tile][slot 0..9][wave 0..PH_WAVES): every wave adds to its own floats (plain read-modify-write: the
+// first version met in 20 shared addresses, and 2048 waves' same-address atomics -- ~110 ns each -- cost more than the kernel)
+constexpr int PH_WAVES = 4096;
+#define PH_FLUSH(base) { const int gw_ = blockIdx.x * (blockDim.x >> 6) + wave; if (lane == 0 && gw_ < PH_WAVES) { for (int i_ = 0; i_ < 10; ++i_) { \
+  p.phase[((size_t)((base) / 10 * 2 + 0) * 10 + i_) * PH_WAVES + gw_] += ph_acc[i_]; p.phase[((size_t)((base) / 10 * 2 + 1) * 10 + i_) * PH_WAVES + gw_] += ph_acc1[i_]; } } }
+#else
+#define PH_DECL
+#define PH_TILE(first)
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
+
 // =============================================================================================
 // AtomConv
 // =============================================================================================
@@ -476,6 +495,7 @@ struct AtomConvArgs {
   float* GQ;           // [Eu,128] zeroed
   float* Gwag;         // [Eu,64] accumulated over layers
   int first_wag;       // this launch is the first writer of Gwag in the sweep: store, do not read (the buffer is not zeroed)
+  float* phase;        // CHG_PHASE_TIMING builds only (kernel slots 6 = forward, 7 = adjoint)
   // training (k_atomconv_bwd<true>) only
   float* dumpG;        // [Ed,128] pair order: adjoint of the second-layer pre-activations (core | gate)
   float* dumpH;        // [Ed,128] pair order: hidden activations (core | gate)
@@ -734,7 +754,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   __syncthreads();
   TrainTile tt{};
   tt.T = T; tt.lane = lane;
+  PH_DECL
   for (int v = 0; v < ts.count; ++v) {
+    PH_TILE(v == 0)
     const int row0 = ts.at(v) * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_edges - row0);   // even: Ed = 2 Eu and tiles are 16 rows
     if (TRAIN) {
@@ -761,7 +783,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     read_dl<VT>(Trow + D, g, zg.t);
     GatedState s;
     V64 y;
+    PH(0)   // next indices, weights / aggregate adjoint rows, old Gwag rows requested; table sums read
     gated_forward<true, false, TRAIN, true>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
+    PH(1)   // forward recomputation
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
     CHG_EV(ft) {
@@ -784,7 +808,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
           if (b < nb) dst[(size_t)b * D] = prev[b];
       }
     }
+    PH(2)   // bond-weight gradient rows
     gated_backward<true, false, TRAIN, true>(gy, zc, zg, W2cT, W2gT, vecs, j, g, s, gzc, gzg, &tt);
+    PH(3)   // gated adjoint
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
@@ -792,12 +818,16 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     {  // the next tile's gathers fly while this tile's run sums are formed and sent
       GatherRegs gr;
       gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
+      PH(4)   // next tile's gathers issued
       acbwd_scatter(T, c, nvalid, k0, p, lane);
+      PH(5)   // scatter: GQ rows, run sums of the two atoms
       __builtin_amdgcn_wave_barrier();
       gather_commit128(gr, T, TS, lane);
+      PH(6)   // next tile's gathers landed
     }
     c = cn; n = nn; k = kn;
   }
+  PH_FLUSH(70)
   if (TRAIN) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) atomicAdd(p.g_ln + q * D + lane, tt.ln[q]);
@@ -842,24 +872,6 @@ constexpr size_t angle_lds() {
   return 16 * (size_t)((BWD ? 2 : 1) * IMG128 + (HIDDEN ? 2 * IMG64 : 0)) + sizeof(float) * (VEC_SLOTS * D + NW * TILE_FLOATS);
 }
 
-// Phase timing (diagnostic builds, -DCHG_PHASE_TIMING): s_memtime deltas between the phases of a tile,
-// summed per wave and added to p.phase[base + i] at the end; read back with chg_debug_fetch("phase")
-// (tests/gpu_phase_probe.py).
-#ifdef CHG_PHASE_TIMING
-#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(); bool ph_first = true; float ph_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_acc1[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define PH_TILE(first) ph_first = (first);
-#define PH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (ph_first) ph_acc1[i] += (float)(t_ - ph_t); else ph_acc[i] += (float)(t_ - ph_t); ph_t = t_; __builtin_amdgcn_sched_barrier(0); }
-// p.phase[kernel 0..3][later / first tile][slot 0..9][wave 0..PH_WAVES): every wave adds to its own floats (plain read-modify-write: the
-// first version met in 20 shared addresses, and 2048 waves' same-address atomics -- ~110 ns each -- cost more than the kernel)
-constexpr int PH_WAVES = 4096;
-#define PH_FLUSH(base) { const int gw_ = blockIdx.x * (blockDim.x >> 6) + wave; if (lane == 0 && gw_ < PH_WAVES) { for (int i_ = 0; i_ < 10; ++i_) { \
-  p.phase[((size_t)((base) / 10 * 2 + 0) * 10 + i_) * PH_WAVES + gw_] += ph_acc[i_]; p.phase[((size_t)((base) / 10 * 2 + 1) * 10 + i_) * PH_WAVES + gw_] += ph_acc1[i_]; } } }
-#else
-#define PH_DECL
-#define PH_TILE(first)
-#define PH(i)
-#define PH_FLUSH(base)
-#endif
 
 // The weight block at the start of the angle kernels' LDS (see atomconv_fwd_stage).
 // mode 1: split images of Wang (and, adjoint, of Wang^T), W2c, W2g.  mode 2 (BondConv adjoint): one row-major image each.

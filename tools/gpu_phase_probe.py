@@ -41,3 +41,14 @@ try:
             if v[i] > 0: print(f"   {nm:30s} {v[i] / (tiles * launches):8.0f}  {100 * v[i] / tot:5.1f} %")
 except Exception as e:
     print("per-atom phases unavailable:", e)
+
+try:
+    ph8 = eng.debug_fetch(batch, "phase", 8 * 2 * 10 * PH_WAVES).reshape(8, 2, 10, PH_WAVES).sum(axis=(1, 3))
+    v = ph8[7]; tot = v.sum(); et = pb.n_directed / 16
+    if tot > 0:
+        print(f"atomconv_bwd: {tot / (et * 4):8.0f} cycles per wave-tile")
+        for i, nm in enumerate(["requests + table sums read", "forward recomputation", "bond-weight gradient rows", "gated adjoint", "next gathers issued",
+                                "scatter (GQ rows, run sums)", "next gathers landed"]):
+            print(f"   {nm:30s} {v[i] / (et * 4):8.0f}  {100 * v[i] / tot:5.1f} %")
+except Exception as e:
+    print("atomconv phases unavailable:", e)
