@@ -215,7 +215,7 @@ int zero(chg_engine* eng, void* p, size_t bytes) {
 // Prebuilt weight blocks (see stage_image, mfma_tile.h): one per tile kernel and layer, laid out by the kernels' own staging code.
 int build_images(chg_engine* eng) {
   const int L = eng->desc.n_conv;
-  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats();
+  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats(true);   // (with the W_bond^T image of the fused adjoint)
   constexpr size_t BF = AngleLds<true, false>::tiles, BB = AngleLds<true, true>::tiles, UF = AngleLds<false, false>::tiles,
                    UB = AngleLds<false, true>::tiles;
   static_assert(AF % 4 == 0 && AB % 4 == 0 && BF % 4 == 0 && BB % 4 == 0 && UF % 4 == 0 && UB % 4 == 0, "images are copied in 16-byte units");
@@ -322,19 +322,41 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
   return rows_gemm(eng, "gemm_out", 64, 64, b->agg_l[l], D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
 }
 
+// The adjoint with the dE/d h_bond update in its tiles (k_atomconv_bwd<false, 7, true>: no dE/dQ table, no gemm_GQ).
+// Same box, ms per headline step: table + gemm_GQ 4.47 + 1.38; fused 5.56 (of which +0.44 for running 7 instead of 8 waves per
+// workgroup -- the W_bond^T image takes one wave's tile -- and +0.65 for the contraction and the row update): -0.3 ms, and one launch
+// fewer per layer for MD-size batches (replay 0.890 -> 0.861 ms).  CHGNET_FUSE_GQ=0 switches back for A/B timing.
+constexpr int ACB_FUSED_WAVES = 7;
+constexpr size_t acb_fused_lds() { return atomconv_lds<ACB_FUSED_WAVES, true>() + 16 * (size_t)IMG128; }
+static bool fuse_gq() {
+  static const bool on = [] { const char* e = std::getenv("CHGNET_FUSE_GQ"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+
 int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
   const ACW& w = eng->w.ac[l];
   if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
   TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
-  {  // pair-ordered edge list: GQ and Gwag rows are owned by one tile each (no zeroing, no atomics)
+  const bool fused = fuse_gq();
+  {  // pair-ordered edge list: GQ (or, fused, Gb) and Gwag rows are owned by one tile each (no zeroing, no atomics)
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;
     a.e_nbr = b->p_nbr;
     a.image = eng->img_ac_bwd[l];
     a.interleave = (interleave_mask() >> 1) & 1;
+    a.Gb = b->Gb;
+    a.gb_accumulate = l == b->L - 1 ? 0 : 1;
     LaunchScope ls(eng, "atomconv_bwd");
-    hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
+    if (fused)
+      hipLaunchKernelGGL((k_atomconv_bwd<false, ACB_FUSED_WAVES, true>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * ACB_FUSED_WAVES)),
+                         dim3(64 * ACB_FUSED_WAVES), acb_fused_lds(), eng->stream, a);
+    else
+      hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
+  }
+  if (fused) {
+    if (l > 0) TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
+    return CHG_OK;
   }
   if (l > 0 && small_rows(b->N) && small_rows(b->Eu)) {   // small batch: both in one launch (targets: atom rows, bond rows)
     MultiGemm m;
@@ -731,6 +753,7 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
+  if ((s = set_lds(eng, (k_atomconv_bwd<false, ACB_FUSED_WAVES, true>), acb_fused_lds()))) return s;
   if ((s = set_lds(eng, k_angleupd_fwd_a, angle_fa_lds()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;

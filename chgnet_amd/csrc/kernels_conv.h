@@ -496,6 +496,8 @@ struct AtomConvArgs {
   float* Gwag;         // [Eu,64] accumulated over layers
   int first_wag;       // this launch is the first writer of Gwag in the sweep: store, do not read (the buffer is not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only (kernel slots 6 = forward, 7 = adjoint)
+  float* Gb;           // fused form of the adjoint (k_atomconv_bwd<false, NW, true>): dE/d h_bond rows [Eu,64], owned by the tile
+  int gb_accumulate;   // ... += (layers below the last) or = (the sweep's first AtomConv)
   // training (k_atomconv_bwd<true>) only
   float* dumpG;        // [Ed,128] pair order: adjoint of the second-layer pre-activations (core | gate)
   float* dumpH;        // [Ed,128] pair order: hidden activations (core | gate)
@@ -515,7 +517,7 @@ constexpr size_t atomconv_lds() {
 // The weight block at the start of the AtomConv kernels' LDS, as a function of the weights alone: staged in the kernel, or built once
 // per weight upload into global memory (k_atomconv_image) and copied (stage_image).
 constexpr int ac_fwd_image_floats() { return 4 * (2 * IMG64 + IMG128) + AC_VEC_SLOTS * D; }
-constexpr int ac_bwd_image_floats() { return 4 * 4 * IMG64 + VEC_SLOTS * D; }
+constexpr int ac_bwd_image_floats(bool fuse_gq = false) { return 4 * 4 * IMG64 + VEC_SLOTS * D + (fuse_gq ? 4 * IMG128 : 0); }
 __device__ __forceinline__ void atomconv_fwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
   h16x8* I2c = reinterpret_cast<h16x8*>(base);
   h16x8* I2g = I2c + IMG64;
@@ -527,12 +529,14 @@ __device__ __forceinline__ void atomconv_fwd_stage(float* base, const AtomConvAr
   stage_gated_vecs(vecs, p.gw, true, tid);
   for (int q = tid; q < 2 * D; q += nthreads) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
 }
+template <bool FUSE_GQ = false>
 __device__ __forceinline__ void atomconv_bwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
   h16x8* I2c = reinterpret_cast<h16x8*>(base);
   h16x8* I2g = I2c + IMG64;
   h16x8* I2cT = I2g + IMG64;
   h16x8* I2gT = I2cT + IMG64;
   float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
+  if (FUSE_GQ) stage_split<true>(reinterpret_cast<h16x8*>(vecs + VEC_SLOTS * D), p.w_bond, 2 * D, D, tid, nthreads);   // W_bond^T: 128 -> 64
   stage_split<false>(I2c, p.gw.w2c, D, D, tid, nthreads);
   stage_split<false>(I2g, p.gw.w2g, D, D, tid, nthreads);
   stage_split<true>(I2cT, p.gw.w2c, D, D, tid, nthreads);
@@ -541,7 +545,7 @@ __device__ __forceinline__ void atomconv_bwd_stage(float* base, const AtomConvAr
 }
 template <bool BWD>
 __global__ __launch_bounds__(BLOCK) void k_atomconv_image(AtomConvArgs p, float* out) {
-  if (BWD) atomconv_bwd_stage(out, p, threadIdx.x, BLOCK);
+  if (BWD) atomconv_bwd_stage<true>(out, p, threadIdx.x, BLOCK);   // (the unfused kernel copies the block without the last image)
   else atomconv_fwd_stage(out, p, threadIdx.x, BLOCK);
 }
 
@@ -684,6 +688,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
 //
 // Scatter of one AtomConv-adjoint tile (gz rows in LDS, pair order).  Lane owns columns
 // (lane, lane+64) of the 128-wide rows.  dE/dQ[k] is a plain store (the tile owns bond k).
+template <bool STORE_GQ = true>
 __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid, int k0, const AtomConvArgs& p, int lane) {
   // Both sides leave the tile as run sums: c1 is sorted along the pair order, and within one c1 the
   // bonds are ordered by c2 (then image), so periodic images of one neighbour are adjacent too
@@ -695,9 +700,11 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
     if (2 * b < nvalid) {
       const float e0 = T[(2 * b) * TS + lane], e1 = T[(2 * b) * TS + 64 + lane];           // gz of direction c1 -> c2
       const float o0 = T[(2 * b + 1) * TS + lane], o1 = T[(2 * b + 1) * TS + 64 + lane];   // gz of direction c2 -> c1
-      float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
-      q[0] = e0 + o0;
-      q[64] = e1 + o1;
+      if (STORE_GQ) {
+        float* q = p.GQ + (size_t)(k0 + b) * 2 * D + lane;
+        q[0] = e0 + o0;
+        q[64] = e1 + o1;
+      }
       const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
       if (c1 != cur1) {
         float* d = p.GP + (size_t)cur1 * 4 * D + lane;
@@ -721,15 +728,21 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
   tile_atomic_add(d2, a2[0]); tile_atomic_add(d2 + 64, a2[1]); tile_atomic_add(d2 + 128, a2[2]); tile_atomic_add(d2 + 192, a2[3]);
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
+// FUSE_GQ: the tile also contracts its dE/dQ rows with W_bond (128 -> 64, split form) and updates the dE/d h_bond rows of its bonds
+// itself -- the rows are in registers (the pair sum is one lane swap), so the [Eu,128] table is neither written nor read back by a
+// row GEMM (gemm_GQ: 1.4 ms per headline step at the HBM rate).  The 32 KB image of W_bond^T needs the LDS of one wave's tile:
+// NW = 7 waves per workgroup.
+template <bool TRAIN, int NW = WAVES, bool FUSE_GQ = false>
+__global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
+  static_assert(!(TRAIN && FUSE_GQ), "the training sweep keeps the dE/dQ table (its weight gradients contract it)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h16x8* I2c = reinterpret_cast<h16x8*>(smem);
   h16x8* I2g = I2c + IMG64;
   h16x8* I2cT = I2g + IMG64;
   h16x8* I2gT = I2cT + IMG64;
   float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
-  float* tiles = vecs + VEC_SLOTS * D;
+  const h16x8* IbT = reinterpret_cast<const h16x8*>(vecs + VEC_SLOTS * D);   // FUSE_GQ only
+  float* tiles = vecs + VEC_SLOTS * D + (FUSE_GQ ? 4 * IMG128 : 0);
   const float* W2c = reinterpret_cast<const float*>(I2c);
   const float* W2g = reinterpret_cast<const float*>(I2g);
   const float* W2cT = reinterpret_cast<const float*>(I2cT);
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const int ntiles = (p.n_edges + TILE_ROWS - 1) / TILE_ROWS;   // wave-tiles: this wave's own sequence (mfma_tile.h wave_tile_seq)
-  const TileSeq ts = wave_tile_seq(ntiles, WAVES, wave, p.interleave);
+  const TileSeq ts = wave_tile_seq(ntiles, NW, wave, p.interleave);
   const int last_row = p.n_edges - 1;
   int c, n, k;
   {   // the first tile's indices and gather land under the staging of the weights (see k_atomconv_fwd)
@@ -747,8 +760,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     c = p.e_center[row]; n = p.e_nbr[row]; k = row >> 1;   // pair-ordered index arrays
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
-    if (TRAIN) atomconv_bwd_stage(smem, p, tid, BLOCK);   // fine-tuning: the weights change every step
-    else stage_image<ac_bwd_image_floats() / 4, BLOCK>(smem, p.image, tid);
+    if (TRAIN) atomconv_bwd_stage(smem, p, tid, 64 * NW);   // fine-tuning: the weights change every step
+    else stage_image<ac_bwd_image_floats(FUSE_GQ) / 4, 64 * NW>(smem, p.image, tid);
     gather_commit128(gr, T, TS, lane);
   }
   __syncthreads();
@@ -811,6 +824,25 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     PH(2)   // bond-weight gradient rows
     gated_backward<true, false, TRAIN, true>(gy, zc, zg, W2cT, W2gT, vecs, j, g, s, gzc, gzg, &tt);
     PH(3)   // gated adjoint
+    if (FUSE_GQ) {
+      // dE/d h_bond[k] (+)= (gz(2b) + gz(2b+1)) . W_bond: contracted per direction (linear), the pair summed by a lane swap; the
+      // even lane of a pair owns the bond's row (four 64-byte segments), plain read-modify-write: the tile owns bonds k0 .. k0 + 7
+      float* gb_row = p.Gb + (size_t)(k0 + (j >> 1)) * D + 4 * g;
+      const bool owner = !(j & 1) && j < nvalid;
+      V64 old = zero64();
+      if (p.gb_accumulate && owner) {
+        CHG_EV(ft) old.t[ft] = *reinterpret_cast<const f32x4*>(gb_row + 16 * ft);
+      }
+      f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
+      V64 gq = zero64();
+      gemm_split<2 * VT, VT, true>(gq.t, IbT, D, gz, j, g);
+      CHG_EW(ft, r) gq.t[ft][r] += __shfl_xor(gq.t[ft][r], 1);
+      CHG_EV(ft) gq.t[ft] += old.t[ft];
+      CHG_EV(ft) asm volatile("" : "+v"(gq.t[ft]));   // (sums before the conditional stores)
+      if (owner) {
+        CHG_EV(ft) *reinterpret_cast<f32x4*>(gb_row + 16 * ft) = gq.t[ft];
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
@@ -819,7 +851,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
       GatherRegs gr;
       gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
       PH(4)   // next tile's gathers issued
-      acbwd_scatter(T, c, nvalid, k0, p, lane);
+      acbwd_scatter<!FUSE_GQ>(T, c, nvalid, k0, p, lane);
       PH(5)   // scatter: GQ rows, run sums of the two atoms
       __builtin_amdgcn_wave_barrier();
       gather_commit128(gr, T, TS, lane);
