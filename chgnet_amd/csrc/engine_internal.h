@@ -68,6 +68,7 @@ struct chg_engine {
   float* d_images = nullptr;
   const float* img_ac_fwd[2][MAX_CONV] = {};   // [without / with q_bias][layer]
   const float* img_ac_bwd[MAX_CONV] = {};
+  const float* img_ac_bwd_rm[MAX_CONV] = {};   // row-major block of the fused adjoint (k_atomconv_image_rm)
   const float* img_angle[2][2 * MAX_CONV] = {};   // [fwd / bwd][slot: BondConv l | L + AngleUpdate l]
   std::string err;
   hipEvent_t t0 = nullptr, t1 = nullptr;

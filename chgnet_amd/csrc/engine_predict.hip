@@ -215,11 +215,11 @@ int zero(chg_engine* eng, void* p, size_t bytes) {
 // Prebuilt weight blocks (see stage_image, mfma_tile.h): one per tile kernel and layer, laid out by the kernels' own staging code.
 int build_images(chg_engine* eng) {
   const int L = eng->desc.n_conv;
-  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats(true);   // (with the W_bond^T image of the fused adjoint)
+  constexpr size_t AF = ac_fwd_image_floats(), AB = ac_bwd_image_floats();
   constexpr size_t BF = AngleLds<true, false>::tiles, BB = AngleLds<true, true>::tiles, UF = AngleLds<false, false>::tiles,
                    UB = AngleLds<false, true>::tiles;
   static_assert(AF % 4 == 0 && AB % 4 == 0 && BF % 4 == 0 && BB % 4 == 0 && UF % 4 == 0 && UB % 4 == 0, "images are copied in 16-byte units");
-  const size_t total = (size_t)L * (2 * AF + AB) + (size_t)(L - 1) * (BF + BB + UF + UB);
+  const size_t total = (size_t)L * (2 * AF + AB + ac_bwd_rm_image_floats()) + (size_t)(L - 1) * (BF + BB + UF + UB);
   if (!eng->d_images) {
     HIP_TRY(eng, hipMalloc(&eng->d_images, total * sizeof(float)));
     HIP_TRY(eng, hipMemsetAsync(eng->d_images, 0, total * sizeof(float), eng->stream));   // slots no staging writes (unused vectors)
@@ -238,6 +238,9 @@ int build_images(chg_engine* eng) {
     float* img = take(AB);
     eng->img_ac_bwd[l] = img;
     hipLaunchKernelGGL(k_atomconv_image<true>, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
+    img = take(ac_bwd_rm_image_floats());
+    eng->img_ac_bwd_rm[l] = img;
+    hipLaunchKernelGGL(k_atomconv_image_rm, dim3(1), dim3(BLOCK), 0, eng->stream, a, img);
   }
   for (int l = 0; l + 1 < L; ++l) {
     const BCW& bc = eng->w.bc[l];
@@ -322,12 +325,10 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
   return rows_gemm(eng, "gemm_out", 64, 64, b->agg_l[l], D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
 }
 
-// The adjoint with the dE/d h_bond update in its tiles (k_atomconv_bwd<false, 7, true>: no dE/dQ table, no gemm_GQ).
-// Same box, ms per headline step: table + gemm_GQ 4.47 + 1.38; fused 5.56 (of which +0.44 for running 7 instead of 8 waves per
-// workgroup -- the W_bond^T image takes one wave's tile -- and +0.65 for the contraction and the row update): -0.3 ms, and one launch
-// fewer per layer for MD-size batches (replay 0.890 -> 0.861 ms).  CHGNET_FUSE_GQ=0 switches back for A/B timing.
-constexpr int ACB_FUSED_WAVES = 7;
-constexpr size_t acb_fused_lds() { return atomconv_lds<ACB_FUSED_WAVES, true>() + 16 * (size_t)IMG128; }
+// The adjoint with the dE/d h_bond update in its tiles (k_atomconv_bwd<false, true>: no dE/dQ table, no gemm_GQ).
+// Same box, ms per headline step: table + gemm_GQ 4.52 + 1.38; fused 5.23: -0.6 ms, and one launch fewer per layer for MD-size
+// batches.  CHGNET_FUSE_GQ=0 switches back for A/B timing.
+constexpr size_t acb_fused_lds() { return sizeof(float) * ((size_t)ac_bwd_rm_image_floats() + WAVES * TILE_FLOATS); }
 static bool fuse_gq() {
   static const bool on = [] { const char* e = std::getenv("CHGNET_FUSE_GQ"); return !e || std::atoi(e) != 0; }();
   return on;
@@ -347,10 +348,10 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
     a.Gb = b->Gb;
     a.gb_accumulate = l == b->L - 1 ? 0 : 1;
     LaunchScope ls(eng, "atomconv_bwd");
-    if (fused)
-      hipLaunchKernelGGL((k_atomconv_bwd<false, ACB_FUSED_WAVES, true>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * ACB_FUSED_WAVES)),
-                         dim3(64 * ACB_FUSED_WAVES), acb_fused_lds(), eng->stream, a);
-    else
+    if (fused) {
+      a.image = eng->img_ac_bwd_rm[l];
+      hipLaunchKernelGGL((k_atomconv_bwd<false, true>), dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), acb_fused_lds(), eng->stream, a);
+    } else
       hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
@@ -753,7 +754,7 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_rows_gemm<128, 64, 2>), (rows_gemm_lds<128, 64, 2>())))) return s;
   if ((s = set_lds(eng, k_atomconv_fwd<FWD_WAVES>, (atomconv_lds<FWD_WAVES, false, true>())))) return s;
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
-  if ((s = set_lds(eng, (k_atomconv_bwd<false, ACB_FUSED_WAVES, true>), acb_fused_lds()))) return s;
+  if ((s = set_lds(eng, (k_atomconv_bwd<false, true>), acb_fused_lds()))) return s;
   if ((s = set_lds(eng, k_angleupd_fwd_a, angle_fa_lds()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;

@@ -517,7 +517,7 @@ constexpr size_t atomconv_lds() {
 // The weight block at the start of the AtomConv kernels' LDS, as a function of the weights alone: staged in the kernel, or built once
 // per weight upload into global memory (k_atomconv_image) and copied (stage_image).
 constexpr int ac_fwd_image_floats() { return 4 * (2 * IMG64 + IMG128) + AC_VEC_SLOTS * D; }
-constexpr int ac_bwd_image_floats(bool fuse_gq = false) { return 4 * 4 * IMG64 + VEC_SLOTS * D + (fuse_gq ? 4 * IMG128 : 0); }
+constexpr int ac_bwd_image_floats() { return 4 * 4 * IMG64 + VEC_SLOTS * D; }
 __device__ __forceinline__ void atomconv_fwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
   h16x8* I2c = reinterpret_cast<h16x8*>(base);
   h16x8* I2g = I2c + IMG64;
@@ -529,23 +529,35 @@ __device__ __forceinline__ void atomconv_fwd_stage(float* base, const AtomConvAr
   stage_gated_vecs(vecs, p.gw, true, tid);
   for (int q = tid; q < 2 * D; q += nthreads) vecs[VEC_SLOTS * D + q] = p.q_bias ? p.q_bias[q] : 0.f;
 }
-template <bool FUSE_GQ = false>
 __device__ __forceinline__ void atomconv_bwd_stage(float* base, const AtomConvArgs& p, int tid, int nthreads) {
   h16x8* I2c = reinterpret_cast<h16x8*>(base);
   h16x8* I2g = I2c + IMG64;
   h16x8* I2cT = I2g + IMG64;
   h16x8* I2gT = I2cT + IMG64;
   float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
-  if (FUSE_GQ) stage_split<true>(reinterpret_cast<h16x8*>(vecs + VEC_SLOTS * D), p.w_bond, 2 * D, D, tid, nthreads);   // W_bond^T: 128 -> 64
   stage_split<false>(I2c, p.gw.w2c, D, D, tid, nthreads);
   stage_split<false>(I2g, p.gw.w2g, D, D, tid, nthreads);
   stage_split<true>(I2cT, p.gw.w2c, D, D, tid, nthreads);
   stage_split<true>(I2gT, p.gw.w2g, D, D, tid, nthreads);
   stage_gated_vecs(vecs, p.gw, true, tid);
 }
+// Block of the fused adjoint (k_atomconv_bwd<false, true>): ONE row-major image per hidden matrix serves both directions
+// (mfma_split.h gemm_rm), which leaves room for the W_bond^T image next to eight waves' tiles:
+// [W2c rm | W2g rm | vectors | W_bond^T split].
+constexpr int AC_RM_IMG = (int)(rm_image_bytes(D, D) / 4);                                       // floats
+constexpr int ac_bwd_rm_image_floats() { return 2 * AC_RM_IMG + VEC_SLOTS * D + 4 * IMG128; }
+__device__ __forceinline__ void atomconv_bwd_stage_rm(float* base, const AtomConvArgs& p, int tid, int nthreads) {
+  stage_rm(reinterpret_cast<_Float16*>(base), p.gw.w2c, D, D, tid, nthreads);
+  stage_rm(reinterpret_cast<_Float16*>(base + AC_RM_IMG), p.gw.w2g, D, D, tid, nthreads);
+  float* vecs = base + 2 * AC_RM_IMG;
+  stage_gated_vecs(vecs, p.gw, true, tid);
+  stage_split<true>(reinterpret_cast<h16x8*>(vecs + VEC_SLOTS * D), p.w_bond, 2 * D, D, tid, nthreads);
+}
+static __global__ __launch_bounds__(BLOCK) void k_atomconv_image_rm(AtomConvArgs p, float* out) { atomconv_bwd_stage_rm(out, p, threadIdx.x, BLOCK); }
+
 template <bool BWD>
 __global__ __launch_bounds__(BLOCK) void k_atomconv_image(AtomConvArgs p, float* out) {
-  if (BWD) atomconv_bwd_stage<true>(out, p, threadIdx.x, BLOCK);   // (the unfused kernel copies the block without the last image)
+  if (BWD) atomconv_bwd_stage(out, p, threadIdx.x, BLOCK);
   else atomconv_fwd_stage(out, p, threadIdx.x, BLOCK);
 }
 
@@ -730,23 +742,23 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
 
 // FUSE_GQ: the tile also contracts its dE/dQ rows with W_bond (128 -> 64, split form) and updates the dE/d h_bond rows of its bonds
 // itself -- the rows are in registers (the pair sum is one lane swap), so the [Eu,128] table is neither written nor read back by a
-// row GEMM (gemm_GQ: 1.4 ms per headline step at the HBM rate).  The 32 KB image of W_bond^T needs the LDS of one wave's tile:
-// NW = 7 waves per workgroup.
-template <bool TRAIN, int NW = WAVES, bool FUSE_GQ = false>
-__global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
+// row GEMM (gemm_GQ: 1.4 ms per headline step at the HBM rate).  The 32 KB image of W_bond^T fits because the hidden layer then
+// uses the row-major images (18 KB per matrix for both directions instead of 32 KB; with the split images and 7 waves per workgroup
+// the kernel was 8 % slower: profiles/r04_experiments.md section 12).
+template <bool TRAIN, bool FUSE_GQ = false>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
   static_assert(!(TRAIN && FUSE_GQ), "the training sweep keeps the dE/dQ table (its weight gradients contract it)");
+  constexpr int NW = WAVES;
+  constexpr bool RM = FUSE_GQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  h16x8* I2c = reinterpret_cast<h16x8*>(smem);
-  h16x8* I2g = I2c + IMG64;
-  h16x8* I2cT = I2g + IMG64;
-  h16x8* I2gT = I2cT + IMG64;
-  float* vecs = reinterpret_cast<float*>(I2gT + IMG64);
+  constexpr int HMODE = RM ? 2 : 1;                                      // gated_forward / gated_backward SPLIT mode
+  float* vecs = RM ? smem + 2 * AC_RM_IMG : smem + 4 * 4 * IMG64;
   const h16x8* IbT = reinterpret_cast<const h16x8*>(vecs + VEC_SLOTS * D);   // FUSE_GQ only
   float* tiles = vecs + VEC_SLOTS * D + (FUSE_GQ ? 4 * IMG128 : 0);
-  const float* W2c = reinterpret_cast<const float*>(I2c);
-  const float* W2g = reinterpret_cast<const float*>(I2g);
-  const float* W2cT = reinterpret_cast<const float*>(I2cT);
-  const float* W2gT = reinterpret_cast<const float*>(I2gT);
+  const float* W2c = smem;
+  const float* W2g = RM ? smem + AC_RM_IMG : smem + 4 * IMG64;
+  const float* W2cT = RM ? W2c : smem + 2 * 4 * IMG64;
+  const float* W2gT = RM ? W2g : smem + 3 * 4 * IMG64;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* T = tiles + wave * TILE_FLOATS;
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_bwd(AtomConv
     GatherRegs gr;
     gather_issue128(gr, p.P, c, p.P + 2 * D, n, p.Q, k, 4 * D, 4 * D, 2 * D, lane);
     if (TRAIN) atomconv_bwd_stage(smem, p, tid, 64 * NW);   // fine-tuning: the weights change every step
-    else stage_image<ac_bwd_image_floats(FUSE_GQ) / 4, 64 * NW>(smem, p.image, tid);
+    else stage_image<(RM ? ac_bwd_rm_image_floats() : ac_bwd_image_floats()) / 4, 64 * NW>(smem, p.image, tid);
     gather_commit128(gr, T, TS, lane);
   }
   __syncthreads();
@@ -797,7 +809,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_bwd(AtomConv
     GatedState s;
     V64 y;
     PH(0)   // next indices, weights / aggregate adjoint rows, old Gwag rows requested; table sums read
-    gated_forward<true, false, TRAIN, true>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
+    gated_forward<true, false, TRAIN, HMODE>(zc, zg, W2c, W2g, vecs, j, g, s, y, &tt);
     PH(1)   // forward recomputation
     asm volatile("" : "+v"(cn), "+v"(nn));   // take the index loads here (landed long ago), not behind later stores
     V64 gy, gw, gzc, gzg;
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_bwd(AtomConv
       }
     }
     PH(2)   // bond-weight gradient rows
-    gated_backward<true, false, TRAIN, true>(gy, zc, zg, W2cT, W2gT, vecs, j, g, s, gzc, gzg, &tt);
+    gated_backward<true, false, TRAIN, HMODE>(gy, zc, zg, W2cT, W2gT, vecs, j, g, s, gzc, gzg, &tt);
     PH(3)   // gated adjoint
     if (FUSE_GQ) {
       // dE/d h_bond[k] (+)= (gz(2b) + gz(2b+1)) . W_bond: contracted per direction (linear), the pair summed by a lane swap; the
