@@ -73,7 +73,10 @@ KERNEL_MODEL = {
     # two 64x64 second-layer blocks per direction + the bond block W_bond (64 -> 128) once per BOND (the kernel contracts it per
     # direction; the algorithmic count is per bond); h_bond 128 + w_ag 128 read, Q table 256 written for the reverse sweep, per direction
     "atomconv_fwd": ("n_directed", 24576, 538),
-    "atomconv_bwd": ("n_directed", 32768, 900),
+    # adjoint (round 4: with the dE/d h_bond update in its tiles): two second-layer blocks and their transposes + W_bond^T
+    # (128 -> 64) per direction; the dE/dQ table (256 B per direction) is no longer written, the bond's dE/d h_bond row is read and
+    # written instead (2 x 128 B per direction)
+    "atomconv_bwd": ("n_directed", 32768 + 16384, 900 - 256 + 256),
     "bondconv_fwd": ("n_angles", 32768, 300),
     "bondconv_bwd": ("n_angles", 65536, 800),
     "angleupd_fwd": ("n_angles", 16384, 524),
