@@ -163,3 +163,58 @@ def test_flat_label_cache_sees_a_refilled_dictionary():
     third = loss.gradients(targ, fast)[0]["loss"]
     want = CombinedLoss(target_str="efsm", criterion="MSE").gradients(targ, pred)[0]["loss"]
     assert abs(third - want) < 1e-12 and abs(third - second) > 0.1
+
+
+def test_run_epoch_hands_every_batch_its_own_upload_in_order():
+    """The loader of ``TrainStep.run_epoch`` (one thread packs batch i + 2, one uploads batch i + 1 while step i runs): every step gets
+    the device batch that was uploaded from ITS packed batch, in order, each batch packed and uploaded exactly once, for epochs of 1, 2
+    and 5 batches.  Stub model and engine: no device."""
+    import threading
+
+    from conftest import load_case
+
+    graph, _ = load_case("limno2")
+    n_at = len(graph.atomic_number)
+
+    class StubEngine:
+        def __init__(self):
+            self.uploads, self.lock = [], threading.Lock()
+
+        def upload(self, packed):
+            with self.lock:
+                self.uploads.append(packed.n_struct)          # (unique per batch in this test; id() is reused after collection)
+            return ("device", packed.n_struct)
+
+    class StubModel:
+        model_args = {}
+
+        def __init__(self):
+            self.engine, self.steps = StubEngine(), []
+            self.w = {"w": np.zeros(3, np.float32)}
+
+        def state_dict(self):
+            return dict(self.w)
+
+        def load_state_dict(self, sd):
+            self.w = dict(sd)
+
+        def forward(self, packed, *, task, device_batch=None):
+            assert device_batch == ("device", packed.n_struct), "a step must run on the upload of its own packed batch"
+            self.steps.append(packed.n_struct)
+            b = packed.n_struct
+            out = {"atoms_per_graph": np.diff(packed.atom_off).astype(np.int64), "e": np.zeros(b, np.float32),
+                   "f": [np.zeros((n_at, 3), np.float32) for _ in range(b)]}
+            return out
+
+        def backward(self, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None):
+            return {"w": np.ones(3, np.float32)}
+
+    for n_batches in (1, 2, 5):
+        model = StubModel()
+        step = TrainStep(model, targets="ef", learning_rate=1e-3)
+        batches = [[graph] * (i + 1) for i in range(n_batches)]          # batch i holds i + 1 structures: the order is visible
+        labels = [{"e": np.zeros(i + 1, np.float32), "f": [np.zeros((n_at, 3), np.float32) for _ in range(i + 1)]} for i in range(n_batches)]
+        infos = step.run_epoch(batches, labels)
+        assert len(infos) == n_batches and model.steps == [i + 1 for i in range(n_batches)]
+        assert model.engine.uploads == [i + 1 for i in range(n_batches)]      # each batch once, in order
+    assert step.run_epoch([], []) == []
