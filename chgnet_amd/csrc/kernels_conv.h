@@ -633,7 +633,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
       bn_n2 = bond_node(p, r2 >> 1);
     }
-    if (nvalid <= 0) continue;
+    // (every tile of a wave_tile_seq is a real tile: nvalid >= 1.  An early `continue` here, never taken, still gave the loop latch a
+    // path on which the requests above are pending -- and the waits the compiler placed there for it stood behind this tile's atomics)
     f32x4 z[2 * VT];
     if (!node) {   // bonds outside the bond graph: constant shift of the 0.2.0 checkpoints (zeros otherwise)
       read_dl<2 * VT>(vecs + VEC_SLOTS * D, g, z);
@@ -657,6 +658,10 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     GatedState s;
     V64 y;
     gated_forward<true, false, false, 1, true>(zc, zg, W2c, W2g, vecs, j, g, s, y);
+    // everything requested for the next tiles is taken here, before this tile's atomics (mfma_tile.h gather_take)
+    gather_take(gr);
+    asm volatile("" : "+v"(c_n2), "+v"(n_n2), "+v"(bn_n2));
+    CHG_EV(ft) asm volatile("" : "+v"(wv_nx.t[ft]));
     __builtin_amdgcn_wave_barrier();
     V64 m;
     CHG_EV(ft) m.t[ft] = y.t[ft] * wv.t[ft];

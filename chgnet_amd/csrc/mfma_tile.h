@@ -386,6 +386,7 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
 // The same gather split in two so that the loads of tile t+1 can be in flight while tile t computes:
 // issue (registers only) ... commit (sum + LDS write).
 struct GatherRegs { f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2]; };
+__device__ __forceinline__ void gather_take(GatherRegs& gr);   // (defined below, next to GatherPH's)
 
 __device__ __forceinline__ void gather_issue128(GatherRegs& gr, const float* __restrict__ t0, int i0, const float* __restrict__ t1,
                                                 int i1, const float* __restrict__ t2, int i2, int ld0, int ld1, int ld2, int lane) {
@@ -413,6 +414,20 @@ __device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* ti
 // Two 128-wide table rows summed + one 64-wide row per tile row (its address as an offset from `hbase`, in floats): the AtomConv
 // gather when the bond partial is contracted in the kernel (kernels_conv.h FUSEQ) instead of read from a table.
 struct GatherPH { f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], h[TILE_ROWS / 4]; };
+// "Take" requested rows: an empty asm on every register, i.e. a wait placed by hand.  Software-pipelined kernels request tile t+1's
+// rows early in tile t and commit them at the top of t+1; left to the compiler, the wait sits at the loop latch, right behind the
+// tile's closing atomics -- and the counter being in order, it waits for those.  Taken before the tile's first atomic, the rows
+// (requested thousands of cycles earlier) cost nothing and the latch waits for nothing.
+__device__ __forceinline__ void gather_take(GatherPH& gr) {
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) asm volatile("" : "+v"(gr.a[it]), "+v"(gr.b[it]));
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 4; ++it) asm volatile("" : "+v"(gr.h[it]));
+}
+__device__ __forceinline__ void gather_take(GatherRegs& gr) {
+#pragma unroll
+  for (int it = 0; it < TILE_ROWS / 2; ++it) asm volatile("" : "+v"(gr.a[it]), "+v"(gr.b[it]), "+v"(gr.c[it]));
+}
 __device__ __forceinline__ void gather_issue_ph(GatherPH& gr, const float* __restrict__ t0, int i0, const float* __restrict__ t1, int i1, int ld0,
                                                 int ld1, const float* __restrict__ hbase, long hoff, int lane) {
   const int hw = lane >> 5, t = lane & 31, sub = lane >> 4, t16 = lane & 15;
