@@ -279,39 +279,32 @@ class TrainStep:
         if self.task not in ("e", "ef", "em", "efs", "efsm"):       # the engine's task strings (chgnet/__init__.py:15 PredTask)
             self.task = "efsm" if "m" in targets else "efs"
 
-    def run_epoch(self, batches, targets) -> list[dict]:
-        """One pass over ``batches`` (lists of CrystalGraphs) with their label dictionaries.  Two loader threads -- the role of the
-        reference's DataLoader workers (chgnet/data/dataset.py ``get_train_val_test_loader``) -- work under the device's step i:
-        one PACKS batch i + 2 (native code, GIL released), the other UPLOADS batch i + 1, packed a step earlier (``Engine.upload`` on
-        its copy stream).  Packing and uploading one batch back to back on a single thread took as long as a step on slower hosts,
-        and the step then waited for its loader."""
+    def run_epoch(self, batches, targets, *, upload_ahead: bool = False) -> list[dict]:
+        """One pass over ``batches`` (lists of CrystalGraphs) with their label dictionaries.  The next batch is packed on a helper
+        thread (native code, GIL released) while the device works on the current one -- the role of the reference's DataLoader workers
+        (chgnet/data/dataset.py ``get_train_val_test_loader``).
+
+        ``upload_ahead=True`` lets the helper also put the packed batch on the device (``Engine.upload`` on its copy stream, under the
+        current step's sweeps).  Measured on MI355X boxes (1024-structure batches, profiles/r04_experiments.md): 5.0-5.2k instead of
+        4.8-5.0k structures/s on most hosts, but 4.2k on a slow one, where packing + uploading one batch took longer than a step --
+        and every variant that splits the two over two threads ran the copies next to the forward's launches and download (its time
+        doubled on some boxes).  Off by default: the epoch time should not depend on the host."""
         from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
 
         from chgnet_amd.pack import pack_batch  # noqa: PLC0415
 
-        n = len(batches)
-        if n == 0:
-            return []
-
-        def pack(i):             # pack the graphs, flatten the label lists (CombinedLoss keeps them)
+        def prepare(i):          # data-loader work of step i: pack the graphs, flatten the label lists (CombinedLoss keeps them)
             packed = pack_batch(batches[i])
             self.loss._flat_targets(targets[i], np.diff(packed.atom_off))
-            return packed
+            return packed, (self.model.engine.upload(packed) if upload_ahead else None)
 
         infos = []
-        with ThreadPoolExecutor(max_workers=1) as pack_pool, ThreadPoolExecutor(max_workers=1) as copy_pool:
-            packed = pack(0)
-            device_batch = self.model.engine.upload(packed)
-            next_packed = pack_pool.submit(pack, 1) if n > 1 else None
-            for i in range(n):
-                next_device = None
-                if i + 1 < n:
-                    nxt = next_packed.result()                                    # packed during step i - 1
-                    next_device = copy_pool.submit(lambda p=nxt: (p, self.model.engine.upload(p)))
-                    next_packed = pack_pool.submit(pack, i + 2) if i + 2 < n else None
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(prepare, 0) if len(batches) else None
+            for i in range(len(batches)):
+                packed, device_batch = nxt.result()
+                nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
                 infos.append(self(packed, targets[i], device_batch=device_batch))
-                if next_device is not None:
-                    packed, device_batch = next_device.result()
         return infos
 
     def __call__(self, graphs, targets: dict, device_batch=None) -> dict:

@@ -166,9 +166,9 @@ def test_flat_label_cache_sees_a_refilled_dictionary():
 
 
 def test_run_epoch_hands_every_batch_its_own_upload_in_order():
-    """The loader of ``TrainStep.run_epoch`` (one thread packs batch i + 2, one uploads batch i + 1 while step i runs): every step gets
-    the device batch that was uploaded from ITS packed batch, in order, each batch packed and uploaded exactly once, for epochs of 1, 2
-    and 5 batches.  Stub model and engine: no device."""
+    """The loader of ``TrainStep.run_epoch`` with ``upload_ahead=True`` (the helper thread packs AND uploads the next batch while a step
+    runs): every step gets the device batch that was uploaded from ITS packed batch, in order, each batch uploaded exactly once, for
+    epochs of 1, 2 and 5 batches; with the default (False) the helper only packs and the step uploads.  Stub model and engine."""
     import threading
 
     from conftest import load_case
@@ -199,7 +199,10 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
             self.w = dict(sd)
 
         def forward(self, packed, *, task, device_batch=None):
-            assert device_batch == ("device", packed.n_struct), "a step must run on the upload of its own packed batch"
+            if self.expect_upload:
+                assert device_batch == ("device", packed.n_struct), "a step must run on the upload of its own packed batch"
+            else:
+                assert device_batch is None
             self.steps.append(packed.n_struct)
             b = packed.n_struct
             out = {"atoms_per_graph": np.diff(packed.atom_off).astype(np.int64), "e": np.zeros(b, np.float32),
@@ -209,12 +212,13 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
         def backward(self, e_grad=None, m_grad=None, f_grad=None, s_grad=None, comm=None):
             return {"w": np.ones(3, np.float32)}
 
-    for n_batches in (1, 2, 5):
+    for n_batches, ahead in ((1, True), (2, True), (5, True), (3, False)):
         model = StubModel()
+        model.expect_upload = ahead
         step = TrainStep(model, targets="ef", learning_rate=1e-3)
         batches = [[graph] * (i + 1) for i in range(n_batches)]          # batch i holds i + 1 structures: the order is visible
         labels = [{"e": np.zeros(i + 1, np.float32), "f": [np.zeros((n_at, 3), np.float32) for _ in range(i + 1)]} for i in range(n_batches)]
-        infos = step.run_epoch(batches, labels)
+        infos = step.run_epoch(batches, labels, upload_ahead=ahead)
         assert len(infos) == n_batches and model.steps == [i + 1 for i in range(n_batches)]
-        assert model.engine.uploads == [i + 1 for i in range(n_batches)]      # each batch once, in order
+        assert model.engine.uploads == ([i + 1 for i in range(n_batches)] if ahead else [])      # each batch once, in order
     assert step.run_epoch([], []) == []
