@@ -65,7 +65,13 @@ def _compile_units(out: str, extra: list[str], obj_dir: str, force: bool) -> Non
     """Compile every unit to an object (in parallel; only those older than a source they depend on), then link."""
     from concurrent.futures import ThreadPoolExecutor
 
+    import hashlib
+
     os.makedirs(obj_dir, exist_ok=True)
+    # objects depend on the flags too: a stamp of the command line next to them forces a rebuild when flags / defines change
+    stamp, flags_id = os.path.join(obj_dir, "flags.sha"), hashlib.sha256(" ".join([*HIP_FLAGS, *extra]).encode()).hexdigest()
+    if not (os.path.exists(stamp) and open(stamp).read().strip() == flags_id):
+        force = True
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(INCLUDE, "chgnet_hip.h")]
     objs, todo = [], []
     for name in HIP_SOURCES:
@@ -75,7 +81,10 @@ def _compile_units(out: str, extra: list[str], obj_dir: str, force: bool) -> Non
             todo.append([hipcc_path(), *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
         list(pool.map(_run, todo))
-    if todo or not os.path.exists(out):
+    with open(stamp, "w") as f:
+        f.write(flags_id)
+    # relink when the library is missing OR older than any object (an interrupted link, objects restored from a snapshot)
+    if todo or not _newer(out, objs):
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
 
 
@@ -98,10 +107,11 @@ def clean_variants() -> None:
     """Remove experiment libraries and their objects from chgnet_amd/lib: a snapshot pushed to the GPU box carries the product only."""
     for f in os.listdir(LIB_DIR):
         p = os.path.join(LIB_DIR, f)
-        if (f.startswith("libchgnet_hip_") and f.endswith(".so")) or f == "split_lab":
-            os.remove(p)
-        elif f.startswith("obj_") and os.path.isdir(p):
-            shutil.rmtree(p)
+        if (f.startswith("libchgnet_hip_") and f.endswith(".so")) or f == "split_lab" or (f.startswith("obj_") and os.path.isdir(p)):
+            if os.path.isdir(p) and not os.path.islink(p):
+                shutil.rmtree(p)
+            else:
+                os.remove(p)
 
 
 def build_all(force: bool = False, keep_variants: bool = False) -> None:

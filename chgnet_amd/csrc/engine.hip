@@ -167,6 +167,11 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   *out = eng;  // returned even on failure so that chg_last_error is readable; destroy it either way
   eng->device = device;
   eng->desc = *desc;
+  if (eng->desc.n_mlp_hidden == 0) eng->desc.n_mlp_hidden = 3;
+  if (eng->desc.n_mlp_hidden != 2 && eng->desc.n_mlp_hidden != 3) {
+    eng->err = "n_mlp_hidden = " + std::to_string(desc->n_mlp_hidden) + ": the energy head has two or three hidden layers";
+    return CHG_EUNSUPPORTED;
+  }
   if (const char* g = std::getenv("CHGNET_HIP_GRAPHS")) eng->use_graphs = std::string(g) != "0";
   if (const char* g = std::getenv("CHGNET_SPEC_BUILD")) eng->spec_builds = std::string(g) != "0";
   HIP_TRY(eng, hipSetDevice(device));

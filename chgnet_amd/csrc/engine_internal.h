@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mfma_tile.h"
@@ -55,6 +56,25 @@ struct Weights {
   const float *mlp_w0_t, *mlp_w1_t, *mlp_w2_t;
 };
 
+// Text of the last failure, one slot PER CALLING THREAD: chg_batch_upload may run on a loader thread while the engine's own thread
+// computes (INTEGRATION.md "Threads"), and both may fail.  Every thread reads -- chg_last_error -- the text of the status IT
+// received; no std::string is shared between threads.
+struct ErrText {
+  std::string& slot() const {
+    thread_local std::unordered_map<const ErrText*, std::string> texts;
+    return texts[this];
+  }
+  ErrText& operator=(const std::string& v) { slot() = v; return *this; }
+  ErrText& operator=(const char* v) { slot() = v; return *this; }
+  operator std::string() const { return slot(); }
+  const char* c_str() const { return slot().c_str(); }
+  ~ErrText() { slot().clear(); }
+};
+inline std::string operator+(const char* a, const ErrText& b) { return std::string(a) + std::string(b); }
+inline std::string operator+(const std::string& a, const ErrText& b) { return a + std::string(b); }
+inline std::string operator+(const ErrText& a, const char* b) { return std::string(a) + b; }
+inline std::string operator+(const ErrText& a, const std::string& b) { return std::string(a) + b; }
+
 struct ProfEntry { std::string label; int64_t launches = 0; double ms = 0.0; };
 struct PendingEvent { int entry; hipEvent_t start, stop; };
 
@@ -70,7 +90,7 @@ struct chg_engine {
   const float* img_ac_bwd[MAX_CONV] = {};
   const float* img_ac_bwd_rm[MAX_CONV] = {};   // row-major block of the fused adjoint (k_atomconv_image_rm)
   const float* img_angle[2][2 * MAX_CONV] = {};   // [fwd / bwd][slot: BondConv l | L + AngleUpdate l]
-  std::string err;
+  ErrText err;                // last failure text of the calling thread
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool profiling = false;
   std::vector<ProfEntry> prof;
@@ -78,7 +98,8 @@ struct chg_engine {
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   // chg_batch_upload may run on a second host thread while this engine computes (a data loader uploading the next batch under the
-  // current step's sweeps): its copies go through copy_stream, the arena pools are guarded, and everything it would launch on the
+  // current step's sweeps): its copies go through copy_stream, BOTH pools below (arena_pool, work_pool / work_kind) are only touched
+  // under pool_mu, the failure text is per thread (ErrText), and everything it would launch on the
   // compute stream (the per-atom index, prepare_windows) waits for the batch's first use (chg_batch::win_pending)
   hipStream_t copy_stream = nullptr;
   std::mutex pool_mu;

@@ -563,7 +563,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = b->N;
     r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
     r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
-    r.has_composition = eng->desc.has_composition;
+    r.has_composition = eng->desc.has_composition; r.n_hidden = eng->desc.n_mlp_hidden;
     r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
     r.Ga = want_grad ? b->Ga : nullptr;
     LaunchScope ls(eng, "readout");

@@ -102,6 +102,7 @@ int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, i
 // of tens of GB per step would dominate it.  One slot per kind (0: first-order workspace, 1: second-order workspace); a request
 // is rounded up by 8 % so that the slightly different batches of an epoch reuse the same block.
 char* acquire_workspace(chg_engine* eng, size_t total, size_t& got, int kind) {
+  std::lock_guard<std::mutex> lk(eng->pool_mu);   // acquire_arena (loader thread) frees work_pool under the same lock when memory is short
   for (int i = 0; i < (int)eng->work_pool.size(); ++i)
     if (eng->work_kind[i] == kind && eng->work_pool[i].second >= total) {
       char* p = eng->work_pool[i].first;
@@ -123,21 +124,22 @@ char* acquire_workspace(chg_engine* eng, size_t total, size_t& got, int kind) {
   for (auto& a : eng->work_pool) hipFree(a.first);   // make room (both pools) and ask for the exact size
   eng->work_pool.clear();
   eng->work_kind.clear();
-  {
-    std::lock_guard<std::mutex> lk(eng->pool_mu);
-    for (auto& a : eng->arena_pool) hipFree(a.first);
-    eng->arena_pool.clear();
-  }
+  for (auto& a : eng->arena_pool) hipFree(a.first);
+  eng->arena_pool.clear();
   if (hipMalloc(&p, total) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   got = total;
   return p;
 }
 void release_workspace(chg_engine* eng, char* p, size_t bytes, int kind) {
   if (!p) return;
+  if (!eng) { hipFree(p); return; }
   bool have = false;
-  if (eng) for (int k : eng->work_kind) have = have || k == kind;
-  if (eng && !have) { eng->work_pool.emplace_back(p, bytes); eng->work_kind.push_back(kind); }
-  else hipFree(p);
+  {
+    std::lock_guard<std::mutex> lk(eng->pool_mu);
+    for (int k : eng->work_kind) have = have || k == kind;
+    if (!have) { eng->work_pool.emplace_back(p, bytes); eng->work_kind.push_back(kind); }
+  }
+  if (have) hipFree(p);   // outside the lock: a multi-GB hipFree takes milliseconds
 }
 
 int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
@@ -197,7 +199,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
     r.atom = b->atom[L]; r.atom_owner = b->atom_owner; r.z = b->z; r.n_atoms = N;
     r.ln_g = w.ro_ln_g; r.ln_b = w.ro_ln_b; r.w0 = w.mlp_w0; r.b0 = w.mlp_b0; r.w1 = w.mlp_w1; r.b1 = w.mlp_b1;
     r.w2 = w.mlp_w2; r.b2 = w.mlp_b2; r.w3 = w.mlp_w3; r.b3 = w.mlp_b3; r.atomref = w.atomref;
-    r.has_composition = eng->desc.has_composition;
+    r.has_composition = eng->desc.has_composition; r.n_hidden = eng->desc.n_mlp_hidden;
     r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
     r.Ga = b->Ga; r.cot = b->t_cot; r.dump = b->t_ro;
     LaunchScope ls(eng, "readout_train");
@@ -209,7 +211,8 @@ int run_backward(chg_engine* eng, chg_batch* b) {
     const float* ro = b->t_ro;
     TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G1 * pl, D, nullptr, ro + RO_X0 * pl, D, nullptr, N, 1.0f, G(w.mlp_w0), D, D, G(w.mlp_b0))));
     TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G2 * pl, D, nullptr, ro + RO_S1 * pl, D, nullptr, N, 1.0f, G(w.mlp_w1), D, D, G(w.mlp_b1))));
-    TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G3 * pl, D, nullptr, ro + RO_S2 * pl, D, nullptr, N, 1.0f, G(w.mlp_w2), D, D, G(w.mlp_b2))));
+    if (eng->desc.n_mlp_hidden == 3)
+      TRY((xty<4, 4>(eng, "wgrad_readout", ro + RO_G3 * pl, D, nullptr, ro + RO_S2 * pl, D, nullptr, N, 1.0f, G(w.mlp_w2), D, D, G(w.mlp_b2))));
     TRY(colsum(eng, ro + RO_S3C * pl, D, nullptr, 0, N, D, G(w.mlp_w3)));
     TRY(colsum(eng, ro + RO_GXX * pl, D, nullptr, 0, N, D, G(w.ro_ln_g)));
     TRY(colsum(eng, ro + RO_GX * pl, D, nullptr, 0, N, D, G(w.ro_ln_b)));
@@ -394,7 +397,10 @@ int ensure_train2_buffers(chg_engine* eng, chg_batch* b) {
   {
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
-    for (auto& a : eng->work_pool) free_b += a.second;
+    {
+      std::lock_guard<std::mutex> lk(eng->pool_mu);
+      for (auto& a : eng->work_pool) free_b += a.second;
+    }
     t->cached = true;
     Carver cc{nullptr};
     layout_train2(b, *t, cc);
@@ -638,19 +644,20 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     const float* Wt[3] = {w.mlp_w0_t, w.mlp_w1_t, w.mlp_w2_t};
     const float* bm[3] = {w.mlp_b0, w.mlp_b1, w.mlp_b2};
     const int sidx[4] = {X0, S1, S2, S3}, sdidx[4] = {X0D, S1D, S2D, S3D}, lidx[3] = {L0, L1, L2}, ldidx[3] = {L0D, L1D, L2D};
-    for (int i = 0; i < 3; ++i) {
+    const int nh = eng->desc.n_mlp_hidden;   // 2 or 3 hidden layers
+    for (int i = 0; i < nh; ++i) {
       TRY(gemm("t2_readout", 64, 64, t.ro[sidx[i]], D, nullptr, Wm[i], bm[i], nullptr, 0, t.ro[lidx[i]], D, nullptr, N, 0));
       TRY(gemm("t2_readout", 64, 64, t.ro[sdidx[i]], D, nullptr, Wm[i], nullptr, nullptr, 0, t.ro[ldidx[i]], D, nullptr, N, 0));
       LaunchScope ls(eng, "t2_readout");
       hipLaunchKernelGGL(k2_silu_t, g1((int64_t)nd), dim3(256), 0, st, t.ro[lidx[i]], t.ro[ldidx[i]], t.ro[sidx[i + 1]], t.ro[sdidx[i + 1]], nd);
     }
     { LaunchScope ls(eng, "t2_readout");
-      hipLaunchKernelGGL(k2_readout_seed, g1((int64_t)nd), dim3(256), 0, st, w.mlp_w3, b->t_cot, b->atom_owner, t.ro[S3], t.ro[S3D], t.ro[BS],
+      hipLaunchKernelGGL(k2_readout_seed, g1((int64_t)nd), dim3(256), 0, st, w.mlp_w3, b->t_cot, b->atom_owner, t.ro[sidx[nh]], t.ro[sdidx[nh]], t.ro[BS],
                          t.ro[GS], t.ro[DW3], N); }
     TRY(colsum(eng, t.ro[DW3], D, nullptr, 0, N, D, G(w.mlp_w3)));
     const float* gW[3] = {G(w.mlp_w0), G(w.mlp_w1), G(w.mlp_w2)};
     const float* gb[3] = {G(w.mlp_b0), G(w.mlp_b1), G(w.mlp_b2)};
-    for (int i = 2; i >= 0; --i) {
+    for (int i = nh - 1; i >= 0; --i) {
       { LaunchScope ls(eng, "t2_readout");
         hipLaunchKernelGGL(k2_hidden_b, g1((int64_t)nd), dim3(256), 0, st, t.ro[lidx[i]], t.ro[ldidx[i]], t.ro[BS], t.ro[GS], t.ro[BL], t.ro[GLr], nd); }
       TRY((xty<4, 4>(eng, "t2_wgrad", t.ro[BL], D, nullptr, t.ro[sidx[i]], D, nullptr, N, 1.0f, (float*)gW[i], D, D, (float*)gb[i])));

@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
 }
 
 // =============================================================================================
-// Readout: LayerNorm -> MLP 64-64-64-64-1 (silu) -> per-structure sums; and its reverse.
+// Readout: LayerNorm -> MLP 64-64-64(-64)-1 (silu; two or three hidden layers) -> per-structure sums; and its reverse.
 //   model.py:497-509 (readout_norm, mlp, pooling); the site_wise magmom head is k_magmom
 // =============================================================================================
 struct ReadoutArgs {
@@ -1179,6 +1179,7 @@ struct ReadoutArgs {
   int n_atoms;
   const float *ln_g, *ln_b, *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3, *atomref;
   int has_composition;
+  int n_hidden;            // hidden layers of the head: 3 (mlp_hidden_dims=[64,64,64]) or 2 ([64,64], the 0.2.0 checkpoint); w2 / b2 unused when 2
   float* site_energy;      // [N]  (includes the AtomRef shift when has_composition)
   float* site_raw;         // [N]  model part only; summed per structure (in order, fp64) by k_finalize
   float* crystal_fea;      // [B,64] zeroed
@@ -1247,7 +1248,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) 
     gemm_dl<VT, VT>(l2.t, W1, WS, sv.t, j, g);
     CHG_EW(ft, r) sv.t[ft][r] = siluf_(l2.t[ft][r]);
     if (dump) write_dl<VT>(drow + RO_S2 * plane, g, sv.t);
-    gemm_dl<VT, VT>(l3.t, W2, WS, sv.t, j, g);
+    const bool three = p.n_hidden != 2;      // uniform
+    if (three) gemm_dl<VT, VT>(l3.t, W2, WS, sv.t, j, g);
+    else l3 = l2;                            // two hidden layers: the last Linear reads silu(l2)
     const V64 w3 = param64(vecs + 5 * D, g);
     float site = 0.f;
     CHG_EW(ft, r) site += w3.t[ft][r] * siluf_(l3.t[ft][r]);
@@ -1264,8 +1267,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) 
     if (p.Ga) {
       V64 g3, g2 = zero64(), g1 = zero64(), gx = zero64();
       CHG_EW(ft, r) g3.t[ft][r] = cot * w3.t[ft][r] * dsiluf_(l3.t[ft][r]);
-      gemm_dl_t<VT, VT>(g2.t, W2, WS, g3.t, j, g);
-      CHG_EW(ft, r) g2.t[ft][r] *= dsiluf_(l2.t[ft][r]);
+      if (three) {
+        gemm_dl_t<VT, VT>(g2.t, W2, WS, g3.t, j, g);
+        CHG_EW(ft, r) g2.t[ft][r] *= dsiluf_(l2.t[ft][r]);
+      } else {
+        g2 = g3;
+      }
       gemm_dl_t<VT, VT>(g1.t, W1, WS, g2.t, j, g);
       CHG_EW(ft, r) g1.t[ft][r] *= dsiluf_(l1.t[ft][r]);
       gemm_dl_t<VT, VT>(gx.t, W0, WS, g1.t, j, g);

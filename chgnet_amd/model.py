@@ -61,12 +61,13 @@ def random_state_dict(model_args: dict, seed: int = 0) -> dict:
     if model_args.get("composition_model", "MPtrj") is not None:
         sd["composition_model.fc.weight"] = np.zeros((1, N_ELEM), np.float32)
     sd["atom_embedding.embedding.weight"] = rng.normal(0, 1, (N_ELEM, D)).astype(np.float32)
-    sd["bond_basis_expansion.rbf_expansion_ag.frequencies"] = (np.pi * np.arange(1, NUM_RADIAL + 1)).astype(np.float32)
-    sd["bond_basis_expansion.rbf_expansion_bg.frequencies"] = (np.pi * np.arange(1, NUM_RADIAL + 1)).astype(np.float32)
-    sd["angle_basis_expansion.fourier_expansion.frequencies"] = np.arange(1, (NUM_ANGULAR - 1) // 2 + 1).astype(np.float32)
+    n_rad, n_ang = int(model_args.get("num_radial", NUM_RADIAL)), int(model_args.get("num_angular", NUM_ANGULAR))
+    sd["bond_basis_expansion.rbf_expansion_ag.frequencies"] = (np.pi * np.arange(1, n_rad + 1)).astype(np.float32)
+    sd["bond_basis_expansion.rbf_expansion_bg.frequencies"] = (np.pi * np.arange(1, n_rad + 1)).astype(np.float32)
+    sd["angle_basis_expansion.fourier_expansion.frequencies"] = np.arange(1, (n_ang - 1) // 2 + 1).astype(np.float32)
     for n in ("bond_embedding", "bond_weights_ag", "bond_weights_bg"):
-        lin(n, D, NUM_RADIAL, bias=False)
-    lin("angle_embedding", D, NUM_ANGULAR, bias=False)
+        lin(n, D, n_rad, bias=False)
+    lin("angle_embedding", D, n_ang, bias=False)
     mlp_out_bias = bool(model_args.get("mlp_out_bias", False))
     for l in range(L):
         p = f"atom_conv_layers.{l}"
@@ -91,9 +92,10 @@ def random_state_dict(model_args: dict, seed: int = 0) -> dict:
         ln(f"{p}.twoBody_bond.bn2")
     lin("site_wise", 1, D)
     ln("readout_norm")
-    for k in (0, 2, 4):
-        lin(f"mlp.layers.{k}", D, D)
-    lin("mlp.layers.7", 1, D)
+    n_hidden = len(model_args.get("mlp_hidden_dims", (64, 64, 64)))     # functions.py:81-91
+    for i in range(n_hidden):
+        lin(f"mlp.layers.{2 * i}", D, D)
+    lin(f"mlp.layers.{2 * n_hidden + 1}", 1, D)
     return sd
 
 

@@ -25,7 +25,7 @@ import numpy as np
 from chgnet_amd.graph.crystalgraph import CrystalGraph
 
 D = 64          # atom = bond = angle feature width of every released CHGNet
-NUM_RADIAL = 31
+NUM_RADIAL = 31     # basis sizes of the KERNELS (0.3.0 / r2scan); smaller expansions (0.2.0: 9 / 9) are zero-padded to them, see pad_bases
 NUM_ANGULAR = 31
 N_ELEM = 94
 
@@ -226,7 +226,7 @@ def _check_index(idx, seg_off, target_off, what: str) -> None:
 # weights
 # ---------------------------------------------------------------------------------------
 SUPPORTED_MODEL_ARGS = {
-    "atom_fea_dim": 64, "bond_fea_dim": 64, "angle_fea_dim": 64, "num_radial": 31, "num_angular": 31,
+    "atom_fea_dim": 64, "bond_fea_dim": 64, "angle_fea_dim": 64,
     "atom_conv_hidden_dim": 64, "bond_conv_hidden_dim": 64, "angle_layer_hidden_dim": 0,
     "update_bond": True, "update_angle": True, "mlp_first": True, "non_linearity": "silu",
     "gMLP_norm": "layer", "readout_norm": "layer", "conv_dropout": 0, "mlp_dropout": 0,
@@ -234,8 +234,11 @@ SUPPORTED_MODEL_ARGS = {
 
 
 def check_model_args(model_args: dict) -> None:
-    """The engine implements the architecture family of every released checkpoint
-    (0.2.0 / 0.3.0 / r2scan: pretrained/*/README.md); anything else is rejected loudly."""
+    """The engine implements the architecture family of the released checkpoints -- 0.3.0 / r2scan
+    (pretrained/0.3.0/README.md: 31 radial / 31 angular functions, a 64-64-64 energy head, cutoffs 6 / 3,
+    envelope exponent 8) and 0.2.0 (pretrained/0.2.0/README.md:12-37: 9 / 9, a 64-64 head, cutoffs 5 / 3,
+    exponent 5, ``mlp_out`` biases) -- and what lies between them: 1..31 radial functions, an odd number of
+    1..31 angular functions, two or three hidden layers of 64.  Anything else is rejected loudly."""
     for key, want in SUPPORTED_MODEL_ARGS.items():
         got = model_args.get(key, want)
         if isinstance(want, bool) or isinstance(want, str) or want is None:
@@ -245,8 +248,15 @@ def check_model_args(model_args: dict) -> None:
         if not ok:
             raise NotImplementedError(f"chgnet_amd engine does not implement {key}={got!r} (supports {want!r})")
     hid = model_args.get("mlp_hidden_dims", (64, 64, 64))
-    if list(hid) != [64, 64, 64]:
-        raise NotImplementedError(f"mlp_hidden_dims={hid!r} not implemented (supports (64, 64, 64))")
+    if isinstance(hid, int) or list(hid) not in ([64, 64, 64], [64, 64]):
+        raise NotImplementedError(f"mlp_hidden_dims={hid!r} not implemented (supports (64, 64, 64) and (64, 64))")
+    nr, na = model_args.get("num_radial", NUM_RADIAL), model_args.get("num_angular", NUM_ANGULAR)
+    if int(nr) != nr or not 1 <= nr <= NUM_RADIAL:
+        raise NotImplementedError(f"num_radial={nr!r} not implemented (supports 1..{NUM_RADIAL})")
+    if int(na) != na or not 1 <= na <= NUM_ANGULAR or na % 2 == 0:
+        # encoders.py:133-146 / basis.py:11-40: the expansion has 1 + 2*((num_angular - 1) // 2) columns, so an even
+        # num_angular cannot feed Linear(num_angular, 64) in the reference either
+        raise NotImplementedError(f"num_angular={na!r} not implemented (supports odd values 1..{NUM_ANGULAR})")
     if model_args.get("conv_norm") is not None:
         raise NotImplementedError("conv_norm is not implemented")
     if model_args.get("final_mlp", "MLP") not in {"normal", "MLP"}:
@@ -258,6 +268,33 @@ def check_model_args(model_args: dict) -> None:
         # basis.py:170-206: p = 0 means "no envelope" and any positive float is allowed there; the kernels
         # evaluate s^(p-1) by repeated squaring, so only integer p >= 1 (every released checkpoint: 5 or 8)
         raise NotImplementedError(f"cutoff_coeff={p!r} is not implemented (supports integers >= 1)")
+
+
+def pad_radial(x: np.ndarray, width: int = NUM_RADIAL) -> np.ndarray:
+    """Last axis zero-padded to ``width`` (frequencies / the columns of a bias-free embedding Linear)."""
+    x = np.asarray(x, np.float32)
+    out = np.zeros((*x.shape[:-1], width), np.float32)
+    out[..., :x.shape[-1]] = x
+    return out
+
+
+def pad_angular(w: np.ndarray) -> np.ndarray:
+    """Columns of ``angle_embedding.weight`` [64, 1 + 2*order] re-laid for the kernels' order-15 expansion
+    ``[1/sqrt2 | sin(f_1 t) .. sin(f_15 t) | cos(f_1 t) .. cos(f_15 t)]`` (basis.py:33-40): constant column,
+    ``order`` sine columns, zeros, ``order`` cosine columns, zeros."""
+    w = np.asarray(w, np.float32)
+    order, full = (w.shape[1] - 1) // 2, (NUM_ANGULAR - 1) // 2
+    out = np.zeros((w.shape[0], NUM_ANGULAR), np.float32)
+    out[:, 0] = w[:, 0]
+    out[:, 1:1 + order] = w[:, 1:1 + order]
+    out[:, 1 + full:1 + full + order] = w[:, 1 + order:1 + 2 * order]
+    return out
+
+
+def unpad_angular(w31: np.ndarray, num_angular: int) -> np.ndarray:
+    """Inverse of ``pad_angular`` (gradients back to the reference's column order)."""
+    order, full = (num_angular - 1) // 2, (NUM_ANGULAR - 1) // 2
+    return np.concatenate([w31[:, :1 + order], w31[:, 1 + full:1 + full + order]], axis=1)
 
 
 def _f32(x):
@@ -276,6 +313,9 @@ class PackedWeights:
     cutoff_coeff: int
     is_intensive: bool
     has_composition: bool
+    n_mlp_hidden: int = 3       # hidden layers of the energy head (2 for the 0.2.0 architecture)
+    num_radial: int = NUM_RADIAL
+    num_angular: int = NUM_ANGULAR
 
     def get(self, name: str) -> np.ndarray:
         off, shape = self.offsets[name]
@@ -335,13 +375,26 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
     has_comp = "composition_model.fc.weight" in sd
     vals["atomref"] = sd["composition_model.fc.weight"].reshape(-1) if has_comp else np.zeros(N_ELEM, np.float32)
     vals["emb"] = sd["atom_embedding.embedding.weight"]
-    vals["freq_ag"] = sd["bond_basis_expansion.rbf_expansion_ag.frequencies"]
-    vals["freq_bg"] = sd["bond_basis_expansion.rbf_expansion_bg.frequencies"]
-    vals["freq_ang"] = sd["angle_basis_expansion.fourier_expansion.frequencies"]
-    vals["w_bond_emb"] = sd["bond_embedding.weight"]
-    vals["w_wag"] = sd["bond_weights_ag.weight"]
-    vals["w_wbg"] = sd["bond_weights_bg.weight"]
-    vals["w_ang_emb"] = sd["angle_embedding.weight"]
+    # Basis sizes below the kernels' 31 / 31 (0.2.0: 9 / 9) are ZERO-PADDED: a radial function of frequency 0 is
+    # identically 0 (sin(0 r) / r, basis.py:108), and a padded column of a bias-free embedding Linear carries weight 0,
+    # so the padded model is the same real-number function and the same fp32 sums plus exact zeros.
+    n_rad = int(sd["bond_embedding.weight"].shape[1])
+    n_ang = int(sd["angle_embedding.weight"].shape[1])
+    if not (1 <= n_rad <= NUM_RADIAL and 1 <= n_ang <= NUM_ANGULAR and n_ang % 2 == 1):
+        raise NotImplementedError(f"basis sizes {n_rad} / {n_ang} are not implemented")
+    order = (n_ang - 1) // 2
+    for key in ("bond_basis_expansion.rbf_expansion_ag.frequencies", "bond_basis_expansion.rbf_expansion_bg.frequencies"):
+        if sd[key].shape != (n_rad,):
+            raise ValueError(f"{key}: expected {n_rad} frequencies")
+    if sd["angle_basis_expansion.fourier_expansion.frequencies"].shape != (order,):
+        raise ValueError(f"angle frequencies: expected {order}")
+    vals["freq_ag"] = pad_radial(sd["bond_basis_expansion.rbf_expansion_ag.frequencies"])
+    vals["freq_bg"] = pad_radial(sd["bond_basis_expansion.rbf_expansion_bg.frequencies"])
+    vals["freq_ang"] = pad_radial(sd["angle_basis_expansion.fourier_expansion.frequencies"], (NUM_ANGULAR - 1) // 2)
+    vals["w_bond_emb"] = pad_radial(sd["bond_embedding.weight"])
+    vals["w_wag"] = pad_radial(sd["bond_weights_ag.weight"])
+    vals["w_wbg"] = pad_radial(sd["bond_weights_bg.weight"])
+    vals["w_ang_emb"] = pad_angular(sd["angle_embedding.weight"])
 
     def cg(prefix, name):  # stack core | gate along the output axis
         return np.concatenate([sd[f"{prefix}.mlp_core.{name}"], sd[f"{prefix}.mlp_gate.{name}"]], axis=0)
@@ -411,12 +464,18 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
     vals["site_w"] = sd["site_wise.weight"].reshape(-1)
     vals["site_b"] = sd["site_wise.bias"].reshape(-1)
     vals["ro_ln_g"], vals["ro_ln_b"] = sd["readout_norm.weight"], sd["readout_norm.bias"]
-    for i, k in enumerate((0, 2, 4)):
-        vals[f"mlp_w{i}"] = sd[f"mlp.layers.{k}.weight"]
-        vals[f"mlp_b{i}"] = sd[f"mlp.layers.{k}.bias"]
+    # energy head (functions.py:81-91): Linear, act per hidden layer, Dropout, Linear(64, 1) -> the last Linear is
+    # layers.{2 n_hidden + 1}: 7 for (64, 64, 64), 5 for (64, 64); an absent third layer leaves zeros in its slots
+    n_hidden = mlp_hidden_layers(sd)
+    for i in range(3):
+        if i < n_hidden:
+            vals[f"mlp_w{i}"] = sd[f"mlp.layers.{2 * i}.weight"]
+            vals[f"mlp_b{i}"] = sd[f"mlp.layers.{2 * i}.bias"]
+        else:
+            vals[f"mlp_w{i}"], vals[f"mlp_b{i}"] = np.zeros((D, D), np.float32), np.zeros(D, np.float32)
         vals[f"mlp_w{i}_t"] = vals[f"mlp_w{i}"].T
-    vals["mlp_w3"] = sd["mlp.layers.7.weight"].reshape(-1)
-    vals["mlp_b3"] = sd["mlp.layers.7.bias"].reshape(-1)
+    vals["mlp_w3"] = sd[f"mlp.layers.{2 * n_hidden + 1}.weight"].reshape(-1)
+    vals["mlp_b3"] = sd[f"mlp.layers.{2 * n_hidden + 1}.bias"].reshape(-1)
 
     offsets, chunks, pos = {}, [], 0
     for name, shape in weight_layout(n_conv):
@@ -438,7 +497,17 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
         cutoff_coeff=int(model_args.get("cutoff_coeff", 8)),
         is_intensive=bool(model_args.get("is_intensive", True)),
         has_composition=has_comp,
+        n_mlp_hidden=n_hidden, num_radial=n_rad, num_angular=n_ang,
     )
+
+
+def mlp_hidden_layers(sd: dict) -> int:
+    """Hidden layers of the energy head of a ``state_dict``: its last Linear is ``mlp.layers.{2 n + 1}`` with one output."""
+    last = max(int(k.split(".")[2]) for k in sd if k.startswith("mlp.layers.") and k.endswith(".weight"))
+    n_hidden = (last - 1) // 2
+    if last % 2 != 1 or n_hidden not in (2, 3) or np.asarray(sd[f"mlp.layers.{last}.weight"]).shape[0] != 1:
+        raise NotImplementedError(f"energy head with last layer mlp.layers.{last} is not implemented (two or three hidden layers of 64)")
+    return n_hidden
 
 
 def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
@@ -455,13 +524,14 @@ def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
     if pw.has_composition:
         out["composition_model.fc.weight"] = np.zeros((1, N_ELEM), grad_blob.dtype)
     out["atom_embedding.embedding.weight"] = G("emb")
-    out["bond_basis_expansion.rbf_expansion_ag.frequencies"] = G("freq_ag")
-    out["bond_basis_expansion.rbf_expansion_bg.frequencies"] = G("freq_bg")
-    out["angle_basis_expansion.fourier_expansion.frequencies"] = G("freq_ang")
-    out["bond_embedding.weight"] = G("w_bond_emb")
-    out["bond_weights_ag.weight"] = G("w_wag")
-    out["bond_weights_bg.weight"] = G("w_wbg")
-    out["angle_embedding.weight"] = G("w_ang_emb")
+    nr, na = pw.num_radial, pw.num_angular                     # the padded tail of a smaller expansion is not a parameter
+    out["bond_basis_expansion.rbf_expansion_ag.frequencies"] = G("freq_ag")[:nr]
+    out["bond_basis_expansion.rbf_expansion_bg.frequencies"] = G("freq_bg")[:nr]
+    out["angle_basis_expansion.fourier_expansion.frequencies"] = G("freq_ang")[:(na - 1) // 2]
+    out["bond_embedding.weight"] = G("w_bond_emb")[:, :nr]
+    out["bond_weights_ag.weight"] = G("w_wag")[:, :nr]
+    out["bond_weights_bg.weight"] = G("w_wbg")[:, :nr]
+    out["angle_embedding.weight"] = unpad_angular(G("w_ang_emb"), na)
 
     def split_cg(pre, name, full):            # rows 0..63 = core, 64..127 = gate
         out[f"{pre}.mlp_core.{name}"], out[f"{pre}.mlp_gate.{name}"] = full[:D], full[D:]
@@ -499,8 +569,9 @@ def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
         ln(p, pre)
     out["site_wise.weight"], out["site_wise.bias"] = G("site_w").reshape(1, D), G("site_b")
     out["readout_norm.weight"], out["readout_norm.bias"] = G("ro_ln_g"), G("ro_ln_b")
-    for i, k in enumerate((0, 2, 4)):
-        out[f"mlp.layers.{k}.weight"], out[f"mlp.layers.{k}.bias"] = G(f"mlp_w{i}"), G(f"mlp_b{i}")
-    out["mlp.layers.7.weight"], out["mlp.layers.7.bias"] = G("mlp_w3").reshape(1, D), G("mlp_b3")
+    nh = pw.n_mlp_hidden
+    for i in range(nh):
+        out[f"mlp.layers.{2 * i}.weight"], out[f"mlp.layers.{2 * i}.bias"] = G(f"mlp_w{i}"), G(f"mlp_b{i}")
+    out[f"mlp.layers.{2 * nh + 1}.weight"], out[f"mlp.layers.{2 * nh + 1}.bias"] = G("mlp_w3").reshape(1, D), G("mlp_b3")
     return out
 

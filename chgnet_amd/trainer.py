@@ -143,14 +143,22 @@ class CombinedLoss:
         cache = self.__dict__.setdefault("_flat_cache", {})
         # a hit must be the same dictionary holding the same label OBJECTS for the same graph sizes: a loader that refills one
         # dictionary (or its lists) in place gets fresh labels, not the previous batch's
-        def probe(x):   # identity + first / last value: an array refilled in place changes the stamp as well (O(1) per array)
+        def probe(x):   # identity + the BYTES of the first / last value: an array refilled in place changes the stamp (O(1) per
+            # array), and a NaN label -- a missing magmom, allow_missing_labels -- compares equal to itself (nan != nan would
+            # make every step a miss)
             if type(x) is np.ndarray:      # the common case, without the detour over a flat iterator (3 x 1024 labels per step)
-                return (id(x), x.item(0), x.item(-1)) if x.size else (id(x), 0.0, 0.0)
-            a = np.asarray(x) if x is not None else np.zeros(0)
-            return (id(x), float(a.flat[0]) if a.size else 0.0, float(a.flat[-1]) if a.size else 0.0)
+                return (id(x), x.reshape(-1)[:1].tobytes(), x.reshape(-1)[-1:].tobytes()) if x.size else (id(x), b"", b"")
+            a = np.asarray(x, np.float64) if x is not None else np.zeros(0)
+            return (id(x), a.reshape(-1)[:1].tobytes(), a.reshape(-1)[-1:].tobytes())
+
+        def items(k):   # the label container of key k: a list of per-structure arrays, or ONE stacked array (stress as [B,3,3])
+            v = targets.get(k)
+            if v is None:
+                return ()
+            return (v,) if isinstance(v, np.ndarray) or hasattr(v, "detach") else v     # a stacked array is probed as a whole
 
         sizes = atoms_per_graph.tobytes() if type(atoms_per_graph) is np.ndarray else tuple(int(n) for n in atoms_per_graph)
-        stamp = (tuple(id(targets.get(k)) for k in ("f", "s", "m")), tuple(probe(x) for k in ("f", "s", "m") for x in (targets.get(k) or ())),
+        stamp = (tuple(id(targets.get(k)) for k in ("f", "s", "m")), tuple(probe(x) for k in ("f", "s", "m") for x in items(k)),
                  sizes, bool(self.allow_missing_labels))
         hit = cache.get(id(targets))
         if hit is not None and hit[0] is targets and hit[2] == stamp:

@@ -201,10 +201,11 @@ class OracleCHGNet:
         atom = atom_conv(self.n_conv - 1, atom, bond)                           # :490-496
         inter[f"atom{self.n_conv}"] = atom
         atom = self._ln(atom, "readout_norm")                                   # :497-498
-        x = atom                                                                # MLP 64-64-64-64-1 (functions.py:81-91)
-        for k in (0, 2, 4):
+        x = atom                                # MLP 64-64-64(-64)-1 (functions.py:81-91): Linear + act per hidden layer, Dropout, Linear
+        last = max(int(k.split(".")[2]) for k in w if k.startswith("mlp.layers.") and k.endswith(".weight"))   # 7 (0.3.0) or 5 (0.2.0)
+        for k in range(0, last - 1, 2):
             x = F.silu(F.linear(x, w[f"mlp.layers.{k}.weight"], w[f"mlp.layers.{k}.bias"]))
-        site_e = F.linear(x, w["mlp.layers.7.weight"], w["mlp.layers.7.bias"])  # [N,1]
+        site_e = F.linear(x, w[f"mlp.layers.{last}.weight"], w[f"mlp.layers.{last}.bias"])  # [N,1]
         energy = self._aggregate(site_e, atom_owner, B).view(-1)                # :503
         crystal = self._aggregate(atom, atom_owner, B)                          # :508-509
 

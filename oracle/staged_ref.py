@@ -228,7 +228,8 @@ class StagedModel:
         x0, xh0, rs0 = ln_fwd(atom[L], W("ro_ln_g"), W("ro_ln_b"))
         l1 = x0 @ W("mlp_w0").T + W("mlp_b0")
         l2 = silu(l1) @ W("mlp_w1").T + W("mlp_b1")
-        l3 = silu(l2) @ W("mlp_w2").T + W("mlp_b2")
+        three = getattr(self.pw, "n_mlp_hidden", 3) == 3          # two hidden layers (0.2.0): the last Linear reads silu(l2)
+        l3 = silu(l2) @ W("mlp_w2").T + W("mlp_b2") if three else l2
         site = silu(l3) @ W("mlp_w3") + W("mlp_b3")[0]
         energy = np.zeros(B, dt)
         np.add.at(energy, pb.atom_owner, site)
@@ -263,12 +264,13 @@ class StagedModel:
             wg["mlp_w3"] = (cot[:, None] * silu(l3)).sum(0)
             wg["mlp_b3"] = np.array([cot.sum()])
         g3 = cot[:, None] * W("mlp_w3")[None, :] * dsilu(l3)
-        g2 = (g3 @ W("mlp_w2")) * dsilu(l2)
+        g2 = (g3 @ W("mlp_w2")) * dsilu(l2) if three else g3
         g1 = (g2 @ W("mlp_w1")) * dsilu(l1)
         gx0 = g1 @ W("mlp_w0")
         Ga = ln_bwd(gx0, W("ro_ln_g"), xh0, rs0)          # dE/d atom[L]
         if train:
-            wg["mlp_w2"], wg["mlp_b2"] = g3.T @ silu(l2), g3.sum(0)
+            if three:
+                wg["mlp_w2"], wg["mlp_b2"] = g3.T @ silu(l2), g3.sum(0)
             wg["mlp_w1"], wg["mlp_b1"] = g2.T @ silu(l1), g2.sum(0)
             wg["mlp_w0"], wg["mlp_b0"] = g1.T @ x0, g1.sum(0)
             wg["ro_ln_g"], wg["ro_ln_b"] = (gx0 * xh0).sum(0), gx0.sum(0)

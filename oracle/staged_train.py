@@ -256,24 +256,25 @@ class StagedTrainer:
         xh0d = ln_tangent(atomd[L], xh0, rs0)
         x0d = W("ro_ln_g") * xh0d
         ls, lds, ss, sds = [], [], [x0], [x0d]
-        for i in range(3):
+        nh = getattr(self.pw, "n_mlp_hidden", 3)                  # hidden layers of the energy head (2: the 0.2.0 architecture)
+        for i in range(nh):
             li = ss[-1] @ W(f"mlp_w{i}").T + W(f"mlp_b{i}")
             lid = sds[-1] @ W(f"mlp_w{i}").T
             ls.append(li)
             lds.append(lid)
             ss.append(silu(li))
             sds.append(dsilu(li) * lid)
-        site = ss[3] @ W("mlp_w3") + W("mlp_b3")[0]
-        sited = sds[3] @ W("mlp_w3")
+        site = ss[nh] @ W("mlp_w3") + W("mlp_b3")[0]
+        sited = sds[nh] @ W("mlp_w3")
         out = {"site": site, "dE": float(sited.sum())}
 
         # ---- reverse sweep with two adjoints -------------------------------------------------------------
         wg = {}
-        wg["mlp_w3"] = (cot[:, None] * ss[3]).sum(0) + sds[3].sum(0)
+        wg["mlp_w3"] = (cot[:, None] * ss[nh]).sum(0) + sds[nh].sum(0)
         wg["mlp_b3"] = np.array([cot.sum()])
         bar_s = cot[:, None] * W("mlp_w3")[None, :]
         g_s = np.ones((N, 1)) * W("mlp_w3")[None, :]
-        for i in (2, 1, 0):
+        for i in reversed(range(nh)):
             bar_l = dsilu(ls[i]) * bar_s + ddsilu(ls[i]) * lds[i] * g_s
             g_l = dsilu(ls[i]) * g_s
             wg[f"mlp_w{i}"] = bar_l.T @ ss[i] + g_l.T @ sds[i]

@@ -127,3 +127,27 @@ def test_product_build_defines_no_experiment_switch():
             used |= set(re.findall(r"#\s*if(?:def|ndef)?\s+(?:defined\()?(CHG_EXP_[A-Z0-9_]+)", open(os.path.join(root, f)).read()))
     assert not used, f"experiment switches in the shipping sources: {used}"
     assert "#if defined(CHG_PHASE_TIMING) && !defined(CHG_EXPERIMENTS)" in hdr and "#error" in hdr
+
+
+def test_ctypes_structs_mirror_the_c_header(tmp_path):
+    """``chg_model_desc`` (with the ``n_mlp_hidden`` field the 0.2.0 head needs) and ``chg_out_host`` as gcc lays them
+    out from include/chgnet_hip.h == the ctypes mirrors in chgnet_amd/_lib.py, field by field."""
+    import subprocess
+
+    from chgnet_amd import _lib
+
+    fields = {"chg_model_desc": _lib.ModelDesc, "chg_out_host": _lib.OutHost, "chg_structs_host": _lib.StructsHost, "chg_batch_host": _lib.BatchHost}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "chgnet_hip.h"', "int main(void) {"]
+    for cname, cls in fields.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", f"-I{os.path.join(REPO, 'include')}", str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in fields.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)

@@ -165,6 +165,32 @@ def test_flat_label_cache_sees_a_refilled_dictionary():
     assert abs(third - want) < 1e-12 and abs(third - second) > 0.1
 
 
+def test_flat_label_cache_with_stacked_stress_and_nan_magmoms():
+    """(i) a label container that is ONE stacked array (stress as [B,3,3]) must not be truth-tested
+    (``ValueError: truth value of an array is ambiguous``); (ii) NaN labels (missing magmoms under
+    ``allow_missing_labels``, the default) must not defeat the cache: the stamp compares bytes, not values (nan != nan)."""
+    from chgnet_amd.model import ForwardResult
+
+    rng = np.random.default_rng(6)
+    targ, pred = _batch(rng, False)
+    targ["s"] = np.stack(targ["s"])                                            # one [B,3,3] array instead of a list
+    targ["m"] = [np.asarray(x, np.float64).copy() for x in targ["m"]]
+    targ["m"][0][0] = np.nan                                                   # first value of the first label array
+    targ["m"][-1][-1] = np.nan
+    apg = np.array([len(x) for x in pred["f"]])
+    fast = ForwardResult(dict(pred, atoms_per_graph=apg))
+    fast.flat = {"f": np.concatenate(pred["f"], 0), "s": np.stack(pred["s"]), "m": np.concatenate(pred["m"])}
+    loss = CombinedLoss(target_str="efsm", criterion="MSE", allow_missing_labels=True)
+    a = loss._flat_targets(targ, apg)
+    assert loss._flat_targets(targ, apg) is a                                  # hit, NaNs and all
+    want = CombinedLoss(target_str="efsm", criterion="MSE", allow_missing_labels=True).gradients(
+        dict(targ, s=list(targ["s"])), pred)[0]
+    got = loss.gradients(targ, fast)[0]
+    assert abs(got["loss"] - want["loss"]) < 1e-12 and got["m_MAE_size"] == want["m_MAE_size"]
+    targ["s"][0, 0, 0] += 1.0                                                  # the stacked array refilled in place: a miss
+    assert loss._flat_targets(targ, apg) is not a
+
+
 def test_run_epoch_hands_every_batch_its_own_upload_in_order():
     """The loader of ``TrainStep.run_epoch`` with ``upload_ahead=True`` (the helper thread packs AND uploads the next batch while a step
     runs): every step gets the device batch that was uploaded from ITS packed batch, in order, each batch uploaded exactly once, for

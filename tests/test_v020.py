@@ -1,0 +1,214 @@
+"""The RELEASED 0.2.0 architecture (chgnet/pretrained/0.2.0/README.md:12-37: 9 radial / 9 angular functions, a 64-64
+energy head, cutoffs 5 / 3, envelope exponent 5, ``mlp_out`` biases) -- what ``CHGNet.load(model_name="0.2.0")``
+(model.py:718-736) instantiates.  Fixtures: tests/golden/make_golden_v020.py (the unmodified reference, run here).
+
+CPU part: the oracle is pinned to the reference's outputs and to its ``loss.backward()`` for this architecture; the
+float64 model of the kernel pipeline (zero-padded bases, two-layer head) equals the oracle; the Python surface
+(``CHGNet(**args)``, ``from_file``, ``load``) accepts it.  GPU part: the engine against the reference's outputs.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+V020_ARGS = dict(num_radial=9, num_angular=9, mlp_hidden_dims=[64, 64], atom_graph_cutoff=5, bond_graph_cutoff=3,
+                 cutoff_coeff=5, mlp_out_bias=True)
+CASES = ["limno2", "noangle", "s16tri", "s40", "li9co7o16"]
+# the same tables as tests/test_oracle_golden.py (oracle vs fixture) and tests/test_gpu_parity.py (engine vs fixture)
+TOL_ORACLE = {"e": 2e-6, "f": 2e-6, "s": 5e-6, "m": 3e-6, "site_energies": 3e-6, "atom_fea": 1e-5, "crystal_fea": 5e-5}
+TOL_ORACLE_TL = {"e": 4e-6, "f": 4e-5, "s": 4e-4, "m": 2e-5, "site_energies": 3e-5, "atom_fea": 1e-4, "crystal_fea": 5e-4}
+TOL = {"e": 5e-6, "f": 1e-5, "s": 1e-4, "m": 1e-5, "site_energies": 1e-5, "atom_fea": 5e-5, "crystal_fea": 3e-4}
+KW = dict(return_site_energies=True, return_atom_feas=True, return_crystal_feas=True)
+
+
+def load_case_v020(name: str):
+    from chgnet_amd.graph.crystalgraph import CrystalGraph
+
+    d = np.load(os.path.join(GOLDEN, f"case_v020_{name}.npz"))
+    g = CrystalGraph(
+        atomic_number=d["atomic_number"], atom_frac_coord=d["atom_frac_coord"], atom_graph=d["atom_graph"],
+        atom_graph_cutoff=5, neighbor_image=d["neighbor_image"], directed2undirected=d["directed2undirected"],
+        undirected2directed=d["undirected2directed"], bond_graph=d["bond_graph"], bond_graph_cutoff=3,
+        lattice=d["lattice"], graph_id=name)
+    return g, d
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return dict(np.load(os.path.join(GOLDEN, "weights_v020.npz")))
+
+
+@pytest.fixture(scope="module")
+def weights_tl():
+    return dict(np.load(os.path.join(GOLDEN, "weights_v020_trained_like.npz")))
+
+
+def _oracle(w, dtype=torch.float32):
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    return OracleCHGNet(w, atom_graph_cutoff=5.0, bond_graph_cutoff=3.0, cutoff_coeff=5, dtype=dtype)
+
+
+# ---- CPU: the checker is pinned -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_reference_on_the_released_020_architecture(weights, weights_tl, name):
+    torch.set_num_threads(1)
+    g, d = load_case_v020(name)
+    for w, prefix, tol in ((weights, "out_", TOL_ORACLE), (weights_tl, "tl_out_", TOL_ORACLE_TL)):
+        out = _oracle(w).predict_graph(g, "efsm", **KW)
+        for key, t in tol.items():
+            ref = d[prefix + key]
+            assert out[key].shape == ref.shape
+            err = float(np.abs(out[key] - ref).max()) if ref.size else 0.0
+            assert err <= t, f"{name}:{prefix}{key} {err:.2e}"
+
+
+def test_oracle_parameter_gradients_match_the_reference_backward_on_020(weights):
+    """All 141 tensors (the 136 of 0.3.0 minus one head layer plus seven ``mlp_out`` biases) of the reference's own
+    ``loss.backward()`` in train mode (trainer.py:399-411) on the five-case batch."""
+    d = np.load(os.path.join(GOLDEN, "grad_v020_five.npz"))
+    want = {k[len("grad/"):]: d[k] for k in d.files if k.startswith("grad/")}
+    graphs = [load_case_v020(str(n))[0] for n in d["order"]]
+    torch.set_num_threads(4)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    ce, gm, gf, gs = d["cot_e"], d["cot_m"], d["cot_f"], d["cot_s"]
+    got = _oracle(weights, torch.float64).parameter_gradients(
+        graphs, lambda o: (o["e"] * t(ce)).sum() + (o["m"] * t(gm)).sum() + (o["f"] * t(gf)).sum() + (o["s"] * t(gs)).sum(), task="efsm")
+    assert set(got) == set(want) and len(want) == 141
+    bad = {}
+    for k, ref in want.items():
+        scale, err = float(np.abs(ref).max()), float(np.abs(got[k] - ref).max())
+        if scale == 0.0:
+            assert err == 0.0, k
+        elif err / scale > 1e-4:
+            bad[k] = err / scale
+    assert not bad, "; ".join(f"{k} {v:.1e}" for k, v in sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+
+
+def test_pipeline_model_with_padded_bases_and_two_layer_head_equals_the_oracle_fp64(weights):
+    """What the kernels compute for this architecture -- 31-wide bases with the tail zero-padded (``pack.pad_radial`` /
+    ``pad_angular``), the head's third layer skipped, ``q_bias`` for the bonds outside the bond graph -- is the
+    reference's function: float64 pipeline model == float64 autograd oracle."""
+    from chgnet_amd.pack import pack_batch, pack_weights
+    from oracle.staged_ref import StagedModel
+
+    pw = pack_weights(weights, V020_ARGS)
+    assert (pw.n_mlp_hidden, pw.num_radial, pw.num_angular, pw.cutoff_coeff, pw.atom_graph_cutoff) == (2, 9, 9, 5, 5.0)
+    graphs = [load_case_v020(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    ref = _oracle(weights, torch.float64).forward(graphs, "efsm", **KW)
+    out = StagedModel(pw).run(pack_batch(graphs))
+    cat = lambda parts: np.concatenate([np.atleast_1d(p) for p in parts])  # noqa: E731
+    assert np.abs(out["e"] - np.array(ref["e"])).max() < 1e-12
+    assert np.abs(out["f"] - cat(ref["f"])).max() < 1e-12
+    assert np.abs(out["s"] - np.stack(ref["s"])).max() < 1e-11
+    assert np.abs(out["m"] - cat(ref["m"])).max() < 1e-12
+    assert np.abs(out["site_energies"] - cat(ref["site_energies"])).max() < 1e-12
+    assert np.abs(out["atom_fea"] - cat(ref["atom_fea"])).max() < 1e-12
+
+
+def test_padding_round_trip_and_rejections():
+    from chgnet_amd.pack import check_model_args, pad_angular, unpad_angular
+
+    w = np.arange(64 * 9, dtype=np.float32).reshape(64, 9)
+    p = pad_angular(w)
+    assert p.shape == (64, 31) and np.array_equal(unpad_angular(p, 9), w)
+    assert np.array_equal(p[:, 5:16], np.zeros((64, 11))) and np.array_equal(p[:, 16:20], w[:, 5:9]) and not p[:, 20:].any()
+    check_model_args(V020_ARGS)
+    for bad in (dict(num_radial=32), dict(num_angular=8), dict(num_angular=33), dict(mlp_hidden_dims=[64]), dict(mlp_hidden_dims=[32, 32]),
+                dict(mlp_hidden_dims=64)):
+        with pytest.raises(NotImplementedError):
+            check_model_args(bad)
+
+
+def test_python_surface_accepts_the_released_020_architecture(weights, tmp_path, capsys):
+    """``CHGNet(**README arguments)`` has the reference's 403,126 parameters; a checkpoint in the reference's file
+    format under the released file name loads through ``CHGNet.load(model_name="0.2.0")`` (model.py:718-736: it passes
+    ``mlp_out_bias=True``, ``version="0.2.0"``)."""
+    from chgnet_amd import CHGNet
+
+    model = CHGNet(**V020_ARGS)
+    assert model.n_params == 403126
+    assert "CHGNet initialized with 403,126 parameters" in capsys.readouterr().out
+    assert set(model.state_dict()) == set(weights) and all(model.state_dict()[k].shape == v.shape for k, v in weights.items())
+    root = tmp_path / "0.2.0"
+    root.mkdir()
+    args = {k: v for k, v in V020_ARGS.items() if k != "mlp_out_bias"}      # the released file's model_args predate the switch
+    torch.save({"model": {"state_dict": {k: torch.tensor(v) for k, v in weights.items()}, "model_args": args}},
+               str(root / "chgnet_0.2.0_e30f77s348m32.pth.tar"))
+    loaded = CHGNet.load(model_name="0.2.0", checkpoint_dir=str(tmp_path), verbose=False)
+    assert loaded.version == "0.2.0" and loaded.n_params == 403126
+    assert "CHGNet v0.2.0 initialized with 403,126 parameters" in capsys.readouterr().out
+    assert loaded.graph_converter.atom_graph_cutoff == 5 and loaded._weights.n_mlp_hidden == 2
+    assert all(np.array_equal(loaded.state_dict()[k], v) for k, v in weights.items())
+
+
+# ---- GPU: the engine against the reference's outputs -------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model_v020(weights):
+    from chgnet_amd import CHGNet
+
+    m = CHGNet(state_dict=weights, **V020_ARGS)
+    yield m
+    if m._engine is not None:
+        m._engine.close()
+
+
+@pytest.fixture(scope="module")
+def model_v020_tl(weights_tl):
+    from chgnet_amd import CHGNet
+
+    m = CHGNet(state_dict=weights_tl, **V020_ARGS)
+    yield m
+    if m._engine is not None:
+        m._engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_engine_matches_the_reference_on_the_released_020_architecture(model_v020, name):
+    g, d = load_case_v020(name)
+    out = model_v020.predict_graph(g, task="efsm", **KW)
+    for key, tol in TOL.items():
+        ref = d["out_" + key]
+        assert out[key].shape == ref.shape and out[key].dtype == np.float32
+        assert np.isfinite(out[key]).all(), key
+        err = float(np.abs(out[key] - ref).max()) if ref.size else 0.0
+        assert err < tol, f"{name}:{key} max|d|={err:.3e} tol={tol:.1e}"
+
+
+@pytest.mark.gpu
+def test_engine_matches_the_reference_020_trained_like_weights_in_one_batch(model_v020_tl):
+    """Trained-checkpoint magnitudes, all five cases in ONE device batch (the zero-angle cell rides with cells that have
+    angles, so it receives the BondConv biases like in the reference: model.py:459 tests the batch, not the structure --
+    the fixture values are single-structure calls, so the zero-angle case is compared on its own)."""
+    names = [n for n in CASES if n != "noangle"]
+    outs = model_v020_tl.predict_graph([load_case_v020(n)[0] for n in names], task="efsm", **KW)
+    for n, out in zip(names, outs):
+        d = load_case_v020(n)[1]
+        scale = {"e": 1.0, "f": max(1.0, float(np.abs(d["tl_out_f"]).max())), "s": max(1.0, float(np.abs(d["tl_out_s"]).max()))}
+        for key, tol in TOL.items():
+            ref = d["tl_out_" + key]
+            err = float(np.abs(out[key] - ref).max())
+            assert err < 4 * tol * scale.get(key, 1.0), f"{n}:{key} max|d|={err:.3e}"
+    g, d = load_case_v020("noangle")
+    out = model_v020_tl.predict_graph(g, task="efsm", **KW)
+    for key, tol in TOL.items():
+        assert float(np.abs(out[key] - d["tl_out_" + key]).max()) < 4 * tol, key
+
+
+@pytest.mark.gpu
+def test_engine_020_predict_structure_builds_the_5A_graph_on_the_device(model_v020):
+    """Structures in, the 5 A / 3 A graph built on the device (the converter's cutoffs come from the model arguments)."""
+    from chgnet_amd.graph.structure import Lattice, Structure
+
+    d = load_case_v020("s16tri")[1]
+    s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"])
+    out = model_v020.predict_structure(s, task="efsm")
+    for key in ("e", "f", "s", "m"):
+        assert float(np.abs(out[key] - d["out_" + key]).max()) < TOL[key], key
