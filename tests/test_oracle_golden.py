@@ -155,3 +155,45 @@ def test_oracle_parameter_gradients_match_the_reference_backward(fname, wset, go
         worst[k] = err / scale
     bad = {k: v for k, v in worst.items() if v > GRAD_REL_TOL}
     assert not bad, f"{fname}: " + "; ".join(f"{k} {v:.1e}" for k, v in sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+
+
+def test_reference_bytecode_archive_is_the_reference(tmp_path):
+    """``oracle/build_ref_model.py``: the reference's Python model byte-compiled from where it lies into ONE archive of .pyc files
+    (``oracle/_ref/``, git-ignored, travels to the GPU box) -- what ``bench.py`` times as ``cpu_baseline.kind == "reference"``.
+    Imported in its own process (this one may hold the reference from /root/reference): the archive's ``CHGNet.predict_graph``
+    reproduces the committed reference outputs bit for bit on one thread, and carries no source file."""
+    import subprocess
+    import sys
+    import zipfile
+
+    from conftest import REPO
+    from oracle import build_ref_model
+
+    archive = build_ref_model.build()
+    if archive is None:
+        pytest.skip("neither /root/reference nor a prebuilt archive")
+    with zipfile.ZipFile(archive) as z:
+        names = z.namelist()
+    assert "chgnet/model/model.pyc" in names and not [n for n in names if n.endswith((".py", ".pyx", ".c"))]
+    code = f"""
+import sys; sys.path.insert(0, {REPO!r})
+import numpy as np, torch
+from oracle.build_ref_model import load
+load()
+from chgnet.graph.crystalgraph import CrystalGraph
+from chgnet.model.model import CHGNet
+torch.set_num_threads(1)
+w = dict(np.load({os.path.join(GOLDEN, 'weights_seed0.npz')!r}))
+m = CHGNet(); m.load_state_dict({{k: torch.tensor(v) for k, v in w.items()}}); m.eval()
+d = np.load({os.path.join(GOLDEN, 'case_limno2.npz')!r})
+i32 = lambda a: torch.tensor(a, dtype=torch.int32)
+g = CrystalGraph(atomic_number=i32(d["atomic_number"]), atom_frac_coord=torch.tensor(d["atom_frac_coord"]), atom_graph=i32(d["atom_graph"]),
+                 neighbor_image=torch.tensor(d["neighbor_image"]), directed2undirected=i32(d["directed2undirected"]),
+                 undirected2directed=i32(d["undirected2directed"]), bond_graph=i32(d["bond_graph"]), lattice=torch.tensor(d["lattice"]),
+                 atom_graph_cutoff=6, bond_graph_cutoff=3)
+out = m.predict_graph(g, task="efsm")
+assert abs(float(out["e"]) - float(d["out_e"])) < 1e-6 and np.abs(out["f"] - d["out_f"]).max() < 1e-6 and np.abs(out["s"] - d["out_s"]).max() < 1e-5
+print("ARCHIVE-OK", CHGNet.__module__)
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert "ARCHIVE-OK chgnet.model.model" in res.stdout, res.stderr[-2000:]
