@@ -29,6 +29,25 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// Second shape of the same copy: every workgroup owns CONTIGUOUS 16 KiB segments (256 lanes x 4 x 16 B, the four loads of a lane
+// 4 KiB apart inside the segment, all in flight before the first store) and walks them grid-stride -- fewer DRAM pages open at a time
+// than the fully interleaved form above.  NT: non-temporal accesses (streaming data that nothing reads again) or plain ones.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_stream_copy_seg(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
+  constexpr size_t SEG = 1024;   // f32x4 per segment
+  const size_t nseg = n / SEG;
+  for (size_t sgm = blockIdx.x; sgm < nseg; sgm += gridDim.x) {
+    const f32x4* s = src + sgm * SEG + threadIdx.x;
+    f32x4* d = dst + sgm * SEG + threadIdx.x;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = NT ? __builtin_nontemporal_load(s + u * 256) : s[u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { if (NT) __builtin_nontemporal_store(v[u], d + u * 256); else d[u * 256] = v[u]; }
+  }
+  for (size_t i = nseg * SEG + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // The tile kernels carry their weights as f16 hi / lo images (mfma_split.h): a weight of magnitude >= 65504 would become inf there.
 // No trained checkpoint comes near (|w| < 10); a blob that does is refused instead of producing NaN where the reference is finite.
 int check_weight_range(chg_engine* eng, const float* blob, size_t n) {
@@ -559,12 +578,14 @@ int chg_stream_copy(chg_engine* eng, int64_t bytes, int iters, float* ms_per_ite
   hipEvent_t e0 = get_event(eng), e1 = get_event(eng);
   int s = CHG_OK;
   float best = 1e30f;
-  for (int variant = 0; variant < 6 && s == CHG_OK; ++variant) {
-    const int unroll = variant < 3 ? 1 : 4;
+  for (int variant = 0; variant < 12 && s == CHG_OK; ++variant) {
+    const int shape = variant / 3;   // 0: interleaved x1, 1: interleaved x4, 2: 16 KiB segments non-temporal, 3: segments, plain accesses
     const unsigned blocks = (unsigned)((variant % 3 == 0 ? 8 : (variant % 3 == 1 ? 32 : 128)) * eng->num_cus);
     auto launch = [&]() {
-      if (unroll == 1) hipLaunchKernelGGL(k_stream_copy<1>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
-      else hipLaunchKernelGGL(k_stream_copy<4>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
+      if (shape == 0) hipLaunchKernelGGL(k_stream_copy<1>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
+      else if (shape == 1) hipLaunchKernelGGL(k_stream_copy<4>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
+      else if (shape == 2) hipLaunchKernelGGL(k_stream_copy_seg<true>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
+      else hipLaunchKernelGGL(k_stream_copy_seg<false>, dim3(blocks), dim3(256), 0, eng->stream, (const f32x4*)a, (f32x4*)b, n);
     };
     launch();   // warm-up (page faults, clocks)
     hipEventRecord(e0, eng->stream);
