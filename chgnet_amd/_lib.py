@@ -32,7 +32,7 @@ class ModelDesc(ctypes.Structure):
         ("n_conv", ctypes.c_int32), ("cutoff_coeff", ctypes.c_int32), ("is_intensive", ctypes.c_int32),
         ("has_composition", ctypes.c_int32), ("atom_graph_cutoff", ctypes.c_float),
         ("bond_graph_cutoff", ctypes.c_float), ("n_weights", ctypes.c_int64),
-        ("n_mlp_hidden", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("n_mlp_hidden", ctypes.c_int32), ("mlp_out_bias", ctypes.c_int32),
     ]
 
 

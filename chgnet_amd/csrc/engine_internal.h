@@ -43,7 +43,7 @@ constexpr size_t PHASE_FLOATS = 64;
 #endif
 constexpr int FWD_WAVES = CHG_FWD_WAVES;   // waves per workgroup of the light forward kernels (12 = 3 per SIMD measured no better: profiles notes)
 
-struct ACW { const float *w_cn, *w_bond, *b1, *q_bias; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
+struct ACW { const float *w_cn, *w_bond, *b1, *q_bias, *q_shift; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_cn_t, *w_bond_t; };
 struct BCW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w2c_t, *w2g_t, *w_out, *b_out, *w_out_t, *w_bij_t, *w_ang_t, *w_ctr_t; };
 struct AUW { const float *w_bij, *w_ang, *w_ctr, *b1; GatedW g; const float *w_bij_t, *w_ang_t, *w_ctr_t; };
 
@@ -184,7 +184,7 @@ struct chg_batch {
   float* t_mcot = nullptr;   // [N] magmom cotangent
   float h_g_b3 = 0.f;        // host-side gradient of the readout's last bias (copied into the blob on the device)
   bool t_has_mcot = false;
-  float *t_grad = nullptr, *t_cot = nullptr, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
+  float *t_grad = nullptr, *t_cot = nullptr, *t_tmp = nullptr /* 256 floats of scratch */, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
         *t_ro = nullptr;
 };
 

@@ -36,7 +36,7 @@ size_t layout_weights(const float* base, int L, Weights& w) {
   w.w_bond_emb = c.take(D * NRAD); w.w_wag = c.take(D * NRAD); w.w_wbg = c.take(D * NRAD); w.w_ang_emb = c.take(D * NANG);
   for (int l = 0; l < L; ++l) {
     ACW& a = w.ac[l];
-    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D); a.q_bias = c.take(2 * D);
+    a.w_cn = c.take(4 * D * D); a.w_bond = c.take(2 * D * D); a.b1 = c.take(2 * D); a.q_bias = c.take(2 * D); a.q_shift = c.take(D);
     take_gated_tail(c, a.g, a.w2c_t, a.w2g_t);
     take_ln(c, a.g);
     a.w_out = c.take(D * D); a.b_out = c.take(D); a.w_out_t = c.take(D * D);
@@ -121,6 +121,13 @@ int tile_grid(chg_engine* eng, int rows, int block_rows) {
   // AtomConv kernels with a second tile, i.e. doubled the kernel's time; a workgroup without tiles costs nothing
   return std::max(1, std::min((ntiles + 7) & ~7, mult * eng->num_cus));
 }
+
+#ifdef CHG_EXPERIMENTS
+static int exp_nw() {
+  static const int v = [] { const char* e = std::getenv("CHGNET_EXP_NW"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+#endif
 
 template <int K, int NOUT, int PARTS = 1>
 int launch_rows_gemm(chg_engine* eng, const char* label, const RowsGemm& p) {
@@ -318,6 +325,12 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
     a.e_nbr = b->p_nbr;
     a.Qout = keep_q ? b->Ql[l] : nullptr;   // the reverse sweep gathers the bond partial as a table
     a.interleave = interleave_mask() & 1;
+#ifdef CHG_EXPERIMENTS
+    if (exp_nw() == 4) {
+      const size_t lds4 = std::max(atomconv_lds<4, false, true>(), (size_t)100 << 10);
+      hipLaunchKernelGGL((k_atomconv_fwd<4>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * 4)), dim3(64 * 4), lds4, eng->stream, a);
+    } else
+#endif
     hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
@@ -440,6 +453,16 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
   }
   plain.image = eng->img_angle[BWD ? 1 : 0][a.slot];
   plain.interleave = (interleave_mask() >> (BWD ? 4 : HIDDEN ? 2 : 3)) & 1;
+#ifdef CHG_EXPERIMENTS
+  // occupancy probe (profiles/r05_experiments.md): the same kernel with FOUR waves per workgroup and the LDS request padded so that
+  // one workgroup fits per CU -> one wave per SIMD.  t(1 wave) / t(2 waves) says how much of a wave's time the SIMD is free.
+  if (exp_nw() == 4 && !BWD && NW == WAVES) {
+    const size_t lds4 = std::max(angle_lds<HIDDEN, 4, BWD>(), (size_t)100 << 10);
+    hipLaunchKernelGGL((k_angle<HIDDEN, BWD, 4>), dim3(tile_grid(eng, b->A, TILE_ROWS * 4)), dim3(64 * 4), lds4, eng->stream, plain);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
+#endif
   const size_t lds = angle_lds<HIDDEN, NW, BWD>();
   hipLaunchKernelGGL((k_angle<HIDDEN, BWD, NW>), dim3(tile_grid(eng, b->A, TILE_ROWS * NW)), dim3(64 * NW), lds, eng->stream, plain);
   HIP_TRY(eng, hipGetLastError());
@@ -762,6 +785,11 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, (angle_lds<false, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_angle<false, false, FWD_WAVES>, (angle_lds<false, FWD_WAVES>())))) return s;
+#ifdef CHG_EXPERIMENTS
+  if ((s = set_lds(eng, (k_angle<true, false, 4>), (size_t)100 << 10))) return s;
+  if ((s = set_lds(eng, (k_angle<false, false, 4>), (size_t)100 << 10))) return s;
+  if ((s = set_lds(eng, k_atomconv_fwd<4>, (size_t)100 << 10))) return s;
+#endif
   if ((s = set_lds(eng, k_readout<false>, readout_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;

@@ -98,6 +98,19 @@ int colsum(chg_engine* eng, const float* A, int lda, const float* Bm, int ldb, i
   return CHG_OK;
 }
 
+// mlp_out biases (0.2.0): bonds outside the bond graph enter AtomConv l as embedding + q_shift (the earlier BondConv biases), so
+// dL/dW_bond += (sum over those bonds of dQ) x q_shift.  dQ: [Eu,128] table adjoint (dE/dQ, or bar(Q) of the second-order sweep).
+int bond_shift_wgrad(chg_engine* eng, chg_batch* b, const float* dQ, const float* q_shift, float* g_w_bond) {
+  if (b->Eu <= 0) return CHG_OK;
+  TRY(zero(eng, b->t_tmp, sizeof(float) * 128));
+  LaunchScope ls(eng, "wgrad_shift");
+  hipLaunchKernelGGL(k_colsum_nonnode, dim3(std::max(1, std::min((b->Eu + 127) / 128, 2 * eng->num_cus))), dim3(256), 0, eng->stream, dQ, 2 * D,
+                     b->u_bnode, b->Eu, b->t_tmp);
+  hipLaunchKernelGGL(k_outer_add, dim3(32), dim3(256), 0, eng->stream, g_w_bond, b->t_tmp, q_shift);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
 // Training workspaces are taken from / returned to the engine: a train step makes a new batch every iteration, and a hipMalloc
 // of tens of GB per step would dominate it.  One slot per kind (0: first-order workspace, 1: second-order workspace); a request
 // is rounded up by 8 % so that the slightly different batches of an epoch reuse the same block.
@@ -149,6 +162,7 @@ int ensure_train_buffers(chg_engine* eng, chg_batch* b) {
   auto lay = [&](Carver& cv) {
     b->t_grad = cv.take<float>((size_t)eng->desc.n_weights);
     b->t_cot = cv.take<float>(b->B);
+    b->t_tmp = cv.take<float>(256);
     b->t_mcot = cv.take<float>(N);
     b->t_dumpG = cv.take<float>(rows * 2 * D);
     b->t_dumpH = cv.take<float>(rows * 2 * D);
@@ -190,6 +204,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   auto G = [&](const float* wp) { return grad_of(eng, b, wp); };
   const int N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
+  const bool bias = eng->desc.mlp_out_bias != 0;   // 0.2.0: mlp_out biases are parameters
   TRY(zero(eng, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights));
   TRY(zero(eng, b->zero2, (size_t)((char*)b->zero2_end - (char*)b->zero2)));
 
@@ -242,6 +257,7 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hbc[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
       TRY((xty<8, 4>(eng, "wgrad_tab", b->GQ, 2 * D, b->bn_und, b->hb0, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
     }
+    if (bias && A > 0 && l > 0) TRY(bond_shift_wgrad(eng, b, b->GQ, aw.q_shift, G(aw.w_bond)));
     TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, b->Ga, nullptr, N, 1));   // l == 0 too: d emb needs dE/d atom[0]
     return rows_gemm(eng, "gemm_GQ", 128, 64, b->GQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, b->Gb, D, nullptr, Eu, l == L - 1 ? 0 : 1);
   };
@@ -281,6 +297,8 @@ int run_backward(chg_engine* eng, chg_batch* b) {
       }
       const BCW& bw = w.bc[l];
       // hbc[l+1] = aggB . Wout^T + b_out + hbc[l]; dE/d hbc[l+1] lives in the node rows of Gb
+      // (the reference adds b_out to EVERY bond, layers.py:252-258: its gradient is the column sum of the running dE/d bond over all Eu rows)
+      if (bias) TRY(colsum(eng, b->Gb, D, nullptr, 0, Eu, D, G(bw.b_out)));
       TRY((xty<4, 4>(eng, "wgrad_out", b->Gb, D, b->bn_und, b->aggB_l[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
       TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Gb, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, b->Gagg, D, nullptr, Eb, 0));
       AngleArgs a = angle_args(b, l, b->ang[l], bw.w_ang, bw.g, nullptr);
@@ -737,6 +755,9 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
       TRY((xty<8, 4>(eng, "t2_wgrad", t.gQ, 2 * D, b->bn_und, t.hbcd[l], D, nullptr, Eb, 1.0f, G(aw.w_bond), D, D)));
       TRY((xty<8, 4>(eng, "t2_wgrad", t.gQ, 2 * D, b->bn_und, t.hb0d, D, b->bn_und, Eb, -1.0f, G(aw.w_bond), D, D)));
     }
+    if (eng->desc.mlp_out_bias && angles && l > 0) {   // constant shift of the bonds outside the bond graph: no tangent, bar(Q) only
+      TRY(bond_shift_wgrad(eng, b, t.barQ, aw.q_shift, G(aw.w_bond)));
+    }
     TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.barP, 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, t.bar_a, nullptr, N, 1));
     TRY(rows_gemm_in2(eng, "t2_gemm_tab", t.gP, 4 * D, aw.w_cn_t, aw.w_cn_t + 2 * D * D, t.g_a, nullptr, N, 1));
     TRY(gemm("t2_gemm_tab", 128, 64, t.barQ, 2 * D, nullptr, aw.w_bond_t, nullptr, nullptr, 0, t.bar_b, D, nullptr, Eu, 1));
@@ -805,7 +826,8 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
                        }));
       }
       const BCW& bw = w.bc[l];
-      // hbc[l+1] = aggB . Wout^T + hbc[l]; its adjoints live in the node rows of bar_b / g_b
+      // hbc[l+1] = aggB . Wout^T + b_out + hbc[l]; its adjoints live in the node rows of bar_b / g_b; b_out reaches every bond (above)
+      if (eng->desc.mlp_out_bias) TRY(colsum(eng, t.bar_b, D, nullptr, 0, Eu, D, G(bw.b_out)));
       TRY((xty<4, 4>(eng, "t2_wgrad", t.bar_b, D, b->bn_und, b->aggB_l[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
       TRY((xty<4, 4>(eng, "t2_wgrad", t.g_b, D, b->bn_und, t.aggBd[l], D, nullptr, Eb, 1.0f, G(bw.w_out), D, D)));
       TRY(gemm("t2_gemm_out", 64, 64, t.bar_b, D, b->bn_und, bw.w_out_t, nullptr, nullptr, 0, t.bar_agg, D, nullptr, Eb, 0));

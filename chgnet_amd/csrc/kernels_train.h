@@ -344,6 +344,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 }
 
 // out[c] += alpha * sum_rows A[row][c] (* Bm[row][c]),  width in {64, 128, 256}
+// out[c] += sum over the rows k with node[k] < 0 of A[k][c]  (width 128): dL/dQ summed over the bonds OUTSIDE the bond graph -- with
+// mlp_out biases (0.2.0) those bonds enter AtomConv as embedding + a constant shift, so dL/dW_bond gains (that sum) x shift
+static __global__ __launch_bounds__(256) void k_colsum_nonnode(const float* __restrict__ A, int lda, const int* __restrict__ node, int rows,
+                                                                float* __restrict__ out) {
+  __shared__ float part[256];
+  const int tid = threadIdx.x, c = tid & 127, grp = tid >> 7;
+  float acc = 0.f;
+  for (int r = blockIdx.x * 2 + grp; r < rows; r += gridDim.x * 2)
+    if (node[r] < 0) acc += A[(size_t)r * lda + c];
+  part[tid] = acc;
+  __syncthreads();
+  if (grp == 0) atomicAdd(out + c, acc + part[128 + c]);
+}
+// W[f][c] += u[f] v[c]   (128 x 64)
+static __global__ __launch_bounds__(256) void k_outer_add(float* __restrict__ W, const float* __restrict__ u, const float* __restrict__ v) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // 32 blocks
+  W[idx] += u[idx >> 6] * v[idx & 63];
+}
+
 struct ColsumArgs {
   const float* A;
   int lda;

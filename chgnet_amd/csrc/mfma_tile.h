@@ -58,8 +58,18 @@ __device__ __forceinline__ V64 zero64() { return V64{{zero4(), zero4(), zero4(),
 // sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp
 // each) -- 4 VALU instructions instead of ~22 for expf + IEEE division, which made the conv kernels
 // VALU-bound (profiles/r01 notes).  Saturates correctly: x -> -inf gives rcp(inf) = 0, x -> +inf gives 1.
+#if defined(CHG_EXPERIMENTS) && defined(CHG_EXP_NO_TRANS)
+// TIMING-ONLY variant build (wrong results; profiles/r05_experiments.md): the two quarter-rate transcendentals of every sigmoid replaced
+// by full-rate arithmetic, to measure what share of a tile kernel's time they are
+__device__ __forceinline__ float exp_rcp_stub(float t) { return 0.5f + 0.1f * t; }
+#define CHG_EXP2(t) (1.0f + 0.05f * (t))
+#define CHG_RCP(t) (2.0f - (t))
+#else
+#define CHG_EXP2(t) __builtin_amdgcn_exp2f(t)
+#define CHG_RCP(t) __builtin_amdgcn_rcpf(t)
+#endif
 __device__ __forceinline__ float sigmoidf_(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+  return CHG_RCP(1.0f + CHG_EXP2(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 // d/dx silu(x) = s (1 + x (1 - s))
@@ -73,9 +83,9 @@ __device__ __forceinline__ float dsiluf_(float x) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
   f32x2 t = x * -1.4426950408889634f;
-  t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+  t[0] = CHG_EXP2(t[0]); t[1] = CHG_EXP2(t[1]);
   t = t + 1.0f;
-  t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+  t[0] = CHG_RCP(t[0]); t[1] = CHG_RCP(t[1]);
   return t;
 }
 __device__ __forceinline__ f32x4 sigmoid4(f32x4 x) {   // pair by pair: four values at once cost the forward kernels ~10 spilled registers

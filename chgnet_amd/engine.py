@@ -95,7 +95,7 @@ class Engine:
         self.device = device
         desc = _lib.ModelDesc(weights.n_conv, weights.cutoff_coeff, int(weights.is_intensive), int(weights.has_composition),
                               weights.atom_graph_cutoff, weights.bond_graph_cutoff, weights.blob.size,
-                              int(getattr(weights, "n_mlp_hidden", 3)), 0)
+                              int(getattr(weights, "n_mlp_hidden", 3)), int(getattr(weights, "mlp_out_bias", False)))
         self.handle = ctypes.c_void_p()
         blob = np.ascontiguousarray(weights.blob, dtype=np.float32)
         status = self.lib.chg_engine_create(ctypes.byref(desc), _fp(blob), int(device), ctypes.byref(self.handle))

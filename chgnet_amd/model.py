@@ -231,8 +231,6 @@ class CHGNet:
         batch = getattr(self, "_fwd_batch", None)
         if batch is None:
             raise RuntimeError("backward() needs the device state of a preceding forward() call")
-        if any(k.endswith("mlp_out.layers.1.bias") for k in self._state_dict):
-            raise NotImplementedError("parameter gradients are not implemented for models with mlp_out bias (0.2.0)")
         return unpack_weight_grads(self.engine.backward(batch, e_grad, m_grad, f_grad, s_grad, comm=comm), self._weights)
 
     def load_state_dict(self, state_dict: dict) -> None:

@@ -313,6 +313,7 @@ class PackedWeights:
     cutoff_coeff: int
     is_intensive: bool
     has_composition: bool
+    mlp_out_bias: bool = False  # the mlp_out Linears of AtomConv / BondConv carry a bias (0.2.0 checkpoint, model.py:734)
     n_mlp_hidden: int = 3       # hidden layers of the energy head (2 for the 0.2.0 architecture)
     num_radial: int = NUM_RADIAL
     num_angular: int = NUM_ANGULAR
@@ -340,6 +341,7 @@ def weight_layout(n_conv: int) -> list[tuple[str, tuple]]:
                 (p + "w_bond", (2 * D, D)),    # bond block (core|gate)
                 (p + "b1", (2 * D,)),
                 (p + "q_bias", (2 * D,)),      # W_bond . (sum of earlier BondConv mlp_out biases): see pack_weights
+                (p + "q_shift", (D,)),         # that sum itself: the constant part of the bond features outside the bond graph (weight gradients)
                 *[(p + n, s) for n, s in gated_tail], *[(p + n, s) for n, s in ln],
                 (p + "w_out", (D, D)), (p + "b_out", (D,)),
                 (p + "w_out_t", (D, D)),       # [in,out] for G(agg) = G(h') . Wout
@@ -459,6 +461,7 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
     shift = np.zeros(D, np.float64)
     for l in range(n_conv):
         vals[f"ac{l}.q_bias"] = (vals[f"ac{l}.w_bond"].astype(np.float64) @ shift).astype(np.float32)
+        vals[f"ac{l}.q_shift"] = shift.astype(np.float32)
         if l < n_conv - 1:
             shift = shift + vals[f"bc{l}.b_out"].astype(np.float64)
     vals["site_w"] = sd["site_wise.weight"].reshape(-1)
@@ -497,6 +500,7 @@ def pack_weights(state_dict: dict, model_args: dict | None = None) -> PackedWeig
         cutoff_coeff=int(model_args.get("cutoff_coeff", 8)),
         is_intensive=bool(model_args.get("is_intensive", True)),
         has_composition=has_comp,
+        mlp_out_bias=any(k.endswith("mlp_out.layers.1.bias") for k in sd),
         n_mlp_hidden=n_hidden, num_radial=n_rad, num_angular=n_ang,
     )
 
@@ -553,6 +557,8 @@ def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
         gated_tail(p, pre)
         ln(p, pre)
         out[f"atom_conv_layers.{l}.mlp_out.layers.1.weight"] = G(p + "w_out")
+        if pw.mlp_out_bias:
+            out[f"atom_conv_layers.{l}.mlp_out.layers.1.bias"] = G(p + "b_out")
     for l in range(L - 1):
         p, pre = f"bc{l}.", f"bond_conv_layers.{l}.twoBody_bond"
         w_bij = G(p + "w_bij")
@@ -561,6 +567,8 @@ def unpack_weight_grads(grad_blob: np.ndarray, pw: PackedWeights) -> dict:
         gated_tail(p, pre)
         ln(p, pre)
         out[f"bond_conv_layers.{l}.mlp_out.layers.1.weight"] = G(p + "w_out")
+        if pw.mlp_out_bias:
+            out[f"bond_conv_layers.{l}.mlp_out.layers.1.bias"] = G(p + "b_out")
     for l in range(L - 1):
         p, pre = f"au{l}.", f"angle_layers.{l}.twoBody_bond"
         w_bij = G(p + "w_bij")

@@ -276,8 +276,6 @@ class TrainStep:
         self.comm = comm                      # RcclComm, or None for the torch.distributed process group (if any)
         self.loss = CombinedLoss(target_str=targets, criterion=criterion, **loss_kwargs)
         state = model.state_dict()
-        if any(k.endswith("mlp_out.layers.1.bias") for k in state):   # fail before the first forward, not at the first backward
-            raise NotImplementedError("training a model with mlp_out bias (CHGNet 0.2.0 checkpoints) is not supported by the engine's backward")
         frozen = ["composition_model.fc.weight"]
         if not getattr(model, "model_args", {}).get("learnable_rbf", True):   # buffers in the reference (basis.py:31-40, 87-98): never updated
             frozen += [k for k in state if k.endswith(".frequencies")]

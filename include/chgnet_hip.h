@@ -62,7 +62,8 @@ typedef struct chg_model_desc {
   int64_t n_weights;           /* length of the blob in floats; layout = chgnet_amd/pack.py:weight_layout */
   int32_t n_mlp_hidden;        /* hidden layers of the energy head: 3 (0.3.0 / r2scan, mlp_hidden_dims=[64,64,64]) or 2 (0.2.0, [64,64]);
                                   0 = 3.  The blob keeps the third layer's slots either way (unused, zero, when 2) */
-  int32_t reserved0;           /* 0 */
+  int32_t mlp_out_bias;        /* 1: the mlp_out Linears of AtomConv / BondConv carry a bias (0.2.0 checkpoint, model.py:734) -- chg_backward then
+                                  also forms their gradients and W_bond's term through the bonds outside the bond graph */
 } chg_model_desc;
 
 /* Packed batch of B structures in global (batch-wide) numbering: chgnet_amd/pack.py:pack_batch. */

@@ -330,7 +330,8 @@ class StagedModel:
                 p = f"bc{l}."
                 cache, y = bc_cache[l]
                 if train:
-                    wg[p + "w_out"], wg[p + "b_out"] = Gb[bn].T @ buf[f"bc{l}.agg"], Gb[bn].sum(0)
+                    # (the bias reaches EVERY bond's layer-(l+1) features, layers.py:252-258: column sum over all Eu rows of the running dE/d bond)
+                    wg[p + "w_out"], wg[p + "b_out"] = Gb[bn].T @ buf[f"bc{l}.agg"], Gb.sum(0)
                 Gagg = Gb[bn] @ W(p + "w_out")
                 Gu = Gagg[b1c]
                 w1, w2 = wbgc[b1c], wbgc[b2c]

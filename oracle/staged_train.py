@@ -133,8 +133,6 @@ class StagedTrainer:
         B, N, Ed, Eu, A, Eb = pb.n_struct, pb.n_atoms, pb.n_directed, pb.n_undirected, pb.n_angles, pb.n_bnodes
         c, n, k = pb.e_center, pb.e_nbr, pb.e_d2u
         ctr, b1c, b2c, bn = pb.a_ctr, pb.a_b1c, pb.a_b2c, pb.bn_und
-        if any(pw.get(f"bc{l}.b_out").any() for l in range(L - 1)):
-            raise NotImplementedError("mlp_out bias (0.2.0) is not covered by the training path")
         n_at = np.diff(pb.atom_off).astype(dt)
         gE = np.zeros(B, dt) if gE is None else np.asarray(gE, dt)
         gF = np.zeros((N, 3), dt) if gF is None else np.asarray(gF, dt)
@@ -190,8 +188,11 @@ class StagedTrainer:
         atom, atomd = [W("emb")[pb.z - 1]], [np.zeros((N, D), dt)]
         hbc, hbcd = [hb0[bn]], [hb0d[bn]]
 
-        def full(rows0, rows_l):            # bond features of all Eu bonds at some layer (nodes carry the layer's rows)
+        def full(rows0, rows_l, l=None):    # bond features of all Eu bonds at some layer (nodes carry the layer's rows)
             h = rows0.copy()
+            if l is not None and A:         # primal rows only: bonds outside the bond graph carry the mlp_out biases of the
+                for m in range(l):          # earlier BondConv layers (0.2.0; layers.py:252-258 aggregates over ALL bonds) -- constants,
+                    h = h + W(f"bc{m}.b_out")   # so the tangent rows are unchanged
             h[bn] = rows_l
             return h
 
@@ -200,7 +201,7 @@ class StagedTrainer:
 
         def atom_conv(l):
             p = f"ac{l}."
-            hb, hbd = full(hb0, hbc[l]), full(hb0d, hbcd[l])
+            hb, hbd = full(hb0, hbc[l], l), full(hb0d, hbcd[l])
             P, Pd = atom[l] @ W(p + "w_cn").T, atomd[l] @ W(p + "w_cn").T
             P[:, :2 * D] += W(p + "b1")
             Q, Qd = hb @ W(p + "w_bond").T, hbd @ W(p + "w_bond").T
@@ -236,7 +237,7 @@ class StagedTrainer:
                 np.add.at(agg, b1c, uu)
                 np.add.at(aggd, b1c, uud)
                 bc[l] = dict(cache=cache, y=y, yd=yd, agg=agg, aggd=aggd)
-                hbc.append(agg @ W(p + "w_out").T + hbc[l])
+                hbc.append(agg @ W(p + "w_out").T + W(p + "b_out") + hbc[l])
                 hbcd.append(aggd @ W(p + "w_out").T + hbcd[l])
                 if l < L - 2:
                     p = f"au{l}."
@@ -340,6 +341,7 @@ class StagedTrainer:
                 p = f"bc{l}."
                 s = bc[l]
                 wg[p + "w_out"] = bar_b[bn].T @ s["agg"] + g_b[bn].T @ s["aggd"]
+                wg[p + "b_out"] = bar_b.sum(0)      # the bias reaches EVERY bond's layer-(l+1) features: column sum over all Eu rows
                 bar_u, g_u = (bar_b[bn] @ W(p + "w_out"))[b1c], (g_b[bn] @ W(p + "w_out"))[b1c]
                 w1, w2, w1d, w2d = wbgc[b1c], wbgc[b2c], wbgcd[b1c], wbgcd[b2c]
                 y, yd = s["y"], s["yd"]

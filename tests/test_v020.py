@@ -212,3 +212,145 @@ def test_engine_020_predict_structure_builds_the_5A_graph_on_the_device(model_v0
     out = model_v020.predict_structure(s, task="efsm")
     for key in ("e", "f", "s", "m"):
         assert float(np.abs(out[key] - d["out_" + key]).max()) < TOL[key], key
+
+
+# ---- parameter gradients incl. the mlp_out biases (CPU: the float64 models of the two training sweeps) -----------------
+def _blob_from(wg: dict, pw) -> np.ndarray:
+    blob = np.zeros(pw.blob.size, np.float64)
+    for name, g in wg.items():
+        off, shape = pw.offsets[name]
+        assert tuple(np.shape(g)) == tuple(shape), (name, np.shape(g), shape)
+        blob[off:off + int(np.prod(shape))] = np.asarray(g, np.float64).reshape(-1)
+    return blob
+
+
+DEAD = ("angle_layers.2.", "composition_model")
+
+
+def test_sweep_models_give_the_mlp_out_bias_gradients_fp64(weights):
+    """The reference adds a BondConv's ``mlp_out`` bias to EVERY bond (layers.py:252-258 aggregates over all of them); the
+    engine keeps bonds outside the bond graph at their embedding + a constant shift (``q_bias`` / ``q_shift``).  The
+    gradient of such a bias is therefore the column sum of dL/d(bond features) over ALL bonds, and W_bond's gradient
+    gains (sum over non-node bonds of dL/dQ) x shift.  First-order sweep (oracle/staged_ref.py) and the two-adjoint sweep
+    for force / stress terms (oracle/staged_train.py) against torch autograd / double backward, float64, all 141 tensors."""
+    from chgnet_amd.pack import pack_batch, pack_weights, unpack_weight_grads
+    from oracle.staged_ref import StagedModel
+    from oracle.staged_train import StagedTrainer
+
+    pw = pack_weights(weights, V020_ARGS)
+    assert pw.mlp_out_bias
+    graphs = [load_case_v020(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    pb = pack_batch(graphs)
+    oracle = _oracle(weights, torch.float64)
+    rng = np.random.default_rng(41)
+    gE, gF, gS = rng.normal(size=pb.n_struct), rng.normal(size=(pb.n_atoms, 3)), rng.normal(size=(pb.n_struct, 3, 3))
+    tE, tF, tS = torch.tensor(gE), torch.tensor(gF), torch.tensor(gS)
+
+    def check(got, want, tol, what):
+        assert set(got) == set(want) == set(weights) and len(want) == 141
+        for k, ref in want.items():
+            if k.startswith(DEAD) or (what == "e" and k.startswith("site_wise")):
+                assert not np.any(got[k]), k
+                continue
+            scale = np.abs(ref).max()
+            if scale == 0:
+                assert np.abs(got[k]).max() < 1e-12, (what, k)
+                continue
+            assert np.abs(got[k] - ref).max() < tol * scale, (what, k, np.abs(got[k] - ref).max(), scale)
+
+    want = oracle.parameter_gradients(graphs, lambda o: (o["e"] * tE).sum())
+    out = StagedModel(pw).run(pb, e_cot=gE)
+    check(unpack_weight_grads(_blob_from(out["wgrad"], pw), pw), want, 1e-10, "e")
+    assert np.abs(want["bond_conv_layers.0.mlp_out.layers.1.bias"]).max() > 0
+
+    want = oracle.parameter_gradients(graphs, lambda o: (o["e"] * tE).sum() + (o["f"] * tF).sum() + (o["s"] * tS).sum(), task="efs")
+    out = StagedTrainer(pw).run(pb, gE=gE, gF=gF, gS=gS)
+    got = unpack_weight_grads(_blob_from(out["wgrad"], pw), pw)
+    for k in list(want):
+        if k.startswith("site_wise"):
+            assert not np.any(got[k])
+            want.pop(k), got.pop(k)
+    assert len(want) == 139
+    for k, ref in want.items():
+        if k.startswith(DEAD):
+            continue
+        scale = np.abs(ref).max()
+        assert scale > 0 and np.abs(got[k] - ref).max() < 2e-9 * scale, (k, np.abs(got[k] - ref).max(), scale)
+
+
+@pytest.mark.gpu
+def test_engine_loss_gradients_match_the_reference_backward_on_020(model_v020):
+    """``chg_backward`` on the released 0.2.0 architecture: the full E + F + S + M loss against ``p.grad`` of the UNMODIFIED
+    reference after ``loss.backward()`` in train mode (tests/golden/make_golden_v020.py; trainer.py:399-411) -- all 141
+    tensors, the seven ``mlp_out`` biases and the padded-basis embeddings among them (VERDICT r04 'missing 5').  Tolerance
+    as for the 0.3.0 fixtures (tests/test_gpu_train.py): the fixture is fp32, 3.2e-4 of each tensor's largest entry."""
+    d = np.load(os.path.join(GOLDEN, "grad_v020_five.npz"))
+    want = {k[len("grad/"):]: d[k] for k in d.files if k.startswith("grad/")}
+    graphs = [load_case_v020(str(n))[0] for n in d["order"]]
+    try:
+        model_v020.forward(graphs, task="efsm")
+        got = model_v020.backward(d["cot_e"], d["cot_m"], d["cot_f"], d["cot_s"])
+    finally:
+        model_v020.release_forward_state()
+    assert set(got) == set(want) and len(want) == 141
+    msgs = []
+    for k, ref in want.items():
+        assert got[k].shape == ref.shape and got[k].dtype == np.float32, k
+        if k.startswith(("angle_layers.2.", "composition_model")) and not np.any(ref):
+            assert not np.any(got[k]), k
+            continue
+        scale, err = float(np.abs(ref).max()), float(np.abs(got[k] - ref).max())
+        if not np.isfinite(got[k]).all() or not err <= 3.2e-4 * scale:
+            msgs.append(f"{k}: {err:.3e} / {scale:.3e} = {err / max(scale, 1e-300):.1e}")
+    assert not msgs, "; ".join(msgs)
+
+
+@pytest.mark.gpu
+def test_engine_energy_loss_gradients_020_vs_autograd_fp64(model_v020, weights):
+    """First-order sweep alone (energy + magmom cotangents) on a batch WITH a zero-angle structure in it, against torch
+    autograd through the float64 oracle: 1e-4 relative per tensor."""
+    graphs = [load_case_v020(n)[0] for n in ("limno2", "noangle", "s16tri")]
+    rng = np.random.default_rng(43)
+    ce = rng.normal(size=3)
+    t = torch.tensor(ce)
+    torch.set_num_threads(8)
+    want = _oracle(weights, torch.float64).parameter_gradients(graphs, lambda o: (o["e"] * t).sum())
+    try:
+        model_v020.forward(graphs, task="e")
+        got = model_v020.backward(ce.astype(np.float32))
+    finally:
+        model_v020.release_forward_state()
+    msgs = []
+    for k, ref in want.items():
+        if k.startswith(("angle_layers.2.", "composition_model", "site_wise")):
+            assert not np.any(got[k]), k
+            continue
+        scale, err = float(np.abs(ref).max()), float(np.abs(got[k] - ref).max())
+        if not err <= 1e-4 * scale:
+            msgs.append(f"{k}: {err:.3e} / {scale:.3e}")
+    assert not msgs, "; ".join(msgs)
+
+
+@pytest.mark.gpu
+def test_train_step_runs_on_the_020_architecture(weights):
+    """``TrainStep`` (forward -> CombinedLoss -> backward -> Adam -> weights back on the engine) accepts a model with
+    ``mlp_out`` biases now and lowers the loss; the biases move."""
+    from chgnet_amd import CHGNet
+    from chgnet_amd.trainer import TrainStep
+
+    model = CHGNet(state_dict=weights, **V020_ARGS)
+    try:
+        graphs = [load_case_v020(n)[0] for n in ("limno2", "s16tri", "s40")]
+        ref = model.predict_graph(graphs, task="efsm")
+        # labels a small COHERENT shift away from the predictions (like tests/test_gpu_train.py::test_train_step_with_force_and_stress_terms)
+        targets = {"e": np.array([r["e"] + 0.05 for r in ref]), "f": [r["f"] * 1.5 for r in ref],
+                   "s": [r["s"] + 0.1 * np.eye(3, dtype=np.float32) for r in ref], "m": [r["m"] + 0.1 for r in ref]}
+        step = TrainStep(model, targets="efsm", learning_rate=2e-4)
+        before = {k: v.copy() for k, v in model.state_dict().items() if k.endswith("mlp_out.layers.1.bias")}
+        losses = [step(graphs, targets)["loss"] for _ in range(10)]
+        assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+        assert all(np.abs(model.state_dict()[k] - v).max() > 0 for k, v in before.items())
+    finally:
+        model.release_forward_state()
+        if model._engine is not None:
+            model._engine.close()
