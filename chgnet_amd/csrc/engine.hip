@@ -61,73 +61,6 @@ int check_weight_range(chg_engine* eng, const float* blob, size_t n) {
   return CHG_OK;
 }
 
-// ---- range diagnostic (only after a prediction returned non-finite energies) --------------------------------------------
-// max |finite value| and the number of non-finite entries of a buffer: out[0] = max as float bits (non-negative floats order like
-// unsigned integers), out[1] = count
-__global__ void k_range_scan(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
-  float m = 0.f;
-  unsigned bad = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float v = x[i];
-    if (v == v && fabsf(v) < 3.0e38f) m = fmaxf(m, fabsf(v)); else ++bad;
-  }
-  atomicMax(out, __float_as_uint(m));
-  if (bad) atomicAdd(out + 1, bad);
-}
-
-int diagnose_non_finite(chg_engine* eng, chg_batch* b) {
-  unsigned* d_out = nullptr;
-  HIP_TRY(eng, hipMalloc(&d_out, 4 * sizeof(unsigned)));
-  auto scan = [&](const float* p, size_t n, float& mx, unsigned& bad) -> int {
-    unsigned h[2] = {0, 0};
-    mx = 0.f; bad = 0;
-    if (!p || n == 0) return CHG_OK;
-    HIP_TRY(eng, hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned), eng->stream));
-    hipLaunchKernelGGL(k_range_scan, dim3(1024), dim3(256), 0, eng->stream, p, n, d_out);
-    HIP_TRY(eng, hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, eng->stream));
-    HIP_TRY(eng, hipStreamSynchronize(eng->stream));
-    std::memcpy(&mx, &h[0], sizeof(float));
-    bad = h[1];
-    return CHG_OK;
-  };
-  int status = CHG_OK;
-  float mx = 0.f;
-  unsigned bad = 0;
-  // 1. the geometry: a zero-length or non-finite bond vector makes the bases NaN in the reference as well (basis.py: sin(w r) / r)
-  status = scan(reinterpret_cast<const float*>(b->ev), (size_t)4 * b->Ed, mx, bad);
-  bool geometry_nan = bad > 0;
-  if (status == CHG_OK && !geometry_nan && b->Ed > 0) {   // any r == 0 ?  (ev = (v, r): scan the embedding rows built from 1 / r instead)
-    status = scan(b->hb0, (size_t)b->Eu * D, mx, bad);
-    geometry_nan = bad > 0;
-  }
-  // 2. the operands of the split contractions: feature rows and first-layer tables of every layer
-  std::string where;
-  float worst = 0.f;
-  if (status == CHG_OK && !geometry_nan) {
-    auto look = [&](const char* name, int l, const float* p, size_t n) {
-      if (status != CHG_OK || !p) return;
-      float m1; unsigned b1;
-      status = scan(p, n, m1, b1);
-      if (m1 > worst) { worst = m1; where = std::string(name) + "[" + std::to_string(l) + "]"; }
-    };
-    const size_t N = b->N, Eu = b->Eu, Eb = b->Eb, A = b->A;
-    for (int l = 0; l <= b->L; ++l) look("atom features", l, b->atom[l], N * D);
-    for (int l = 0; l < b->L; ++l) look("bond features", l, b->hbc[l], Eb * D);
-    for (int l = 0; l < b->L - 1; ++l) look("angle features", l, b->ang[l], A * D);
-    for (int l = 0; l < b->L; ++l) { look("AtomConv atom table", l, b->Pl[l], N * 4 * D); look("AtomConv bond table", l, b->Ql[l], Eu * 2 * D); }
-    for (int t = 0; t < 2 * b->L; ++t) { look("angle-layer bond table", t, b->Rl[t], Eb * 4 * D); look("angle-layer atom table", t, b->Sl[t], N * 2 * D); }
-  }
-  hipFree(d_out);
-  if (status != CHG_OK) return status;
-  if (!geometry_nan && worst >= 0.25f * F16_OPERAND_LIMIT) {
-    eng->err = "non-finite results: " + where + " reaches |x| = " + std::to_string(worst) + ", at or beyond the f16 operand range of the "
-               "split-precision contractions (65504; csrc/mfma_split.h) -- the reference's fp32 path does not overflow here.  Weights this far "
-               "from any trained checkpoint are outside the engine's domain";
-    return CHG_ERANGE;
-  }
-  return CHG_OK;   // coincident atoms / non-finite inputs: NaN like the reference
-}
-
 // ---- self-test of the split-precision contractions (chg_test_split_gemm): the exact device functions of the tile kernels, W [F][64]
 // MODE 0 / 1: split images (forward / adjoint of W^T);  MODE 2 / 3: one row-major image, forward / adjoint (mfma_split.h)
 template <int MODE, int F>
@@ -217,7 +150,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   layout_weights(eng->d_weights, desc->n_conv, eng->w);
   { const int si = build_images(eng); if (si) return si; }
   // kernels that need more than the default 64 KiB of dynamic LDS: every unit sets the attributes of the kernels it launches
-  { int s; if ((s = predict_set_lds(eng)) || (s = train_set_lds(eng))) return s; }
+  { int s; if ((s = predict_set_lds(eng)) || (s = chgh_wide::predict_set_lds(eng)) || (s = train_set_lds(eng))) return s; }
   return CHG_OK;
 }
 
@@ -390,6 +323,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   HIP_TRY(eng, hipSetDevice(eng->device));
   const uint32_t task = task_mask | CHG_TASK_E;
   TRY(ensure_windows(eng, b));
+  if (b->wide_range) return chgh_wide::run_predict(eng, b, task);   // an earlier prediction of this batch overflowed the f16 operands
   if (eng->profiling || !eng->use_graphs) return run_predict(eng, b, task);   // per-kernel events need eager launches
   if (b->graph_task != task) {
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
@@ -477,39 +411,55 @@ int chg_batch_download(chg_engine* eng, chg_batch* b, const chg_out_host* o) {
       {o->crystal_fea, b->crystal_fea, B * D}};
   size_t total = 0;
   for (const Piece& pc : pieces) if (pc.dst) total += pc.n;
-  // Small results (MD-size batches: 4-7 pieces of a few KB) go through pinned staging: a copy to pageable memory is staged and waited
-  // for piece by piece (~20 us of idle GPU each, 6 % of a 256-atom MD step); into pinned memory the copies queue back to back.
-  constexpr size_t PINNED_MAX = (size_t)4 << 20;   // floats (16 MB)
-  if (total > 0 && total <= PINNED_MAX) {
-    if (total * sizeof(float) > eng->h_out_bytes) {
-      if (eng->h_out) hipHostFree(eng->h_out);
-      eng->h_out = nullptr; eng->h_out_bytes = 0;
-      const size_t want = std::max(total * sizeof(float) * 2, (size_t)1 << 16);
-      if (hipHostMalloc(&eng->h_out, want, hipHostMallocDefault) != hipSuccess) { eng->h_out = nullptr; eng->err = "chg_batch_download: pinned staging allocation failed"; return CHG_ENOMEM; }
-      eng->h_out_bytes = want;
+  auto copy_out = [&]() -> int {
+    // Small results (MD-size batches: 4-7 pieces of a few KB) go through pinned staging: a copy to pageable memory is staged and waited
+    // for piece by piece (~20 us of idle GPU each, 6 % of a 256-atom MD step); into pinned memory the copies queue back to back.
+    constexpr size_t PINNED_MAX = (size_t)4 << 20;   // floats (16 MB)
+    if (total > 0 && total <= PINNED_MAX) {
+      if (total * sizeof(float) > eng->h_out_bytes) {
+        if (eng->h_out) hipHostFree(eng->h_out);
+        eng->h_out = nullptr; eng->h_out_bytes = 0;
+        const size_t want = std::max(total * sizeof(float) * 2, (size_t)1 << 16);
+        if (hipHostMalloc(&eng->h_out, want, hipHostMallocDefault) != hipSuccess) { eng->h_out = nullptr; eng->err = "chg_batch_download: pinned staging allocation failed"; return CHG_ENOMEM; }
+        eng->h_out_bytes = want;
+      }
+      float* stage = reinterpret_cast<float*>(eng->h_out);
+      size_t off = 0;
+      for (const Piece& pc : pieces)
+        if (pc.dst && pc.n) { HIP_TRY(eng, hipMemcpyAsync(stage + off, pc.src, pc.n * sizeof(float), hipMemcpyDeviceToHost, eng->stream)); off += pc.n; }
+      TRY(chg_synchronize(eng));
+      off = 0;
+      for (const Piece& pc : pieces)
+        if (pc.dst && pc.n) { std::memcpy(pc.dst, stage + off, pc.n * sizeof(float)); off += pc.n; }
+    } else {
+      int s = CHG_OK;
+      for (const Piece& pc : pieces)
+        if (s == CHG_OK) s = d2h(eng, pc.dst, pc.src, pc.n);
+      if (s != CHG_OK) return s;
+      TRY(chg_synchronize(eng));
     }
-    float* stage = reinterpret_cast<float*>(eng->h_out);
-    size_t off = 0;
-    for (const Piece& pc : pieces)
-      if (pc.dst && pc.n) { HIP_TRY(eng, hipMemcpyAsync(stage + off, pc.src, pc.n * sizeof(float), hipMemcpyDeviceToHost, eng->stream)); off += pc.n; }
-    TRY(chg_synchronize(eng));
-    off = 0;
-    for (const Piece& pc : pieces)
-      if (pc.dst && pc.n) { std::memcpy(pc.dst, stage + off, pc.n * sizeof(float)); off += pc.n; }
-  } else {
-    int s = CHG_OK;
-    for (const Piece& pc : pieces)
-      if (s == CHG_OK) s = d2h(eng, pc.dst, pc.src, pc.n);
-    if (s != CHG_OK) return s;
-    TRY(chg_synchronize(eng));
+    return CHG_OK;
+  };
+  auto all_finite = [&]() {
+    for (int q = 0; q < 4; ++q)    // energy, forces, stress, magmoms as requested
+      if (pieces[q].dst)
+        for (size_t i = 0; i < pieces[q].n; ++i)
+          if (!std::isfinite(pieces[q].dst[i])) return false;
+    return true;
+  };
+  TRY(copy_out());
+  // Non-finite results.  The reference gives them too for coincident atoms (1 / r of a zero-length bond): passed through.  But an
+  // activation past the f16 operand range of the split contractions (|x| >= 65504, mfma_split.h) ALSO ends as inf / NaN here where the
+  // reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE) stays finite -- an overflow cannot stay silent: an inf operand makes the
+  // accumulator inf / NaN, LayerNorm spreads it over the row, the sums carry it to the energy.  Such a batch is COMPUTED AGAIN by the
+  // wide-range sweep (engine_predict_wide.hip: every operand row scaled by a power of two before the split, exact, any fp32 magnitude)
+  // and stays on it; what is still non-finite then is non-finite in the reference as well.  The check costs nothing until it triggers.
+  if (!b->wide_range && b->last_task != 0 && !all_finite()) {
+    b->wide_range = true;
+    if (b->graph_exec) { hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+    TRY(chgh_wide::run_predict(eng, b, b->last_task));
+    TRY(copy_out());
   }
-  // Non-finite energies: the reference gives them too for coincident atoms (1 / r of a zero-length bond) -- passed through.  But an
-  // activation past the f16 operand range of the split contractions (mfma_split.h) ALSO ends as NaN here where the reference's fp32
-  // path stays finite: that case is an error, not a result.  An overflow cannot stay silent (an inf operand makes the accumulator
-  // inf / NaN, LayerNorm spreads it over the row, the sums carry it to the energy), so the check costs nothing until it triggers.
-  bool finite = true;
-  if (o->energy) for (size_t i = 0; i < B && finite; ++i) finite = std::isfinite(o->energy[i]);
-  if (!finite) TRY(diagnose_non_finite(eng, b));
   return CHG_OK;
 }
 

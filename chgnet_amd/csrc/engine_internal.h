@@ -183,6 +183,7 @@ struct chg_batch {
   struct Train2* t2 = nullptr;
   float* t_mcot = nullptr;   // [N] magmom cotangent
   float h_g_b3 = 0.f;        // host-side gradient of the readout's last bias (copied into the blob on the device)
+  bool wide_range = false;     // a prediction of this batch left the f16 operand range: it runs through chgh_wide::run_predict from then on
   bool t_has_mcot = false;
   float *t_grad = nullptr, *t_cot = nullptr, *t_tmp = nullptr /* 256 floats of scratch */, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,
         *t_ro = nullptr;
@@ -306,6 +307,12 @@ int acquire_arena(chg_engine* eng, chg_batch* b, size_t total);
 int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double numerical_tol, chg_batch** out);
 
 }  // namespace chgh
+
+// engine_predict_wide.hip: the prediction sweep with every operand row of the split contractions scaled (any fp32 magnitude)
+namespace chgh_wide {
+int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
+int predict_set_lds(chg_engine* eng);
+}  // namespace chgh_wide
 
 using namespace chgh;
 

@@ -44,6 +44,12 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #ifndef CHG_SPLIT_LO_SEPARATE
 #define CHG_SPLIT_LO_SEPARATE 1
 #endif
+// CHG_WIDE_RANGE (engine_predict_wide.hip): EVERY operand row is scaled by a power of two before the split, not only the adjoint rows
+#ifdef CHG_WIDE_RANGE
+constexpr bool WIDE_RANGE = true;
+#else
+constexpr bool WIDE_RANGE = false;
+#endif
 constexpr bool LO_SEPARATE = CHG_SPLIT_LO_SEPARATE;   // low planes scaled by 2^11 in their own accumulator (see above)
 constexpr float LO_SCALE = LO_SEPARATE ? 2048.0f : 1.0f, LO_UNSCALE = 1.0f / LO_SCALE;
 
@@ -251,9 +257,10 @@ __device__ __forceinline__ void gemm_split2(f32x4* acc, const h16x8* img, int F,
   }
 }
 
-template <int KT, int NFT, bool SCALED, bool LEAN = false>
+template <int KT, int NFT, bool SCALED_, bool LEAN = false>
 __device__ __forceinline__ void gemm_split(f32x4 (&acc)[NFT], const h16x8* img, int F, const f32x4 (&x)[KT], int i, int g) {
   static_assert(NFT % 4 == 0, "output width must be a multiple of 64");
+  constexpr bool SCALED = SCALED_ || WIDE_RANGE;    // acc += W x either way: the scaled form adds the product, the plain one seeds with acc
   SplitRow<KT / 2> s;
   split_row<KT, SCALED>(s, x);
 #pragma unroll
@@ -344,10 +351,11 @@ __device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F,
 }
 
 // acc[o] += W x (forward: W [F][K], x has K values, F / 16 output tiles) or W^T x (adjoint: x has F values, K / 16 output tiles)
-template <int KT, int NOT, bool SCALED, bool ADJOINT>
+template <int KT, int NOT, bool SCALED_, bool ADJOINT>
 __device__ __forceinline__ void gemm_rm(f32x4 (&acc)[NOT], const _Float16* img, int F, int K, const f32x4 (&x)[KT], int i, int g, int lane) {
   static_assert(NOT % 4 == 0 && KT % 2 == 0, "widths are multiples of 64 / 32");
   static_assert(LO_SEPARATE, "row-major images carry the low plane scaled");
+  constexpr bool SCALED = SCALED_ || WIDE_RANGE;
   SplitRow<KT / 2> s;
   split_row<KT, SCALED>(s, x);
 #pragma unroll

@@ -34,8 +34,8 @@ class EngineOutOfMemory(RuntimeError):
 
 
 class EngineRangeError(RuntimeError, FloatingPointError):
-    """CHG_ERANGE: a weight or an activation left the f16 operand range of the split-precision contractions (|x| >= 65504), where
-    the reference's fp32 path stays finite.  Raised instead of returning inf / NaN results."""
+    """CHG_ERANGE: a WEIGHT of magnitude >= 65504 (the tile kernels carry their weights as f16 hi / lo images); raised by ``Engine()`` /
+    ``update_weights``.  Activations beyond that range are not an error: ``download`` re-runs such a batch on the wide-range sweep."""
 
 
 class DeviceBatch:

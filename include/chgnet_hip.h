@@ -36,9 +36,11 @@ typedef enum {
   CHG_ENOMEM = -3,     /* device or host allocation failed */
   CHG_ENODEV = -4,     /* no usable gfx950 device */
   CHG_EUNSUPPORTED = -5,
-  CHG_ERANGE = -6      /* a weight or an activation left the operand range of the split-precision contractions (|x| >= 65504):
-                          the results would be inf / NaN where the reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE) stays
-                          finite -- reported instead of returned (chg_engine_create / update_weights, chg_batch_download) */
+  CHG_ERANGE = -6      /* a WEIGHT left the operand range of the split-precision contractions (|w| >= 65504: the tile kernels hold
+                          their weights as f16 hi / lo images) -- chg_engine_create / chg_engine_update_weights.  ACTIVATIONS of any fp32
+                          magnitude are computed: a batch whose product sweep overflows the f16 operands is detected at
+                          chg_batch_download (non-finite results) and run again on the wide-range sweep (csrc/engine_predict_wide.hip),
+                          like the reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE) */
 } chg_status;
 
 /* task bits (reference task strings "e","ef","em","efs","efsm": chgnet/__init__.py:15) */
