@@ -85,6 +85,18 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
     assert len(lines) == 1, out.stdout                       # stdout carries ONE line, the result of rank 0: library chatter
     line = json.loads(lines[0])                              # (gloo / RCCL banners, model banners) goes to stderr
     assert line["n_gpus"] == 2 and line["ranks_in_all_gather"] == [0, 1] and line["backend"] == "gloo"
+    # the dry run also WALKS the two sharded legs of run_configs with a stand-in model (bench.py DryModel): the C3 sweep (LPT shards,
+    # zero-padded all-gather -- every rank checks every slot of the energy table and exits non-zero otherwise) and the C5 epoch
+    # (TrainStep, gradient all-reduce, Adam; the profiled steps after the epoch are taken by EVERY rank -- rank 0 alone used to enter
+    # that all-reduce, which would have blocked a real multi-GPU run for ever)
+    assert line["legs"]["C3_sweep"]["energies_gathered"] == 48 and line["legs"]["C3_sweep"]["shard_atoms_max_over_mean"] < 1.05
+    assert line["legs"]["C5_train_epoch"]["ms_per_step"] > 0
+    assert line["allreduced_gradient_values"][:3] == [2.0, 3.5, 5.0]        # mean over the ranks of (rank + 1) * call, rank 0 one call ahead
+    # ... and every rank pinned itself to its own share of the cores (rank 0: the first half of this box's CPUs)
+    aff = line["cpu_affinity"]
+    assert aff is not None and aff["cpus"] >= 1 and aff["first_cpu"] == 0
+    ncpu = len(os.sched_getaffinity(0))
+    assert aff["cpus"] <= max(1, ncpu // 2) or aff["numa_nodes"] > 1
     # under a launcher --gpus must agree with the world size
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True,
@@ -162,3 +174,26 @@ def test_rccl_rendezvous_ignores_other_jobs_and_times_out():
         p.join(timeout=30)
     with pytest.raises(TimeoutError):
         exchange_unique_id(1, 2, None, addr="127.0.0.1", port=_free_port(), timeout_s=0.5)
+
+
+def test_rank_cpu_sets_are_disjoint_and_cover_one_node_each():
+    """``bench.pin_rank_cpus``: the ranks of a node take disjoint, contiguous shares of the allowed CPUs (in a subprocess per rank:
+    the call changes the caller's affinity)."""
+    import json
+    import subprocess
+
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; r = bench.pin_rank_cpus(int(sys.argv[1]), 4); "
+            "print(json.dumps({'info': r, 'cpus': sorted(os.sched_getaffinity(0)), 'omp': os.environ.get('OMP_NUM_THREADS')}))" % REPO)
+    env = {k: v for k, v in os.environ.items() if k != "CHGNET_BENCH_NO_PIN"}
+    got = [json.loads(subprocess.run([sys.executable, "-c", code, str(r)], env=env, capture_output=True, text=True, check=True).stdout)
+           for r in range(4)]
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("fewer than four CPUs")
+    sets = [set(g["cpus"]) for g in got]
+    assert all(s and s <= set(allowed) for s in sets)
+    assert all(sets[i].isdisjoint(sets[j]) for i in range(4) for j in range(i + 1, 4))
+    assert all(g["omp"] == str(min(len(g["cpus"]), 16)) for g in got)
+    off = json.loads(subprocess.run([sys.executable, "-c", code, "0"], env=dict(env, CHGNET_BENCH_NO_PIN="1"), capture_output=True, text=True,
+                                    check=True).stdout)
+    assert off["info"] is None and off["cpus"] == allowed
