@@ -148,6 +148,18 @@ __device__ __forceinline__ void split_row(SplitRow<KT / 2>& s, const f32x4 (&x)[
   }
 }
 
+// TIMING-ONLY (wrong results; -DCHG_EXPERIMENTS -DCHG_EXP_NO_OPERAND_READS, profiles/r05_experiments.md section 5): the weight operands
+// come out of a register instead of LDS -- what the LDS operand supply of the contractions costs
+#if defined(CHG_EXPERIMENTS) && defined(CHG_EXP_NO_OPERAND_READS)
+#define CHG_OPERAND(expr, salt) fake_operand(salt)
+__device__ __forceinline__ h16x8 fake_operand(int salt) {
+  const _Float16 v = (_Float16)(0.001f * (float)(salt & 7));
+  return h16x8{v, v, v, v, v, v, v, v};
+}
+#else
+#define CHG_OPERAND(expr, salt) (expr)
+#endif
+
 // four output tiles fo0 .. fo0+3 from an already split row.  LO_SEPARATE: the low-order products (low planes scaled by 2^11)
 // are accumulated first, the sum is scaled back -- powers of two, exact -- and the high-order products follow into the SAME
 // accumulators: separate scaled accumulators without a second register set (the forward kernels carry the next tile's
@@ -171,7 +183,7 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
       const h16x8* base = base0 + mk * 4 * F;
       h16x8 wh[4], wl[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+      for (int q = 0; q < 4; ++q) { wh[q] = CHG_OPERAND(base[16 * q], q + mk); wl[q] = CHG_OPERAND(base[nchunks + 16 * q], q + mk + 1); }
 #pragma unroll
       for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
 #pragma unroll
@@ -184,7 +196,7 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
       const h16x8* base = base0 + mk * 4 * F;
       h16x8 wh[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wh[q] = base[16 * q];
+      for (int q = 0; q < 4; ++q) wh[q] = CHG_OPERAND(base[16 * q], q + mk);
 #pragma unroll
       for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
     }
@@ -203,7 +215,7 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
     const h16x8* base = base0 + mk * 4 * F;
     h16x8 wh[4], wl[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { wh[q] = base[16 * q]; wl[q] = base[nchunks + 16 * q]; }
+    for (int q = 0; q < 4; ++q) { wh[q] = CHG_OPERAND(base[16 * q], q + mk); wl[q] = CHG_OPERAND(base[nchunks + 16 * q], q + mk + 1); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
     if (LO_SEPARATE) {
@@ -331,7 +343,7 @@ __device__ __forceinline__ void gemm_rm4(f32x4* acc, const _Float16* img, int F,
   for (int m = 0; m < MS; ++m) {
     h16x8 wh[4], wl[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { wh[q] = rm_operand<ADJOINT>(img, F, K, 0, o0 + q, m, i, g, lane); wl[q] = rm_operand<ADJOINT>(img, F, K, 1, o0 + q, m, i, g, lane); }
+    for (int q = 0; q < 4; ++q) { wh[q] = CHG_OPERAND(rm_operand<ADJOINT>(img, F, K, 0, o0 + q, m, i, g, lane), q + m); wl[q] = CHG_OPERAND(rm_operand<ADJOINT>(img, F, K, 1, o0 + q, m, i, g, lane), q + m + 1); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[m], t[q], 0, 0, 0);
 #pragma unroll
