@@ -1,4 +1,4 @@
-"""Table of SQ counters per tile kernel from the three passes of tools/gpu_pmc_run.sh (gpurun_out/prof2/sq{1,2,3}_*.csv).
+"""Table of SQ counters per tile kernel from the three passes of tools/gpu_round5_profiles.sh (SQ pass) (gpurun_out/prof2/sq{1,2,3}_*.csv).
 
     python profiles/sq_table.py            # prints the markdown table used in r01_sq_counters.md
 """

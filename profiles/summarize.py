@@ -56,7 +56,7 @@ with open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.csv"), "w", newline
     w_ = csv.writer(fh)
     w_.writerow(["kernel", "launches", "mean_FETCH_SIZE_KiB_reported", "mean_WRITE_SIZE_KiB_reported", "hbm_bytes_per_launch_corrected"])
     w_.writerows(rows)
-# L2 hit rates (separate --pmc TCC_HIT_sum TCC_MISS_sum pass, tools/gpu_round4_profiles.sh) next to the traffic
+# L2 hit rates (separate --pmc TCC_HIT_sum TCC_MISS_sum pass, tools/gpu_round5_profiles.sh) next to the traffic
 l2_path = os.path.join(SRC, "l2a_counter_collection.csv")
 if os.path.exists(l2_path):
     hit, miss = mean_counter(l2_path, "TCC_HIT_sum"), mean_counter(l2_path, "TCC_MISS_sum")
