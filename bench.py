@@ -671,7 +671,7 @@ def run_configs(eng, weights, ranks: Ranks, args, model=None, legs=("C1", "C3", 
         for targets in ("efsm", "em"):
             step = TrainStep(model, targets=targets, learning_rate=1e-4, comm=ranks.comm)
             use = slice(0, n_steps if targets == "efsm" else min(n_steps, 3))
-            step(batches[0], labels[0])                                  # warm-up: allocations, first touch
+            step.run_epoch(batches[:1], labels[:1])                      # warm-up through the epoch's own path: allocations, first touch
             step.seconds.clear()
             ranks.barrier()
             t0 = time.perf_counter()

@@ -51,7 +51,10 @@ class CombinedLoss:
         self.mag_loss_ratio = mag_loss_ratio if "m" in target_str else 0
         self.allow_missing_labels = allow_missing_labels
 
-    def gradients(self, targets: dict, prediction: dict) -> tuple[dict, dict]:
+    def gradients(self, targets: dict, prediction: dict, flat_targets: dict | None = None) -> tuple[dict, dict]:
+        """``flat_targets``: the result of ``_flat_targets(targets, atoms_per_graph)`` when the caller already holds it (the loader
+        thread of ``TrainStep.run_epoch`` flattens the labels of the next batch while the device works): the per-step validity stamp
+        of the label cache -- a probe of every label array, 4 of the 6 ms of this call at 1024 structures -- is then skipped."""
         out: dict = {"loss": 0.0}
         grads: dict = {}
 
@@ -80,7 +83,7 @@ class CombinedLoss:
         # label lists of a batch are flattened once and kept with the label dictionary -- 1024-element lists re-concatenated every
         # step were most of this function's time in a training loop.  Same arithmetic, same results (tests/test_trainer_cpu.py).
         pflat = getattr(prediction, "flat", None)
-        tflat = self._flat_targets(targets, prediction["atoms_per_graph"]) if pflat is not None else None
+        tflat = (flat_targets if flat_targets is not None else self._flat_targets(targets, prediction["atoms_per_graph"])) if pflat is not None else None
         if "e" in self.target_str:
             grads["e"], _ = term("e", self.energy_loss_ratio, targets["e"], prediction["e"])
             out["e_MAE_size"] = int(np.asarray(prediction["e"]).shape[0])
@@ -137,6 +140,56 @@ class CombinedLoss:
             grads["m"] = np.concatenate(gm) if gm else np.zeros(0)
         return out, grads
 
+    def flatten_targets(self, targets: dict, atoms_per_graph) -> dict:
+        """Flattened labels of one batch (no cache): ``f`` [N,3], ``s`` [3B,3], ``m`` of the structures whose magmom labels count
+        (trainer.py:846: a missing or partly-NaN label drops the structure) with the atoms they belong to.  One concatenation per key
+        and one NaN scan over the flat array -- the per-structure Python loop this replaces held the interpreter lock for 12 ms per
+        1024-structure batch on the loader thread, next to the main thread's loss."""
+        flat = {}
+        if "f" in targets:
+            flat["f"] = np.concatenate(targets["f"], 0).astype(np.float64, copy=False) if len(targets["f"]) else np.zeros((0, 3))
+        if "s" in targets:
+            ts = targets["s"]
+            flat["s"] = (np.asarray(ts, np.float64).reshape(-1, 3) if isinstance(ts, np.ndarray) else
+                         np.concatenate(ts, 0).astype(np.float64, copy=False) if len(ts) else np.zeros((0, 3)))
+        if "m" in targets:
+            tm = targets["m"]
+            n_at = np.asarray(atoms_per_graph, np.int64).reshape(-1)
+            present = np.fromiter((mt is not None for mt in tm), bool, len(tm))
+            if not self.allow_missing_labels:
+                keep = np.ones(len(tm), bool)
+                cat = np.concatenate([np.asarray(mt, np.float64).reshape(-1) for mt in tm]) if len(tm) else np.zeros(0)
+                sizes = np.fromiter((np.size(mt) for mt in tm), np.int64, len(tm))
+            else:
+                have = [np.asarray(mt, np.float64).reshape(-1) for mt in tm if mt is not None]
+                sizes = np.zeros(len(tm), np.int64)
+                sizes[present] = [h.size for h in have]
+                cat = np.concatenate(have) if have else np.zeros(0)
+                keep = present.copy()
+                if cat.size:
+                    bad = np.isnan(cat)
+                    if bad.any():                      # structures with a NaN anywhere in their label are dropped as a whole
+                        starts = np.concatenate([[0], np.cumsum(sizes[present])[:-1]])
+                        nonempty = sizes[present] > 0
+                        has_nan = np.zeros(int(present.sum()), bool)
+                        has_nan[nonempty] = np.add.reduceat(bad, starts[nonempty]) > 0 if nonempty.any() else False
+                        keep[np.flatnonzero(present)[has_nan]] = False
+            if keep.all():
+                flat["m"], flat["m_keep_atoms"], flat["m_size"] = cat, None, int(sizes.sum())
+            else:
+                off = np.concatenate([[0], np.cumsum(n_at)])
+                moff = np.concatenate([[0], np.cumsum(sizes)])
+                kept = np.flatnonzero(keep)
+                flat["m"] = np.concatenate([cat_slice for cat_slice in (self._label_slices(cat, moff, present, kept))]) if kept.size else np.zeros(0)
+                flat["m_keep_atoms"] = np.concatenate([np.arange(off[i], off[i + 1]) for i in kept]) if kept.size else np.zeros(0, np.int64)
+                flat["m_size"] = int(sizes[kept].sum())
+        return flat
+
+    @staticmethod
+    def _label_slices(cat, moff, present, kept):
+        """Slices of the concatenated PRESENT labels that belong to the kept structures (``moff`` counts absent ones as empty)."""
+        return [cat[moff[i]:moff[i + 1]] for i in kept]
+
     def _flat_targets(self, targets: dict, atoms_per_graph) -> dict:
         """Flattened labels of one batch, built once per label dictionary (kept in a small cache on this object, keyed by the
         dictionary's identity: the label sets of an epoch come back every epoch)."""
@@ -163,26 +216,7 @@ class CombinedLoss:
         hit = cache.get(id(targets))
         if hit is not None and hit[0] is targets and hit[2] == stamp:
             return hit[1]
-        flat = {}
-        if "f" in targets:
-            flat["f"] = np.concatenate([np.asarray(x, np.float64) for x in targets["f"]], 0)
-        if "s" in targets:
-            flat["s"] = np.concatenate([np.asarray(x, np.float64) for x in targets["s"]], 0)
-        if "m" in targets:
-            parts, atoms, pos, size, all_kept = [], [], 0, 0, True
-            for i, mt in enumerate(targets["m"]):
-                n = int(atoms_per_graph[i])
-                ok = (mt is not None and not np.isnan(np.asarray(mt, np.float64)).any()) if self.allow_missing_labels else True
-                if ok:
-                    parts.append(np.asarray(mt, np.float64))
-                    atoms.append(np.arange(pos, pos + n))
-                    size += len(mt)
-                else:
-                    all_kept = False
-                pos += n
-            flat["m"] = np.concatenate(parts) if parts else np.zeros(0)
-            flat["m_keep_atoms"] = None if all_kept else (np.concatenate(atoms) if atoms else np.zeros(0, np.int64))
-            flat["m_size"] = size
+        flat = self.flatten_targets(targets, atoms_per_graph)
         if len(cache) >= 256:
             cache.clear()
         cache[id(targets)] = (targets, flat, stamp)
@@ -299,28 +333,40 @@ class TrainStep:
 
         from chgnet_amd.pack import pack_batch  # noqa: PLC0415
 
-        def prepare(i):          # data-loader work of step i: pack the graphs, flatten the label lists (CombinedLoss keeps them)
+        def prepare(i):          # data-loader work of step i: flatten the label lists (handed to the step as they are), pack the graphs
+            # the interpreter-bound part first (the main thread is inside the upload / launch calls of its step then, which release the
+            # lock), the native packing after it
+            flat = self.loss.flatten_targets(targets[i], np.fromiter((len(g.atomic_number) for g in batches[i]), np.int64, len(batches[i])))
             packed = pack_batch(batches[i])
-            self.loss._flat_targets(targets[i], np.diff(packed.atom_off))
-            return packed, (self.model.engine.upload(packed) if upload_ahead else None)
+            return packed, (self.model.engine.upload(packed) if upload_ahead else None), flat
+
+        import sys  # noqa: PLC0415
 
         infos = []
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(prepare, 0) if len(batches) else None
-            for i in range(len(batches)):
-                packed, device_batch = nxt.result()
-                nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
-                infos.append(self(packed, targets[i], device_batch=device_batch))
+        # Two interpreter threads: with CPython's default 5 ms switch interval the main thread's loss (a few dozen small numpy calls,
+        # 0.3 ms alone) took 20-27 ms next to the loader -- every time it gave the lock up it waited a full interval to get it back
+        # (tools/gpu_train_anatomy.py).  A 0.2 ms interval for the epoch keeps both threads moving.
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                nxt = pool.submit(prepare, 0) if len(batches) else None
+                for i in range(len(batches)):
+                    packed, device_batch, flat = nxt.result()
+                    nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
+                    infos.append(self(packed, targets[i], device_batch=device_batch, flat_targets=flat))
+        finally:
+            sys.setswitchinterval(interval)
         return infos
 
-    def __call__(self, graphs, targets: dict, device_batch=None) -> dict:
+    def __call__(self, graphs, targets: dict, device_batch=None, flat_targets: dict | None = None) -> dict:
         import time  # noqa: PLC0415
 
         model = self.model
         t0 = time.perf_counter()
         pred = model.forward(graphs, task=self.task, device_batch=device_batch)
         t1 = time.perf_counter()
-        info, g = self.loss.gradients(targets, pred)
+        info, g = self.loss.gradients(targets, pred, flat_targets=flat_targets)
         t2 = time.perf_counter()
         if self.comm is not None and self.comm.world > 1:
             # RCCL straight from the engine library: the 1.65 MB blob is summed in HBM on the engine's stream
