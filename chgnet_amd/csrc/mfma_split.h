@@ -160,13 +160,11 @@ __device__ __forceinline__ h16x8 fake_operand(int salt) {
 #define CHG_OPERAND(expr, salt) (expr)
 #endif
 
-// four output tiles fo0 .. fo0+3 from an already split row.  LO_SEPARATE: the low-order products (low planes scaled by 2^11)
-// are accumulated first, the sum is scaled back -- powers of two, exact -- and the high-order products follow into the SAME
-// accumulators: separate scaled accumulators without a second register set (the forward kernels carry the next tile's
-// gathered rows in registers and spilled ~100 dwords with one).
-// LEAN: the two-sweep form (one accumulator set; the high plane is read again for the main product): 16 registers fewer, a third
-// more LDS reads -- the forward kernels, which spill otherwise (same-box A/B: atomconv_fwd +8 %, bondconv_fwd +11 % single-sweep;
-// the adjoint kernels -1 .. -5 %).
+// four output tiles fo0 .. fo0+3 from an already split row.  LO_SEPARATE: the cross products (low planes scaled by 2^11) and the
+// main product go to separate accumulators, the former are scaled back -- a power of two, exact -- and added once; every operand is
+// read from LDS once.  LEAN: the same two tiles at a time (half the accumulator / operand registers in flight): the forward kernels,
+// which carry the next tile's gathered rows in registers and spill with the wide form (same-box A/B: atomconv_fwd +8 %, bondconv_fwd
+// +11 % with it; the adjoint kernels -1 .. -5 %).
 template <int MK, bool SCALED, bool LEAN = false>
 __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F, const SplitRow<MK>& s, int fo0, int i, int g) {
   const int nchunks = MK * 4 * F;
@@ -174,36 +172,35 @@ __device__ __forceinline__ void gemm_split4(f32x4* acc, const h16x8* img, int F,
   // LO_SEPARATE: the cross products (hi x lo, lo x hi, carried at 2^11) and the main product in separate accumulators, so that
   // every operand is read from LDS ONCE (a second sweep over the high plane cost a third more LDS reads than the contraction needs;
   // the tile kernels' weight reads are a large share of their LDS traffic)
+  // LEAN (the forward kernels, which sit at the register limit): TWO output tiles at a time with both accumulators (cross products at
+  // 2^11 | main product) -- every operand read from LDS once, like the wide form below, at 16 accumulator + 16 operand registers.
+  // (Rounds 3-4 used a two-sweep form here -- four tiles, one accumulator set, the high plane read twice: a third more LDS operand
+  // reads; same-box A/B of round 5: atomconv_fwd -2 %, bondconv_fwd -2.5 %, profiles/r05_experiments.md section 6.)
   if constexpr (LEAN && LO_SEPARATE) {
-    f32x4 t[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = SCALED ? zero4() : acc[q] * LO_SCALE;
+    for (int h = 0; h < 2; ++h) {
+      f32x4 t[2], u[2];
 #pragma unroll
-    for (int mk = 0; mk < MK; ++mk) {
-      const h16x8* base = base0 + mk * 4 * F;
-      h16x8 wh[4], wl[4];
+      for (int q = 0; q < 2; ++q) { t[q] = zero4(); u[q] = SCALED ? zero4() : acc[2 * h + q]; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { wh[q] = CHG_OPERAND(base[16 * q], q + mk); wl[q] = CHG_OPERAND(base[nchunks + 16 * q], q + mk + 1); }
+      for (int mk = 0; mk < MK; ++mk) {
+        const h16x8* base = base0 + mk * 4 * F + 32 * h;
+        h16x8 wh[2], wl[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) { wh[q] = CHG_OPERAND(base[16 * q], q + mk); wl[q] = CHG_OPERAND(base[nchunks + 16 * q], q + mk + 1); }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
-    }
+        for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.lo[mk], t[q], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] *= LO_UNSCALE;
+        for (int q = 0; q < 2; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], u[q], 0, 0, 0);
 #pragma unroll
-    for (int mk = 0; mk < MK; ++mk) {
-      const h16x8* base = base0 + mk * 4 * F;
-      h16x8 wh[4];
+        for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q], s.hi[mk], t[q], 0, 0, 0);
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wh[q] = CHG_OPERAND(base[16 * q], q + mk);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q], s.hi[mk], t[q], 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (SCALED) acc[q] += t[q] * s.up;
-      else acc[q] = t[q];
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 r = u[q] + t[q] * LO_UNSCALE;
+        if (SCALED) acc[2 * h + q] += r * s.up;
+        else acc[2 * h + q] = r;
+      }
     }
     return;
   }
