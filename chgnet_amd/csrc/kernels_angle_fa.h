@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angleupd_fwd_a(AngleWAr
     const int ra = min(r0 + j, r0 + n * (n - 1) - 1);
     aA = w.q_a[ra]; q1A = w.q_ab1[ra]; q2A = w.q_ab2[ra];
     fa_request(rows, p, c, min(n, FA_NSL), bkv, lane);
-    read_dl<VT>(p.ang + (size_t)aA * D, g, xn.t);
+    read_dl_g<VT>(p.ang, (unsigned)aA, D, g, xn.t);
   }
   V64 y_prev;                                    // the previous tile's result: stored one tile late, behind this tile's requests
   CHG_EV(ft) y_prev.t[ft] = zero4();
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angleupd_fwd_a(AngleWAr
       const bool last = row0 + TILE_ROWS >= r_end;
       // requests for later tiles: angle rows of the next tile (after this atom's last tile: of the next atom's first), indices two ahead
       const int a_ld = last ? (c_next >= 0 ? aA_n : a) : a_n;
-      read_dl<VT>(p.ang + (size_t)a_ld * D, g, xn.t);
+      read_dl_g<VT>(p.ang, (unsigned)a_ld, D, g, xn.t);
       const int rr2 = min(row0 + 2 * TILE_ROWS + j, r_end - 1);
       const int a_n2 = w.q_a[rr2], q1_n2 = w.q_ab1[rr2], q2_n2 = w.q_ab2[rr2];
       // ---- z = W_ang x + (R_i + S)[first bond] + R_j[second bond] ----
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angleupd_fwd_a(AngleWAr
       gemm_split<VT, 2 * VT, false, true>(z, Wang, 2 * D, x.t, j, g);
       // the previous tile's rows leave now: behind this tile's requests, so that no wait for those covers the stores
       asm volatile("" ::: "memory");
-      if (j < nvalid_prev) write_dl<VT>(p.out + (size_t)a_prev * D, g, y_prev.t);
+      if (j < nvalid_prev) write_dl_g<VT>(p.out, (unsigned)a_prev, D, g, y_prev.t);
       asm volatile("" ::: "memory");
       const bool in_lds = r1 < FA_NSL && r2 >= 0 && r2 < FA_NSL;        // (r1 >= 0 always: the row's own first bond)
       if (__builtin_amdgcn_ballot_w64(!in_lds) == 0) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angleupd_fwd_a(AngleWAr
     c_nx = c_n2; n_nraw = n_n2raw; ab_nraw = ab_n2raw; r_nraw = r_n2raw; c_n2 = c_n3;
     aA = aA_n; q1A = q1A_n; q2A = q2A_n;
   }
-  if (j < nvalid_prev) write_dl<VT>(p.out + (size_t)a_prev * D, g, y_prev.t);
+  if (j < nvalid_prev) write_dl_g<VT>(p.out, (unsigned)a_prev, D, g, y_prev.t);
 }
 
 }  // namespace chg

@@ -211,9 +211,9 @@ __device__ __forceinline__ void gather64_issue(Gather64& gr, const float* __rest
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
-    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
+    gr.a[it] = *grow<f32x4>(t0, (unsigned)r0[it], ld0, 4 * t);
+    gr.b[it] = *grow<f32x4>(t1, (unsigned)r1[it], ld1, 4 * t);
+    gr.c[it] = *grow<f32x4>(t2, (unsigned)r2[it], ld2, 4 * t);
   }
 }
 __device__ __forceinline__ void gather64_commit(const Gather64& gr, float* tile, int lane) {
@@ -242,7 +242,7 @@ __device__ __forceinline__ void run_sum64(const Cols64& c, int nvalid, int key, 
     if (rr < nvalid) {
       const int k = __builtin_amdgcn_readlane(key, rr);
       if (k != cur) {
-        if (cur >= 0) atomicAdd(dst + (size_t)cur * ld + lane, sum);
+        if (cur >= 0) atomicAdd(grow<float>(dst, (unsigned)cur, ld, lane), sum);
         sum = 0.f;
         cur = k;
       }
@@ -251,14 +251,14 @@ __device__ __forceinline__ void run_sum64(const Cols64& c, int nvalid, int key, 
   }
 }
 __device__ __forceinline__ void run_flush64(float& sum, int& cur, float* __restrict__ dst, int ld, int lane) {
-  if (cur >= 0) atomicAdd(dst + (size_t)cur * ld + lane, sum);
+  if (cur >= 0) atomicAdd(grow<float>(dst, (unsigned)cur, ld, lane), sum);
   sum = 0.f;
   cur = -1;
 }
 __device__ __forceinline__ void row_add64(const Cols64& c, int nvalid, float* __restrict__ base, int row, int ld, int lane) {
 #pragma unroll
   for (int rr = 0; rr < TILE_ROWS; ++rr)
-    if (rr < nvalid) atomicAdd(base + (size_t)__builtin_amdgcn_readlane(row, rr) * ld + lane, c.v[rr]);
+    if (rr < nvalid) atomicAdd(grow<float>(base, (unsigned)__builtin_amdgcn_readlane(row, rr), ld, lane), c.v[rr]);
 }
 // Second-bond rows (NB column blocks of 64) into the wave-private LDS rows: plain read-modify-write, two rows per step
 // (neighbouring rows of the centre-major order never share a second bond; rows further apart may, and the LDS executes a
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);
       V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
       if (HIDDEN) {
-        read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
-        read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
-        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
+        read_dl_g<VT>(p.wbgc, (unsigned)b1, D, g, w1.t);
+        read_dl_g<VT>(p.wbgc, (unsigned)b2, D, g, w2.t);
+        read_dl_g<VT>(p.Gagg, (unsigned)b1, D, g, gu.t);
       }
       if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane_t);
       else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     run_flush64(ri0, cur0, p.GR, 4 * D, lane_f);
     run_flush64(ri1, cur1, p.GR + D, 4 * D, lane_f);
     if (HIDDEN) run_flush64(rg, curg, p.Gwbgc, D, lane_f);
-    atomicAdd(p.GS + (size_t)c * 2 * D + lane_f, rs0);
-    atomicAdd(p.GS + (size_t)c * 2 * D + D + lane_f, rs1);
+    atomicAdd(grow<float>(p.GS, (unsigned)c, 2 * D, lane_f), rs0);
+    atomicAdd(grow<float>(p.GS, (unsigned)c, 2 * D, D + lane_f), rs1);
     const int nrows = min(n, NS);
     const int bond_of = w.abbond[ab0 + min(lane_f, nrows - 1)];
     for (int sl = 0; sl < nrows; ++sl) {
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       float* src = pacc + sl * PST;
       const float v0 = src[lane_f], v1 = src[D + lane_f];
       src[lane_f] = 0.f; src[D + lane_f] = 0.f;
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 2 * D + lane_f, v0);
-      atomicAdd(p.GR + (size_t)bond * 4 * D + 3 * D + lane_f, v1);
+      atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 2 * D + lane_f), v0);
+      atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 3 * D + lane_f), v1);
     }
     PH(4)   // per-atom flush
   }

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     c_nx = p.e_center[r0]; n_nx = p.e_nbr[r0];
     bn_nx = bond_node(p, r0 >> 1);
     gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, bond_row_offset(p, r0 >> 1, bn_nx), lane);
-    read_dl<VT>(p.wag + (size_t)(r0 >> 1) * D, g, wv_nx.t);
+    read_dl_g<VT>(p.wag, (unsigned)(r0 >> 1), D, g, wv_nx.t);
     const int r1 = row_of(1);
     c_n2 = p.e_center[r1]; n_n2 = p.e_nbr[r1];
     bn_n2 = bond_node(p, r1 >> 1);
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
     if (v + 1 < ts.count) {
       const int r1 = row_of(v + 1);
       gather_issue_ph(gr, p.P, c_nx, p.P + 2 * D, n_nx, 4 * D, 4 * D, p.hb0, bond_row_offset(p, r1 >> 1, bn_nx), lane);
-      read_dl<VT>(p.wag + (size_t)(r1 >> 1) * D, g, wv_nx.t);
+      read_dl_g<VT>(p.wag, (unsigned)(r1 >> 1), D, g, wv_nx.t);
       const int r2 = row_of(v + 2);
       c_n2 = p.e_center[r2]; n_n2 = p.e_nbr[r2];
       bn_n2 = bond_node(p, r2 >> 1);
@@ -676,12 +676,12 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
         if (2 * b < nvalid) {
           const int c1 = __builtin_amdgcn_readlane(c, 2 * b), c2 = __builtin_amdgcn_readlane(c, 2 * b + 1);
           if (c1 != cur1) {
-            tile_atomic_add(p.agg + (size_t)cur1 * D + lane, acc1);
+            tile_atomic_add(grow<float>(p.agg, (unsigned)cur1, D, lane), acc1);
             acc1 = 0.f;
             cur1 = c1;
           }
           if (c2 != cur2) {
-            tile_atomic_add(p.agg + (size_t)cur2 * D + lane, acc2);
+            tile_atomic_add(grow<float>(p.agg, (unsigned)cur2, D, lane), acc2);
             acc2 = 0.f;
             cur2 = c2;
           }
@@ -689,8 +689,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_atomconv_fwd(AtomConv
           acc2 += T[(2 * b + 1) * TS + lane];
         }
       }
-      tile_atomic_add(p.agg + (size_t)cur1 * D + lane, acc1);
-      tile_atomic_add(p.agg + (size_t)cur2 * D + lane, acc2);
+      tile_atomic_add(grow<float>(p.agg, (unsigned)cur1, D, lane), acc1);
+      tile_atomic_add(grow<float>(p.agg, (unsigned)cur2, D, lane), acc2);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -800,8 +800,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
       cn = p.e_center[row]; nn = p.e_nbr[row]; kn = row >> 1;
     }
     V64 wv, gm;
-    read_dl<VT>(p.wag + (size_t)k * D, g, wv.t);
-    read_dl<VT>(p.GA + (size_t)c * D, g, gm.t);
+    read_dl_g<VT>(p.wag, (unsigned)k, D, g, wv.t);
+    read_dl_g<VT>(p.GA, (unsigned)c, D, g, gm.t);
     const int k0 = row0 >> 1, nb = nvalid >> 1;
     float* gwag_rows = p.Gwag + (size_t)k0 * D + lane;     // this tile owns these rows of Gwag: old values read here,
     float prev[TILE_ROWS / 2];                             // under the forward recomputation
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     ctr_nx = p.a_ctr[a0]; b1_nx = p.a_b1c[a0]; b2_nx = p.a_b2c[a0];
     if (PIPE) {
       gather_issue128(gr_p, p.R, b1_nx, p.R + 2 * D, b2_nx, p.S, ctr_nx, 4 * D, 4 * D, 2 * D, lane);
-      read_dl<VT>(p.ang + (size_t)a0 * D, g, x_p.t);
+      read_dl_g<VT>(p.ang, (unsigned)a0, D, g, x_p.t);
       if (1 < ts.count) {
         const int a1 = row_of(1);
         ctr_n2 = p.a_ctr[a1]; b1_n2 = p.a_b1c[a1]; b2_n2 = p.a_b2c[a1];
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
         // over the whole tile -- at 256 registers it is spilled, and its reload waits (vmcnt, in order) behind the gathers just issued
         int lane_here;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
-        read_dl<VT>(p.ang + (size_t)a1 * D, lane_here >> 4, x_p.t);
+        read_dl_g<VT>(p.ang, (unsigned)a1, D, lane_here >> 4, x_p.t);
         ctr_nx = ctr_n2; b1_nx = b1_n2; b2_nx = b2_n2;
         if (v + 2 < ts.count) {   // (row index from the recomputed lane_t as well: the strength-reduced constant 2 stride + j was spilled too)
           const int a2 = max(0, min(ts.at(v + 2) * tstride + (lane_here & 15), p.n_angles - 1));
@@ -1085,8 +1085,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
     PH(3)   // gated forward
     V64 w1, w2;   // small L2-resident tables: loaded after the MFMA phase to keep its register pressure low
     if (HIDDEN) {
-      read_dl<VT>(p.wbgc + (size_t)b1 * D, g, w1.t);
-      read_dl<VT>(p.wbgc + (size_t)b2 * D, g, w2.t);
+      read_dl_g<VT>(p.wbgc, (unsigned)b1, D, g, w1.t);
+      read_dl_g<VT>(p.wbgc, (unsigned)b2, D, g, w2.t);
     }
     if (!BWD) {
       CHG_EV(ft) {
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       V64 gy, gzc, gzg;
       if (HIDDEN) {
         V64 g1, g2, gu;
-        read_dl<VT>(p.Gagg + (size_t)b1 * D, g, gu.t);
+        read_dl_g<VT>(p.Gagg, (unsigned)b1, D, g, gu.t);
         CHG_EV(ft) {
           const f32x4 gyu = gu.t[ft] * y.t[ft];
           g1.t[ft] = gyu * w2.t[ft];      // dE/d wbgc[b1]
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       PH(5)   // gated backward
       // dE/d(angle in) += W_ang^T gz   (the residual identity is already in Gang)
       f32x4 gz[2 * VT] = {gzc.t[0], gzc.t[1], gzc.t[2], gzc.t[3], gzg.t[0], gzg.t[1], gzg.t[2], gzg.t[3]};
-      if (TRAIN && HIDDEN && valid) write_dl<2 * VT>(p.dumpZ + (size_t)a * 2 * D, g, gz);
+      if (TRAIN && HIDDEN && valid) write_dl_g<2 * VT>(p.dumpZ, (unsigned)a, 2 * D, g, gz);
       V64 ga = zero64();
       if (HIDDEN) {
         // BondConv: this tile owns rows a of Gang; their read is issued above the contraction that produces

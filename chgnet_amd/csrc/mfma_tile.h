@@ -98,6 +98,32 @@ __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] +
 // elementwise loop over this lane's 16 floats of a 64-wide vector
 #define CHG_EW(ft, r) _Pragma("unroll") for (int ft = 0; ft < VT; ++ft) _Pragma("unroll") for (int r = 0; r < 4; ++r)
 
+// ---- global row addressing ------------------------------------------------------------------------------------------------
+// Row `r` of a row-major float table with `ld` floats per row, at float column `c`.  CHG_ADDR32=1 forms the byte offset in 32 bits
+// against the uniform table base (`global_load ... v_off, s[base:base+1]`: one 32-bit multiply-add and one VGPR per address instead
+// of three 64-bit vector instructions and a register pair).  Measured (profiles/r05_experiments.md section 7): 231 -> 99 64-bit
+// address instructions in the BondConv adjoint, -1.5 % of its vector instructions, -1 % of the step -- not worth the 4 GiB-per-table
+// limit it brings (a 4096-structure batch has 4.2 GB of angle rows): the product keeps 64-bit offsets.
+#ifndef CHG_ADDR32
+#define CHG_ADDR32 0
+#endif
+template <class T>
+__device__ __forceinline__ const T* grow(const float* __restrict__ base, unsigned r, int ld, int c) {
+#if CHG_ADDR32
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (r * (unsigned)(ld * 4) + (unsigned)(c * 4)));
+#else
+  return reinterpret_cast<const T*>(base + (size_t)r * ld + c);
+#endif
+}
+template <class T>
+__device__ __forceinline__ T* grow(float* __restrict__ base, unsigned r, int ld, int c) {
+#if CHG_ADDR32
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (r * (unsigned)(ld * 4) + (unsigned)(c * 4)));
+#else
+  return reinterpret_cast<T*>(base + (size_t)r * ld + c);
+#endif
+}
+
 // ---- D-layout loads / stores ---------------------------------------------------------------
 // `row` points at feature 0 of the lane's row in a row-major buffer (LDS tile or global table)
 template <int NT>
@@ -109,6 +135,18 @@ template <int NT>
 __device__ __forceinline__ void write_dl(float* row, int g, const f32x4 (&x)[NT]) {
 #pragma unroll
   for (int ft = 0; ft < NT; ++ft) *reinterpret_cast<f32x4*>(row + 16 * ft + 4 * g) = x[ft];
+}
+
+// the same for row `r` of a global table (32-bit offsets: grow above)
+template <int NT>
+__device__ __forceinline__ void read_dl_g(const float* __restrict__ base, unsigned r, int ld, int g, f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft) x[ft] = *grow<f32x4>(base, r, ld, 16 * ft + 4 * g);
+}
+template <int NT>
+__device__ __forceinline__ void write_dl_g(float* __restrict__ base, unsigned r, int ld, int g, const f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft) *grow<f32x4>(base, r, ld, 16 * ft + 4 * g) = x[ft];
 }
 
 // ---- MFMA GEMMs in swapped form ---------------------------------------------------------------
@@ -333,7 +371,7 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
     if (kk != cur) {
       if (cur >= 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) tile_atomic_add(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
+        for (int c = 0; c < NC; ++c) tile_atomic_add(grow<float>(dst, (unsigned)cur, ldd, 64 * c + lane), acc[c]);
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = 0.f;
@@ -344,7 +382,7 @@ __device__ __forceinline__ void seg_colsum_atomic(const float* tile, int stride,
   }
   if (cur >= 0) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) tile_atomic_add(dst + (size_t)cur * ldd + 64 * c + lane, acc[c]);
+    for (int c = 0; c < NC; ++c) tile_atomic_add(grow<float>(dst, (unsigned)cur, ldd, 64 * c + lane), acc[c]);
   }
 }
 
@@ -357,7 +395,7 @@ __device__ __forceinline__ void row_atomic_add(const float* tile, int stride, in
     const int kk = __builtin_amdgcn_readlane(key, rr);   // rows past the end carry key -1
     if (kk >= 0) {
 #pragma unroll
-      for (int c = 0; c < W / 64; ++c) tile_atomic_add(dst + (size_t)kk * ldd + 64 * c + lane, tile[rr * stride + 64 * c + lane]);
+      for (int c = 0; c < W / 64; ++c) tile_atomic_add(grow<float>(dst, (unsigned)kk, ldd, 64 * c + lane), tile[rr * stride + 64 * c + lane]);
     }
   }
 }
@@ -382,9 +420,9 @@ __device__ __forceinline__ void gather_sum128(float* tile, int stride, const flo
   f32x4 a[TILE_ROWS / 2], b[TILE_ROWS / 2], c[TILE_ROWS / 2];
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
-    b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
-    c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
+    a[it] = *grow<f32x4>(t0, (unsigned)r0[it], ld0, 4 * t);
+    b[it] = *grow<f32x4>(t1, (unsigned)r1[it], ld1, 4 * t);
+    c[it] = *grow<f32x4>(t2, (unsigned)r2[it], ld2, 4 * t);
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
@@ -409,9 +447,9 @@ __device__ __forceinline__ void gather_issue128(GatherRegs& gr, const float* __r
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
-    gr.c[it] = *reinterpret_cast<const f32x4*>(t2 + (size_t)(unsigned)r2[it] * ld2 + 4 * t);
+    gr.a[it] = *grow<f32x4>(t0, (unsigned)r0[it], ld0, 4 * t);
+    gr.b[it] = *grow<f32x4>(t1, (unsigned)r1[it], ld1, 4 * t);
+    gr.c[it] = *grow<f32x4>(t2, (unsigned)r2[it], ld2, 4 * t);
   }
 }
 __device__ __forceinline__ void gather_commit128(const GatherRegs& gr, float* tile, int stride, int lane) {
@@ -456,8 +494,8 @@ __device__ __forceinline__ void gather_issue_ph(GatherPH& gr, const float* __res
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 2; ++it) {
-    gr.a[it] = *reinterpret_cast<const f32x4*>(t0 + (size_t)(unsigned)r0[it] * ld0 + 4 * t);
-    gr.b[it] = *reinterpret_cast<const f32x4*>(t1 + (size_t)(unsigned)r1[it] * ld1 + 4 * t);
+    gr.a[it] = *grow<f32x4>(t0, (unsigned)r0[it], ld0, 4 * t);
+    gr.b[it] = *grow<f32x4>(t1, (unsigned)r1[it], ld1, 4 * t);
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) gr.h[it] = *reinterpret_cast<const f32x4*>(hbase + ho[it] + 4 * t16);
@@ -482,7 +520,7 @@ __device__ __forceinline__ void rows64_issue(Rows64& rr, const float* __restrict
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)r[it] * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) rr.v[it] = *grow<f32x4>(src, (unsigned)r[it], D, 4 * t);
 }
 __device__ __forceinline__ void rows64_commit(const Rows64& rr, float* tile, int stride, int lane) {
   const int sub = lane >> 4, t = lane & 15;
@@ -512,7 +550,7 @@ __device__ __forceinline__ void scatter_rows64_add(const float* tile, int stride
     // these stores: the wait for a scratch reload is a wait for every store before it -- 3 store round trips per tile
     int lim = nvalid - 4 * it;
     if (OPAQUE) asm volatile("" : "+v"(lim));
-    if (sub < lim) *reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)r[it] * D + 4 * t) = v[it];
+    if (sub < lim) *grow<f32x4>(dst, (unsigned)r[it], D, 4 * t) = v[it];
   }
 }
 
@@ -524,7 +562,7 @@ __device__ __forceinline__ void gather_rows64(float* tile, int stride, const flo
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = __shfl(idx, 4 * it + sub);
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)r[it] * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *grow<f32x4>(src, (unsigned)r[it], D, 4 * t);
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it) *reinterpret_cast<f32x4*>(tile + (4 * it + sub) * stride + 4 * t) = v[it];
 }
@@ -534,13 +572,13 @@ template <bool ACCUM>
 __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, float* __restrict__ dst, int idx, int nvalid,
                                                int lane) {
   const int sub = lane >> 4, t = lane & 15;
-  f32x4* p[TILE_ROWS / 4];
+  unsigned r[TILE_ROWS / 4];
   f32x4 v[TILE_ROWS / 4];
 #pragma unroll
-  for (int it = 0; it < TILE_ROWS / 4; ++it) p[it] = reinterpret_cast<f32x4*>(dst + (size_t)(unsigned)__shfl(idx, 4 * it + sub) * D + 4 * t);
+  for (int it = 0; it < TILE_ROWS / 4; ++it) r[it] = (unsigned)__shfl(idx, 4 * it + sub);
   if (ACCUM) {   // all loads first: one memory round trip for the tile, not one per step (idx of rows past nvalid is a valid row)
 #pragma unroll
-    for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *p[it];
+    for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] = *grow<f32x4>(dst, r[it], D, 4 * t);
 #pragma unroll
     for (int it = 0; it < TILE_ROWS / 4; ++it) v[it] += *reinterpret_cast<const f32x4*>(tile + (4 * it + sub) * stride + 4 * t);
   } else {
@@ -549,7 +587,7 @@ __device__ __forceinline__ void scatter_rows64(const float* tile, int stride, fl
   }
 #pragma unroll
   for (int it = 0; it < TILE_ROWS / 4; ++it)
-    if (sub < nvalid - 4 * it) *p[it] = v[it];
+    if (sub < nvalid - 4 * it) *grow<f32x4>(dst, r[it], D, 4 * t) = v[it];
 }
 
 }  // namespace chg
