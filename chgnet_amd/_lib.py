@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "chg_comm_destroy", "chg_comm_last_error",
     "chg_comm_all_gather_f32_device", "chg_comm_all_reduce_sum_f32_device", "chg_comm_reserve", "chg_comm_info",
     "chg_backward_allreduce", "chg_batch_all_gather_energy", "chg_engine_stream", "chg_engine_device",
+    "chg_host_alloc", "chg_host_free",
 )
 
 
@@ -109,6 +110,8 @@ def load() -> ctypes.CDLL:
     lib.chg_batch_bytes_required.argtypes = [ctypes.c_int32] * 6
     lib.chg_batch_bytes_required.restype = ctypes.c_int64
     lib.chg_batch_upload.argtypes = [vp, ctypes.POINTER(BatchHost), ctypes.POINTER(vp)]
+    lib.chg_host_alloc.argtypes = [ctypes.c_int64, ctypes.POINTER(vp)]
+    lib.chg_host_free.argtypes = [vp]
     lib.chg_batch_build.argtypes = [vp, ctypes.POINTER(StructsHost), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.POINTER(vp), c_int_p]
     lib.chg_debug_fetch_i32.argtypes = [vp, vp, ctypes.c_char_p, c_int_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]

@@ -149,6 +149,8 @@ class Engine:
         return int(self.lib.chg_batch_bytes_required(self.weights.n_conv, n_struct, n_atoms, n_directed, n_angles, n_bnodes))
 
     def close(self) -> None:
+        for ptr, _ in self.__dict__.pop("_pinned", {}).values():
+            self.lib.chg_host_free(ctypes.c_void_p(ptr))
         if self.handle:
             self.lib.chg_engine_destroy(self.handle)
             self.handle = ctypes.c_void_p()
@@ -160,6 +162,39 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------
+    def pinned_allocator(self, slot: int = 0):
+        """``alloc`` argument for ``pack_batch``: the packed arrays of a batch carved out of ONE page-locked block per ``slot`` (grown when
+        a batch needs more, freed with the engine).  ``upload`` from such arrays is asynchronous DMA at the link rate (1024 x 40 atoms:
+        ~250 MB in 5 ms instead of 22 ms from pageable memory).  A slot's block is REUSED by the next ``pack_batch`` with the same
+        slot: alternate two slots when one batch is packed while the previous one is still in use (``TrainStep.run_epoch`` does)."""
+        pools = self.__dict__.setdefault("_pinned", {})
+
+        def alloc(spec: dict) -> dict:
+            offs, pos = {}, 0
+            for name, (shape, dtype) in spec.items():
+                offs[name] = pos
+                pos += (int(np.prod(shape)) * np.dtype(dtype).itemsize + 255) & ~255
+            need = max(pos, 256)
+            ptr, have = pools.get(slot, (None, 0))
+            if have < need:
+                if ptr:
+                    self.lib.chg_host_free(ctypes.c_void_p(ptr))
+                    pools.pop(slot, None)
+                out = ctypes.c_void_p()
+                want = need + need // 8
+                if self.lib.chg_host_alloc(want, ctypes.byref(out)) != 0 or not out.value:
+                    return {k: np.empty(shape, dtype) for k, (shape, dtype) in spec.items()}    # no page-locked memory: pageable arrays
+                ptr, have = out.value, want
+                pools[slot] = (ptr, have)
+            raw = (ctypes.c_char * have).from_address(ptr)
+            arrays = {}
+            for name, (shape, dtype) in spec.items():
+                n = int(np.prod(shape))
+                arrays[name] = np.frombuffer(raw, dtype=dtype, count=n, offset=offs[name]).reshape(shape)
+            return arrays
+
+        return alloc
+
     def upload(self, graphs_or_packed) -> DeviceBatch:
         packed = graphs_or_packed if isinstance(graphs_or_packed, PackedBatch) else pack_batch(graphs_or_packed)
         return DeviceBatch(self, packed)

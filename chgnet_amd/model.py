@@ -10,6 +10,7 @@ module graph and no CPU fallback.
 
 from __future__ import annotations
 
+import itertools
 import math
 import os
 from collections.abc import Sequence
@@ -342,9 +343,14 @@ class CHGNet:
             res, atom_off = collect(launch(chunk, pack_batch(chunk)))
             return _split_results(res, atom_off, len(chunk))
 
+        slots = itertools.cycle((0, 1))     # chunks are packed into two alternating page-locked blocks (one batch alive at a time)
+
+        def pack_pinned(chunk):
+            return pack_batch(chunk, alloc=eng.pinned_allocator(next(slots)))
+
         floor = self.min_atoms_per_batch if min_atoms_per_batch is None else int(min_atoms_per_batch)
         chunks = [graphs[a:b] for a, b in _plan_chunks([len(g.atomic_number) for g in graphs], batch_size, floor)]
-        predictions = _run_pipelined(chunks, pack_batch, launch, collect, run)   # the next chunk is packed during the sweep
+        predictions = _run_pipelined(chunks, pack_pinned, launch, collect, run)   # the next chunk is packed during the sweep
         return predictions[0] if len(graphs) == 1 else predictions
 
     # ---- (de)serialisation (model.py:667-745) ----------------------------------------------------------

@@ -63,9 +63,11 @@ class _PackedOut(ctypes.Structure):      # include/chgnet_graph.h: chg_packed_ou
     _fields_ = [(name, ctypes.c_void_p) for name in _PACKED_FIELDS]
 
 
-def pack_batch(graphs) -> PackedBatch:
+def pack_batch(graphs, alloc=None) -> PackedBatch:
     """Concatenate graphs into one disjoint-union batch with global indices: one pass in native code
-    (``chg_pack_batch``, csrc/host_graph.cpp; ~30x the numpy formulation kept below as ``pack_batch_numpy``)."""
+    (``chg_pack_batch``, csrc/host_graph.cpp; ~30x the numpy formulation kept below as ``pack_batch_numpy``).
+    ``alloc(sizes: {name: (shape, dtype)}) -> {name: array}``: where the output arrays live -- ``Engine.pinned_allocator`` hands out
+    page-locked memory, from which ``Engine.upload`` copies at the link rate."""
     from chgnet_amd.graph.converter import graph_lib  # noqa: PLC0415
 
     graphs = [CrystalGraph.from_reference(g) for g in graphs]
@@ -92,14 +94,19 @@ def pack_batch(graphs) -> PackedBatch:
              "lattice": (B, 3, 3), "e_image": (Ed, 3), "e_center": Ed, "e_nbr": Ed, "e_d2u": Ed, "e_owner": Ed, "e_rev": Ed,
              "p_center": Ed, "p_nbr": Ed, "u_u2d": Eu, "u_bnode": Eu, "bn_und": Eu, "a_ctr": A, "a_b1": A, "a_d1": A, "a_b2": A,
              "a_d2": A, "a_b1c": A, "a_b2c": A}
-    arr = {k: np.empty(sizes[k], np.float32 if k in ("frac", "lattice", "e_image") else np.int32) for k in _PACKED_FIELDS}
+    spec = {k: (sizes[k] if isinstance(sizes[k], tuple) else (sizes[k],), np.float32 if k in ("frac", "lattice", "e_image") else np.int32)
+            for k in _PACKED_FIELDS}
+    arr = alloc(spec) if alloc is not None else {k: np.empty(shape, dtype) for k, (shape, dtype) in spec.items()}
     out = _PackedOut(*[arr[k].ctypes.data for k in _PACKED_FIELDS])
     n_bn, bad = ctypes.c_int32(), ctypes.c_int32(-1)
     status = lib.chg_pack_batch(B, views, ctypes.byref(out), ctypes.byref(n_bn), ctypes.byref(bad))
     if status != 0:
         pack_batch_numpy(graphs)          # phrases the IndexError / ValueError for the offending array
         raise ValueError(f"graph {bad.value}: {lib.chg_graph_strerror(status).decode()}")
-    arr["bn_und"] = arr["bn_und"][:n_bn.value].copy()
+    arr["bn_und"] = arr["bn_und"][:n_bn.value] if alloc is not None else arr["bn_und"][:n_bn.value].copy()
+    if alloc is not None:       # the offset tables outlive the upload (results are split by them): keep them out of the reusable buffer
+        for k in ("atom_off", "edge_off", "und_off", "ang_off"):
+            arr[k] = arr[k].copy()
     return PackedBatch(B, N, Ed, Eu, A, int(n_bn.value), arr)
 
 

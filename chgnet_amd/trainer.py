@@ -337,7 +337,10 @@ class TrainStep:
             # the interpreter-bound part first (the main thread is inside the upload / launch calls of its step then, which release the
             # lock), the native packing after it
             flat = self.loss.flatten_targets(targets[i], np.fromiter((len(g.atomic_number) for g in batches[i]), np.int64, len(batches[i])))
-            packed = pack_batch(batches[i])
+            # packed into page-locked memory (two alternating blocks: batch i + 1 is packed while batch i is in use): the step's upload is
+            # then DMA at the link rate
+            pinned = getattr(getattr(self.model, "engine", None), "pinned_allocator", None)
+            packed = pack_batch(batches[i], alloc=pinned(i & 1) if pinned is not None else None)
             return packed, (self.model.engine.upload(packed) if upload_ahead else None), flat
 
         import sys  # noqa: PLC0415

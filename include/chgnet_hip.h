@@ -124,6 +124,10 @@ int chg_engine_memory_info(chg_engine* eng, int64_t* free_bytes, int64_t* total_
 int64_t chg_batch_bytes_required(int32_t n_conv, int32_t n_struct, int32_t n_atoms, int32_t n_directed, int32_t n_angles, int32_t n_bnodes);
 
 int chg_batch_upload(chg_engine* eng, const chg_batch_host* host, chg_batch** out);
+/* Page-locked host buffers for the arrays of a chg_batch_host (optional): uploads from them run as asynchronous DMA at the link rate
+ * instead of staged copies from pageable memory (the reference's counterpart is DataLoader(pin_memory=True), data/dataset.py). */
+int chg_host_alloc(int64_t bytes, void** out);
+int chg_host_free(void* p);
 
 /* Structures only (no graph): the periodic neighbour list, bond numbering and bond graph are built on
  * the device, bit-for-bit the arrays of chg_graph_build (include/chgnet_graph.h) + pack.py.  Replaces
