@@ -51,14 +51,16 @@ SPLIT_MFMA_PER_PRODUCT = 3      # csrc/mfma_split.h: x.w = xh.wh + xl.wh + xh.wl
 
 
 def csrc_hash() -> str:
-    """Hash of the kernel sources: profiles/pmc_latest.json and sq_latest.json carry the hash of the sources their counters were taken
-    on (profiles/summarize.py); counters of OTHER sources are not quoted in the line (they went stale silently before)."""
+    """Hash of the sources of the prediction kernels: profiles/pmc_latest.json and sq_latest.json carry the hash of the sources their
+    counters were taken on (profiles/summarize.py); counters of OTHER sources are not quoted in the line (they went stale silently
+    before).  Covered: every kernel header and the unit that instantiates and launches the prediction kernels (engine_predict.hip) --
+    not the ABI / training / graph-build units, whose edits do not change these kernels."""
     import hashlib
 
     h = hashlib.sha256()
     d = os.path.join(REPO, "chgnet_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip", ".cpp")):
+        if name.endswith(".h") or name == "engine_predict.hip":
             h.update(name.encode())
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(fh.read())
