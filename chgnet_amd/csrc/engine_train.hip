@@ -927,6 +927,11 @@ int backward_compute(chg_engine* eng, chg_batch* b, const float* energy_cotangen
                             const float* force_cotangent, const float* stress_cotangent) {
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
   if ((int)b->h_atom_off.size() != b->B + 1) { eng->err = "chg_backward: batch has no host atom offsets"; return CHG_EINVAL; }
+  if (b->wide_range) {   // the training sweeps exist in the product (unscaled-operand) form only
+    eng->err = "chg_backward: this batch left the f16 operand range of the split contractions and runs on the wide-range prediction "
+               "sweep (engine_predict_wide.hip); parameter gradients are not available for it";
+    return CHG_EUNSUPPORTED;
+  }
   TRY(ensure_train_buffers(eng, b));
   // cotangent of the per-structure energy SUMS: e_b = E_b / n_b for an intensive model (model.py:538-540); AtomRef is frozen
   std::vector<float> cot(b->B);

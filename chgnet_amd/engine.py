@@ -149,7 +149,7 @@ class Engine:
         return int(self.lib.chg_batch_bytes_required(self.weights.n_conv, n_struct, n_atoms, n_directed, n_angles, n_bnodes))
 
     def close(self) -> None:
-        for ptr, _ in self.__dict__.pop("_pinned", {}).values():
+        for ptr in [p for p, _ in self.__dict__.pop("_pinned", {}).values()] + self.__dict__.pop("_pinned_retired", []):
             self.lib.chg_host_free(ctypes.c_void_p(ptr))
         if self.handle:
             self.lib.chg_engine_destroy(self.handle)
@@ -177,8 +177,8 @@ class Engine:
             need = max(pos, 256)
             ptr, have = pools.get(slot, (None, 0))
             if have < need:
-                if ptr:
-                    self.lib.chg_host_free(ctypes.c_void_p(ptr))
+                if ptr:     # a block that proved too small is RETIRED, not freed: earlier PackedBatch objects may still point into it
+                    self.__dict__.setdefault("_pinned_retired", []).append(ptr)     # (freed with the engine; blocks grow geometrically)
                     pools.pop(slot, None)
                 out = ctypes.c_void_p()
                 want = need + need // 8
