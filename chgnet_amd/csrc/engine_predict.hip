@@ -511,7 +511,7 @@ int angleupd_bwd(chg_engine* eng, chg_batch* b, int l) {
 BondEmbedTArgs bond_embed_args(chg_engine* eng, chg_batch* b) {
   const Weights& w = eng->w;
   BondEmbedTArgs a{};
-  a.ev = b->ev; a.u_u2d = b->u_u2d; a.u_bnode = b->u_bnode; a.n_und = b->Eu;
+  a.ev = b->ev; a.u_u2d = b->u_u2d; a.u_bnode = b->u_bnode; a.n_und = b->Eu; a.bn_und = b->bn_und; a.n_nodes = b->Eb;
   a.freq_ag = w.freq_ag; a.freq_bg = w.freq_bg; a.w_emb = w.w_bond_emb; a.w_ag = w.w_wag; a.w_bg = w.w_wbg;
   a.rc_ag = eng->desc.atom_graph_cutoff; a.rc_bg = eng->desc.bond_graph_cutoff;
   const double p = eng->desc.cutoff_coeff;   // basis.py:184-186
@@ -551,8 +551,10 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   if (b->Ed > 0) {
     { LaunchScope ls(eng, "edge_geom");
       hipLaunchKernelGGL(k_edge_geom, g1(b->Ed), dim3(256), 0, st, b->cart, b->lattice, b->e_center, b->e_nbr, b->e_image, b->e_owner, b->ev, b->eu, b->Ed); }
-    { LaunchScope ls(eng, "bond_embed_fwd");
-      hipLaunchKernelGGL((k_bond_embed_t<false>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
+    { LaunchScope ls(eng, "bond_embed_fwd");   // atom-graph expansion for every bond, bond-graph expansion for the bond-graph nodes only
+      hipLaunchKernelGGL((k_bond_embed_t<false, false, 1>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
+      if (b->Eb > 0)
+        hipLaunchKernelGGL((k_bond_embed_t<false, false, 2>), dim3(grid_for(b->Eb, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
   }
   if (b->A > 0) {
     LaunchScope ls(eng, "angle_embed_fwd");
@@ -606,7 +608,9 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     }
     if (b->Ed > 0) {
       { LaunchScope ls(eng, "bond_embed_bwd");
-        hipLaunchKernelGGL((k_bond_embed_t<true>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
+        hipLaunchKernelGGL((k_bond_embed_t<true, false, 1>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
+        if (b->Eb > 0)
+          hipLaunchKernelGGL((k_bond_embed_t<true, false, 2>), dim3(grid_for(b->Eb, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
       if (b->A > 0) {
         LaunchScope ls(eng, "angle_embed_bwd");
         hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
@@ -791,8 +795,10 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_atomconv_fwd<4>, (size_t)100 << 10))) return s;
 #endif
   if ((s = set_lds(eng, k_readout<false>, readout_lds()))) return s;
-  if ((s = set_lds(eng, k_bond_embed_t<false>, bond_embed_lds()))) return s;
-  if ((s = set_lds(eng, k_bond_embed_t<true>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_bond_embed_t<false, false, 1>), bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_bond_embed_t<false, false, 2>), bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_bond_embed_t<true, false, 1>), bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, (k_bond_embed_t<true, false, 2>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<true>, angle_embed_lds()))) return s;
   return CHG_OK;

@@ -76,7 +76,8 @@ struct BondEmbedTArgs {
   const f32x4* ev;            // [Ed] (v, r)
   const int* u_u2d;           // [Eu]
   const int* u_bnode;         // [Eu] compact bond-node index or -1
-  int n_und;
+  const int* bn_und;          // [Eb] undirected bond of every bond-graph node (PART 2)
+  int n_und, n_nodes;
   const float *freq_ag, *freq_bg;   // [31]
   const float *w_emb, *w_ag, *w_bg; // [64][31]
   float rc_ag, rc_bg;
@@ -92,9 +93,16 @@ struct BondEmbedTArgs {
 
 constexpr size_t bond_embed_lds() { return sizeof(float) * (3 * D * WSB + WAVES * TILE_ROWS * ETS); }
 
-template <bool BWD, bool TRAIN = false>
+// PART: 0 = both radial expansions for every bond (the training variant); 1 = the atom-graph part, all Eu bonds (hb0, wag; adjoint: Grk
+// written); 2 = the bond-graph part over the Eb bonds that are bond-graph nodes only (wbgc; adjoint: Grk[k] += ...; launched after
+// part 1).  Only 12 % of the bonds of a 6 A / 3 A graph are nodes, and the kernel is bound by its 62 sin / cos per bond: evaluating the
+// 31 bond-graph functions for the nodes only takes 44 % of the transcendentals out (forward 0.34 -> 0.2x ms, section 6 of DESIGN.md).
+template <bool BWD, bool TRAIN = false, int PART = 0>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedTArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
+  static_assert(!TRAIN || PART == 0, "the training variant keeps both expansions in one pass (it dumps them side by side)");
+  constexpr bool AG = PART != 2, BG = PART != 1;     // which expansion(s) this instantiation evaluates
+  const int n_rows = PART == 2 ? p.n_nodes : p.n_und;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
   float* Wa = We + D * WSB;
@@ -102,13 +110,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   float* tiles = Wb + D * WSB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   if (BWD) {   // adjoint: split images of the transposes (2,048 of the 2,304 floats of a slot)
-    stage_embed_split_t(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
-    stage_embed_split_t(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
-    stage_embed_split_t(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
+    if (AG) stage_embed_split_t(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
+    if (AG) stage_embed_split_t(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
+    if (BG) stage_embed_split_t(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
   } else {   // forward: split images in the same slots (2,048 of the 2,304 floats)
-    stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
-    stage_embed_split(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
-    stage_embed_split(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
+    if (AG) stage_embed_split(reinterpret_cast<h16x8*>(We), p.w_emb, tid);
+    if (AG) stage_embed_split(reinterpret_cast<h16x8*>(Wa), p.w_ag, tid);
+    if (BG) stage_embed_split(reinterpret_cast<h16x8*>(Wb), p.w_bg, tid);
   }
   // this lane's 8 basis indices k = 16*kt + 4*g + r and their frequencies (k = 31 is padding)
   float f6[2][4], f3[2][4];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   __syncthreads();
   float* T = tiles + wave * TILE_ROWS * ETS;
   float* Trow = T + j * ETS;
-  const int ntiles = (p.n_und + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int ntiles = (n_rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
   tile_range(ntiles, tb, te);
   float fa6[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, fa3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // TRAIN: d freq, this lane's rows
@@ -131,29 +139,31 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   // tile t+2 are requested at the top of tile t and taken (an empty asm: a wait placed by hand) after the basis functions, BEFORE the
   // tile's stores.  Read in place, every tile began with two dependent round trips, waited for behind the previous tile's stores
   // (conditional, so the compiler's wait covered them all): SQ_WAIT_ANY 61 % of the wave cycles of the forward kernel.
-  auto row_k = [&](int tile) { return max(0, min(tile * BLOCK_ROWS + wave * TILE_ROWS + j, p.n_und - 1)); };
+  // (PART 2 walks the node list: row n -> bond bn_und[n]; the bond index rides in `node_n*` there, one more dependent load per request)
+  auto row_k = [&](int tile) { return max(0, min(tile * BLOCK_ROWS + wave * TILE_ROWS + j, n_rows - 1)); };
+  auto bond_of = [&](int row) { return PART == 2 ? p.bn_und[row] : row; };
   int d_n = 0, node_n = -1, d_n2 = 0, node_n2 = -1;
   float rlen_n = 1.f;
   if (tb < te) {
-    const int k0 = row_k(tb), k1 = row_k(tb + 1);
-    d_n = p.u_u2d[k0]; node_n = p.u_bnode[k0];
-    d_n2 = p.u_u2d[k1]; node_n2 = p.u_bnode[k1];
+    const int k0 = bond_of(row_k(tb)), k1 = bond_of(row_k(tb + 1));
+    d_n = p.u_u2d[k0]; node_n = PART == 2 ? k0 : p.u_bnode[k0];
+    d_n2 = p.u_u2d[k1]; node_n2 = PART == 2 ? k1 : p.u_bnode[k1];
     rlen_n = p.ev[d_n][3];
   }
   for (int tile = tb; tile < te; ++tile) {
     const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
-    const int nvalid = min(TILE_ROWS, p.n_und - row0);
+    const int nvalid = min(TILE_ROWS, n_rows - row0);
     const float rlen = rlen_n;
-    const int node = node_n;
+    const int node = node_n;      // PART 0 / 1: compact node index of this bond (or -1); PART 2: the bond of this node row
     {   // requests for the next two tiles (clamped rows: harmless reads past the end)
       node_n = node_n2;
       rlen_n = p.ev[d_n2][3];
-      const int k2 = row_k(tile + 2);
-      d_n2 = p.u_u2d[k2]; node_n2 = p.u_bnode[k2];
+      const int k2 = bond_of(row_k(tile + 2));
+      d_n2 = p.u_u2d[k2]; node_n2 = PART == 2 ? k2 : p.u_bnode[k2];
     }
     if (nvalid <= 0) continue;
     const bool valid = j < nvalid;
-    const int k = row0 + (valid ? j : 0);
+    const int k = row0 + (valid ? j : 0);      // row of this instantiation's list: bond (PART 0 / 1) or node (PART 2)
     f32x4 x6[2], x3[2], d6[2], d3[2], q6[2], q3[2];
     const EnvAt e6 = env_at(rlen, p.rc_ag, p.env), e3 = env_at(rlen, p.rc_bg, p.env);
 #pragma unroll
@@ -161,22 +171,29 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool pad = 16 * kt + 4 * g + r >= NRAD;
-        float v, dv, df;
-        rbf_eval(rlen, p.rc_ag, f6[kt][r], e6, v, dv, df);
-        x6[kt][r] = pad ? 0.f : v;
-        d6[kt][r] = pad ? 0.f : dv;
-        q6[kt][r] = pad ? 0.f : df;
-        rbf_eval(rlen, p.rc_bg, f3[kt][r], e3, v, dv, df);
-        x3[kt][r] = pad ? 0.f : v;
-        d3[kt][r] = pad ? 0.f : dv;
-        q3[kt][r] = pad ? 0.f : df;
+        float v = 0.f, dv = 0.f, df = 0.f;
+        if (AG) rbf_eval(rlen, p.rc_ag, f6[kt][r], e6, v, dv, df);
+        x6[kt][r] = (pad || !AG) ? 0.f : v;
+        d6[kt][r] = (pad || !AG) ? 0.f : dv;
+        q6[kt][r] = (pad || !AG) ? 0.f : df;
+        if (BG) rbf_eval(rlen, p.rc_bg, f3[kt][r], e3, v, dv, df);
+        x3[kt][r] = (pad || !BG) ? 0.f : v;
+        d3[kt][r] = (pad || !BG) ? 0.f : dv;
+        q3[kt][r] = (pad || !BG) ? 0.f : df;
       }
     asm volatile("" : "+v"(rlen_n), "+v"(d_n2), "+v"(node_n2));   // the requests above have landed by now; nothing is stored before here
     if (TRAIN && valid) {   // bases of this bond: B operand of the embedding-weight gradients (kernels_train.h)
       write_dl<2>(p.Xb + (size_t)k * D, g, x6);
       write_dl<2>(p.Xb + (size_t)k * D + KB, g, x3);
     }
-    if (!BWD) {
+    if (!BWD && PART == 2) {     // bond-graph weights of the node rows: contiguous rows of wbgc
+      V64 h = zero64();
+      gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(Wb), D, x3, j, g);
+      write_dl<VT>(Trow, g, h.t);
+      __builtin_amdgcn_wave_barrier();
+      scatter_rows64<false>(T, ETS, p.wbgc, k, nvalid, lane);
+      __builtin_amdgcn_wave_barrier();
+    } else if (!BWD) {
       V64 h = zero64();
       gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(We), D, x6, j, g);
       write_dl<VT>(Trow, g, h.t);
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
       __builtin_amdgcn_wave_barrier();
       scatter_rows64<false>(T, ETS, p.wag, k, nvalid, lane);
       __builtin_amdgcn_wave_barrier();
-      if (__any(valid && node >= 0)) {
+      if (BG && __any(valid && node >= 0)) {
         h = zero64();
         gemm_split<2, VT, true>(h.t, reinterpret_cast<const h16x8*>(Wb), D, x3, j, g);
         write_dl<VT>(Trow, g, h.t);
@@ -215,6 +232,19 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
         }
       }
       __builtin_amdgcn_wave_barrier();
+    } else if (PART == 2) {      // dE/dr of the node bonds through the bond-graph weights: Grk[bond] += (Wb^T Gwbgc[node]) . d(basis)/dr
+      f32x4 t3[2] = {zero4(), zero4()};
+      V64 gin;
+      const float old = valid ? p.Grk[node] : 0.f;      // (node = this row's bond here; part 1 has written Grk)
+      read_dl<VT>(p.Gwbgc + (size_t)k * D, g, gin.t);
+      embed_adjoint(t3, Wb, gin, j, g);
+      float acc = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += t3[kt][r] * d3[kt][r];
+      acc = quad_sum(acc);
+      if (valid && g == 0) p.Grk[node] = old + acc;
     } else {
       // t6 = We^T Gb[k] + Wa^T Gwag[k],  t3 = Wb^T Gwbgc[node]   (64 -> 32 each), then dot with d(basis)/dr
       f32x4 t6[2] = {zero4(), zero4()}, t3[2] = {zero4(), zero4()};
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
       read_dl<VT>(Trow, g, gin.t);
       embed_adjoint(t6, Wa, gin, j, g);
       __builtin_amdgcn_wave_barrier();
-      if (__any(valid && node >= 0)) {
+      if (BG && __any(valid && node >= 0)) {
         read_dl<VT>(p.Gwbgc + (size_t)(node >= 0 ? node : 0) * D, g, gin.t);
         if (node < 0) gin = zero64();
         embed_adjoint(t3, Wb, gin, j, g);
