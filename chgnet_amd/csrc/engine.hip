@@ -293,6 +293,7 @@ int chg_batch_update_geometry(chg_engine* eng, chg_batch* b, const float* frac, 
       b->h_volume[q] = Lf[0] * (Lf[4] * Lf[8] - Lf[5] * Lf[7]) + Lf[1] * (Lf[5] * Lf[6] - Lf[3] * Lf[8]) + Lf[2] * (Lf[3] * Lf[7] - Lf[4] * Lf[6]);
     }
   }
+  b->q_tables = false;             // tables of the previous geometry
   if (s == CHG_OK) HIP_TRY(eng, hipStreamSynchronize(eng->stream));
   return s;
 }
@@ -347,6 +348,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   HIP_TRY(eng, hipGraphLaunch(b->graph_exec, eng->stream));
   b->last_task = task;
   b->seed1_adjoints = (task & (CHG_TASK_F | CHG_TASK_S)) != 0;
+  b->q_tables = b->seed1_adjoints;
   return CHG_OK;
 }
 

@@ -183,6 +183,7 @@ struct chg_batch {
   struct Train2* t2 = nullptr;
   float* t_mcot = nullptr;   // [N] magmom cotangent
   float h_g_b3 = 0.f;        // host-side gradient of the readout's last bias (copied into the blob on the device)
+  bool q_tables = false;       // Ql[l] hold the bond partials of the LAST prediction (its forward kernels store them when a reverse sweep follows)
   bool wide_range = false;     // a prediction of this batch left the f16 operand range: it runs through chgh_wide::run_predict from then on
   bool t_has_mcot = false;
   float *t_grad = nullptr, *t_cot = nullptr, *t_tmp = nullptr /* 256 floats of scratch */, *t_dumpG = nullptr, *t_dumpH = nullptr, *t_dumpZ = nullptr, *t_Xb = nullptr, *t_Xa = nullptr,

@@ -635,6 +635,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   }
   b->last_task = task;
   b->seed1_adjoints = want_grad;
+  b->q_tables = want_grad;      // atomconv_fwd(keep_q = want_grad) left the bond partials behind as tables
   return CHG_OK;
 }
 

@@ -965,7 +965,11 @@ int backward_compute(chg_engine* eng, chg_batch* b, const float* energy_cotangen
   }
   HIP_TRY(eng, hipStreamSynchronize(eng->stream));   // cot is a stack-lifetime host buffer
   // the forward kernels contract the bond partials in place (and store them only for force / stress tasks); the training sweeps gather them as tables
-  if (b->Ed > 0) for (int l = 0; l < b->L; ++l) TRY(atomconv_q_table(eng, b, l));
+  // (an energy-only prediction does not: build them then; 4 row GEMMs over all bonds, 1.6 ms per 1024 structures)
+  if (b->Ed > 0 && !b->q_tables) {
+    for (int l = 0; l < b->L; ++l) TRY(atomconv_q_table(eng, b, l));
+    b->q_tables = true;
+  }
   TRY(second_order ? run_backward2(eng, b) : run_backward(eng, b));
   // the b3 slot joins the blob ON THE DEVICE, so that a following all-reduce sums it over the ranks like every other entry (it used
   // to be written into the host copy after the collective: every rank then applied its LOCAL value / world -- ADVICE r03)
