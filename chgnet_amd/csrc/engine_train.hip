@@ -7,6 +7,7 @@
 #include "kernels_train.h"
 #include "kernels_train2.h"
 #include "kernels_train2_tile.h"
+#include "kernels_train2_freq.h"
 
 struct Train2 {
   float *ux, *Wst;                                   // direction: [N,3], [B,9]
@@ -869,25 +870,44 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     TRY((xty<4, 2>(eng, "t2_wgrad", g_wag, D, nullptr, t.X6d, KB2, nullptr, Eu, 1.0f, G(w.w_wag), NRAD, NRAD)));
     TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_wbg, D, nullptr, t.X3, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
     TRY((xty<4, 2>(eng, "t2_wgrad", g_wbg, D, nullptr, t.X3d, KB2, b->bn_und, Eb, 1.0f, G(w.w_wbg), NRAD, NRAD)));
+    // frequency gradients on 16-row tiles (kernels_train2_freq.h; CHGNET_T2_FREQ_ROWS=1 keeps the one-row-per-wave kernels for A/B runs)
+    static const bool freq_rows = [] { const char* e = std::getenv("CHGNET_T2_FREQ_ROWS"); return e && std::atoi(e) != 0; }();
     {
-      FreqGradArgs a{Eu, nullptr, b->ev, t.vd4, b->u_u2d, w.freq_ag, eng->desc.atom_graph_cutoff, env, t.bar_b, t.g_b, w.w_bond_emb,
-                     t.bar_wag, g_wag, w.w_wag, G(w.freq_ag)};
       LaunchScope ls(eng, "t2_freq");
-      hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eu), dim3(256), 0, st, a);
+      if (freq_rows) {
+        FreqGradArgs a{Eu, nullptr, b->ev, t.vd4, b->u_u2d, w.freq_ag, eng->desc.atom_graph_cutoff, env, t.bar_b, t.g_b, w.w_bond_emb,
+                       t.bar_wag, g_wag, w.w_wag, G(w.freq_ag)};
+        hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eu), dim3(256), 0, st, a);
+      } else {
+        FreqGradTArgs a{Eu, nullptr, b->ev, t.vd4, b->u_u2d, w.freq_ag, eng->desc.atom_graph_cutoff, env, t.bar_b, t.g_b, w.w_bond_emb,
+                        t.bar_wag, g_wag, w.w_wag, G(w.freq_ag)};
+        hipLaunchKernelGGL(k2_freq_grad_t, dim3(grid_for(Eu, 2 * eng->num_cus)), dim3(BLOCK), freq_grad_lds(), st, a);
+      }
     }
     if (Eb > 0) {
-      FreqGradArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, g_wbg, w.w_wbg,
-                     nullptr, nullptr, nullptr, G(w.freq_bg)};
       LaunchScope ls(eng, "t2_freq");
-      hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eb), dim3(256), 0, st, a);
+      if (freq_rows) {
+        FreqGradArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, g_wbg, w.w_wbg,
+                       nullptr, nullptr, nullptr, G(w.freq_bg)};
+        hipLaunchKernelGGL(k2_freq_grad, wave_rows_grid(eng, Eb), dim3(256), 0, st, a);
+      } else {
+        FreqGradTArgs a{Eb, b->bn_und, b->ev, t.vd4, b->u_u2d, w.freq_bg, eng->desc.bond_graph_cutoff, env, t.bar_wbg, g_wbg, w.w_wbg,
+                        nullptr, nullptr, nullptr, G(w.freq_bg)};
+        hipLaunchKernelGGL(k2_freq_grad_t, dim3(grid_for(Eb, 2 * eng->num_cus)), dim3(BLOCK), freq_grad_lds(), st, a);
+      }
     }
   }
   if (angles) {
     TRY((xty<4, 2>(eng, "t2_wgrad", t.bar_ang, D, nullptr, t.X4, KB2, nullptr, A, 1.0f, G(w.w_ang_emb), NANG, NANG)));
     TRY((xty<4, 2>(eng, "t2_wgrad", t.g_ang, D, nullptr, t.X4d, KB2, nullptr, A, 1.0f, G(w.w_ang_emb), NANG, NANG)));
     LaunchScope ls(eng, "t2_freq");
-    hipLaunchKernelGGL(k2_angle_freq_grad, wave_rows_grid(eng, A), dim3(256), 0, st, t.bar_ang, t.g_ang, w.w_ang_emb, t.th2, w.freq_ang,
-                       G(w.freq_ang), A);
+    static const bool freq_rows_a = [] { const char* e = std::getenv("CHGNET_T2_FREQ_ROWS"); return e && std::atoi(e) != 0; }();
+    if (freq_rows_a)
+      hipLaunchKernelGGL(k2_angle_freq_grad, wave_rows_grid(eng, A), dim3(256), 0, st, t.bar_ang, t.g_ang, w.w_ang_emb, t.th2, w.freq_ang,
+                         G(w.freq_ang), A);
+    else
+      hipLaunchKernelGGL(k2_angle_freq_grad_t, dim3(grid_for(A, 2 * eng->num_cus)), dim3(BLOCK), angle_freq_grad_lds(), st, t.bar_ang, t.g_ang,
+                         w.w_ang_emb, t.th2, w.freq_ang, G(w.freq_ang), A);
   }
   {
     LaunchScope ls(eng, "wgrad_atom_embed");
@@ -919,6 +939,8 @@ int train_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_xty<4, 4>), (xty_lds<4, 4>())))) return s;
   if ((s = set_lds(eng, (k_xty<4, 2>), (xty_lds<4, 2>())))) return s;
   if ((s = set_lds(eng, k2_scatter_z, scatter_z_lds()))) return s;
+  if ((s = set_lds(eng, k2_freq_grad_t, freq_grad_lds()))) return s;
+  if ((s = set_lds(eng, k2_angle_freq_grad_t, angle_freq_grad_lds()))) return s;
   return CHG_OK;
 }
 

@@ -510,6 +510,53 @@ np.save(sys.argv[2], np.stack([g1, g2, g3]))
     assert np.abs(out["fused"][1] - out["unfused"][1]).max() <= 1e-4 * scale, float(np.abs(out["fused"][1] - out["unfused"][1]).max() / scale)
 
 
+def test_tile_frequency_gradient_kernels_equal_the_one_row_per_wave_ones():
+    """kernels_train2_freq.h (16-row tiles, MFMA adjoints) against kernels_train2.h's k2_freq_grad / k2_angle_freq_grad
+    (CHGNET_T2_FREQ_ROWS=1, read once per process: a child process each).  Compared per ``frequencies`` tensor, each against its
+    own magnitude -- next to the weight gradients of the same blob they are small."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bench
+from chgnet_amd.engine import Engine
+from chgnet_amd.pack import pack_batch, pack_weights, unpack_weight_grads
+W = dict(np.load(sys.argv[1] + "/tests/golden/weights_trained_like.npz"))
+pw = pack_weights(W)
+from chgnet_amd import CrystalGraphConverter
+conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+pb = pack_batch(bench.build_workload(40, 7100) + [conv(bench.sweep_structure(i)) for i in range(3)])
+rng = np.random.default_rng(12)
+n = pb.n_struct
+gf = rng.normal(size=(pb.n_atoms, 3)).astype(np.float32); gs = rng.normal(size=(n, 3, 3)).astype(np.float32)
+eng = Engine(pw, 0)
+b = eng.upload(pb)
+eng.predict(b, "efs")
+g = unpack_weight_grads(eng.backward(b, rng.normal(size=n).astype(np.float32), None, f_grad=gf, s_grad=gs), pw)
+np.savez(sys.argv[2], **{k: v for k, v in g.items() if k.endswith("frequencies")})
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("tiles", "rows"):
+            env = dict(os.environ)
+            env.pop("CHGNET_T2_FREQ_ROWS", None)
+            if mode == "rows":
+                env["CHGNET_T2_FREQ_ROWS"] = "1"
+            path = os.path.join(tmp, mode + ".npz")
+            subprocess.run([sys.executable, "-c", code, repo, path], check=True, env=env, timeout=600)
+            out[mode] = dict(np.load(path))
+    assert len(out["rows"]) == 3, sorted(out["rows"])
+    for k, want in out["rows"].items():
+        scale = float(np.abs(want).max())
+        assert scale > 0 and np.isfinite(out["tiles"][k]).all(), k
+        assert float(np.abs(out["tiles"][k] - want).max()) <= 2e-4 * scale, (k, float(np.abs(out["tiles"][k] - want).max()) / scale)
+
+
 def test_three_piece_bf16_weight_gradient_contraction_equals_the_f32_mfma_one():
     """k_xty3 (long row operands: fp32 cut exactly into three bf16 pieces, six bf16 MFMAs per product) against k_xty (f32 MFMA,
     CHGNET_XTY3=0, chosen once per process: a child process each): first- and second-order gradient blobs agree to fp32
