@@ -324,11 +324,12 @@ class TrainStep:
         thread (native code, GIL released) while the device works on the current one -- the role of the reference's DataLoader workers
         (chgnet/data/dataset.py ``get_train_val_test_loader``).
 
-        ``upload_ahead=True`` lets the helper also put the packed batch on the device (``Engine.upload`` on its copy stream, under the
-        current step's sweeps).  Measured on MI355X boxes (1024-structure batches, profiles/r04_experiments.md): 5.0-5.2k instead of
-        4.8-5.0k structures/s on most hosts, but 4.2k on a slow one, where packing + uploading one batch took longer than a step --
-        and every variant that splits the two over two threads ran the copies next to the forward's launches and download (its time
-        doubled on some boxes).  Off by default: the epoch time should not depend on the host."""
+        ``upload_ahead=True`` lets the helper also put the packed batch on the device (``Engine.upload`` on its copy stream).  The
+        copy is held back until the CURRENT step's forward results are on the host: it then runs under the backward sweeps (5 ms of
+        DMA from the page-locked packing buffer under ~120 ms of kernels) and never next to the forward's launches and download --
+        started right after packing it collided with them and doubled the forward's time on some hosts (round 4).  Two batches are
+        resident on the device then.  Measured on MI355X boxes (1024-structure batches, tools/gpu_train_ab.py): 3 % more
+        structures/s; off by default because a host that packs slower than the device steps gains nothing from it."""
         from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
 
         from chgnet_amd.pack import pack_batch  # noqa: PLC0415
@@ -341,10 +342,18 @@ class TrainStep:
             # then DMA at the link rate
             pinned = getattr(getattr(self.model, "engine", None), "pinned_allocator", None)
             packed = pack_batch(batches[i], alloc=pinned(i & 1) if pinned is not None else None)
-            return packed, (self.model.engine.upload(packed) if upload_ahead else None), flat
+            device_batch = None
+            if upload_ahead:
+                if i > 0:
+                    forward_done[i - 1].wait()
+                device_batch = self.model.engine.upload(packed)
+            return packed, device_batch, flat
 
         import sys  # noqa: PLC0415
 
+        import threading  # noqa: PLC0415
+
+        forward_done = [threading.Event() for _ in batches]
         infos = []
         # Two interpreter threads: with CPython's default 5 ms switch interval the main thread's loss (a few dozen small numpy calls,
         # 0.3 ms alone) took 20-27 ms next to the loader -- every time it gave the lock up it waited a full interval to get it back
@@ -357,17 +366,23 @@ class TrainStep:
                 for i in range(len(batches)):
                     packed, device_batch, flat = nxt.result()
                     nxt = pool.submit(prepare, i + 1) if i + 1 < len(batches) else None
-                    infos.append(self(packed, targets[i], device_batch=device_batch, flat_targets=flat))
+                    infos.append(self(packed, targets[i], device_batch=device_batch, flat_targets=flat, after_forward=forward_done[i].set))
         finally:
+            for ev in forward_done:      # a step that raised must not leave the helper waiting
+                ev.set()
             sys.setswitchinterval(interval)
         return infos
 
-    def __call__(self, graphs, targets: dict, device_batch=None, flat_targets: dict | None = None) -> dict:
+    def __call__(self, graphs, targets: dict, device_batch=None, flat_targets: dict | None = None, after_forward=None) -> dict:
         import time  # noqa: PLC0415
 
         model = self.model
         t0 = time.perf_counter()
-        pred = model.forward(graphs, task=self.task, device_batch=device_batch)
+        try:
+            pred = model.forward(graphs, task=self.task, device_batch=device_batch)
+        finally:
+            if after_forward is not None:     # run_epoch: the helper thread may start the next batch's upload now
+                after_forward()
         t1 = time.perf_counter()
         info, g = self.loss.gradients(targets, pred, flat_targets=flat_targets)
         t2 = time.perf_counter()

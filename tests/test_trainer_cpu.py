@@ -196,6 +196,7 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
     runs): every step gets the device batch that was uploaded from ITS packed batch, in order, each batch uploaded exactly once, for
     epochs of 1, 2 and 5 batches; with the default (False) the helper only packs and the step uploads.  Stub model and engine."""
     import threading
+    import time
 
     from conftest import load_case
 
@@ -204,11 +205,12 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
 
     class StubEngine:
         def __init__(self):
-            self.uploads, self.lock = [], threading.Lock()
+            self.uploads, self.events, self.lock = [], [], threading.Lock()
 
         def upload(self, packed):
             with self.lock:
                 self.uploads.append(packed.n_struct)          # (unique per batch in this test; id() is reused after collection)
+                self.events.append(("upload", packed.n_struct))
             return ("device", packed.n_struct)
 
     class StubModel:
@@ -230,6 +232,11 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
             else:
                 assert device_batch is None
             self.steps.append(packed.n_struct)
+            if self.fail_at == packed.n_struct:
+                raise RuntimeError("forward failed")
+            time.sleep(0.02)                                  # the helper has packed the next batch long before this returns
+            with self.engine.lock:
+                self.engine.events.append(("forward done", packed.n_struct))
             b = packed.n_struct
             out = {"atoms_per_graph": np.diff(packed.atom_off).astype(np.int64), "e": np.zeros(b, np.float32),
                    "f": [np.zeros((n_at, 3), np.float32) for _ in range(b)]}
@@ -240,11 +247,27 @@ def test_run_epoch_hands_every_batch_its_own_upload_in_order():
 
     for n_batches, ahead in ((1, True), (2, True), (5, True), (3, False)):
         model = StubModel()
-        model.expect_upload = ahead
+        model.expect_upload, model.fail_at = ahead, -1
         step = TrainStep(model, targets="ef", learning_rate=1e-3)
         batches = [[graph] * (i + 1) for i in range(n_batches)]          # batch i holds i + 1 structures: the order is visible
         labels = [{"e": np.zeros(i + 1, np.float32), "f": [np.zeros((n_at, 3), np.float32) for _ in range(i + 1)]} for i in range(n_batches)]
         infos = step.run_epoch(batches, labels, upload_ahead=ahead)
         assert len(infos) == n_batches and model.steps == [i + 1 for i in range(n_batches)]
         assert model.engine.uploads == ([i + 1 for i in range(n_batches)] if ahead else [])      # each batch once, in order
+        # the copy of batch i + 1 is held back until the forward of batch i has returned (it then runs under the backward sweeps,
+        # never next to the forward's launches and download)
+        ev = model.engine.events
+        for i in range(2, n_batches + 1):
+            if ahead:
+                assert ev.index(("upload", i)) > ev.index(("forward done", i - 1)), ev
     assert step.run_epoch([], []) == []
+    # a step that raises does not leave the helper thread waiting for its forward
+    model = StubModel()
+    model.expect_upload, model.fail_at = True, 2
+    step = TrainStep(model, targets="ef", learning_rate=1e-3)
+    batches = [[graph] * (i + 1) for i in range(4)]
+    labels = [{"e": np.zeros(i + 1, np.float32), "f": [np.zeros((n_at, 3), np.float32) for _ in range(i + 1)]} for i in range(4)]
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="forward failed"):
+        step.run_epoch(batches, labels, upload_ahead=True)
+    assert time.perf_counter() - t0 < 30 and model.steps == [1, 2]
