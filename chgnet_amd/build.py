@@ -24,7 +24,7 @@ GRAPH_LIB = os.path.join(LIB_DIR, "libchgnet_graph.so")
 HIP_LIB = os.path.join(LIB_DIR, "libchgnet_hip.so")
 
 # one translation unit per subsystem (csrc/engine_internal.h): a kernel edit recompiles the unit that launches it
-HIP_SOURCES = ["engine.hip", "engine_predict.hip", "engine_predict_wide.hip", "engine_train.hip", "engine_graph.hip", "comm.hip"]
+HIP_SOURCES = ["engine.hip", "engine_predict.hip", "engine_predict_wide.hip", "engine_train.hip", "engine_train_wide.hip", "engine_graph.hip", "comm.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-munsafe-fp-atomics",      # native global_atomic_add_f32, no CAS loops
@@ -77,7 +77,7 @@ def _compile_units(out: str, extra: list[str], obj_dir: str, force: bool) -> Non
     for name in HIP_SOURCES:
         src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name.replace(".hip", ".o"))
         objs.append(obj)
-        deps = [src, *headers] + ([os.path.join(CSRC, "engine_predict.hip")] if name == "engine_predict_wide.hip" else [])   # it includes that unit
+        deps = [src, *headers] + ([os.path.join(CSRC, name.replace("_wide", ""))] if name.endswith("_wide.hip") else [])   # it includes that unit
         if force or not _newer(obj, deps):
             todo.append([hipcc_path(), *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:

@@ -125,6 +125,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
     return CHG_EUNSUPPORTED;
   }
   if (const char* g = std::getenv("CHGNET_HIP_GRAPHS")) eng->use_graphs = std::string(g) != "0";
+  if (const char* g = std::getenv("CHGNET_WIDE_RANGE")) eng->force_wide = std::string(g) == "1";
   if (const char* g = std::getenv("CHGNET_SPEC_BUILD")) eng->spec_builds = std::string(g) != "0";
   HIP_TRY(eng, hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -150,7 +151,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   layout_weights(eng->d_weights, desc->n_conv, eng->w);
   { const int si = build_images(eng); if (si) return si; }
   // kernels that need more than the default 64 KiB of dynamic LDS: every unit sets the attributes of the kernels it launches
-  { int s; if ((s = predict_set_lds(eng)) || (s = chgh_wide::predict_set_lds(eng)) || (s = train_set_lds(eng))) return s; }
+  { int s; if ((s = predict_set_lds(eng)) || (s = chgh_wide::predict_set_lds(eng)) || (s = train_set_lds(eng)) || (s = chgh_wide::train_set_lds(eng))) return s; }
   return CHG_OK;
 }
 
@@ -270,6 +271,11 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
 
 int chg_debug_fetch_i32(chg_engine* eng, chg_batch* b, const char* name, int32_t* dst, int64_t capacity, int64_t* n_written) {
   if (!eng || !b || !name || !dst) return CHG_EINVAL;
+  if (std::strcmp(name, "wide_range") == 0) {   // host-side state: 1 = the batch runs on the wide-range sweeps (engine_*_wide.hip)
+    if (capacity >= 1) dst[0] = b->wide_range ? 1 : 0;
+    if (n_written) *n_written = capacity >= 1 ? 1 : 0;
+    return CHG_OK;
+  }
   auto it = b->named_i32.find(name);
   if (it == b->named_i32.end()) { eng->err = std::string("chg_debug_fetch_i32: unknown buffer ") + name; return CHG_EINVAL; }
   const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));
@@ -324,6 +330,7 @@ int chg_predict(chg_engine* eng, chg_batch* b, uint32_t task_mask) {
   HIP_TRY(eng, hipSetDevice(eng->device));
   const uint32_t task = task_mask | CHG_TASK_E;
   TRY(ensure_windows(eng, b));
+  if (eng->force_wide) b->wide_range = true;
   if (b->wide_range) return chgh_wide::run_predict(eng, b, task);   // an earlier prediction of this batch overflowed the f16 operands
   if (eng->profiling || !eng->use_graphs) return run_predict(eng, b, task);   // per-kernel events need eager launches
   if (b->graph_task != task) {

@@ -107,6 +107,7 @@ struct chg_engine {
   std::vector<std::pair<char*, size_t>> work_pool;    // released training workspaces (tens of GB: a hipMalloc per step would dominate it)
   std::vector<int> work_kind;                         // 0: first-order workspace, 1: second-order workspace
   bool use_graphs = true;   // CHGNET_HIP_GRAPHS=0 forces eager launches
+  bool force_wide = false;  // CHGNET_WIDE_RANGE=1: every batch runs on the wide-range sweeps from its first prediction (tests: the goldens through them)
   char* scratch = nullptr;  // grow-only scratch of chg_batch_build (MD rebuilds the graph every step)
   size_t scratch_bytes = 0, scratch_wanted = 0;
   char* h_stage = nullptr;   // pinned staging for the inputs of chg_batch_build
@@ -310,9 +311,13 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
 }  // namespace chgh
 
 // engine_predict_wide.hip: the prediction sweep with every operand row of the split contractions scaled (any fp32 magnitude)
+// engine_train_wide.hip: the fine-tuning sweeps likewise
 namespace chgh_wide {
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
 int predict_set_lds(chg_engine* eng);
+int backward_compute(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent, const float* force_cotangent,
+                     const float* stress_cotangent);
+int train_set_lds(chg_engine* eng);
 }  // namespace chgh_wide
 
 using namespace chgh;

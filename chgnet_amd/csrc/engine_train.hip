@@ -949,11 +949,11 @@ int backward_compute(chg_engine* eng, chg_batch* b, const float* energy_cotangen
                             const float* force_cotangent, const float* stress_cotangent) {
   if (b->last_task == 0) { eng->err = "chg_backward: run chg_predict on this batch first (the reverse sweep reuses its activations)"; return CHG_EINVAL; }
   if ((int)b->h_atom_off.size() != b->B + 1) { eng->err = "chg_backward: batch has no host atom offsets"; return CHG_EINVAL; }
-  if (b->wide_range) {   // the training sweeps exist in the product (unscaled-operand) form only
-    eng->err = "chg_backward: this batch left the f16 operand range of the split contractions and runs on the wide-range prediction "
-               "sweep (engine_predict_wide.hip); parameter gradients are not available for it";
-    return CHG_EUNSUPPORTED;
-  }
+#ifndef CHG_WIDE_RANGE
+  // a batch that left the f16 operand range of the split contractions (chg_batch_download moved it to the wide-range prediction
+  // sweep) gets its gradients from the same sweeps compiled with row-scaled operands: engine_train_wide.hip
+  if (b->wide_range) return chgh_wide::backward_compute(eng, b, energy_cotangent, magmom_cotangent, force_cotangent, stress_cotangent);
+#endif
   TRY(ensure_train_buffers(eng, b));
   // cotangent of the per-structure energy SUMS: e_b = E_b / n_b for an intensive model (model.py:538-540); AtomRef is frozen
   std::vector<float> cot(b->B);
@@ -1041,6 +1041,7 @@ int backward_impl(chg_engine* eng, chg_batch* b, const float* energy_cotangent, 
 
 }  // namespace chgh
 
+#ifndef CHG_WIDE_RANGE   // (engine_train_wide.hip compiles this unit a second time for the sweeps only)
 extern "C" {
 
 int chg_backward(chg_engine* eng, chg_batch* b, const float* energy_cotangent, const float* magmom_cotangent,
@@ -1054,3 +1055,4 @@ int chg_backward_allreduce(chg_engine* eng, chg_batch* b, const float* energy_co
 }
 
 }  // extern "C"
+#endif
