@@ -40,7 +40,8 @@ typedef enum {
                           their weights as f16 hi / lo images) -- chg_engine_create / chg_engine_update_weights.  ACTIVATIONS of any fp32
                           magnitude are computed: a batch whose product sweep overflows the f16 operands is detected at
                           chg_batch_download (non-finite results) and run again on the wide-range sweep (csrc/engine_predict_wide.hip),
-                          like the reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE) */
+                          like the reference's fp32 path (crystalgraph.py:12 TORCH_DTYPE); chg_backward follows it there
+                          (csrc/engine_train_wide.hip) */
 } chg_status;
 
 /* task bits (reference task strings "e","ef","em","efs","efsm": chgnet/__init__.py:15) */
