@@ -45,7 +45,7 @@ __device__ __forceinline__ void hidden_t(const V64& z, const V64& zd, V64& h, V6
 // the reverse kernels' 8,000 vector instructions per tile there (profiles/r05_experiments.md section 13).
 __device__ __forceinline__ float row_mean64(const f32x4& s) { return quad_sum(hsum4(s)) * (1.0f / 64.0f); }
 __device__ __forceinline__ f32x4 vec4(const float* vec, int ft, int g) { return *reinterpret_cast<const f32x4*>(vec + 16 * ft + 4 * g); }   // LDS parameter vector
-__device__ __forceinline__ f32x4 rd4(const float* __restrict__ base, int row, int ft, int g) { return *grow<f32x4>(base, (unsigned)row, D, 16 * ft + 4 * g); }
+__device__ __forceinline__ f32x4 rd4(const float* base, int row, int ft, int g, int ld = D) { return *grow<f32x4>(base, (unsigned)row, ld, 16 * ft + 4 * g); }
 
 // c <- xhat, cd <- P(cd) = cd - mean(cd) - xhat mean(cd xhat);  rstd and mt = mean(cd xhat) of this lane's row
 __device__ __forceinline__ void ln2_forward(V64& c, V64& cd, float& rstd, float& mt) {
@@ -130,7 +130,7 @@ __device__ __forceinline__ void ln2_backward(V64& bn, V64& gn, const float* gamm
   }
 }
 
-// k2_atom keeps the one-row-at-a-time form of its row-local part only in CHG_T2_ROWS=1 builds (A/B; k2_angle: t2_rows below)
+// k2_atom<reverse> keeps the one-row-at-a-time form of its row-local part (t2_rows below: why); CHG_T2_ROWS=1: the tangent forward as well
 #ifndef CHG_T2_ROWS
 #define CHG_T2_ROWS 0
 #endif
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  float* Arow = T + (j & 7) * T2_AS;
-  const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
+  [[maybe_unused]] float* Arow = T + (j & 7) * T2_AS;
+  [[maybe_unused]] const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
   float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (p.n_edges + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
@@ -213,11 +213,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         read_dl<VT>(Trow, g, zd.t);
         hidden_t(zc, zd, h, hd, d1c, ec);
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
-        // silu'(z), silu''(z) zd: needed again on the way back through the hidden layer -- parked in this row's BCG / GCG dump (written for
-        // good only after the row-local part) instead of 64 registers across it
-        if (REVERSE && !t2_rows_atom(REVERSE) && j < nvalid) {
-          write_dl<VT>(p.BCG + (size_t)(row0 + j) * 2 * D, g, d1c.t); write_dl<VT>(p.GCG + (size_t)(row0 + j) * 2 * D, g, ec.t);
-        }
         cc = param64(vecs + 0 * D, g);
         cdc = zero64();
         gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
@@ -228,9 +223,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         read_dl<VT>(Trow + D, g, zd.t);
         hidden_t(zg, zd, h, hd, d1g, eg);
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
-        if (REVERSE && !t2_rows_atom(REVERSE) && j < nvalid) {
-          write_dl<VT>(p.BCG + (size_t)(row0 + j) * 2 * D + D, g, d1g.t); write_dl<VT>(p.GCG + (size_t)(row0 + j) * 2 * D + D, g, eg.t);
-        }
         cg = param64(vecs + 1 * D, g);
         cdg = zero64();
         gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
@@ -317,90 +309,29 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
       continue;
     }
     } else {
-    // ---- row-local part in the accumulator layout: sixteen rows at once (as in k2_angle below) ----
-    const bool valid = j < nvalid;
+    // ---- row-local part in the accumulator layout, sixteen rows at once (tangent forward only: t2_rows_atom) ----
+    static_assert(!REVERSE, "the AtomConv reverse kernel keeps the one-row-at-a-time form (t2_rows_atom)");
     float r1, r2, mt1, mt2;
     ln2_forward(cc, cdc, r1, mt1);            // cc = xhat1, cdc = P(cd)
     ln2_forward(cg, cdg, r2, mt2);
-    float sum[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float m[10];
-    int sk = k, sc = c, sg = g;               // the slices' bond / centre rows and column group (made opaque between the two reverse passes)
-    struct SliceIn { f32x4 w, wd, bar_a, g_a, obw; };
-    auto slice_in = [&](int ft) {
-      SliceIn in;
-      in.bar_a = in.g_a = in.obw = zero4();
-      in.w = rd4(p.wag, sk, ft, sg);
-      in.wd = rd4(p.wagd, sk, ft, sg);
-      if (REVERSE) { in.bar_a = rd4(p.bar_agg, sc, ft, sg); in.g_a = rd4(p.g_agg, sc, ft, sg); }
-      return in;
-    };
-    // PASS 0: tangent forward (m = yd w + y wd -> tile).  Reverse: PASS 1 forms the ten row sums of the two LayerNorm adjoints, the bar
-    // adjoint of the bond's weight row (pair sum of the two directions, plain update: the tile owns the bond) and the LayerNorm-affine
-    // terms of the second branch (-> tile); PASS 2 recomputes the slice and finishes in place (first branch's affine terms -> tile).
-    auto slice = [&](int ft, const SliceIn& in, auto pass_c) {
-      constexpr int PASS = decltype(pass_c)::value;
-      const f32x4 ga1 = vec4(vecs + 2 * D, ft, sg), be1 = vec4(vecs + 3 * D, ft, sg), ga2 = vec4(vecs + 4 * D, ft, sg), be2 = vec4(vecs + 5 * D, ft, sg);
-      f32x4 o0 = zero4(), o1 = zero4(), bw = zero4();
-      if (PASS == 1) bw = rd4(p.bar_w, sk, ft, sg);      // old value of this bond's row
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float xh1 = cc.t[ft][r], pt1 = cdc.t[ft][r], xh2 = cg.t[ft][r], pt2 = cdg.t[ft][r];
-        const Gate1 e = gate1(xh1, pt1, xh2, pt2, r1, r2, ga1[r], be1[r], ga2[r], be2[r]);
-        if (PASS == 0) {
-          o0[r] = e.yd * in.w[r] + e.y * in.wd[r];
-        } else {
-          const float bar_y = in.w[r] * in.bar_a[r] + in.wd[r] * in.g_a[r], g_y = in.w[r] * in.g_a[r];
-          float bn1, gn1, bn2, gn2;
-          gate1_bwd(e, bar_y, g_y, bn1, gn1, bn2, gn2);
-          const float h1 = gn1 * ga1[r], p1 = bn1 * ga1[r], h2 = gn2 * ga2[r], p2 = bn2 * ga2[r];
-          if (PASS == 1) {
-            const float mine = valid ? e.y * in.bar_a[r] + e.yd * in.g_a[r] : 0.f;
-            bw[r] += mine + __builtin_amdgcn_update_dpp(0.f, mine, 0xB1, 0xF, 0xF, false);   // + the other direction of the bond (lane j ^ 1)
-            sum[0] += h1; sum[1] += h1 * xh1; sum[2] += h1 * pt1; sum[3] += p1; sum[4] += p1 * xh1;
-            sum[5] += h2; sum[6] += h2 * xh2; sum[7] += h2 * pt2; sum[8] += p2; sum[9] += p2 * xh2;
-            o0[r] = bn2 * xh2 + gn2 * (pt2 * r2);     // LayerNorm-affine terms of the second branch
-            o1[r] = bn2;
-          } else {
-            o0[r] = bn1 * xh1 + gn1 * (pt1 * r1);     // ... of the first
-            o1[r] = bn1;
-            const float ph1 = h1 - m[0] - xh1 * m[1], pb1 = p1 - m[3] - xh1 * m[4];
-            const float ph2 = h2 - m[5] - xh2 * m[6], pb2 = p2 - m[8] - xh2 * m[9];
-            cc.t[ft][r] = pb1 * r1 - (xh1 * m[2] + ph1 * mt1 + pt1 * m[1]) * (r1 * r1);     // bar(c)
-            cdc.t[ft][r] = ph1 * r1;                                                            // G(c)
-            cg.t[ft][r] = pb2 * r2 - (xh2 * m[7] + ph2 * mt2 + pt2 * m[6]) * (r2 * r2);      // bar(g)
-            cdg.t[ft][r] = ph2 * r2;                                                            // G(g)
-          }
-        }
-      }
-      *reinterpret_cast<f32x4*>(Trow + 16 * ft + 4 * g) = o0;
-      if (PASS != 0) *reinterpret_cast<f32x4*>(Trow + D + 16 * ft + 4 * g) = o1;
-      if (PASS == 1 && valid && !(j & 1)) *grow<f32x4>(p.bar_w, (unsigned)sk, D, 16 * ft + 4 * sg) = bw;
-    };
-    auto sweep = [&](auto pass_c) {
-      SliceIn cur = slice_in(0);
-      CHG_EV(ft) {
-        const SliceIn nxt = slice_in(ft + 1 < VT ? ft + 1 : ft);
-        slice(ft, cur, pass_c);
-        cur = nxt;
-      }
-    };
-    // column sums of the tile's two 64-wide halves over its valid rows (column = lane)
-    auto tile_colsums = [&](float& d0, float& d1) {
-      __builtin_amdgcn_wave_barrier();
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < TILE_ROWS; ++rr) {
-        const float a = T[rr * TS + lane_t], b = T[rr * TS + D + lane_t];
-        s0 += rr < nvalid ? a : 0.f;
-        s1 += rr < nvalid ? b : 0.f;
-      }
-      d0 += s0; d1 += s1;
-      __builtin_amdgcn_wave_barrier();
-    };
     __builtin_amdgcn_wave_barrier();
-    if (!REVERSE) {
-      sweep(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_wave_barrier();
+    {
+      f32x4 w = rd4(p.wag, k, 0, g), wd = rd4(p.wagd, k, 0, g);     // the bond's weight row and its tangent, one slice ahead
+      CHG_EV(ft) {
+        const f32x4 wn = rd4(p.wag, k, ft + 1 < VT ? ft + 1 : ft, g), wdn = rd4(p.wagd, k, ft + 1 < VT ? ft + 1 : ft, g);
+        const f32x4 ga1 = vec4(vecs + 2 * D, ft, g), be1 = vec4(vecs + 3 * D, ft, g), ga2 = vec4(vecs + 4 * D, ft, g), be2 = vec4(vecs + 5 * D, ft, g);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const Gate1 e = gate1(cc.t[ft][r], cdc.t[ft][r], cg.t[ft][r], cdg.t[ft][r], r1, r2, ga1[r], be1[r], ga2[r], be2[r]);
+          o[r] = e.yd * w[r] + e.y * wd[r];     // tangent of the message  y wag[k]
+        }
+        *reinterpret_cast<f32x4*>(Trow + 16 * ft + 4 * g) = o;
+        w = wn; wd = wdn;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
       // tangent of the aggregates: run sums over the centres of the even rows (direction c1 -> c2, sorted) and of the odd rows
       float acc1 = 0.f, acc2 = 0.f;
       int cur1 = __builtin_amdgcn_readlane(c, 0), cur2 = __builtin_amdgcn_readlane(c, 1);
@@ -415,29 +346,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         }
       tile_atomic_add(p.aggd + (size_t)cur1 * D + lane_t, acc1);
       tile_atomic_add(p.aggd + (size_t)cur2 * D + lane_t, acc2);
-      __builtin_amdgcn_wave_barrier();
-      continue;
     }
-    sweep(std::integral_constant<int, 1>{});
-    tile_colsums(lnacc[2], lnacc[3]);
-#pragma unroll
-    for (int q = 0; q < 10; ++q) m[q] = quad_sum(sum[q]) * (1.0f / 64.0f);
-    // (the inputs made opaque: otherwise the compiler keeps pass 1's loads and arithmetic alive for pass 2 instead of recomputing)
-    CHG_EW(ft, r) asm volatile("" : "+v"(cc.t[ft][r]), "+v"(cdc.t[ft][r]), "+v"(cg.t[ft][r]), "+v"(cdg.t[ft][r]));
-    asm volatile("" : "+v"(sk), "+v"(sc), "+v"(sg), "+v"(r1), "+v"(r2));
-    sweep(std::integral_constant<int, 2>{});
-    tile_colsums(lnacc[0], lnacc[1]);
+    __builtin_amdgcn_wave_barrier();
+    continue;
     }
     // cc | cg = bar(c | g), cdc | cdg = G(c | g)
-    if constexpr (!t2_rows_atom(REVERSE)) {      // the parked derivatives of the hidden activation come back before their rows are overwritten
-      if (j < nvalid) {
-        const float* brow = p.BCG + (size_t)(row0 + j) * 2 * D;
-        const float* grow = p.GCG + (size_t)(row0 + j) * 2 * D;
-        read_dl<VT>(brow, g, d1c.t); read_dl<VT>(brow + D, g, d1g.t);
-        read_dl<VT>(grow, g, ec.t); read_dl<VT>(grow + D, g, eg.t);
-      } else { d1c = zero64(); d1g = zero64(); ec = zero64(); eg = zero64(); }
-      CHG_EV(ft) asm volatile("" : "+v"(d1c.t[ft]), "+v"(d1g.t[ft]), "+v"(ec.t[ft]), "+v"(eg.t[ft]));   // (landed before the stores below)
-    }
     if (j < nvalid) {               // A operands of dW2 (column sums of bar(c|g) = d b2)
       float* brow = p.BCG + (size_t)(row0 + j) * 2 * D;
       float* grow = p.GCG + (size_t)(row0 + j) * 2 * D;
@@ -524,9 +437,11 @@ constexpr size_t t2_angle_lds() {
   return rm_image_bytes(2 * D, D) + (HIDDEN ? 2 * rm_image_bytes(D, D) : 0) + sizeof(float) * (VEC_SLOTS * D + WAVES * TILE_FLOATS);
 }
 
-// Which instantiations keep the one-row-at-a-time form of the row-local part (lane = feature, kernels_train2.h): the BondConv reverse
-// kernel -- with the hidden layer's state next to the two passes' it does not fit 256 registers in the accumulator layout (225 spilled
-// registers, 40 ms instead of 29 per step; profiles/r05_experiments.md section 13).  CHG_T2_ROWS=1: all of them (A/B builds).
+// Which instantiations keep the one-row-at-a-time form of the row-local part (lane = feature, kernels_train2.h): the reverse kernels
+// WITH a hidden layer (BondConv here, AtomConv above).  Next to the hidden layer's state and six gathered rows per angle the two passes
+// of the accumulator-layout form do not fit 256 registers (225-270 spilled registers: 40 ms instead of 29 per step), and a form that
+// parks the row state in the dump rows and streams it back slice by slice waits for its own loads behind the scatter's atomics (57 ms);
+// profiles/r05_experiments.md section 13.  CHG_T2_ROWS=1: every instantiation (A/B builds).
 constexpr bool t2_rows(bool hidden, bool reverse) { return CHG_T2_ROWS != 0 || (hidden && reverse); }
 
 template <bool HIDDEN, bool REVERSE>
@@ -548,8 +463,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
   __syncthreads();
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
-  float* Arow = T + (j & 7) * T2_AS;
-  const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
+  [[maybe_unused]] float* Arow = T + (j & 7) * T2_AS;
+  [[maybe_unused]] const float ln_g1 = vecs[2 * D + lane], ln_b1 = vecs[3 * D + lane], ln_g2 = vecs[4 * D + lane], ln_b2 = vecs[5 * D + lane];
   float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
@@ -597,9 +512,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           V64 h, hd;
           hidden_t(cc, cdc, h, hd, d1c, ec);
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
-          // silu'(z) and silu''(z) zd are needed again on the way back through the hidden layer: parked in this row's BZ / GZ dump (the
-          // row is written for good only after that) instead of 64 registers across the row-local part
-          if (REVERSE && !t2_rows(HIDDEN, REVERSE) && j < nvalid) { write_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D, g, d1c.t); write_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D, g, ec.t); }
           cc = param64(vecs + 0 * D, g);
           cdc = zero64();
           gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
@@ -609,7 +521,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           V64 h, hd;
           hidden_t(cg, cdg, h, hd, d1g, eg);
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
-          if (REVERSE && !t2_rows(HIDDEN, REVERSE) && j < nvalid) { write_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D + D, g, d1g.t); write_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D + D, g, eg.t); }
           cg = param64(vecs + 1 * D, g);
           cdg = zero64();
           gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
@@ -717,74 +628,57 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     }
     } else {
     // ---- row-local part in the accumulator layout: sixteen rows at once (the helpers above) ----
+    static_assert(!(HIDDEN && REVERSE), "the BondConv reverse kernel keeps the one-row-at-a-time form (t2_rows)");
     const bool valid = j < nvalid;
-    const int kb1 = valid ? b1 : -1, kb2 = valid ? b2 : -1;
+    const int kb1 = valid ? b1 : -1;
     float r1, r2, mt1, mt2;
     ln2_forward(cc, cdc, r1, mt1);            // cc = xhat1, cdc = P(cd): what the way back needs of the first LayerNorm
     ln2_forward(cg, cdg, r2, mt2);
     float sum[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // reverse, pass 1: this lane's share of the ten row sums
     float m[10];                              // reverse, pass 2: the row means  m_h, m_hx, m_hpt, m_b, m_bx  of branch 1, then of branch 2
-    V64 l2, l3;                               // reverse, pass 2: LayerNorm-affine terms of the second branch (the tile takes the first's)
-    // One 4-feature slice, element by element.  PASS 0: tangent forward.  Reverse, two passes over the slices: PASS 1 only forms the row
-    // sums the two LayerNorm adjoints need (and sends the bond-weight adjoints to the tile); PASS 2 RECOMPUTES the slice (2 x 16
-    // transcendentals per lane more) and finishes in place.  Keeping the four adjoint arrays of the first pass instead costs 64 registers
-    // next to the 64 of xhat / P(cd): 350 spilled registers in the BondConv kernel, 1.8x its time (profiles/r05_experiments.md section 13).
-    // what a slice reads from memory, requested one slice ahead (the scheduling barriers below keep everything else in program order)
     int sb1 = b1, sb2 = b2, srow = row, sg = g;   // the slices' row indices and column group (made opaque between the two reverse passes)
-    struct SliceIn { f32x4 w1, w1d, w2, w2d, bar_a, g_a, o0; };
+    // what a slice reads from memory, requested one slice ahead
+    struct SliceIn { f32x4 w1, w1d, w2, w2d, a, b; };
     auto slice_in = [&](int ft) {
       SliceIn in;
-      in.w1 = in.w1d = in.w2 = in.w2d = in.bar_a = in.g_a = in.o0 = zero4();
-      if (HIDDEN) {                          // BondConv: u = y wbg[b1] wbg[b2] summed over the angles of bond b1
+      in.w1 = in.w1d = in.w2 = in.w2d = in.a = in.b = zero4();
+      if (HIDDEN) {                          // BondConv (tangent forward): u = y wbg[b1] wbg[b2] summed over the angles of bond b1
         in.w1 = rd4(p.w, sb1, ft, sg); in.w1d = rd4(p.wd, sb1, ft, sg); in.w2 = rd4(p.w, sb2, ft, sg); in.w2d = rd4(p.wd, sb2, ft, sg);
-        if (REVERSE) { in.bar_a = rd4(p.bar_agg, sb1, ft, sg); in.g_a = rd4(p.g_agg, sb1, ft, sg); }
       } else if (!REVERSE) {                 // AngleUpdate: ang' = ang + y
-        in.o0 = rd4(p.angd, srow, ft, sg);
+        in.a = rd4(p.angd, srow, ft, sg);
       } else {
-        in.bar_a = rd4(p.bar_ang, srow, ft, sg);  // (= bar(y), G(y) of the row)
-        in.g_a = rd4(p.g_ang, srow, ft, sg);
+        in.a = rd4(p.bar_ang, srow, ft, sg);   // bar(y), G(y) of the row
+        in.b = rd4(p.g_ang, srow, ft, sg);
       }
       return in;
     };
+    // One 4-feature slice, element by element.  PASS 0: tangent forward.  Reverse (AngleUpdate), two passes over the slices: PASS 1 forms
+    // the ten row sums the two LayerNorm adjoints need (and sends the LayerNorm-affine terms of the second branch to the tile); PASS 2
+    // RECOMPUTES the slice (2 x 16 transcendentals per lane more), finishes in place and sends the first branch's affine terms.  Keeping
+    // the four adjoint arrays of the first pass instead costs 64 registers next to the 64 of xhat / P(cd) (spills).
     auto slice = [&](int ft, const SliceIn& in, auto pass_c) {
       constexpr int PASS = decltype(pass_c)::value;
       const f32x4 ga1 = vec4(vecs + 2 * D, ft, sg), be1 = vec4(vecs + 3 * D, ft, sg), ga2 = vec4(vecs + 4 * D, ft, sg), be2 = vec4(vecs + 5 * D, ft, sg);
-      const f32x4 w1 = in.w1, w1d = in.w1d, w2 = in.w2, w2d = in.w2d, bar_a = in.bar_a, g_a = in.g_a;
-      f32x4 o0 = in.o0, o1 = zero4();
+      f32x4 o0 = in.a, o1 = zero4();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float xh1 = cc.t[ft][r], pt1 = cdc.t[ft][r], xh2 = cg.t[ft][r], pt2 = cdg.t[ft][r];
         const Gate1 e = gate1(xh1, pt1, xh2, pt2, r1, r2, ga1[r], be1[r], ga2[r], be2[r]);
-        float bar_y = 0.f, g_y = 0.f;
-        if (HIDDEN) {
-          if (PASS == 0) {
-            o0[r] = e.yd * w1[r] * w2[r] + e.y * (w1d[r] * w2[r] + w1[r] * w2d[r]);
-          } else {
-            if (PASS == 1) {   // bar adjoints of the two bond-weight rows: first bond as run sums, second bond one atomic row per angle (below)
-              o0[r] = e.y * w2[r] * bar_a[r] + (e.yd * w2[r] + e.y * w2d[r]) * g_a[r];
-              o1[r] = e.y * w1[r] * bar_a[r] + (e.yd * w1[r] + e.y * w1d[r]) * g_a[r];
-            }
-            bar_y = w1[r] * w2[r] * bar_a[r] + (w1d[r] * w2[r] + w1[r] * w2d[r]) * g_a[r];
-            g_y = w1[r] * w2[r] * g_a[r];
-          }
-        } else if (PASS == 0) {
-          o0[r] += e.yd;
+        if (PASS == 0) {
+          if (HIDDEN) o0[r] = e.yd * in.w1[r] * in.w2[r] + e.y * (in.w1d[r] * in.w2[r] + in.w1[r] * in.w2d[r]);
+          else o0[r] += e.yd;
         } else {
-          bar_y = bar_a[r];
-          g_y = g_a[r];
-        }
-        if (PASS != 0) {
           float bn1, gn1, bn2, gn2;
-          gate1_bwd(e, bar_y, g_y, bn1, gn1, bn2, gn2);
+          gate1_bwd(e, in.a[r], in.b[r], bn1, gn1, bn2, gn2);
           const float h1 = gn1 * ga1[r], p1 = bn1 * ga1[r], h2 = gn2 * ga2[r], p2 = bn2 * ga2[r];
           if (PASS == 1) {
             sum[0] += h1; sum[1] += h1 * xh1; sum[2] += h1 * pt1; sum[3] += p1; sum[4] += p1 * xh1;
             sum[5] += h2; sum[6] += h2 * xh2; sum[7] += h2 * pt2; sum[8] += p2; sum[9] += p2 * xh2;
+            o0[r] = bn2 * xh2 + gn2 * (pt2 * r2);     // LayerNorm-affine terms (d gamma | d beta) of the second branch -> tile
+            o1[r] = bn2;
           } else {
-            o0[r] = bn1 * xh1 + gn1 * (pt1 * r1);     // LayerNorm-affine terms: d gamma | d beta of the first branch -> tile
+            o0[r] = bn1 * xh1 + gn1 * (pt1 * r1);     // ... of the first
             o1[r] = bn1;
-            l2.t[ft][r] = bn2 * xh2 + gn2 * (pt2 * r2);
-            l3.t[ft][r] = bn2;
             const float ph1 = h1 - m[0] - xh1 * m[1], pb1 = p1 - m[3] - xh1 * m[4];
             const float ph2 = h2 - m[5] - xh2 * m[6], pb2 = p2 - m[8] - xh2 * m[9];
             cc.t[ft][r] = pb1 * r1 - (xh1 * m[2] + ph1 * mt1 + pt1 * m[1]) * (r1 * r1);     // bar(c)
@@ -793,78 +687,48 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
             cdg.t[ft][r] = ph2 * r2;                                                            // G(g)
           }
         }
-#if CHG_T2_SB == 2
-        if (r & 1) __builtin_amdgcn_sched_barrier(0);
-#endif
       }
-#if CHG_T2_SB == 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if (HIDDEN ? PASS != 2 : false) *reinterpret_cast<f32x4*>(Trow + 16 * ft + 4 * g) = o0;
-      if (HIDDEN && PASS == 1) *reinterpret_cast<f32x4*>(Trow + D + 16 * ft + 4 * g) = o1;
-      if (PASS == 2) {
-        *reinterpret_cast<f32x4*>(Trow + 16 * ft + 4 * g) = o0;
-        *reinterpret_cast<f32x4*>(Trow + D + 16 * ft + 4 * g) = o1;
-      }
+      if (HIDDEN || PASS != 0) *reinterpret_cast<f32x4*>(Trow + 16 * ft + 4 * g) = o0;
+      if (PASS != 0) *reinterpret_cast<f32x4*>(Trow + D + 16 * ft + 4 * g) = o1;
       if (!HIDDEN && PASS == 0 && valid) *grow<f32x4>(p.angd_out, (unsigned)row, D, 16 * ft + 4 * g) = o0;
     };
-    __builtin_amdgcn_wave_barrier();
     auto sweep = [&](auto pass_c) {
+      __builtin_amdgcn_wave_barrier();
       SliceIn cur = slice_in(0);
       CHG_EV(ft) {
         const SliceIn nxt = slice_in(ft + 1 < VT ? ft + 1 : ft);
         slice(ft, cur, pass_c);
         cur = nxt;
       }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // column sums of the tile's two 64-wide halves over its valid rows (column = lane).  Into locals first: the four running sums live
+    // across the whole kernel, and where the allocator keeps them in scratch a read-modify-write per row is sixteen dependent round trips
+    auto tile_colsums = [&](float& d0, float& d1) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < TILE_ROWS; ++rr) {
+        const float a = T[rr * TS + lane_t], b = T[rr * TS + D + lane_t];
+        s0 += rr < nvalid ? a : 0.f;
+        s1 += rr < nvalid ? b : 0.f;
+      }
+      d0 += s0; d1 += s1;
     };
     if (!REVERSE) {
       sweep(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_wave_barrier();
       if (HIDDEN) seg_colsum_atomic<D>(T, TS, kb1, nvalid, p.aggd, D, lane_t);
       __builtin_amdgcn_wave_barrier();
       continue;
     }
     sweep(std::integral_constant<int, 1>{});
-    if (HIDDEN) {
-      __builtin_amdgcn_wave_barrier();
-      seg_colsum_atomic<D>(T, TS, kb1, nvalid, p.bar_w, D, lane_t);
-      row_atomic_add<D>(T + D, TS, kb2, nvalid, p.bar_w, D, lane_t);
-      __builtin_amdgcn_wave_barrier();
-    }
+    tile_colsums(lnacc[2], lnacc[3]);
 #pragma unroll
     for (int q = 0; q < 10; ++q) m[q] = quad_sum(sum[q]) * (1.0f / 64.0f);
-    // (the inputs made opaque: otherwise the compiler recognises pass 2's arithmetic as pass 1's and keeps all of it alive instead)
+    // (the inputs made opaque: otherwise the compiler keeps pass 1's loads and arithmetic alive for pass 2 instead of recomputing)
     CHG_EW(ft, r) asm volatile("" : "+v"(cc.t[ft][r]), "+v"(cdc.t[ft][r]), "+v"(cg.t[ft][r]), "+v"(cdg.t[ft][r]));
     asm volatile("" : "+v"(sb1), "+v"(sb2), "+v"(srow), "+v"(sg), "+v"(r1), "+v"(r2));
     sweep(std::integral_constant<int, 2>{});
-    // LayerNorm-affine gradients: column sums over the tile's valid rows (column = lane)
-    __builtin_amdgcn_wave_barrier();
-    // (into locals first: the four running sums live across the whole kernel, and where the allocator keeps them in scratch a
-    // read-modify-write per row is sixteen dependent memory round trips)
-    {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < TILE_ROWS; ++rr) {
-        const float a = T[rr * TS + lane_t], b = T[rr * TS + D + lane_t];
-        s0 += rr < nvalid ? a : 0.f;
-        s1 += rr < nvalid ? b : 0.f;
-      }
-      lnacc[0] += s0; lnacc[1] += s1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    write_dl<VT>(Trow, g, l2.t);
-    write_dl<VT>(Trow + D, g, l3.t);
-    __builtin_amdgcn_wave_barrier();
-    {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < TILE_ROWS; ++rr) {
-        const float a = T[rr * TS + lane_t], b = T[rr * TS + D + lane_t];
-        s0 += rr < nvalid ? a : 0.f;
-        s1 += rr < nvalid ? b : 0.f;
-      }
-      lnacc[2] += s0; lnacc[3] += s1;
-    }
+    tile_colsums(lnacc[0], lnacc[1]);
     __builtin_amdgcn_wave_barrier();
     }
     // cc | cg = bar(c | g), cdc | cdg = G(c | g)
@@ -877,10 +741,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
       // back through the second layer and the hidden activation, branch by branch
       {
-        if constexpr (!t2_rows(HIDDEN, REVERSE)) {
-          if (j < nvalid) { read_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D, g, d1c.t); read_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D, g, ec.t); }
-          else { d1c = zero64(); ec = zero64(); }
-        }
         V64 bh = zero64(), gh = zero64();
         gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane_t);
         gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane_t);
@@ -890,10 +750,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         }
       }
       {
-        if constexpr (!t2_rows(HIDDEN, REVERSE)) {
-          if (j < nvalid) { read_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D + D, g, d1g.t); read_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D + D, g, eg.t); }
-          else { d1g = zero64(); eg = zero64(); }
-        }
         V64 bh = zero64(), gh = zero64();
         gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane_t);
         gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane_t);
