@@ -570,7 +570,7 @@ int run_backward2(chg_engine* eng, chg_batch* b) {
     a.n_edges = Ed; a.e_center = b->p_center; a.e_nbr = b->p_nbr;
     a.P = b->Pl[l]; a.Q = b->Ql[l]; a.Pd = t.Pd; a.Qd = t.Qd; a.gw = w.ac[l].g; a.wag = b->wag; a.wagd = t.wagd;
     a.aggd = t.aggd[l]; a.bar_agg = t.bar_agg; a.g_agg = t.g_agg; a.bar_w = t.bar_wag;
-    a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG;
+    a.H = t.scratch6[2]; a.Hd = t.scratch6[3]; a.BCG = t.BCG; a.GCG = t.GCG; a.park0 = t.BZ; a.park1 = t.GZ;
     a.barP = t.barP; a.barQ = t.barQ; a.gQ = t.gQ; a.g_ln = G(w.ac[l].g.ln1_g);
     return a;
   };

@@ -147,6 +147,7 @@ struct Atom2Args {
   const float *bar_agg, *g_agg;       // [N,64] the two adjoints of the aggregate
   float* bar_w;                       // [Eu,64] bar adjoint of wag, accumulated over the layers (zeroed once per sweep)
   float *H, *Hd, *BCG, *GCG;          // [Ed,128] pair order: operands of the second-layer weight gradients
+  float *park0, *park1;               // [Ed,128] x 2 scratch rows (the angle kernels' BZ / GZ dumps, idle here): silu'(z) | silu''(z) zd parked over the row loop
   float* barP;                        // [N,256] (zeroed): bar adjoint of the P table
   float *barQ, *gQ;                   // [Eu,128]: adjoints of the Q table, plain stores (the tile owns its bonds)
   // The G adjoints of everything that only LEAVES the sweep -- G(wag), G(P) -- are the first-order adjoints with seed 1: the
@@ -213,6 +214,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         read_dl<VT>(Trow, g, zd.t);
         hidden_t(zc, zd, h, hd, d1c, ec);
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
+        // silu'(z), silu''(z) zd come back on the way back through the hidden layer: parked in scratch rows (L2) instead of 64 registers
+        // across the row loop (the kernel spilled 90 registers around them; a reload behind the loop's stores waits for their round trip)
+        if (REVERSE && j < nvalid) { write_dl<VT>(p.park0 + (size_t)(row0 + j) * 2 * D, g, d1c.t); write_dl<VT>(p.park1 + (size_t)(row0 + j) * 2 * D, g, ec.t); }
         cc = param64(vecs + 0 * D, g);
         cdc = zero64();
         gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
         read_dl<VT>(Trow + D, g, zd.t);
         hidden_t(zg, zd, h, hd, d1g, eg);
         if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
+        if (REVERSE && j < nvalid) { write_dl<VT>(p.park0 + (size_t)(row0 + j) * 2 * D + D, g, d1g.t); write_dl<VT>(p.park1 + (size_t)(row0 + j) * 2 * D + D, g, eg.t); }
         cg = param64(vecs + 1 * D, g);
         cdg = zero64();
         gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
@@ -361,6 +366,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
     //      bar(z) = silu'(z) bar(H) + silu''(z) zd G(H),  G(z) = silu'(z) G(H);  bar(z) goes to the tile at once ----
     __builtin_amdgcn_wave_barrier();
     {
+      const size_t po = (size_t)min(row0 + j, last_row) * 2 * D;
+      read_dl<VT>(p.park0 + po, g, d1c.t); read_dl<VT>(p.park1 + po, g, ec.t);
       V64 bh = zero64(), gh = zero64();
       gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane_t);
       gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane_t);
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_atom(Atom2Args p) {
       write_dl<VT>(Trow, g, bh.t);
     }
     {
+      const size_t po = (size_t)min(row0 + j, last_row) * 2 * D + D;
+      read_dl<VT>(p.park0 + po, g, d1g.t); read_dl<VT>(p.park1 + po, g, eg.t);
       V64 bh = zero64(), gh = zero64();
       gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane_t);
       gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane_t);
@@ -512,6 +521,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           V64 h, hd;
           hidden_t(cc, cdc, h, hd, d1c, ec);
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow, g, h.t); write_dl<VT>(hdrow, g, hd.t); }
+          // silu'(z), silu''(z) zd: parked in this row's BZ / GZ dump (written for good only after they are used again) instead of 64
+          // registers across the row loop
+          if (REVERSE && j < nvalid) { write_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D, g, d1c.t); write_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D, g, ec.t); }
           cc = param64(vecs + 0 * D, g);
           cdc = zero64();
           gemm_rm<VT, VT, false, false>(cc.t, I2c, D, D, h.t, j, g, lane_t);
@@ -521,6 +533,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
           V64 h, hd;
           hidden_t(cg, cdg, h, hd, d1g, eg);
           if (REVERSE && j < nvalid) { write_dl<VT>(hrow + D, g, h.t); write_dl<VT>(hdrow + D, g, hd.t); }
+          if (REVERSE && j < nvalid) { write_dl<VT>(p.BZ + (size_t)(row0 + j) * 2 * D + D, g, d1g.t); write_dl<VT>(p.GZ + (size_t)(row0 + j) * 2 * D + D, g, eg.t); }
           cg = param64(vecs + 1 * D, g);
           cdg = zero64();
           gemm_rm<VT, VT, false, false>(cg.t, I2g, D, D, h.t, j, g, lane_t);
@@ -741,6 +754,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       }
       // back through the second layer and the hidden activation, branch by branch
       {
+        const size_t po = (size_t)row * 2 * D;     // (rows past the end read the last row's: never stored)
+        read_dl<VT>(p.BZ + po, g, d1c.t); read_dl<VT>(p.GZ + po, g, ec.t);
         V64 bh = zero64(), gh = zero64();
         gemm_rm<VT, VT, true, true>(bh.t, I2c, D, D, cc.t, j, g, lane_t);
         gemm_rm<VT, VT, true, true>(gh.t, I2c, D, D, cdc.t, j, g, lane_t);
@@ -750,6 +765,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         }
       }
       {
+        const size_t po = (size_t)row * 2 * D + D;
+        read_dl<VT>(p.BZ + po, g, d1g.t); read_dl<VT>(p.GZ + po, g, eg.t);
         V64 bh = zero64(), gh = zero64();
         gemm_rm<VT, VT, true, true>(bh.t, I2g, D, D, cg.t, j, g, lane_t);
         gemm_rm<VT, VT, true, true>(gh.t, I2g, D, D, cdg.t, j, g, lane_t);
