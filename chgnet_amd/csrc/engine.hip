@@ -477,7 +477,9 @@ int chg_batch_download(chg_engine* eng, chg_batch* b, const chg_out_host* o) {
 int chg_host_alloc(int64_t bytes, void** out) {
   if (bytes <= 0 || !out) return CHG_EINVAL;
   *out = nullptr;
-  if (hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return CHG_ENOMEM; }
+  // portable: the caller may be a loader thread whose current device is not the engine's (rank k > 0 of a multi-GPU node: a new
+  // thread starts on device 0), and the block is then read by that engine's copy stream
+  if (hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return CHG_ENOMEM; }
   return CHG_OK;
 }
 int chg_host_free(void* p) {
