@@ -214,6 +214,34 @@ def test_engine_020_predict_structure_builds_the_5A_graph_on_the_device(model_v0
         assert float(np.abs(out[key] - d["out_" + key]).max()) < TOL[key], key
 
 
+@pytest.mark.gpu
+def test_engine_020_full_size_batch_vs_oracle_and_singles(model_v020_tl, weights_tl):
+    """BASELINE's full batch size on the released architecture: 1024 perturbed LiMnO2 5x1x1 cells (40 atoms) through
+    ``predict_structure`` (graphs built on the device at the model's 5 A / 3 A cutoffs, one device batch), a sample of them against the
+    fp32 oracle on host-built graphs, and against the same structures predicted one at a time (results do not depend on the batch)."""
+    import torch
+
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+    from oracle.chgnet_oracle import OracleCHGNet
+
+    torch.set_num_threads(8)
+    structs = bench.workload_structures(1024, 9100)
+    outs = model_v020_tl.predict_structure(structs, task="efs", batch_size=1024)
+    assert len(outs) == 1024 and all(np.isfinite(o["e"]) and np.isfinite(o["f"]).all() and np.isfinite(o["s"]).all() for o in outs)
+    pick = [0, 1, 257, 511, 768, 1023]
+    conv = CrystalGraphConverter(atom_graph_cutoff=5, bond_graph_cutoff=3)
+    ref = OracleCHGNet(weights_tl, atom_graph_cutoff=5.0, bond_graph_cutoff=3.0, cutoff_coeff=5).predict_graph([conv(structs[i]) for i in pick], "efs", batch_size=len(pick))
+    for i, r in zip(pick, ref):
+        fs, ss = max(1.0, float(np.abs(r["f"]).max())), max(1.0, float(np.abs(r["s"]).max()))
+        assert abs(float(outs[i]["e"]) - float(r["e"])) < 4 * TOL["e"] * max(1.0, abs(float(r["e"]))), i
+        assert float(np.abs(outs[i]["f"] - r["f"]).max()) < 4 * TOL["f"] * fs, i
+        assert float(np.abs(outs[i]["s"] - r["s"]).max()) < 4 * TOL["s"] * ss, i
+        one = model_v020_tl.predict_structure(structs[i], task="efs")
+        assert abs(float(one["e"]) - float(outs[i]["e"])) < 2e-6 * max(1.0, abs(float(one["e"])))
+        assert float(np.abs(one["f"] - outs[i]["f"]).max()) < 2e-5 * fs and float(np.abs(one["s"] - outs[i]["s"]).max()) < 2e-4 * ss
+
+
 # ---- parameter gradients incl. the mlp_out biases (CPU: the float64 models of the two training sweeps) -----------------
 def _blob_from(wg: dict, pw) -> np.ndarray:
     blob = np.zeros(pw.blob.size, np.float64)
