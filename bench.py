@@ -629,17 +629,6 @@ def run_configs(eng, weights, ranks: Ranks, args, model=None, legs=("C1", "C3", 
         configs["C4_md"]["cell_4x2x2_512_atoms"] = {
             "atoms": len(cell512), "steps": n512, "steps_per_s": round(out5["steps_per_s"], 1),
             "ms_per_step": round(1e3 / out5["steps_per_s"], 3), "temperature_K": round(out5["temperature_K"], 1)}
-        # the device-resident variant: graph built with both cutoffs + skin, kept in HBM and replayed as a hipGraph
-        # while no atom has moved more than skin / 2 -- same E/F (the envelope closes the skin shell), no rebuild on most steps
-        calc_skin = CHGNetCalculator(model, skin=0.5)
-        md2 = BerendsenNVT(li9co7o16_supercell(), calc_skin, temperature_K=1000.0, timestep_fs=2.0, task="ef")
-        md2.run(10)
-        builds0 = calc_skin.n_graph_builds
-        out2 = md2.run(args.md_steps)
-        configs["C4_md"]["with_skin_0.5A"] = {
-            "steps_per_s": round(out2["steps_per_s"], 1), "ms_per_step": round(1e3 / out2["steps_per_s"], 3),
-            "graph_builds": int(calc_skin.n_graph_builds - builds0), "temperature_K": round(out2["temperature_K"], 1),
-            "what": "CHGNetCalculator(skin=0.5): positions in -> E/F out on a resident graph, rebuilt only when an atom has moved 0.25 A"}
     # ---- C5: one fine-tuning epoch, data-parallel: Trainer step with the full CombinedLoss (E + F + S + magmom) --------
     if args.train_structures > 0 and "C5" in legs:
         from chgnet_amd.trainer import TrainStep

@@ -113,6 +113,12 @@ def clean_variants() -> None:
                 shutil.rmtree(p)
             else:
                 os.remove(p)
+    # ... and objects in lib/obj that no product unit produces (an experiment unit compiled by hand)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    keep = {name.replace(".hip", ".o") for name in HIP_SOURCES} | {"flags.sha"}
+    for f in os.listdir(obj_dir) if os.path.isdir(obj_dir) else ():
+        if f not in keep:
+            os.remove(os.path.join(obj_dir, f))
 
 
 def build_all(force: bool = False, keep_variants: bool = False) -> None:

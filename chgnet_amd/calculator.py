@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from chgnet_amd.graph.structure import Lattice, Structure, atomic_numbers_of
+from chgnet_amd.graph.structure import Lattice, Structure
 from chgnet_amd.model import CHGNet
 
 GPA_TO_EV_A3 = 1.0 / 160.21766208   # ase.units.GPa
@@ -61,17 +61,15 @@ class CHGNetCalculator(Calculator):
 
     def __init__(self, model: CHGNet | None = None, *, use_device: str | None = None, check_cuda_mem: bool = False,  # noqa: ARG002
                  stress_weight: float = GPA_TO_EV_A3, on_isolated_atoms: str = "warn", return_site_energies: bool = False,
-                 skin: float = 0.0, **kwargs) -> None:
-        """Same arguments as the reference (dynamics.py:63-107) plus ``skin`` (Angstrom, default 0 = the
-        reference behaviour: graph rebuilt on the host every call).
+                 **kwargs) -> None:
+        """Same arguments as the reference (dynamics.py:63-107).  Like the reference (dynamics.py:156-157) every call rebuilds the
+        graph -- here on the device (``chg_batch_build``), ~0.2 ms for a 256-atom cell.
 
-        ``skin > 0`` enables the device-resident MD fast path: the graph is built once with both cutoffs
-        enlarged by ``skin`` and kept in HBM; while no atom has moved more than ``skin / 2`` (and the cell
-        is unchanged) a call only uploads positions (``chg_batch_update_geometry``) and re-runs the
-        kernels.  This is exact, not an approximation: the polynomial envelope is identically zero beyond
-        the cutoff (basis.py:205), so bonds in the skin shell carry zero features, zero weights and zero
-        gradients.  It requires ``mlp_out`` without bias (0.3.0 / r2scan; the 0.2.0 bias would leak into
-        skin bonds) and is refused otherwise."""
+        (Rounds 2-5 had a ``skin`` option that kept a graph with both cutoffs enlarged by a skin resident and only moved the atoms.
+        It was exact -- the envelope is zero beyond the cutoff -- but computed 1.3x the bonds and 2.5x the angles to save that 0.2 ms
+        and ran 25 % SLOWER than rebuilding; removed in round 6.)"""
+        if "skin" in kwargs:
+            raise TypeError("CHGNetCalculator(skin=...) was removed: rebuilding the exact-cutoff graph on the device every call is faster")
         super().__init__(**kwargs)
         if model is None:
             self.model = CHGNet.load(verbose=False, use_device=use_device)
@@ -81,18 +79,7 @@ class CHGNetCalculator(Calculator):
         self.model.graph_converter.set_isolated_atom_response(on_isolated_atoms)
         self.stress_weight = stress_weight
         self.return_site_energies = return_site_energies
-        self.skin = float(skin)
-        self._resident = None
         self.n_graph_builds = 0
-        if self.skin > 0:
-            if any(k.endswith("mlp_out.layers.1.bias") for k in self.model.state_dict()):
-                raise ValueError("skin > 0 needs a model without mlp_out bias (0.3.0 / r2scan); got mlp_out_bias=True")
-            from chgnet_amd.graph import CrystalGraphConverter
-
-            conv = self.model.graph_converter
-            self._skin_converter = CrystalGraphConverter(
-                atom_graph_cutoff=conv.atom_graph_cutoff + self.skin, bond_graph_cutoff=conv.bond_graph_cutoff + self.skin,
-                on_isolated_atoms=on_isolated_atoms)
         print(f"CHGNet will run on {self.device}")
 
     @classmethod
@@ -112,12 +99,9 @@ class CHGNetCalculator(Calculator):
         system_changes = system_changes or all_changes
         super().calculate(atoms=atoms, properties=properties, system_changes=system_changes)
         structure = atoms_to_structure(atoms)
-        if self.skin > 0:
-            pred = self._predict_resident(structure, task)
-        else:
-            self.n_graph_builds += 1   # graph rebuilt every call like dynamics.py:156-157, but on the device
-            pred = self.model.predict_structure(structure, task=task, return_crystal_feas=True,
-                                                return_site_energies=self.return_site_energies)
+        self.n_graph_builds += 1   # graph rebuilt every call like dynamics.py:156-157, but on the device
+        pred = self.model.predict_structure(structure, task=task, return_crystal_feas=True,
+                                            return_site_energies=self.return_site_energies)
         extensive_factor = len(structure) if self.model.is_intensive else 1
         key_map = {"e": ("energy", extensive_factor), "f": ("forces", 1), "m": ("magmoms", 1), "s": ("stress", self.stress_weight)}
         self.results.update({long_key: pred[key] * factor for key, (long_key, factor) in key_map.items() if key in pred})
@@ -125,39 +109,3 @@ class CHGNetCalculator(Calculator):
         self.results["crystal_fea"] = pred["crystal_fea"]
         if self.return_site_energies:
             self.results["energies"] = pred["site_energies"]
-
-    # ---- device-resident fast path (skin > 0) ----------------------------------------------------------
-    def _predict_resident(self, structure, task: str) -> dict:
-        from chgnet_amd import VALID_TASKS
-
-        if task not in VALID_TASKS:
-            raise ValueError(f"Invalid {task=}. Must be one of {VALID_TASKS}.")
-        eng = self.model.engine
-        lattice = np.asarray(structure.lattice.matrix, dtype=np.float64)
-        frac = np.asarray(structure.frac_coords, dtype=np.float64)          # unwrapped: images stay valid
-        z = atomic_numbers_of(structure)
-        cart = frac @ lattice
-        res = self._resident
-        reuse = (res is not None and len(z) == len(res["z"]) and np.array_equal(z, res["z"])
-                 and np.array_equal(lattice, res["lattice"])
-                 and float(np.sqrt(((cart - res["cart"]) ** 2).sum(1).max())) < 0.5 * self.skin)
-        if reuse:
-            res["batch"].update_geometry(frac.astype(np.float32), lattice.astype(np.float32)[None])
-        else:
-            if res is not None:
-                res["batch"].free()
-            conv = self._skin_converter
-            self.n_graph_builds += 1
-            batch = eng.build_batch([structure], conv.atom_graph_cutoff, conv.bond_graph_cutoff)
-            if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
-                conv(structure)   # phrases the reference's isolated-atom error / warning
-            res = self._resident = {"z": z, "lattice": lattice.copy(), "cart": cart.copy(), "batch": batch}
-        eng.predict(res["batch"], task)
-        out = eng.download(res["batch"], task, site_energies=self.return_site_energies, crystal_feas=True)
-        pred = {"e": out["e"][0], "crystal_fea": out["crystal_fea"][0]}
-        for key in ("f", "m", "site_energies"):
-            if key in out:
-                pred[key] = out[key]
-        if "s" in out:
-            pred["s"] = out["s"][0]
-        return pred

@@ -246,7 +246,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
     if (sa != CHG_OK) { delete b; return sa; }
   }
   carve(b, b->arena, total);
-  register_names(b);
+  // (debug names: registered on the first chg_debug_fetch -- ~70 map insertions per batch are 10 us of an MD step)
   if (h->atom_off) b->h_atom_off.assign(h->atom_off, h->atom_off + h->n_struct + 1);
   b->h_volume.resize(h->n_struct);
   for (int q = 0; q < h->n_struct; ++q) {
@@ -276,6 +276,7 @@ int chg_debug_fetch_i32(chg_engine* eng, chg_batch* b, const char* name, int32_t
     if (n_written) *n_written = capacity >= 1 ? 1 : 0;
     return CHG_OK;
   }
+  if (b->named_i32.empty()) register_names(b);
   auto it = b->named_i32.find(name);
   if (it == b->named_i32.end()) { eng->err = std::string("chg_debug_fetch_i32: unknown buffer ") + name; return CHG_EINVAL; }
   const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));
@@ -425,21 +426,34 @@ int chg_batch_download(chg_engine* eng, chg_batch* b, const chg_out_host* o) {
     // for piece by piece (~20 us of idle GPU each, 6 % of a 256-atom MD step); into pinned memory the copies queue back to back.
     constexpr size_t PINNED_MAX = (size_t)4 << 20;   // floats (16 MB)
     if (total > 0 && total <= PINNED_MAX) {
-      if (total * sizeof(float) > eng->h_out_bytes) {
+      if ((total + 1024) * sizeof(float) > eng->h_out_bytes) {
         if (eng->h_out) hipHostFree(eng->h_out);
         eng->h_out = nullptr; eng->h_out_bytes = 0;
-        const size_t want = std::max(total * sizeof(float) * 2, (size_t)1 << 16);
+        const size_t want = std::max((total + 1024) * sizeof(float) * 2, (size_t)1 << 16);
         if (hipHostMalloc(&eng->h_out, want, hipHostMallocDefault) != hipSuccess) { eng->h_out = nullptr; eng->err = "chg_batch_download: pinned staging allocation failed"; return CHG_ENOMEM; }
         eng->h_out_bytes = want;
       }
       float* stage = reinterpret_cast<float*>(eng->h_out);
-      size_t off = 0;
+      // pieces that are neighbours in the arena (engine_predict.hip carve: crystal_fea | force | virial | energy | magmom) travel as ONE
+      // copy of their span when the gaps are small
+      const float *lo = nullptr, *hi = nullptr;
       for (const Piece& pc : pieces)
-        if (pc.dst && pc.n) { HIP_TRY(eng, hipMemcpyAsync(stage + off, pc.src, pc.n * sizeof(float), hipMemcpyDeviceToHost, eng->stream)); off += pc.n; }
-      TRY(chg_synchronize(eng));
-      off = 0;
-      for (const Piece& pc : pieces)
-        if (pc.dst && pc.n) { std::memcpy(pc.dst, stage + off, pc.n * sizeof(float)); off += pc.n; }
+        if (pc.dst && pc.n) { lo = (!lo || pc.src < lo) ? pc.src : lo; hi = (!hi || pc.src + pc.n > hi) ? pc.src + pc.n : hi; }
+      const size_t span = lo ? (size_t)(hi - lo) : 0;
+      if (span <= total + 1024 && span * sizeof(float) <= eng->h_out_bytes) {
+        HIP_TRY(eng, hipMemcpyAsync(stage, lo, span * sizeof(float), hipMemcpyDeviceToHost, eng->stream));
+        TRY(chg_synchronize(eng));
+        for (const Piece& pc : pieces)
+          if (pc.dst && pc.n) std::memcpy(pc.dst, stage + (pc.src - lo), pc.n * sizeof(float));
+      } else {
+        size_t off = 0;
+        for (const Piece& pc : pieces)
+          if (pc.dst && pc.n) { HIP_TRY(eng, hipMemcpyAsync(stage + off, pc.src, pc.n * sizeof(float), hipMemcpyDeviceToHost, eng->stream)); off += pc.n; }
+        TRY(chg_synchronize(eng));
+        off = 0;
+        for (const Piece& pc : pieces)
+          if (pc.dst && pc.n) { std::memcpy(pc.dst, stage + off, pc.n * sizeof(float)); off += pc.n; }
+      }
     } else {
       int s = CHG_OK;
       for (const Piece& pc : pieces)
@@ -528,6 +542,7 @@ int chg_profile_read(chg_engine* eng, int i, char* label, int label_cap, int64_t
 
 int chg_debug_fetch(chg_engine* eng, chg_batch* b, const char* name, float* dst, int64_t capacity, int64_t* n_written) {
   if (!eng || !b || !name || !dst) return CHG_EINVAL;
+  if (b->named.empty()) register_names(b);
   auto it = b->named.find(name);
   if (it == b->named.end()) { eng->err = std::string("chg_debug_fetch: unknown buffer ") + name; return CHG_EINVAL; }
   const size_t n = std::min<size_t>(it->second.second, (size_t)std::max<int64_t>(capacity, 0));

@@ -61,8 +61,13 @@ struct TmpPool {   // scratch device memory of one chg_batch_build call: bump al
   }
 };
 
-int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n) {
+// `state`: SCAN_STATE_INTS zeroed ints (graph_pass clears them with its counters): mid-size arrays are scanned by ONE chained launch
+int exclusive_scan(chg_engine* eng, TmpPool& tmp, const int* in, int* out, int n, int* state = nullptr) {
   if (n <= 0) return CHG_OK;
+  if (state && n > SCAN_CHUNK && (n + 8191) / 8192 <= SCAN_CHAIN_MAX) {
+    hipLaunchKernelGGL(k_scan_chained, dim3((n + 8191) / 8192), dim3(1024), 0, eng->stream, in, out, n, state);
+    return CHG_OK;
+  }
   if ((size_t)n / SCAN_CHUNK + 1 > (1u << 16)) { eng->err = "graph build: array too long for the two-level scan"; return CHG_EINVAL; }
   int* scratch = tmp.get<int>(scan_scratch_ints(n));
   if (!scratch) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
@@ -123,7 +128,7 @@ int d2d(chg_engine* eng, T* dst, const T* src, size_t n) {
 //    chunk of similar structures): the scratch arrays are sized from the PREVIOUS build's per-atom counts plus
 //    headroom, every kernel takes its counts from device memory, and the host reads {Ed, A, Eb, flags} once at the
 //    end.  A capacity that turns out too small raises a device-side flag and the build is repeated exactly.
-struct GraphCounts { int Ed = 0, A = 0, Eb = 0, unpaired = 0, isolated = 0; bool cell_overflow = false; };
+struct GraphCounts { int Ed = 0, A = 0, Eb = 0, unpaired = 0, isolated = 0; bool cell_overflow = false, noncanonical = false; };
 
 // device copies of the host-side binning (one entry per structure; all-pairs structures have off = -1)
 struct CellLists { const int *off, *nb, *reach, *bin_start, *bin_atoms, *bin3, *shift; };
@@ -194,13 +199,22 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   const int N = h->n_atoms;
   hipStream_t st = eng->stream;
   overflowed = false;
-  int* d_ccnt = tmp.get<int>(N + 1);
+  // Everything that starts at zero sits in ONE block cleared by one memset (they were six, ~3.4 us each on the device): the per-centre
+  // counts, the flags, the state of the chained scans and -- single-pass builds know the capacities up front -- the per-bond /
+  // per-edge counters below.  (The exact build learns Ed only after its first round trip: those get a second block.)
+  const size_t z_ccnt = 0, z_flags = z_ccnt + (size_t)N + 1, z_scan = z_flags + 8, z_head = z_scan + 3 * (size_t)SCAN_STATE_INTS;
+  const int capU0 = capE / 2;
+  auto tail_ints = [&](int cE, int cU) { return 2 * ((size_t)cU + 1) + ((size_t)cE + 1) + (size_t)std::max(N, 1); };
+  const size_t z_total = z_head + (speculative ? tail_ints(capE, capU0) : 0);
+  int* zblock = tmp.get<int>(z_total);
   int* d_coff = tmp.get<int>(N + 1);
-  int* d_flags = tmp.get<int>(4);   // [0] unpaired directed edge, [1] isolated atoms, [2] speculative capacity exceeded
   int* d_counts = tmp.get<int>(8);
-  if (!d_ccnt || !d_coff || !d_flags || !d_counts) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-  HIP_TRY(eng, hipMemsetAsync(d_ccnt, 0, sizeof(int) * (N + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
+  if (!zblock || !d_coff || !d_counts) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  int* d_ccnt = zblock + z_ccnt;
+  int* d_flags = zblock + z_flags;   // [0] unpaired directed edge, [1] isolated atoms, [2] speculative capacity exceeded, [3] cell list overflow,
+                                     // [4] angle sets not the canonical n (n - 1) blocks (k_short_count / k_angle_count)
+  int* scan_state = zblock + z_scan;
+  HIP_TRY(eng, hipMemsetAsync(zblock, 0, sizeof(int) * z_total, st));
   NlArgs nl{};
   nl.cart = d_cart; nl.frac = d_frac; nl.lattice = d_lat; nl.reach = d_reach; nl.atom_owner = d_owner; nl.atom_off = d_aoff;
   nl.n_atoms = N; nl.r2 = r_atom * r_atom; nl.tol = tol; nl.center_cnt = d_ccnt; nl.overflow = d_flags + 2; nl.cell_flag = d_flags + 3;
@@ -225,43 +239,43 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   e_image = tmp.get<float>(3 * (size_t)capE);
   double* e_dist = tmp.get<double>(capE);
   e_owner = tmp.get<int>(capE); e_rev = tmp.get<int>(capE); e_d2u = tmp.get<int>(capE);
-  int* is_first = tmp.get<int>(capE + 1); int* first_scan = tmp.get<int>(capE + 1);
   p_center = tmp.get<int>(capE); p_nbr = tmp.get<int>(capE);
   u_u2d = tmp.get<int>(capU);
-  int* short_cnt = tmp.get<int>(N); int* ang_cnt = tmp.get<int>(capU + 1); int* ang_off = tmp.get<int>(capU + 1);
-  int* is_node = tmp.get<int>(capU + 1); int* node_scan = tmp.get<int>(capU + 1);
+  int* zblock2 = speculative ? zblock + z_head : tmp.get<int>(tail_ints(capE, capU));
+  int* ang_off = tmp.get<int>(capU + 1);
+  int* node_scan = tmp.get<int>(capU + 1);
   u_bnode = tmp.get<int>(capU);
+  int* ang_cnt = zblock2; int* is_node = zblock2 ? ang_cnt + capU + 1 : nullptr; int* is_first = zblock2 ? is_node + capU + 1 : nullptr;
+  int* short_cnt = zblock2 ? is_first + capE + 1 : nullptr;
+  int* first_scan = tmp.get<int>(capE + 1);
   if (!e_center || !e_nbr || !e_img || !e_image || !e_dist || !e_owner || !e_rev || !e_d2u || !is_first || !first_scan || !p_center ||
       !p_nbr || !u_u2d || !short_cnt || !ang_cnt || !ang_off || !is_node || !node_scan || !u_bnode) {
     eng->err = "graph build: scratch allocation failed";
     return CHG_ENOMEM;
   }
-  HIP_TRY(eng, hipMemsetAsync(ang_cnt, 0, sizeof(int) * (capU + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(is_node, 0, sizeof(int) * (capU + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(is_first, 0, sizeof(int) * (capE + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(short_cnt, 0, sizeof(int) * std::max(N, 1), st));
+  if (!speculative) HIP_TRY(eng, hipMemsetAsync(zblock2, 0, sizeof(int) * tail_ints(capE, capU), st));
   if (capE > 0) {
     nl.center_off = d_coff; nl.e_center = e_center; nl.e_nbr = e_nbr; nl.e_img = e_img; nl.e_image = e_image; nl.e_dist = e_dist;
     nl.e_owner = e_owner; nl.cap_edges = capE;
     hipLaunchKernelGGL((k_neighbors<true>), wave_per_atom, dim3(256), 0, st, nl);
     hipLaunchKernelGGL(k_reverse, g1(capE), dim3(256), 0, st, e_center, e_nbr, e_img, d_coff, nE, e_rev, is_first, d_flags);
-    TRY(exclusive_scan(eng, tmp, is_first, first_scan, capE + 1));
+    TRY(exclusive_scan(eng, tmp, is_first, first_scan, capE + 1, scan_state));
     hipLaunchKernelGGL(k_undirected, g1(capE), dim3(256), 0, st, e_center, e_nbr, e_rev, is_first, first_scan, nE, e_d2u, u_u2d, p_center, p_nbr,
                        d_flags + 2);
   }
   hipLaunchKernelGGL(k_short_count, g1((int64_t)N * 64), dim3(256), 0, st, (const double*)e_dist, (const int*)d_coff, N, r_bond, short_cnt, d_flags + 1,
-                     d_flags + 2);
+                     d_flags + 2, WIN_LIST, d_flags + 4);
   int A = 0, Eb = 0;
   if (capU > 0) {
-    hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2);
-    TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1));   // entries past Eu are zero: the total sits at ang_off[capU]
+    hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2, d_flags + 4);
+    TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1, scan_state + SCAN_STATE_INTS));   // entries past Eu are zero: the total sits at ang_off[capU]
   } else {
     HIP_TRY(eng, hipMemsetAsync(ang_off, 0, sizeof(int) * (capU + 1), st));
   }
-  int flags[4] = {0, 0, 0, 0};
+  int flags[5] = {0, 0, 0, 0, 0};
   if (!speculative) {
     HIP_TRY(eng, hipMemcpyAsync(&A, ang_off + capU, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipMemcpyAsync(flags, d_flags, sizeof(int) * 5, hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipStreamSynchronize(st));
     if (flags[3]) { gc.cell_overflow = true; overflowed = true; return CHG_OK; }
     if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
@@ -272,7 +286,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   if (capA > 0 && capU > 0) {
     hipLaunchKernelGGL(k_angle_fill, g1((int64_t)capU * 64), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
                        a_d1, a_b2, a_d2, is_node, capA, d_flags + 2);
-    TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1));
+    TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1, scan_state + 2 * SCAN_STATE_INTS));
   } else {
     HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (capU + 1), st));
   }
@@ -291,15 +305,15 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, (const int*)(d_coff + N), (const int*)(ang_off + capU),
                        (const int*)(node_scan + capU), (const int*)d_flags, d_counts);
-    HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 7, hipMemcpyDeviceToHost, st));
+    HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipStreamSynchronize(st));
-    Ed = hc[0]; A = hc[1]; Eb = hc[2]; flags[0] = hc[3]; flags[1] = hc[4]; flags[2] = hc[5];
+    Ed = hc[0]; A = hc[1]; Eb = hc[2]; flags[0] = hc[3]; flags[1] = hc[4]; flags[2] = hc[5]; flags[4] = hc[7];
     if (hc[6]) { gc.cell_overflow = true; overflowed = true; return CHG_OK; }
     if (flags[2] || Ed > capE || A > capA || Eb > capEb) { overflowed = true; return CHG_OK; }
     if (Ed & 1) { eng->err = "graph build: odd number of directed edges"; return CHG_EINVAL; }
     if (flags[0]) { eng->err = "graph build: number of directed edges != 2 * number of undirected edges (directed edges are not complete)"; return CHG_EINVAL; }
   }
-  gc.Ed = Ed; gc.A = A; gc.Eb = Eb; gc.unpaired = flags[0]; gc.isolated = flags[1];
+  gc.Ed = Ed; gc.A = A; gc.Eb = Eb; gc.unpaired = flags[0]; gc.isolated = flags[1]; gc.noncanonical = flags[4] != 0;
   return CHG_OK;
 }
 
@@ -416,12 +430,12 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     chg_batch* b = new (std::nothrow) chg_batch();
     if (!b) return CHG_ENOMEM;
     b->B = B; b->N = N; b->Ed = Ed; b->Eu = Eu; b->A = A; b->Eb = Eb; b->L = eng->desc.n_conv;
+    b->canonical = !gc.noncanonical;   // built here: the angle sets are complete n (n - 1) blocks unless the builder saw one of the two exceptions
     size_t total = 0;
     carve(b, nullptr, total);
     int s = acquire_arena(eng, b, total);
     if (s != CHG_OK) { delete b; return s; }
     carve(b, b->arena, total);
-    register_names(b);
     b->h_atom_off.assign(h->atom_off, h->atom_off + B + 1);
     b->h_volume.resize(B);
     for (int q = 0; q < B; ++q) {   // float32 lattice like k_finalize (model.py:834-836)
@@ -445,14 +459,15 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       add(b->u_u2d, u_u2d, Eu); add(b->u_bnode, u_bnode, Eu); add(b->bn_und, bn_und, Eb);
       add(b->a_ctr, a_ctr, A); add(b->a_d1, a_d1, A); add(b->a_d2, a_d2, A);
       static_assert(MULTI_COPY_MAX >= 17, "one slot per array");
-      if (nseg > 0) {
-        const unsigned gx = (unsigned)std::min<unsigned long long>((most / 4 + 255) / 256 + 1, (unsigned long long)4 * eng->num_cus);
-        hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)nseg), dim3(256), 0, st, mc);
-      }
-      hipLaunchKernelGGL(k_f64_to_f32, g1(3 * (int64_t)N), dim3(256), 0, st, d_frac, b->frac, 3 * N);
-      hipLaunchKernelGGL(k_f64_to_f32, g1(9 * (int64_t)B), dim3(256), 0, st, d_lat, b->lattice, 9 * B);
+      // ... and the float32 copies of the coordinates / lattices and the angles' compact bond indices ride in the same launch
+      mc.n_copy = nseg;
+      mc.cvt_src[0] = d_frac; mc.cvt_dst[0] = b->frac; mc.cvt_n[0] = 3 * N;
+      mc.cvt_src[1] = d_lat; mc.cvt_dst[1] = b->lattice; mc.cvt_n[1] = 9 * B;
+      mc.a_b1 = a_b1; mc.a_b2 = a_b2; mc.u_bnode_new = u_bnode; mc.a_b1c = b->a_b1c; mc.a_b2c = b->a_b2c; mc.n_ang = A;
+      most = std::max<unsigned long long>(most, std::max<unsigned long long>((unsigned long long)A * 4, (unsigned long long)12 * N));
+      const unsigned gx = (unsigned)std::min<unsigned long long>((most / 4 + 255) / 256 + 1, (unsigned long long)4 * eng->num_cus);
+      hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)nseg + 3), dim3(256), 0, st, mc);
     }
-    if (s == CHG_OK && A > 0) hipLaunchKernelGGL(k_angle_compact, g1(A), dim3(256), 0, st, a_b1, a_b2, b->u_bnode, A, b->a_b1c, b->a_b2c);
     if (s == CHG_OK) s = prepare_windows(eng, b);
     // the scratch (TmpPool) is reused by the next build on this same stream, so stream order protects it; overflow
     // allocations of the pool are freed by its destructor and need the copies to have finished

@@ -86,6 +86,7 @@ struct chg_engine {
   Weights w{};
   // prebuilt LDS weight blocks of the inference tile kernels (kernels_conv.h k_*_image), rebuilt by every weight upload
   float* d_images = nullptr;
+  const float* p_elem = nullptr;               // [94][256] P table of the first AtomConv per element (k_prologue; rebuilt with the images)
   const float* img_ac_fwd[2][MAX_CONV] = {};   // [without / with q_bias][layer]
   const float* img_ac_bwd[MAX_CONV] = {};
   const float* img_ac_bwd_rm[MAX_CONV] = {};   // row-major block of the fused adjoint (k_atomconv_image_rm)
@@ -161,9 +162,14 @@ struct chg_batch {
   int *win_tmp = nullptr, *win_scan = nullptr;
   int win_grid = 64;        // workgroups of the per-atom kernels (a multiple of 64: the atom schedule is built for it, k_win_schedule)
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
+  bool canonical = false;   // built by chg_batch_build and known to have the canonical angle structure (uploaded graphs: unknown -> false):
+                            // the per-atom / team adjoints then need no row-order launch behind them
+  int win_team = 0;         // > 0: small batch in TEAM mode (kernels_angle_w.h) -- the index without the schedule exists and the angle
+                            // adjoints give every atom to a team of this many waves; win_grid is their workgroup count
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
   int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
+  float* zero2_keep_end = nullptr;                // group 2 holds [energy, magmom) up to here: results of the prediction a later chg_backward keeps
   uint32_t last_task = 0;
   bool seed1_adjoints = false;   // the first-order adjoints (seed 1) of the last force / stress sweep are still in the batch (GP_l, GR_l, GS_l, Gwag, Gwbgc)
   // the whole launch sequence of one chg_predict, captured once per (batch, task) and replayed:

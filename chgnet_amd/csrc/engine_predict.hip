@@ -5,6 +5,7 @@
 
 #include "kernels_geom.h"
 #include "kernels_angle_fa.h"
+#include "kernels_chain.h"
 
 namespace chgh {
 
@@ -226,7 +227,8 @@ int build_images(chg_engine* eng) {
   constexpr size_t BF = AngleLds<true, false>::tiles, BB = AngleLds<true, true>::tiles, UF = AngleLds<false, false>::tiles,
                    UB = AngleLds<false, true>::tiles;
   static_assert(AF % 4 == 0 && AB % 4 == 0 && BF % 4 == 0 && BB % 4 == 0 && UF % 4 == 0 && UB % 4 == 0, "images are copied in 16-byte units");
-  const size_t total = (size_t)L * (2 * AF + AB + ac_bwd_rm_image_floats()) + (size_t)(L - 1) * (BF + BB + UF + UB);
+  constexpr size_t PE = (size_t)94 * 4 * D;     // per-element P table of AtomConv 0 (k_prologue)
+  const size_t total = (size_t)L * (2 * AF + AB + ac_bwd_rm_image_floats()) + (size_t)(L - 1) * (BF + BB + UF + UB) + PE;
   if (!eng->d_images) {
     HIP_TRY(eng, hipMalloc(&eng->d_images, total * sizeof(float)));
     HIP_TRY(eng, hipMemsetAsync(eng->d_images, 0, total * sizeof(float), eng->stream));   // slots no staging writes (unused vectors)
@@ -262,8 +264,22 @@ int build_images(chg_engine* eng) {
     eng->img_angle[1][L + l] = img = take(UB);
     hipLaunchKernelGGL((k_angle_image<false, true>), dim3(1), dim3(BLOCK), 0, eng->stream, au.w_ang, au.g, img);
   }
+  {   // P table of the first AtomConv for every element: atom[0] = emb[z], so P(0)[i] = p_elem[z_i] (same contraction as atomconv_tables)
+    float* tab = take(PE);
+    eng->p_elem = tab;
+    const ACW& w0 = eng->w.ac[0];
+    TRY(rows_gemm_out2(eng, "gemm_Pelem", eng->w.emb, nullptr, w0.w_cn, w0.w_cn + 2 * D * D, w0.b1, tab, 4 * D, 94));
+  }
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
+}
+
+// MD-size batches: launches are merged where the data allows (k_prologue, the merged embedding launches, the chained row GEMMs) --
+// a launch costs ~4.5 us before its first instruction and such a prediction is ~60 dependent ones.  CHGNET_TINY_FUSE=0: the
+// launch sequence of the large batches (A/B timing, parity tests).
+static bool tiny_batch(const chg_batch* b) {
+  static const bool on = [] { const char* e = std::getenv("CHGNET_TINY_FUSE"); return !e || std::atoi(e) != 0; }();
+  return on && b->N <= SMALL_GEMM_ROWS && b->Ed <= (1 << 18) && b->A <= (1 << 19);
 }
 
 static RowsGemm atomconv_p_problem(chg_engine* eng, chg_batch* b, int l) {
@@ -313,10 +329,8 @@ AtomConvArgs atomconv_args(chg_engine* eng, chg_batch* b, int l) {
   return a;
 }
 
-int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
-  const ACW& w = eng->w.ac[l];
-  if (b->Ed > 0) {
-    TRY(atomconv_tables(eng, b, l));
+int atomconv_fwd_kernel(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
+  {
     LaunchScope ls(eng, "atomconv_fwd");
     const size_t lds = atomconv_lds<FWD_WAVES, false, true>();
     AtomConvArgs a = atomconv_args(eng, b, l);
@@ -334,6 +348,15 @@ int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
     hipLaunchKernelGGL((k_atomconv_fwd<FWD_WAVES>), dim3(tile_grid(eng, b->Ed, TILE_ROWS * FWD_WAVES)), dim3(64 * FWD_WAVES), lds, eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
+  return CHG_OK;
+}
+
+int atomconv_fwd(chg_engine* eng, chg_batch* b, int l, bool keep_q) {
+  const ACW& w = eng->w.ac[l];
+  if (b->Ed > 0) {
+    TRY(atomconv_tables(eng, b, l));
+    TRY(atomconv_fwd_kernel(eng, b, l, keep_q));
+  }
   // atom[l+1] = agg . Wout^T + b_out + atom[l]       (layers.py:127-132)
   return rows_gemm(eng, "gemm_out", 64, 64, b->agg_l[l], D, nullptr, w.w_out, w.b_out, b->atom[l], D, b->atom[l + 1], D, nullptr, b->N, 0);
 }
@@ -347,11 +370,7 @@ static bool fuse_gq() {
   return on;
 }
 
-int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
-  const ACW& w = eng->w.ac[l];
-  if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
-  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
-  const bool fused = fuse_gq();
+int atomconv_bwd_kernel(chg_engine* eng, chg_batch* b, int l, bool fused) {
   {  // pair-ordered edge list: GQ (or, fused, Gb) and Gwag rows are owned by one tile each (no zeroing, no atomics)
     AtomConvArgs a = atomconv_args(eng, b, l);
     a.e_center = b->p_center;
@@ -368,6 +387,15 @@ int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
       hipLaunchKernelGGL(k_atomconv_bwd<false>, dim3(tile_grid(eng, b->Ed)), dim3(BLOCK), (atomconv_lds<WAVES, true>()), eng->stream, a);
     HIP_TRY(eng, hipGetLastError());
   }
+  return CHG_OK;
+}
+
+int atomconv_bwd(chg_engine* eng, chg_batch* b, int l) {
+  const ACW& w = eng->w.ac[l];
+  if (b->Ed == 0) return CHG_OK;  // agg == 0: only the residual path, already in Ga
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
+  const bool fused = fuse_gq();
+  TRY(atomconv_bwd_kernel(eng, b, l, fused));
   if (fused) {
     if (l > 0) TRY(rows_gemm_in2(eng, "gemm_GP", b->GP_l[l], 4 * D, w.w_cn_t, w.w_cn_t + 2 * D * D, b->Ga, nullptr, b->N, 1));
     return CHG_OK;
@@ -441,13 +469,25 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     w.a.image = eng->img_angle[0][a.slot];
     hipLaunchKernelGGL(k_angleupd_fwd_a, dim3(b->win_grid), dim3(BLOCK), angle_fa_lds(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
+    if (b->canonical) return CHG_OK;
+  } else if (BWD && b->win_team > 0) {
+    // MD-size batch: an atom per team of waves (kernels_angle_w.h TEAM); the row-order kernel below returns at once unless the graph
+    // turned out not to have the canonical angle structure
+    AngleWArgs w{};
+    w.a = a; w.w = b->win; w.team_waves = b->win_team; w.n_atoms = b->N;
+    w.a.image = eng->img_angle[1][a.slot];
+    hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN, true>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
+    HIP_TRY(eng, hipGetLastError());
+    if (b->canonical) return CHG_OK;    // built on the device: the index is valid by construction (a launch less per layer: ~4.5 us each)
   } else if (BWD && b->win_built && per_atom_adjoint(HIDDEN)) {
     // per-atom adjoint (kernels_angle_w.h) when the batch has the canonical angle structure, else the row-order one: both are
     // launched, the device flag picks (no host round trip, and a captured hipGraph stays valid across rebuilt graphs)
     AngleWArgs w{};
     w.a = a; w.w = b->win;
+    w.a.image = eng->img_angle[1][a.slot];
     hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
+    if (b->canonical) return CHG_OK;
   } else {
     plain.skip_flag = nullptr;
   }
@@ -535,6 +575,142 @@ static int embed_grid_mult() {
   return m;
 }
 
+// ---- MD-size batches: the row GEMMs between two tile kernels as ONE chained launch (kernels_chain.h) -------------------------------
+struct ChainBuilder {
+  ChainArgs a{};
+  int max_rows = 0;
+  ChainProb& add(int rows) {
+    ChainProb& p = a.p[a.n++];
+    p = ChainProb{};
+    p.rows = rows;
+    max_rows = std::max(max_rows, rows);
+    return p;
+  }
+  static void term(ChainProb& p, const float* X, int ldx, const int* idx, const float* W, int K) { p.t[p.nterms++] = ChainTerm{X, idx, W, ldx, K}; }
+  static void out(ChainProb& p, const float* W, const float* bias, float* Y, int ldy, int ncols) { p.o[p.nouts++] = ChainOut{W, bias, Y, ldy, ncols}; }
+};
+int launch_chain(chg_engine* eng, const char* label, ChainBuilder& cb) {
+  int blocks = 0;
+  for (int i = 0; i < cb.a.n; ++i) {
+    ChainProb& p = cb.a.p[i];
+    p.col_blocks = 0;
+    for (int o = 0; o < p.nouts; ++o) p.col_blocks += p.o[o].ncols / D;
+    // in-place stage 1 (Y1 is the array `add` is read from): one workgroup per row block does everything (kernels_chain.h)
+    p.serial_outs = (p.Y1 && p.Y1 == p.add) ? 1 : 0;
+    if (p.serial_outs) {
+      if (p.nouts > 1 || (p.nouts == 1 && p.o[0].ncols != D)) { eng->err = "launch_chain: an in-place problem takes one 64-column output"; return CHG_EINVAL; }
+      p.col_blocks = 1;
+    }
+    p.col_blocks = std::max(1, p.col_blocks);
+    blocks += p.col_blocks;
+  }
+  if (cb.max_rows <= 0 || blocks == 0) return CHG_OK;
+  LaunchScope ls(eng, label);
+  hipLaunchKernelGGL(k_rows_chain, dim3((cb.max_rows + BLOCK_ROWS - 1) / BLOCK_ROWS, blocks), dim3(BLOCK), chain_lds(), eng->stream, cb.a);
+  HIP_TRY(eng, hipGetLastError());
+  return CHG_OK;
+}
+
+// Forward message passing of a small batch with bonds and angles (model.py:442-496): per layer
+//   AtomConv | chain A: atom[l+1] -> S_bc, P(l+1), S_au (+ R_bc(0)) | BondConv | chain B: hbc[l+1] -> R_au, R_bc(l+1) | AngleUpdate
+// -- five launches where the large-batch sequence (atomconv_fwd / bondconv_fwd / angleupd_fwd above) has seven.
+int forward_tiny(chg_engine* eng, chg_batch* b, bool want_grad, bool want_m) {
+  const Weights& w = eng->w;
+  const int L = b->L;
+  for (int l = 0; l < L - 1; ++l) {
+    TRY(atomconv_fwd_kernel(eng, b, l, want_grad));
+    {
+      ChainBuilder cb;
+      ChainProb& p = cb.add(b->N);                       // atom[l+1] = agg . Wout^T + b_out + atom[l]   (layers.py:127-132)
+      cb.term(p, b->agg_l[l], D, nullptr, w.ac[l].w_out, D);
+      p.bias1 = w.ac[l].b_out; p.add = b->atom[l]; p.lda = D; p.Y1 = b->atom[l + 1]; p.ldy1 = D;
+      cb.out(p, w.bc[l].w_ctr, w.bc[l].b1, b->Sl[l], 2 * D, 2 * D);                                        // S of BondConv l
+      cb.out(p, w.ac[l + 1].w_cn, w.ac[l + 1].b1, b->Pl[l + 1], 4 * D, 2 * D);                              // P of AtomConv l + 1: centre half
+      cb.out(p, w.ac[l + 1].w_cn + 2 * D * D, nullptr, b->Pl[l + 1] + 2 * D, 4 * D, 2 * D);                 //   ... neighbour half
+      if (l < L - 2) cb.out(p, w.au[l].w_ctr, w.au[l].b1, b->Sl[L + l], 2 * D, 2 * D);                      // S of AngleUpdate l
+      if (l == 0) {                                      // R of BondConv 0 from the embedded bond features (later layers: chain B)
+        ChainProb& q = cb.add(b->Eb);
+        q.add = b->hbc[0]; q.lda = D;
+        cb.out(q, w.bc[0].w_bij, nullptr, b->Rl[0], 4 * D, 2 * D);
+        cb.out(q, w.bc[0].w_bij + 2 * D * D, nullptr, b->Rl[0] + 2 * D, 4 * D, 2 * D);
+      }
+      TRY(launch_chain(eng, "chain_A", cb));
+    }
+    TRY((launch_angle<true, false>(eng, "bondconv_fwd", b, angle_args(b, l, b->ang[l], w.bc[l].w_ang, w.bc[l].g, b->aggB_l[l]))));
+    {
+      ChainBuilder cb;
+      ChainProb& p = cb.add(b->Eb);                      // hbc[l+1] = agg . Wout^T + b_out + hbc[l]     (layers.py:255-260)
+      cb.term(p, b->aggB_l[l], D, nullptr, w.bc[l].w_out, D);
+      p.bias1 = w.bc[l].b_out; p.add = b->hbc[l]; p.lda = D; p.Y1 = b->hbc[l + 1]; p.ldy1 = D;
+      if (l < L - 2) {
+        cb.out(p, w.au[l].w_bij, nullptr, b->Rl[L + l], 4 * D, 2 * D);                                      // R of AngleUpdate l
+        cb.out(p, w.au[l].w_bij + 2 * D * D, nullptr, b->Rl[L + l] + 2 * D, 4 * D, 2 * D);
+        cb.out(p, w.bc[l + 1].w_bij, nullptr, b->Rl[l + 1], 4 * D, 2 * D);                                  // R of BondConv l + 1
+        cb.out(p, w.bc[l + 1].w_bij + 2 * D * D, nullptr, b->Rl[l + 1] + 2 * D, 4 * D, 2 * D);
+      }
+      TRY(launch_chain(eng, "chain_B", cb));
+    }
+    if (l < L - 2)
+      TRY((launch_angle<false, false, FWD_WAVES>(eng, "angleupd_fwd", b, angle_args(b, L + l, b->ang[l], w.au[l].w_ang, w.au[l].g, b->ang[l + 1]))));
+  }
+  if (want_m) {
+    LaunchScope ls(eng, "magmom");
+    hipLaunchKernelGGL(k_magmom, dim3(wave_grid(eng, b->N)), dim3(256), 0, eng->stream, b->atom[L - 1], w.site_w, w.site_b, b->magmom, b->N);
+  }
+  b->p_table_done = L - 1;                               // chain A of layer L - 2 contracted it
+  return atomconv_fwd(eng, b, L - 1, want_grad);
+}
+
+// ... and its reverse sweep: per layer
+//   AngleUpdate adj. | chain B': Gb[bn] += GR_au . W -> Gagg  (+ Ga += GS_au . W) | BondConv adj. |
+//   chain A': Ga += GS_bc . W + GP(l+1) . W -> GA  (+ Gb[bn] += GR_bc . W) | AtomConv adj.
+// -- five launches for the eight of atomconv_bwd / bondconv_bwd / angleupd_bwd.  The P-table gradient of AtomConv l + 1 joins the atom
+// rows one launch later than in the large-batch order; nothing reads Ga in between.
+int reverse_tiny(chg_engine* eng, chg_batch* b) {
+  const Weights& w = eng->w;
+  const int L = b->L;
+  TRY(rows_gemm(eng, "gemm_Gagg", 64, 64, b->Ga, D, nullptr, w.ac[L - 1].w_out_t, nullptr, nullptr, 0, b->GA, D, nullptr, b->N, 0));
+  TRY(atomconv_bwd_kernel(eng, b, L - 1, true));
+  for (int l = L - 2; l >= 0; --l) {
+    const bool au = l < L - 2;
+    if (au) TRY((launch_angle<false, true>(eng, "angleupd_bwd", b, angle_args(b, L + l, b->ang[l], w.au[l].w_ang, w.au[l].g, nullptr))));
+    {
+      ChainBuilder cb;
+      ChainProb& p = cb.add(b->Eb);                      // dE/d hbc[l+1] complete -> dE/d agg of BondConv l
+      if (au) {
+        cb.term(p, b->GR_l[L + l], 4 * D, nullptr, w.au[l].w_bij_t, 2 * D);
+        cb.term(p, b->GR_l[L + l] + 2 * D, 4 * D, nullptr, w.au[l].w_bij_t + 2 * D * D, 2 * D);
+        p.Y1 = b->Gb; p.y1_idx = b->bn_und; p.ldy1 = D;
+      }
+      p.add = b->Gb; p.add_idx = b->bn_und; p.lda = D;
+      cb.out(p, w.bc[l].w_out_t, nullptr, b->Gagg, D, D);
+      if (au) {
+        ChainProb& q = cb.add(b->N);                     // Ga += GS_au . Wctr
+        cb.term(q, b->GS_l[L + l], 2 * D, nullptr, w.au[l].w_ctr_t, 2 * D);
+        q.add = b->Ga; q.lda = D; q.Y1 = b->Ga; q.ldy1 = D;
+      }
+      TRY(launch_chain(eng, "chain_Bt", cb));
+    }
+    TRY((launch_angle<true, true>(eng, "bondconv_bwd", b, angle_args(b, l, b->ang[l], w.bc[l].w_ang, w.bc[l].g, nullptr))));
+    {
+      ChainBuilder cb;
+      ChainProb& p = cb.add(b->N);                       // dE/d atom[l+1] complete -> dE/d agg of AtomConv l
+      cb.term(p, b->GS_l[l], 2 * D, nullptr, w.bc[l].w_ctr_t, 2 * D);
+      cb.term(p, b->GP_l[l + 1], 4 * D, nullptr, w.ac[l + 1].w_cn_t, 2 * D);
+      cb.term(p, b->GP_l[l + 1] + 2 * D, 4 * D, nullptr, w.ac[l + 1].w_cn_t + 2 * D * D, 2 * D);
+      p.add = b->Ga; p.lda = D; p.Y1 = b->Ga; p.ldy1 = D;
+      cb.out(p, w.ac[l].w_out_t, nullptr, b->GA, D, D);
+      ChainProb& q = cb.add(b->Eb);                      // Gb[bn] += GR_bc . [Wi;Wj]
+      cb.term(q, b->GR_l[l], 4 * D, nullptr, w.bc[l].w_bij_t, 2 * D);
+      cb.term(q, b->GR_l[l] + 2 * D, 4 * D, nullptr, w.bc[l].w_bij_t + 2 * D * D, 2 * D);
+      q.add = b->Gb; q.add_idx = b->bn_und; q.lda = D; q.Y1 = b->Gb; q.y1_idx = b->bn_und; q.ldy1 = D;
+      TRY(launch_chain(eng, "chain_At", cb));
+    }
+    TRY(atomconv_bwd_kernel(eng, b, l, true));
+  }
+  return CHG_OK;
+}
+
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
   const Weights& w = eng->w;
   const int L = b->L;
@@ -546,29 +722,55 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
 #endif
 
   // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
-  { LaunchScope ls(eng, "cart");
-    hipLaunchKernelGGL(k_cart, g1(b->N), dim3(256), 0, st, b->frac, b->lattice, b->atom_owner, b->cart, b->N); }
+  const bool tiny = tiny_batch(b);
+  const size_t zero_bytes = (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1);
+  b->p_table_done = -1;
+  if (tiny) {   // coordinates, bond vectors, atom embedding, the first P table and the cleared scatter targets: one launch
+    PrologueArgs a{};
+    a.frac = b->frac; a.lattice = b->lattice; a.atom_owner = b->atom_owner; a.z = b->z; a.n_atoms = b->N;
+    a.e_center = b->e_center; a.e_nbr = b->e_nbr; a.e_owner = b->e_owner; a.e_image = b->e_image; a.n_edges = b->Ed;
+    a.cart = b->cart; a.ev = b->ev; a.eu = b->eu; a.emb = w.emb; a.atom0 = b->atom[0];
+    a.p_elem = b->Ed > 0 ? eng->p_elem : nullptr; a.P0 = b->Pl[0];
+    a.zero_begin = reinterpret_cast<f32x4*>(b->zero1); a.zero_n = zero_bytes / sizeof(f32x4);
+    LaunchScope ls(eng, "prologue");
+    hipLaunchKernelGGL(k_prologue, dim3(std::min<unsigned>(4 * eng->num_cus, g1(std::max<int64_t>(b->Ed, (int64_t)b->N * D)).x)), dim3(256), 0, st, a);
+    if (a.p_elem) b->p_table_done = 0;
+  } else {
+    LaunchScope ls(eng, "cart");
+    hipLaunchKernelGGL(k_cart, g1(b->N), dim3(256), 0, st, b->frac, b->lattice, b->atom_owner, b->cart, b->N);
+  }
   if (b->Ed > 0) {
-    { LaunchScope ls(eng, "edge_geom");
+    if (!tiny) { LaunchScope ls(eng, "edge_geom");
       hipLaunchKernelGGL(k_edge_geom, g1(b->Ed), dim3(256), 0, st, b->cart, b->lattice, b->e_center, b->e_nbr, b->e_image, b->e_owner, b->ev, b->eu, b->Ed); }
-    { LaunchScope ls(eng, "bond_embed_fwd");   // atom-graph expansion for every bond, bond-graph expansion for the bond-graph nodes only
+    if (tiny) {   // both parts of the bond expansion and the angle expansion: one launch
+      EmbedAllArgs ea{bond_embed_args(eng, b), angle_embed_args(eng, b), grid_for(b->Eu, 2 * eng->num_cus),
+                      b->Eb > 0 ? grid_for(b->Eb, 2 * eng->num_cus) : 0, b->A > 0 ? grid_for(b->A, embed_grid_mult() * eng->num_cus) : 0};
+      LaunchScope ls(eng, "embed_fwd");
+      hipLaunchKernelGGL(k_embed_all<false>, dim3(ea.g_bond1 + ea.g_bond2 + ea.g_angle), dim3(BLOCK), bond_embed_lds(), st, ea);
+    } else { LaunchScope ls(eng, "bond_embed_fwd");   // atom-graph expansion for every bond, bond-graph expansion for the bond-graph nodes only
       hipLaunchKernelGGL((k_bond_embed_t<false, false, 1>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
       if (b->Eb > 0)
         hipLaunchKernelGGL((k_bond_embed_t<false, false, 2>), dim3(grid_for(b->Eb, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
   }
-  if (b->A > 0) {
+  if (b->A > 0 && !(tiny && b->Ed > 0)) {
     LaunchScope ls(eng, "angle_embed_fwd");
     hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
   }
-  { LaunchScope ls(eng, "atom_embed");
+  if (!tiny) { LaunchScope ls(eng, "atom_embed");
     hipLaunchKernelGGL(k_atom_embed, g1((int64_t)b->N * (D / 4)), dim3(256), 0, st, b->z, w.emb, b->atom[0], b->N); }
   HIP_TRY(eng, hipGetLastError());   // (hbc[0], the nodes' copy of their embedding rows, is written by k_bond_embed_t)
 
   // ---- message passing (model.py:442-496) ----
   // every forward scatter target + crystal_fea -- and, when a reverse sweep follows, its accumulators too (the two ranges are
   // adjacent in the arena: one memset instead of two)
-  TRY(zero(eng, b->zero1, (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1)));
-  b->p_table_done = -1;
+  if (!tiny) TRY(zero(eng, b->zero1, zero_bytes));
+  // small batches with bonds and angles: the chained schedule (forward_tiny / reverse_tiny); CHGNET_TINY_CHAIN=0 keeps the launch
+  // sequence of the large batches
+  static const bool chain_on = [] { const char* e = std::getenv("CHGNET_TINY_CHAIN"); return !e || std::atoi(e) != 0; }();
+  const bool chained = tiny && chain_on && fuse_gq() && L >= 2 && b->Ed > 0 && b->A > 0 && b->Eb > 0 && b->p_table_done == 0;
+  if (chained) {
+    TRY(forward_tiny(eng, b, want_grad, want_m));
+  } else {
   for (int l = 0; l < L - 1; ++l) {
     TRY(atomconv_fwd(eng, b, l, want_grad));
     if (b->A > 0) {
@@ -581,6 +783,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     hipLaunchKernelGGL(k_magmom, dim3(wave_grid(eng, b->N)), dim3(256), 0, st, b->atom[L - 1], w.site_w, w.site_b, b->magmom, b->N);
   }
   TRY(atomconv_fwd(eng, b, L - 1, want_grad));
+  }
 
   // ---- readout (model.py:497-509) and its adjoint ----
   {
@@ -598,6 +801,9 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
 
   // ---- reverse sweep: dE/dv_e ----
   if (want_grad) {
+    if (chained) {
+      TRY(reverse_tiny(eng, b));
+    } else {
     TRY(atomconv_bwd(eng, b, L - 1));
     for (int l = L - 2; l >= 0; --l) {
       if (b->A > 0) {
@@ -606,12 +812,18 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
       }
       TRY(atomconv_bwd(eng, b, l));
     }
+    }
     if (b->Ed > 0) {
-      { LaunchScope ls(eng, "bond_embed_bwd");
+      if (tiny) {
+        EmbedAllArgs ea{bond_embed_args(eng, b), angle_embed_args(eng, b), grid_for(b->Eu, 2 * eng->num_cus),
+                        b->Eb > 0 ? grid_for(b->Eb, 2 * eng->num_cus) : 0, b->A > 0 ? grid_for(b->A, embed_grid_mult() * eng->num_cus) : 0};
+        LaunchScope ls(eng, "embed_bwd");
+        hipLaunchKernelGGL(k_embed_all<true>, dim3(ea.g_bond1 + ea.g_bond2 + ea.g_angle), dim3(BLOCK), bond_embed_lds(), st, ea);
+      } else { LaunchScope ls(eng, "bond_embed_bwd");
         hipLaunchKernelGGL((k_bond_embed_t<true, false, 1>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
         if (b->Eb > 0)
           hipLaunchKernelGGL((k_bond_embed_t<true, false, 2>), dim3(grid_for(b->Eb, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
-      if (b->A > 0) {
+      if (b->A > 0 && !tiny) {
         LaunchScope ls(eng, "angle_embed_bwd");
         hipLaunchKernelGGL((k_angle_embed_t<true>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
       }
@@ -658,17 +870,23 @@ void carve(chg_batch* b, char* base, size_t& total) {
   for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
   for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
   for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
-  b->energy = c.take<float>(B); b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->magmom = c.take<float>(N); b->volume = c.take<float>(B);
+  b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->volume = c.take<float>(B);
   // zero group 1 (cleared with one memset before the readout)
   b->zero1 = c.take<float>(0);
-  b->crystal_fea = c.take<float>(B * D);
   for (int l = 0; l < L; ++l) b->agg_l[l] = c.take<float>(N * D);
   for (int l = 0; l < L - 1; ++l) b->aggB_l[l] = c.take<float>(Eb * D);
+  // the results a download copies sit side by side across the border of the two groups -- crystal_fea | force | virial | energy | magmom --
+  // so that an MD-size download is ONE device-to-host copy (chg_batch_download: every copy is ~5 us of dependent device time); energy
+  // and magmom are plain stores, clearing them with group 2 is harmless
+  b->crystal_fea = c.take<float>(B * D);
   b->zero1_end = c.take<float>(0);
   // zero group 2 (cleared with one memset before the reverse sweep)
   b->zero2 = c.take<float>(0);
+  b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B); b->energy = c.take<float>(B); b->magmom = c.take<float>(N);
+  b->zero2_keep_end = c.take<float>(0);   // (chg_backward clears group 2 again AFTER the prediction: energy / magmom are skipped there)
   b->Gwbgc = c.take<float>(Eb * D);
-  b->Gu = c.take<float>(4 * Ed); b->force = c.take<float>(3 * N); b->virial = c.take<float>(9 * B);
+  b->Gu = c.take<float>(4 * Ed);
+  b->Grk = c.take<float>(Eu);   // (cleared for the merged embedding adjoint of small batches, whose two parts add into it concurrently)
   for (int l = 0; l < L; ++l) b->GP_l[l] = c.take<float>(N * 4 * D);
   for (int t = 0; t < 2 * L; ++t) {
     const bool used = (t < L - 1) || (t >= L && t < 2 * L - 2);   // BondConv 0..L-2, AngleUpdate L..2L-3
@@ -681,7 +899,6 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->Ga = c.take<float>(N * D); b->GA = c.take<float>(N * D);
   b->GQ = c.take<float>(Eu * 2 * D);
   b->Gagg = c.take<float>(Eb * D);
-  b->Grk = c.take<float>(Eu);
   b->phase = c.take<float>(PHASE_FLOATS);
   {   // windowed angle adjoints (kernels_angle_w.h)
     WinIndex& w = b->win;
@@ -715,7 +932,26 @@ int prepare_windows(chg_engine* eng, chg_batch* b) {
   // (CHGNET_WIN_MIN_ATOMS_PER_WAVE=0 sends small batches through the per-atom kernels too: parity tests on the golden cases)
   const char* min_env = std::getenv("CHGNET_WIN_MIN_ATOMS_PER_WAVE");
   const long min_atoms = min_env ? std::atol(min_env) : WIN_MIN_ATOMS_PER_WAVE;
-  if (b->A == 0 || (long)b->N < min_atoms * b->win_grid * WAVES) return CHG_OK;
+  b->win_team = 0;
+  if (b->A == 0) return CHG_OK;
+  if ((long)b->N < min_atoms * b->win_grid * WAVES) {
+    // TEAM mode (round 6): below a few atoms per wave an atom goes to a team of waves.  Worth its five index launches from a few
+    // tiles per workgroup on (CHGNET_TEAM_MIN_ANGLES, default 24k angles; 0 in the parity tests sends every batch through it)
+    static const long team_min = [] { const char* e = std::getenv("CHGNET_TEAM_MIN_ANGLES"); return e ? std::atol(e) : 24576L; }();
+    if (team_min < 0 || b->A < team_min || b->N + 1 > 8192) return CHG_OK;
+    const int cus = std::max(1, std::min(eng->num_cus, WIN_MAX_GRID));
+    int tw = WAVES;
+    while (tw > 1 && (long)cus * (WAVES / tw) < b->N) tw >>= 1;           // the largest team that still gives every atom its own
+    b->win_team = tw;
+    b->win_grid = std::max(1, std::min(cus, (b->N + WAVES / tw - 1) / (WAVES / tw)));
+    hipLaunchKernelGGL(k_win_clear, g1(std::max(b->Ed, b->N + 1)), dim3(256), 0, st, w, b->N, b->Ed, b->win_grid);
+    hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
+    hipLaunchKernelGGL(k_win_scan2, dim3(1), dim3(1024), 0, st, b->N, w);
+    hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
+    hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
+  }
   if (scan_scratch_ints(b->N + 1) > (size_t)(1u << 17)) return CHG_OK;      // beyond the two-level scan (65,536 chunks): plain adjoints
   b->win_built = true;
   HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
@@ -786,6 +1022,8 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_angleupd_fwd_a, angle_fa_lds()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
+  if ((s = set_lds(eng, (k_angle_bwd_w<true, true>), angle_w_lds<true>()))) return s;
+  if ((s = set_lds(eng, (k_angle_bwd_w<false, true>), angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;
   if ((s = set_lds(eng, k_angle<false, true>, (angle_lds<false, WAVES, true>())))) return s;
@@ -802,6 +1040,9 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_bond_embed_t<true, false, 2>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<true>, angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_rows_chain, chain_lds()))) return s;
+  if ((s = set_lds(eng, k_embed_all<false>, bond_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_embed_all<true>, bond_embed_lds()))) return s;
   return CHG_OK;
 }
 

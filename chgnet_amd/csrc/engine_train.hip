@@ -207,7 +207,9 @@ int run_backward(chg_engine* eng, chg_batch* b) {
   const int N = b->N, Ed = b->Ed, Eu = b->Eu, A = b->A, Eb = b->Eb;
   const bool bias = eng->desc.mlp_out_bias != 0;   // 0.2.0: mlp_out biases are parameters
   TRY(zero(eng, b->t_grad, sizeof(float) * (size_t)eng->desc.n_weights));
-  TRY(zero(eng, b->zero2, (size_t)((char*)b->zero2_end - (char*)b->zero2)));
+  // group 2 without the energies / magmoms of the prediction in its middle (they stay readable: chg_batch_all_gather_energy, download)
+  TRY(zero(eng, b->zero2, (size_t)((char*)b->energy - (char*)b->zero2)));
+  TRY(zero(eng, b->zero2_keep_end, (size_t)((char*)b->zero2_end - (char*)b->zero2_keep_end)));
 
   // ---- readout: dE/d atom[L] from the cotangent; per-atom operands of the MLP / LayerNorm gradients ----
   {

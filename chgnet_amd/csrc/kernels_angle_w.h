@@ -110,6 +110,41 @@ static __global__ void k_win_rows(const int* __restrict__ a_ctr, const int* __re
   w.q_ab2[row] = r2 >= 0 ? w.boff[c] + r2 : -1;
 }
 
+// ---- small batches (team mode, below): the index without the schedule, in five launches -----------------------------------------
+// every array k_win_heads accumulates into, and the flags, in one launch (instead of four memsets and k_win_init)
+static __global__ void k_win_clear(WinIndex w, int N, int Ed, int grid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int k = i; k <= N; k += stride) w.na[k] = 0;
+  for (int k = i; k < Ed; k += stride) { w.head[k] = -1; w.rank[k] = -1; }
+  if (i == 0) { w.flag[0] = 1; w.flag[1] = 0; w.flag[2] = 0; w.flag[3] = grid; }
+}
+
+// boff = exclusive scan of na, aoff = exclusive scan of na (na - 1), both over the N + 1 entries, by ONE workgroup (N + 1 <= 8192:
+// a few thousand atoms is all team mode is for): each thread sums a contiguous run, the 1024 run sums are scanned through LDS
+static __global__ __launch_bounds__(1024) void k_win_scan2(int N, WinIndex w) {
+  __shared__ int tot_b[16], tot_a[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = N + 1, per = (n + 1023) / 1024;
+  const int b = min(tid * per, n), e = min(b + per, n);
+  int sb = 0, sa = 0;
+  for (int k = b; k < e; ++k) { const int v = k < N ? w.na[k] : 0; sb += v; sa += v * (v - 1); }
+  int ib = sb, ia = sa;                     // inclusive scans over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off);
+    if (lane >= off) { ib += ub; ia += ua; }
+  }
+  if (lane == 63) { tot_b[wave] = ib; tot_a[wave] = ia; }
+  __syncthreads();
+  int rb = ib - sb, ra = ia - sa;
+  for (int q = 0; q < wave; ++q) { rb += tot_b[q]; ra += tot_a[q]; }
+  for (int k = b; k < e; ++k) {
+    const int v = k < N ? w.na[k] : 0;
+    w.boff[k] = rb; w.aoff[k] = ra;
+    rb += v; ra += v * (v - 1);
+  }
+}
+
 // ---- which wave works on which atom: a static schedule with the locality of a dynamic one ----------------------------------
 // With one contiguous atom range per wave (round 3) the 256 waves of an XCD sat in ~128 different structures at any moment and their
 // tables (R: 1 KB per bond node) missed the 4 MiB L2: hit rates of 24-37 %, fabric traffic 1.5-2.3x the compulsory bytes
@@ -182,6 +217,7 @@ static __global__ __launch_bounds__(64) void k_win_schedule(int grid, WinIndex w
 struct AngleWArgs {
   AngleArgs a;                // tables, weights, gradient buffers as for k_angle
   WinIndex w;                 // incl. the per-wave atom lists (k_win_schedule); the grid is the one the schedule was built for
+  int team_waves, n_atoms;    // TEAM kernels: waves that share one atom (1, 2, 4, 8), atoms of the batch
 };
 
 // Private second-bond rows per wave: dE/dR_j (128 wide).  AngleUpdate: the angle block as two split images (64 KiB), 14 rows.
@@ -279,11 +315,20 @@ __device__ __forceinline__ void private_add(const Cols64 (&c)[NB], int nvalid, i
   }
 }
 
-template <bool HIDDEN>
+// TEAM (round 6; MD-size batches): an atom belongs to a TEAM of 1 / 2 / 4 / 8 waves of one workgroup instead of to one wave, so that
+// a 256-atom cell still occupies 2,048 waves.  The waves of a team deal the atom's tiles among themselves (tile t to wave t mod team),
+// each accumulates the second-bond sums of ITS tiles in its own private rows as before, and when the atom is done the team adds its
+// copies of every row together in LDS (two workgroup barriers per atom) and sends n rows out -- not n (n - 1) as the row-order
+// adjoints do, which at this size are bound by exactly those memory-side atomics (939 B per angle at ~1.2 TB/s: 53 of the 72 us of
+// a 67,536-angle launch).  Atoms are dealt to the teams round robin (team g: atoms g, g + teams, ...; every team of a workgroup
+// runs the same number of iterations, idle ones included, so the barriers match).  Run sums of a wave's non-adjacent tiles simply
+// end at the tile's last row.
+template <bool HIDDEN, bool TEAM = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs pw) {
   const AngleArgs& p = pw.a;
   const WinIndex& w = pw.w;
   if (w.flag[0] != 1) return;                   // this batch runs the plain adjoint (k_angle<.., true>)
+  PH_START
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NS = win_ns<HIDDEN>(), PST = win_pst<HIDDEN>();
   // AngleUpdate: split images of W_ang and W_ang^T.  BondConv: row-major images of W_ang, W2c, W2g (each serves both directions).
@@ -297,35 +342,63 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
   float* paccs = tiles + WAVES * TILE64_FLOATS;   // [WAVES][NS][PST]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (HIDDEN) {
+  // the weight block is the row-order adjoint's (AngleLds<HIDDEN, true>: same images at the same offsets), prebuilt once per weight
+  // upload (k_angle_image): a 16-byte-per-lane copy.  Building it here from the fp32 weights -- strided reads + the hi / lo split in
+  // every workgroup of every launch -- is nothing next to a large batch's hundreds of tiles per wave, but was a quarter of a TEAM
+  // launch's two tiles per wave (~30k of 118k clocks per wave on a 256-atom cell).
+  static_assert((size_t)AngleLds<HIDDEN, true>::tiles * sizeof(float) == (HIDDEN ? WIN_RM_ANG + 2 * WIN_RM_W2 : 16 * (size_t)(2 * IMG128)) + sizeof(float) * VEC_SLOTS * D,
+                "the per-atom adjoints share the weight image of k_angle<HIDDEN, true>");
+  if (p.image) {
+    stage_image<AngleLds<HIDDEN, true>::tiles / 4, BLOCK>(smem, p.image, tid);
+  } else if (HIDDEN) {
     stage_rm(reinterpret_cast<_Float16*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
     stage_rm(reinterpret_cast<_Float16*>(W2c), p.gw.w2c, D, D, tid, BLOCK);
     stage_rm(reinterpret_cast<_Float16*>(W2g), p.gw.w2g, D, D, tid, BLOCK);
+    stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   } else {
     stage_split<false>(reinterpret_cast<h16x8*>(Wang), p.w_ang, 2 * D, D, tid, BLOCK);
     stage_split<true>(reinterpret_cast<h16x8*>(WangT), p.w_ang, 2 * D, D, tid, BLOCK);
+    stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   }
-  stage_gated_vecs(vecs, p.gw, HIDDEN, tid);
   for (int q = tid; q < WAVES * NS * PST; q += BLOCK) paccs[q] = 0.f;
   __syncthreads();
   float* T = tiles + wave * TILE64_FLOATS;
   float* Trow = T + j * TS64;
   float* pacc = paccs + wave * NS * PST;
   PH_DECL
-  int c_next = w.wave_head[blockIdx.x * WAVES + wave];     // this wave's atoms (k_win_schedule): a list, one atom ahead
-  for (int c = __builtin_amdgcn_readfirstlane(c_next); c >= 0; c = __builtin_amdgcn_readfirstlane(c_next)) {
-    c_next = w.next_atom[c];
-    const int n = __builtin_amdgcn_readfirstlane(w.na[c]);
-    const int r_begin = __builtin_amdgcn_readfirstlane(w.aoff[c]), r_end = r_begin + n * (n - 1), ab0 = __builtin_amdgcn_readfirstlane(w.boff[c]);
+  // TEAM: the waves [team0, team0 + tw) of this workgroup share atoms gt, gt + GT, ...; tiles wt, wt + tw, ... of an atom are this wave's
+  const int tw = TEAM ? pw.team_waves : 1;
+  const int wt = TEAM ? (wave & (tw - 1)) : 0, team0 = wave - wt;
+  const int GT = TEAM ? (int)gridDim.x * (WAVES / tw) : 1, gt = TEAM ? (int)blockIdx.x * (WAVES / tw) + wave / tw : 0;
+  const int iters = TEAM ? (pw.n_atoms + GT - 1) / GT : 0;
+  const int tstep = tw * TILE_ROWS;
+  int c_next = TEAM ? 0 : w.wave_head[blockIdx.x * WAVES + wave];     // this wave's atoms (k_win_schedule): a list, one atom ahead
+  for (int it = 0;; ++it) {
+    int c, n = 0, ab0 = 0;
+    bool active = true;
+    if (TEAM) {
+      if (it >= iters) break;
+      c = __builtin_amdgcn_readfirstlane(gt + it * GT);
+      active = c < pw.n_atoms;
+      if (active) { n = __builtin_amdgcn_readfirstlane(w.na[c]); active = n >= 2; }
+    } else {
+      c = __builtin_amdgcn_readfirstlane(c_next);
+      if (c < 0) break;
+      c_next = w.next_atom[c];
+      n = __builtin_amdgcn_readfirstlane(w.na[c]);
+    }
+    if (active) {
+    const int r_begin = __builtin_amdgcn_readfirstlane(w.aoff[c]), r_end = r_begin + n * (n - 1);
+    ab0 = __builtin_amdgcn_readfirstlane(w.boff[c]);
     // run sums carried over the tiles of this atom (lane = column): first bond (core | gate halves), centre, bond weights
     float ri0 = 0.f, ri1 = 0.f, rs0 = 0.f, rs1 = 0.f, rg = 0.f;
     int cur0 = -1, cur1 = -1, curg = -1;
     int a_n, b1_n, b2_n, ab2_n;
     {
-      const int row = min(r_begin + j, r_end - 1);
+      const int row = min(r_begin + wt * TILE_ROWS + j, r_end - 1);
       a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
     }
-    for (int row0 = r_begin; row0 < r_end; row0 += TILE_ROWS) {
+    for (int row0 = r_begin + wt * TILE_ROWS; row0 < r_end; row0 += tstep) {
       // lane index made opaque once per tile: everything derived from it (64-bit row pointers base + 4 lane for every buffer, row
       // constants) is recomputed where it is used instead of living -- and being spilled -- across the whole kernel; a spilled
       // value reloaded between stores or atomics costs their full round trip (the reload's wait is in order behind them)
@@ -334,8 +407,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       if (HIDDEN) asm volatile("" : "+v"(lane_t));
       const int nvalid = min(TILE_ROWS, r_end - row0);
       const int a = a_n, b1 = b1_n, b2 = b2_n, ab2 = ab2_n;
-      if (row0 + TILE_ROWS < r_end) {
-        const int row = min(row0 + TILE_ROWS + j, r_end - 1);
+      if (row0 + tstep < r_end) {
+        const int row = min(row0 + tstep + j, r_end - 1);
         a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
       }
       int s2 = ab2 - ab0;                         // rank of the second bond at this atom = private row
@@ -458,17 +531,41 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     if (HIDDEN) run_flush64(rg, curg, p.Gwbgc, D, lane_f);
     atomicAdd(grow<float>(p.GS, (unsigned)c, 2 * D, lane_f), rs0);
     atomicAdd(grow<float>(p.GS, (unsigned)c, 2 * D, D + lane_f), rs1);
-    const int nrows = min(n, NS);
-    const int bond_of = w.abbond[ab0 + min(lane_f, nrows - 1)];
-    for (int sl = 0; sl < nrows; ++sl) {
-      const int bond = __builtin_amdgcn_readlane(bond_of, sl);
-      float* src = pacc + sl * PST;
-      const float v0 = src[lane_f], v1 = src[D + lane_f];
-      src[lane_f] = 0.f; src[D + lane_f] = 0.f;
-      atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 2 * D + lane_f), v0);
-      atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 3 * D + lane_f), v1);
+    if (!TEAM) {
+      const int nrows = min(n, NS);
+      const int bond_of = w.abbond[ab0 + min(lane_f, nrows - 1)];
+      for (int sl = 0; sl < nrows; ++sl) {
+        const int bond = __builtin_amdgcn_readlane(bond_of, sl);
+        float* src = pacc + sl * PST;
+        const float v0 = src[lane_f], v1 = src[D + lane_f];
+        src[lane_f] = 0.f; src[D + lane_f] = 0.f;
+        atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 2 * D + lane_f), v0);
+        atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 3 * D + lane_f), v1);
+      }
     }
     PH(4)   // per-atom flush
+    }   // active
+    if (TEAM) {
+      // the team's copies of the private rows, summed and sent out: row sl by wave sl mod team.  (Workgroup barriers: the teams of
+      // a workgroup run the same number of iterations.)
+      __syncthreads();
+      if (active) {
+        const int nrows = min(n, NS);
+        const int bond_of = w.abbond[ab0 + min(lane, nrows - 1)];
+        for (int sl = wt; sl < nrows; sl += tw) {
+          const int bond = __builtin_amdgcn_readlane(bond_of, sl);
+          float v0 = 0.f, v1 = 0.f;
+          for (int k = 0; k < tw; ++k) {
+            float* src = paccs + ((team0 + k) * NS + sl) * PST;
+            v0 += src[lane]; v1 += src[D + lane];
+            src[lane] = 0.f; src[D + lane] = 0.f;
+          }
+          atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 2 * D + lane), v0);
+          atomicAdd(grow<float>(p.GR, (unsigned)bond, 4 * D, 3 * D + lane), v1);
+        }
+      }
+      __syncthreads();
+    }
   }
   PH_FLUSH(HIDDEN ? 40 : 50)
 }

@@ -462,10 +462,16 @@ constexpr size_t rows_gemm_lds() {
 // p.phase[kernel 0..3][later / first tile][slot 0..9][wave 0..PH_WAVES): every wave adds to its own floats (plain read-modify-write: the
 // first version met in 20 shared addresses, and 2048 waves' same-address atomics -- ~110 ns each -- cost more than the kernel)
 constexpr int PH_WAVES = 4096;
+// PH_START (first statement of a kernel) / PH_FLUSH: the wave's entry and exit stamps (low 32 bits, bit pattern) of the LAST launch of a kernel
+// go to the otherwise unused kernel slot 6: stamps[kernel][entry / exit][wave] -- when the waves of a launch really start and end.
+#define PH_START const unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
 #define PH_FLUSH(base) { const int gw_ = blockIdx.x * (blockDim.x >> 6) + wave; if (lane == 0 && gw_ < PH_WAVES) { for (int i_ = 0; i_ < 10; ++i_) { \
-  p.phase[((size_t)((base) / 10 * 2 + 0) * 10 + i_) * PH_WAVES + gw_] += ph_acc[i_]; p.phase[((size_t)((base) / 10 * 2 + 1) * 10 + i_) * PH_WAVES + gw_] += ph_acc1[i_]; } } }
+  p.phase[((size_t)((base) / 10 * 2 + 0) * 10 + i_) * PH_WAVES + gw_] += ph_acc[i_]; p.phase[((size_t)((base) / 10 * 2 + 1) * 10 + i_) * PH_WAVES + gw_] += ph_acc1[i_]; } \
+  p.phase[((size_t)6 * 20 + (base) / 10 * 2 + 0) * PH_WAVES + gw_] = __uint_as_float((unsigned)ph_t0); \
+  p.phase[((size_t)6 * 20 + (base) / 10 * 2 + 1) * PH_WAVES + gw_] = __uint_as_float((unsigned)__builtin_amdgcn_s_memtime()); } }
 #else
 #define PH_DECL
+#define PH_START
 #define PH_TILE(first)
 #define PH(i)
 #define PH_FLUSH(base)
@@ -753,6 +759,7 @@ __device__ __forceinline__ void acbwd_scatter(const float* T, int c, int nvalid,
 template <bool TRAIN, bool FUSE_GQ = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvArgs p) {
   static_assert(!(TRAIN && FUSE_GQ), "the training sweep keeps the dE/dQ table (its weight gradients contract it)");
+  PH_START
   constexpr int NW = WAVES;
   constexpr bool RM = FUSE_GQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -864,7 +871,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
     write_dl<VT>(Trow, g, gzc.t);
     write_dl<VT>(Trow + D, g, gzg.t);
     __builtin_amdgcn_wave_barrier();
-    {  // the next tile's gathers fly while this tile's run sums are formed and sent
+    if (v + 1 < ts.count) {  // the next tile's gathers fly while this tile's run sums are formed and sent
       GatherRegs gr;
       gather_issue128(gr, p.P, cn, p.P + 2 * D, nn, p.Q, kn, 4 * D, 4 * D, 2 * D, lane);
       PH(4)   // next tile's gathers issued
@@ -873,6 +880,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_atomconv_bwd(AtomConvAr
       __builtin_amdgcn_wave_barrier();
       gather_commit128(gr, T, TS, lane);
       PH(6)   // next tile's gathers landed
+    } else {   // the wave's last tile (MD-size batches: its only one) does not wait for rows nobody reads: 5.6k of 47k clocks per wave
+      PH(4)
+      acbwd_scatter<!FUSE_GQ>(T, c, nvalid, k0, p, lane);
+      PH(5)
     }
     c = cn; n = nn; k = kn;
   }
@@ -967,6 +978,7 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernels");
   if (!TRAIN && p.skip_flag && *p.skip_flag == 1) return;   // a per-atom kernel does this launch's work (kernels_angle_w.h / kernels_angle_fa.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  PH_START
   PH_DECL
   constexpr int SPLIT = angle_split(HIDDEN, BWD);
   using L = AngleLds<HIDDEN, BWD>;

@@ -97,8 +97,10 @@ constexpr size_t bond_embed_lds() { return sizeof(float) * (3 * D * WSB + WAVES 
 // written); 2 = the bond-graph part over the Eb bonds that are bond-graph nodes only (wbgc; adjoint: Grk[k] += ...; launched after
 // part 1).  Only 12 % of the bonds of a 6 A / 3 A graph are nodes, and the kernel is bound by its 62 sin / cos per bond: evaluating the
 // 31 bond-graph functions for the nodes only takes 44 % of the transcendentals out (forward 0.34 -> 0.2x ms, section 6 of DESIGN.md).
-template <bool BWD, bool TRAIN = false, int PART = 0>
-__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedTArgs p) {
+// MERGED (small batches): parts 1 and 2 -- and the angle expansion -- run as bodies of ONE launch (k_embed_all), i.e. concurrently: the
+// adjoint's two contributions to Grk then meet as atomic adds on a cleared array instead of store + read-modify-write.
+template <bool BWD, bool TRAIN = false, int PART = 0, bool MERGED = false>
+__device__ __forceinline__ void bond_embed_body(const BondEmbedTArgs& p, int vG, int vb) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
   static_assert(!TRAIN || PART == 0, "the training variant keeps both expansions in one pass (it dumps them side by side)");
   constexpr bool AG = PART != 2, BG = PART != 1;     // which expansion(s) this instantiation evaluates
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   float* Trow = T + j * ETS;
   const int ntiles = (n_rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
-  tile_range(ntiles, tb, te);
+  tile_range_of(ntiles, vG, vb, tb, te);
   float fa6[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, fa3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // TRAIN: d freq, this lane's rows
   // Inputs run ahead of the tiles: the bond length of tile t+1 (a load through the index requested during tile t-1) and the indices of
   // tile t+2 are requested at the top of tile t and taken (an empty asm: a wait placed by hand) after the basis functions, BEFORE the
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
     } else if (PART == 2) {      // dE/dr of the node bonds through the bond-graph weights: Grk[bond] += (Wb^T Gwbgc[node]) . d(basis)/dr
       f32x4 t3[2] = {zero4(), zero4()};
       V64 gin;
-      const float old = valid ? p.Grk[node] : 0.f;      // (node = this row's bond here; part 1 has written Grk)
+      const float old = (valid && !MERGED) ? p.Grk[node] : 0.f;      // (node = this row's bond here; part 1 has written Grk)
       read_dl<VT>(p.Gwbgc + (size_t)k * D, g, gin.t);
       embed_adjoint(t3, Wb, gin, j, g);
       float acc = 0.f;
@@ -244,7 +246,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc += t3[kt][r] * d3[kt][r];
       acc = quad_sum(acc);
-      if (valid && g == 0) p.Grk[node] = old + acc;
+      if (valid && g == 0) {
+        if (MERGED) atomicAdd(p.Grk + node, acc); else p.Grk[node] = old + acc;
+      }
     } else {
       // t6 = We^T Gb[k] + Wa^T Gwag[k],  t3 = Wb^T Gwbgc[node]   (64 -> 32 each), then dot with d(basis)/dr
       f32x4 t6[2] = {zero4(), zero4()}, t3[2] = {zero4(), zero4()};
@@ -270,7 +274,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc += t6[kt][r] * d6[kt][r] + t3[kt][r] * d3[kt][r];
       acc = quad_sum(acc);
-      if (valid && g == 0) p.Grk[k] = acc;
+      if (valid && g == 0) {
+        if (MERGED) atomicAdd(p.Grk + k, acc); else p.Grk[k] = acc;
+      }
       if (TRAIN && valid) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -302,6 +308,11 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   }
 }
 
+template <bool BWD, bool TRAIN = false, int PART = 0>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedTArgs p) {
+  bond_embed_body<BWD, TRAIN, PART>(p, gridDim.x, blockIdx.x);
+}
+
 struct AngleEmbedTArgs {
   const f32x4* eu;            // [Ed] unit vectors
   const int *a_d1, *a_d2;     // [A] directed edges of the two bonds
@@ -319,7 +330,7 @@ struct AngleEmbedTArgs {
 constexpr size_t angle_embed_lds() { return sizeof(float) * (D * WSB + WAVES * TILE_ROWS * ETS); }
 
 template <bool BWD, bool TRAIN = false>
-__global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
+__device__ __forceinline__ void angle_embed_body(const AngleEmbedTArgs& p, int vG, int vb) {
   static_assert(!TRAIN || BWD, "TRAIN is a variant of the adjoint kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* We = smem;
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEm
   float* Trow = T + j * ETS;
   const int ntiles = (p.n_angles + BLOCK_ROWS - 1) / BLOCK_ROWS;
   int tb, te;
-  tile_range(ntiles, tb, te);
+  tile_range_of(ntiles, vG, vb, tb, te);
   float fas[4] = {0.f, 0.f, 0.f, 0.f}, fac[4] = {0.f, 0.f, 0.f, 0.f};   // TRAIN: d freq through the sin / cos columns of this lane
   // Software pipeline over tiles (three dependent memory round trips per tile -- indices, unit vectors, adjoint rows -- left the waves
   // waiting 55-73 % of their cycles): indices two tiles ahead, unit vectors and the adjoint rows one tile ahead.
@@ -452,6 +463,29 @@ __global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEm
       }
     }
   }
+}
+
+template <bool BWD, bool TRAIN = false>
+__global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
+  angle_embed_body<BWD, TRAIN>(p, gridDim.x, blockIdx.x);
+}
+
+// Small batches: the three basis-expansion launches of a direction as ONE (blocks [0, g_bond1) are part 1 of the bond expansion,
+// the next g_bond2 part 2, the rest the angle expansion; a count of zero leaves a body out).  They only share their inputs (bond
+// vectors) -- three dependent launches of 6-14 us each become one of the longest's length.
+struct EmbedAllArgs {
+  BondEmbedTArgs b;
+  AngleEmbedTArgs a;
+  int g_bond1, g_bond2, g_angle;
+};
+template <bool BWD>
+__global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_embed_all(EmbedAllArgs p) {
+  int b = blockIdx.x;
+  if (b < p.g_bond1) { bond_embed_body<BWD, false, 1, true>(p.b, p.g_bond1, b); return; }
+  b -= p.g_bond1;
+  if (b < p.g_bond2) { bond_embed_body<BWD, false, 2, true>(p.b, p.g_bond2, b); return; }
+  b -= p.g_bond2;
+  angle_embed_body<BWD, false>(p.a, p.g_angle, b);
 }
 
 }  // namespace chg

@@ -75,6 +75,66 @@ static __global__ void k_edge_geom(const float* __restrict__ cart, const float* 
   eu[e] = b;
 }
 
+// ---- small batches: everything that precedes the basis expansions in ONE launch ------------------------------------------------
+// An MD-size prediction is ~60 dependent launches of 4-70 us, and a launch costs ~4.5 us before its first instruction: k_cart,
+// k_edge_geom, k_atom_embed, the memset of the scatter targets and the first AtomConv's P table (atom[0] = emb[z], so its table is a
+// row of a per-ELEMENT table contracted once per weight upload: engine_predict.hip build_images) were five of them.  Same arithmetic
+// per value as the kernels above (the edge's end points are transformed by the same fmaf chain k_cart uses).
+struct PrologueArgs {
+  const float *frac, *lattice;
+  const int *atom_owner, *z;
+  int n_atoms;
+  const int *e_center, *e_nbr, *e_owner;
+  const float* e_image;
+  int n_edges;
+  float* cart;
+  f32x4 *ev, *eu;
+  const float* emb;        // [94][64]
+  float* atom0;            // [N][64]
+  const float* p_elem;     // [94][256] P table of the first AtomConv per element (null: the table is contracted by its own launch)
+  float* P0;               // [N][256]
+  f32x4* zero_begin;       // range cleared for the sweeps (16-byte units)
+  size_t zero_n;
+};
+static __global__ __launch_bounds__(256) void k_prologue(PrologueArgs p) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = tid; e < (size_t)p.n_edges; e += stride) {
+    const float* L = p.lattice + 9 * p.e_owner[e];
+    const int c = p.e_center[e], n = p.e_nbr[e];
+    const float i0 = p.e_image[3 * e], i1 = p.e_image[3 * e + 1], i2 = p.e_image[3 * e + 2];
+    const float c0 = p.frac[3 * c], c1 = p.frac[3 * c + 1], c2 = p.frac[3 * c + 2];
+    const float n0 = p.frac[3 * n], n1 = p.frac[3 * n + 1], n2 = p.frac[3 * n + 2];
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float off = fmaf(i2, L[6 + k], fmaf(i1, L[3 + k], i0 * L[k]));
+      const float xc = fmaf(c2, L[6 + k], fmaf(c1, L[3 + k], c0 * L[k]));      // k_cart
+      const float xn = fmaf(n2, L[6 + k], fmaf(n1, L[3 + k], n0 * L[k]));
+      v[k] = xc - (xn + off);
+    }
+    const float r = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    p.ev[e] = f32x4{v[0], v[1], v[2], r};
+    p.eu[e] = f32x4{v[0] / r, v[1] / r, v[2] / r, 0.f};
+  }
+  for (size_t i = tid; i < (size_t)p.n_atoms; i += stride) {
+    const float* L = p.lattice + 9 * p.atom_owner[i];
+    const float f0 = p.frac[3 * i], f1 = p.frac[3 * i + 1], f2 = p.frac[3 * i + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.cart[3 * i + k] = fmaf(f2, L[6 + k], fmaf(f1, L[3 + k], f0 * L[k]));
+  }
+  for (size_t idx = tid; idx < (size_t)p.n_atoms * (D / 4); idx += stride) {
+    const size_t i = idx / (D / 4), q = idx % (D / 4);
+    reinterpret_cast<f32x4*>(p.atom0)[idx] = reinterpret_cast<const f32x4*>(p.emb + (size_t)(p.z[i] - 1) * D)[q];
+  }
+  if (p.p_elem)
+    for (size_t idx = tid; idx < (size_t)p.n_atoms * D; idx += stride) {       // 4 D floats per atom = D 16-byte units
+      const size_t i = idx / D, q = idx % D;
+      reinterpret_cast<f32x4*>(p.P0)[idx] = reinterpret_cast<const f32x4*>(p.p_elem + (size_t)(p.z[i] - 1) * 4 * D)[q];
+    }
+  const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+  for (size_t idx = tid; idx < p.zero_n; idx += stride) p.zero_begin[idx] = zz;
+}
+
 // ---- radial basis helpers ----------------------------------------------------------------------
 struct Envelope { float a, b, c; int p; };
 __device__ __forceinline__ float ipow(float x, int n) {

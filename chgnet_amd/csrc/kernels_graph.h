@@ -282,8 +282,10 @@ static __global__ void k_undirected(const int* __restrict__ e_center, const int*
 
 // per centre: number of edges strictly shorter than the bond-graph cutoff (graph.py:313 uses '<')
 // One wave per atom (a thread per atom walked ~110 edges of dependent loads: 38 us for a 256-atom cell).
+// (noncanon: raised when an atom has more short bonds than the per-atom angle adjoints index, kernels_angle_w.h WIN_LIST)
 static __global__ __launch_bounds__(256) void k_short_count(const double* __restrict__ e_dist, const int* __restrict__ center_off, int n_atoms, double r_bond,
-                                                     int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow) {
+                                                     int* __restrict__ short_cnt, int* __restrict__ n_isolated, const int* __restrict__ overflow,
+                                                     int max_short, int* __restrict__ noncanon) {
   const int lane = threadIdx.x & 63;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n_atoms || *overflow) return;
@@ -295,16 +297,20 @@ static __global__ __launch_bounds__(256) void k_short_count(const double* __rest
   if (lane == 0) {
     short_cnt[i] = c;
     if (e == b) atomicAdd(n_isolated, 1);
+    if (c > max_short) *noncanon = 1;
   }
 }
 
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
 static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
-                              int* __restrict__ ang_cnt, const int* __restrict__ overflow) {
+                              int* __restrict__ ang_cnt, const int* __restrict__ overflow, int* __restrict__ noncanon) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_und.get() || *overflow) return;
   const int f = u_u2d[k], s = e_rev[f];
+  // a bond EXACTLY at the cutoff (or one whose two directions disagree about it) owns angles without being anybody's short bond: the
+  // angle set of its end atoms is then not the complete n (n - 1) block the per-atom adjoints assume
+  if (!(e_dist[f] > r_bond) != (e_dist[f] < r_bond) || (e_dist[f] < r_bond) != (e_dist[s] < r_bond)) *noncanon = 1;
   int c = 0;
   if (!(e_dist[f] > r_bond)) {   // note '>' on the first directed edge's distance (graph.py:289)
     c += short_cnt[e_center[f]] - (e_dist[f] < r_bond ? 1 : 0);
@@ -373,7 +379,7 @@ static __global__ void k_angle_compact(const int* __restrict__ a_b1, const int* 
 // {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow, cell-sort overflow}
 static __global__ void k_collect_counts(const int* ed, const int* a, const int* eb, const int* flags, int* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2]; out[6] = flags[3];
+    out[0] = *ed; out[1] = *a; out[2] = *eb; out[3] = flags[0]; out[4] = flags[1]; out[5] = flags[2]; out[6] = flags[3]; out[7] = flags[4];
   }
 }
 
@@ -398,6 +404,59 @@ static __global__ __launch_bounds__(1024) void k_small_scan(const int* __restric
     const int v = in[k];
     out[k] = run;
     run += v;
+  }
+}
+
+// Exclusive prefix sum of a few chunks in ONE launch (chained scan): workgroups take chunk numbers from a ticket counter (so a chunk's
+// predecessor is always running), scan their chunk, wait for the predecessor's running total and publish their own.  The arrays of an
+// MD-size build (18-35k entries: 3-5 chunks) took the three launches below, 17.5 us against ~6 for this one -- a launch costs more than
+// the scan.  state: SCAN_STATE_INTS zeroed ints per scan ([0] ticket, [16 + c] chunk c's inclusive total | 0x80000000 once published).
+constexpr int SCAN_CHAIN_MAX = 64;              // chunks (every chunk reads all its predecessors' totals: longer arrays take the three launches below)
+constexpr int SCAN_STATE_INTS = 16 + SCAN_CHAIN_MAX;
+static __global__ __launch_bounds__(1024) void k_scan_chained(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ state) {
+  __shared__ int wave_tot[16];
+  __shared__ int s_chunk, s_prefix;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_chunk = atomicAdd(state, 1);
+  __syncthreads();
+  const int chunk = s_chunk;
+  constexpr int PER = 8;                        // 8,192 entries per chunk
+  const int b = min(chunk * 8192 + tid * PER, n), e = min(b + PER, n);
+  int v[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { v[k] = b + k < e ? in[b + k] : 0; s += v[k]; }
+  int incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int run = incl - s;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  // every chunk publishes its OWN total at once and sums its predecessors' totals (lanes of wave 0 in parallel): one memory round trip
+  // whatever the chunk count -- waiting for the predecessor's running total instead chained 3-5 round trips (10.5 us per scan)
+  if (wave == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += wave_tot[w];
+    if (lane == 0) __hip_atomic_store(state + 16 + chunk, total | (int)0x80000000, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int prefix = 0;
+    for (int q = lane; q < chunk; q += 64) {
+      int f;
+      do { f = __hip_atomic_load(state + 16 + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (f == 0);
+      prefix += f & 0x7fffffff;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) prefix += __shfl_xor(prefix, off);
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  run += s_prefix;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (b + k < e) out[b + k] = run;
+    run += v[k];
   }
 }
 
@@ -451,9 +510,30 @@ struct MultiCopy {
   void* dst[MULTI_COPY_MAX];
   const void* src[MULTI_COPY_MAX];
   unsigned long long words[MULTI_COPY_MAX];
+  // rows of the grid past the n_copy plain copies (the small kernels that used to follow: a launch costs more than they do):
+  int n_copy;
+  const double* cvt_src[2];   // rows n_copy, n_copy + 1: float64 -> float32 (fractional coordinates, lattices)
+  float* cvt_dst[2];
+  int cvt_n[2];
+  const int *a_b1, *a_b2, *u_bnode_new;   // row n_copy + 2: compact bond-node indices of the angles (reads the builder's u_bnode, not the copy)
+  int *a_b1c, *a_b2c;
+  int n_ang;
 };
 static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
   const int seg = blockIdx.y;
+  if (seg >= m.n_copy) {
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, tstride = gridDim.x * blockDim.x;
+    const int q = seg - m.n_copy;
+    if (q < 2) {
+      for (int t = t0; t < m.cvt_n[q]; t += tstride) m.cvt_dst[q][t] = (float)m.cvt_src[q][t];
+    } else {
+      for (int a = t0; a < m.n_ang; a += tstride) {
+        m.a_b1c[a] = m.u_bnode_new[m.a_b1[a]];
+        m.a_b2c[a] = m.u_bnode_new[m.a_b2[a]];
+      }
+    }
+    return;
+  }
   const unsigned long long n = m.words[seg];
   const unsigned* __restrict__ src = static_cast<const unsigned*>(m.src[seg]);
   unsigned* __restrict__ dst = static_cast<unsigned*>(m.dst[seg]);

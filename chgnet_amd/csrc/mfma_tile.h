@@ -334,14 +334,15 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // ---- tile scheduling: contiguous tile ranges per workgroup, neighbouring ranges on one XCD -------
 // Workgroup b is dispatched to XCD b % 8 (observed, speed only); giving XCD x the logical blocks
 // [x*G/8, (x+1)*G/8) keeps one structure's tables inside one XCD's L2.
-__device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) {
-  const int G = gridDim.x, b = blockIdx.x;
+// (tile_range_of: the same for a kernel that runs as one of several bodies of a merged launch -- its own block count and index)
+__device__ __forceinline__ void tile_range_of(int ntiles, int G, int b, int& begin, int& end) {
   int lb = b;
   if ((G & 7) == 0) lb = (b & 7) * (G >> 3) + (b >> 3);
   const int per = ntiles / G, rem = ntiles - per * G;
   begin = lb * per + (lb < rem ? lb : rem);
   end = begin + per + (lb < rem ? 1 : 0);
 }
+__device__ __forceinline__ void tile_range(int ntiles, int& begin, int& end) { tile_range_of(ntiles, gridDim.x, blockIdx.x, begin, end); }
 
 // The tile kernels run 8 waves per CU (LDS-limited), i.e. two per SIMD, whatever their register count:
 // telling the compiler lets its scheduler spend the 256-register budget on overlap instead of

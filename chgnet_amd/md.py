@@ -43,6 +43,8 @@ class BerendsenNVT:
         self.taut = taut_fs / FS_PER_TIME_UNIT
         self.task = task
         self.mass = ATOMIC_MASS[self.structure.atomic_numbers][:, None]
+        self._m3 = np.repeat(self.mass, 3, axis=1)                   # per-component masses / half-step factors (step() runs ~10 numpy calls)
+        self._half_dt_over_m = 0.5 * (timestep_fs / FS_PER_TIME_UNIT) / self._m3
         rng = np.random.default_rng(seed)
         self.vel = rng.normal(0.0, 1.0, (len(self.structure), 3)) * np.sqrt(KB_EV * temperature_K / self.mass)
         self.vel -= (self.vel * self.mass).sum(0) / self.mass.sum()      # no centre-of-mass drift
@@ -51,8 +53,8 @@ class BerendsenNVT:
         self.timing = {"graph+predict": 0.0, "steps": 0}
 
     def temperature(self) -> float:
-        ke = 0.5 * float((self.mass * self.vel**2).sum())
-        return 2.0 * ke / (3.0 * len(self.structure) * KB_EV)
+        ke2 = float(np.vdot(self.vel, self._m3 * self.vel))            # 2 x kinetic energy
+        return ke2 / (3.0 * len(self.structure) * KB_EV)
 
     def _evaluate(self) -> None:
         t0 = time.perf_counter()
@@ -65,15 +67,20 @@ class BerendsenNVT:
         if self.forces is None:
             self._evaluate()
         lam = np.sqrt(1.0 + self.dt / self.taut * (self.T0 / max(self.temperature(), 1e-12) - 1.0))
-        self.vel *= min(max(lam, 0.9), 1.1)
-        self.vel += 0.5 * self.dt * self.forces / self.mass
-        cart = self.structure.cart_coords + self.dt * self.vel
+        vel = self.vel
+        vel *= min(max(lam, 0.9), 1.1)
+        vel += self._half_dt_over_m * self.forces
         lattice = self.structure.lattice                       # fixed cell: the Lattice object and its inverse are reused
         if getattr(self, "_inv_of", None) is not lattice:
             self._inv_of, self._inv = lattice, np.linalg.inv(lattice.matrix)
-        self.structure = Structure(lattice, self.structure.atomic_numbers, cart @ self._inv)
+            self._dt_inv = self.dt * self._inv
+        # x(t + dt) = x + dt v in fractional coordinates: frac += (dt v) . L^-1  (one small matrix product; no cartesian round trip)
+        new = Structure.__new__(Structure)
+        new.lattice, new.atomic_numbers = lattice, self.structure.atomic_numbers
+        new.frac_coords = self.structure.frac_coords + vel @ self._dt_inv
+        self.structure = new
         self._evaluate()
-        self.vel += 0.5 * self.dt * self.forces / self.mass
+        vel += self._half_dt_over_m * self.forces
         self.timing["steps"] += 1
 
     def run(self, n_steps: int) -> dict:

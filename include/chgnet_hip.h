@@ -157,7 +157,7 @@ int chg_engine_cell_stats(chg_engine* eng, int64_t* cell_builds, int64_t* all_pa
 /* int32 index array of a batch by pack.py name (e_center, e_nbr, e_d2u, u_u2d, a_ctr, ...) -- tests only; "wide_range": one int,
  * 1 when chg_batch_download has moved the batch to the wide-range sweeps (an activation beyond the f16 operand range) */
 int chg_debug_fetch_i32(chg_engine* eng, chg_batch* batch, const char* name, int32_t* dst, int64_t capacity, int64_t* n_written);
-/* new positions / cells on an unchanged graph topology (MD with a Verlet-skin graph) */
+/* new positions / cells on an unchanged graph topology (finite differences, strain scans, a relaxation step that keeps its neighbours) */
 int chg_batch_update_geometry(chg_engine* eng, chg_batch* batch, const float* frac, const float* lattice);
 int chg_batch_free(chg_engine* eng, chg_batch* batch);
 int64_t chg_batch_device_bytes(const chg_batch* batch);

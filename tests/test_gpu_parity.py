@@ -395,37 +395,30 @@ def test_update_geometry_reuses_topology(hip_engine):
         assert np.abs(moved[key] - fresh[key]).max() < 1e-6, key
 
 
-def test_calculator_skin_fast_path_is_exact(hip_engine, golden_weights):
-    """Device-resident MD path (skin > 0): same E/F/S as rebuilding the exact-cutoff graph every step,
-    with far fewer graph builds (the envelope is identically zero in the skin shell)."""
+def test_calculator_rebuilds_the_graph_every_call_and_matches_predict_structure(hip_engine, golden_weights):
+    """CHGNetCalculator.calculate (dynamics.py:129-181): graph rebuilt on the device at every call, results = predict_structure's in
+    ASE's units.  (The ``skin`` option of rounds 2-5 is gone: it was slower than rebuilding.)"""
     from chgnet_amd import Structure
-    from chgnet_amd.calculator import CHGNetCalculator
+    from chgnet_amd.calculator import GPA_TO_EV_A3, CHGNetCalculator
     from chgnet_amd.graph.structure import Lattice
     from chgnet_amd.model import CHGNet
 
     _, d = load_case("s16tri")
     s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"])
     model = CHGNet(state_dict=golden_weights)
-    exact = CHGNetCalculator(model)
-    fast = CHGNetCalculator(model, skin=0.4)
+    calc = CHGNetCalculator(model)
     rng = np.random.default_rng(4)
-    n_graph = 0
-    for step in range(12):
+    for step in range(4):
         s = Structure(s.lattice, s.atomic_numbers, s.frac_coords + rng.normal(0, 1.5e-3, s.frac_coords.shape))
-        exact.calculate(s)
-        fast.calculate(s)
-        assert abs(exact.results["energy"] - fast.results["energy"]) < 16 * 2e-6
-        assert np.abs(exact.results["forces"] - fast.results["forces"]).max() < 2e-6
-        assert np.abs(exact.results["stress"] - fast.results["stress"]).max() < 2e-7
-        assert np.abs(exact.results["magmoms"] - fast.results["magmoms"]).max() < 2e-6
-    assert exact.n_graph_builds == 12 and fast.n_graph_builds < 6
-    with pytest.raises(ValueError, match="mlp_out bias"):
-        w02 = dict(golden_weights)
-        for l in range(4):
-            w02[f"atom_conv_layers.{l}.mlp_out.layers.1.bias"] = np.zeros(64, np.float32)
-        for l in range(3):
-            w02[f"bond_conv_layers.{l}.mlp_out.layers.1.bias"] = np.zeros(64, np.float32)
-        CHGNetCalculator(CHGNet(state_dict=w02, mlp_out_bias=True), skin=0.4)
+        calc.calculate(s)
+        ref = model.predict_structure(s, task="efsm")
+        assert abs(calc.results["energy"] - float(ref["e"]) * len(s)) < 16 * 2e-6
+        assert np.abs(calc.results["forces"] - ref["f"]).max() < 2e-6
+        assert np.abs(calc.results["stress"] - ref["s"] * GPA_TO_EV_A3).max() < 2e-7
+        assert np.abs(calc.results["magmoms"] - ref["m"]).max() < 2e-6
+    assert calc.n_graph_builds == 4
+    with pytest.raises(TypeError, match="skin"):
+        CHGNetCalculator(model, skin=0.4)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -310,7 +310,7 @@ def test_bridge_gradients_equal_the_reference_backward_fixtures(golden_weights, 
             if not err <= 3.2e-4 * scale:
                 msgs.append(f"{k}: {err:.3e} / {scale:.3e}")
         assert not msgs, "; ".join(msgs)
-        assert checked >= 130
+        assert checked >= 120
         e0 = out["e"].detach().clone()
         opt.step(); sched.step()
         with torch.no_grad():

@@ -23,9 +23,3 @@ t = time.perf_counter(); calc.model.predict_graph(g, task="ef"); tp = time.perf_
 print(f"graph build {tg*1e3:.2f} ms, predict_graph (pack+upload+predict+download) {tp*1e3:.2f} ms, N={len(s)} Ed={len(g.atom_graph)} A={len(g.bond_graph)}", flush=True)
 out = md.run(n_steps)
 print("exact rebuild every step:", out, flush=True)
-for skin in (0.3, 0.5):
-    calc2 = CHGNetCalculator(CHGNet(state_dict=W), skin=skin)
-    md2 = BerendsenNVT(s, calc2, temperature_K=1000.0, timestep_fs=2.0, task="ef")
-    md2.run(5)
-    out2 = md2.run(n_steps)
-    print(f"device-resident skin={skin}: graph builds {calc2.n_graph_builds}", out2, flush=True)
