@@ -255,11 +255,13 @@ class Ranks:
         self.cpu_affinity = pin_rank_cpus(self.local_rank, self.world)
         self.dist = None
         self.torch = None
-        self.backend = "gloo" if args.dry_run else "nccl"   # "nccl" IS RCCL on ROCm
+        self.shared_device = bool(getattr(args, "shared_device", False))
+        self.device_index = 0 if self.shared_device else self.local_rank   # --shared-device: every rank's engine sits on GPU 0
+        self.backend = "gloo" if (args.dry_run or self.shared_device) else "nccl"   # "nccl" IS RCCL on ROCm
         self.comm = None
         self.comm_note = None
         self.rccl_info = None
-        if args.comm in ("rccl", "auto") and not args.dry_run and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
+        if args.comm in ("rccl", "auto") and not args.dry_run and not self.shared_device and (self.world > 1 or os.environ.get("CHGNET_BENCH_FORCE_DIST")):
             from chgnet_amd.distributed import RcclComm      # RCCL through the engine library's C-ABI: no torch.distributed
 
             try:
@@ -629,6 +631,57 @@ def run_configs(eng, weights, ranks: Ranks, args, model=None, legs=("C1", "C3", 
         configs["C4_md"]["cell_4x2x2_512_atoms"] = {
             "atoms": len(cell512), "steps": n512, "steps_per_s": round(out5["steps_per_s"], 1),
             "ms_per_step": round(1e3 / out5["steps_per_s"], 3), "temperature_K": round(out5["temperature_K"], 1)}
+        # the use case north_star names next to the single trajectory: an MD ENSEMBLE -- R replicas of the 256-atom cell (same topology,
+        # own velocities) advanced in lockstep, all R graphs built and swept by ONE predict_structure call per step
+        ens = {}
+        for R in (8, 32):
+            reps = [BerendsenNVT(li9co7o16_supercell(), None, temperature_K=1000.0, timestep_fs=2.0, seed=r, task="ef") for r in range(R)]
+            single = BerendsenNVT(li9co7o16_supercell(), CHGNetCalculator(model), temperature_K=1000.0, timestep_fs=2.0, seed=0, task="ef")
+
+            def ens_step(first=False):
+                preds = model.predict_structure([m.structure for m in reps], task="ef", batch_size=R, min_atoms_per_batch=0)
+                for m, pr in zip(reps, preds):
+                    if not first:
+                        m.vel += m._half_dt_over_m * np.asarray(pr["f"], np.float64)      # second half kick of the previous step
+                        m.T_end = m.temperature()
+                    m.forces, m.energy = np.asarray(pr["f"], np.float64), float(pr["e"]) * len(m.structure)
+                    m.advance_positions()                                                # thermostat, first half kick, drift
+
+            ens_step(first=True)
+            for _ in range(5):
+                ens_step()
+            n_ens = max(50, args.md_steps // (R // 2))
+            t0 = time.perf_counter()
+            for _ in range(n_ens):
+                ens_step()
+            dt_ens = time.perf_counter() - t0
+            # replica 0 against the single-trajectory driver (same seed, same integrator): same temperature path to fp32 reassociation
+            single.run(5 + n_ens)                       # the replicas' last evaluation is the end of their step 5 + n_ens
+            ens[f"R{R}"] = {"replicas": R, "steps": n_ens, "replica_steps_per_s": round(R * n_ens / dt_ens, 1),
+                            "ms_per_ensemble_step": round(1e3 * dt_ens / n_ens, 3),
+                            "replica0_vs_single_trajectory": {"dT_K": round(abs(reps[0].T_end - single.temperature()), 4),
+                                                               "dE_eV": round(abs(reps[0].energy - single.energy), 5)}}
+        configs["C4_md"]["ensemble"] = {"what": "R replicas of the 256-atom cell in lockstep, one predict_structure call (device graph build + sweep "
+                                                "of all replicas) per step; replica-steps/s per GPU", **ens}
+    # ---- C2 batch-size curve: the headline workload at 128 ... 4096 structures, resident (where min_atoms_per_batch sits on it) ----
+    if ranks.rank == 0 and "C1" in legs and not getattr(args, "dry_run", False):
+        curve = {}
+        for nb in (64, 128, 256, 512, 1024, 2048, 4096):
+            try:
+                bb = eng.build_batch(workload_structures(nb, 0))
+            except Exception as exc:  # noqa: BLE001  (memory on a shared device)
+                curve[str(nb)] = {"error": str(exc)[:80]}
+                continue
+
+            def step_nb():
+                eng.predict(bb, "efs")
+                return eng.download(bb, "efs")
+
+            dt, _ = timed(step_nb, 5)
+            curve[str(nb)] = {"ms_per_step": round(1e3 * dt, 3), "structures_per_s": round(nb / dt, 1), "atoms": int(bb.packed.n_atoms)}
+            bb.free()
+        configs["C2_batch_curve"] = {"workload": "headline workload (perturbed LiMnO2 5x1x1, 40 atoms) at other batch sizes, task efs, device-resident, "
+                                                 "best of 5 steps", "by_structures": curve}
     # ---- C5: one fine-tuning epoch, data-parallel: Trainer step with the full CombinedLoss (E + F + S + magmom) --------
     if args.train_structures > 0 and "C5" in legs:
         from chgnet_amd.trainer import TrainStep
@@ -883,6 +936,132 @@ def dry_run(args, ranks: Ranks) -> None:
         emit(line)
 
 
+def shared_device_run(args, ranks: Ranks) -> None:
+    """``--gpus N --shared-device``: N ranks, each with its OWN ``chg_engine``, all on GPU 0, collectives over gloo -- the only N > 1 run
+    a one-GPU lease can give.  It measures NO scaling (the ranks share one device) and reports none: what it
+    proves is that the REAL sharded legs hold together at world size N -- the C2 step with its energy all-gather, the C3 LPT-sharded
+    ragged sweep, and C5 data-parallel fine-tuning steps -- by checking every slot of the gathered energy tables against rank 0's own
+    single-engine results for ALL shards, and the all-reduced gradient against the mean of the per-shard gradients."""
+    from chgnet_amd import CrystalGraphConverter
+    from chgnet_amd.distributed import shard_indices
+    from chgnet_amd.model import CHGNet
+    from chgnet_amd.trainer import TrainStep
+
+    world, rank = ranks.world, ranks.rank
+    weights = dict(np.load(os.path.join(REPO, "tests", "golden", "weights_seed0.npz")))
+    model = CHGNet(state_dict=weights, use_device=0)
+    model.graph_converter.set_isolated_atom_response("ignore")
+    eng = model.engine
+    conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+    n_c2 = min(args.structures, 256)
+    flags, legs = {}, {}
+
+    def check(name, ok, **info):
+        flags[name] = bool(ok)
+        legs[name] = {"ok": bool(ok), **info}
+
+    # ---- C2: this rank's share of the headline workload, energies all-gathered; rank 0 recomputes every share on its engine ----
+    batch = eng.upload(build_workload(n_c2, first_seed=rank * n_c2))
+    for _ in range(2):
+        eng.predict(batch, "efs")
+        res = eng.download(batch, "efs")
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.predict(batch, "efs")
+        res = eng.download(batch, "efs")
+        table = ranks.all_gather(res["e"])
+    ranks.barrier()
+    c2_ms = 1e3 * ranks.max_over_ranks(time.perf_counter() - t0) / 3
+    batch.free()
+    if rank == 0:
+        worst = 0.0
+        for r in range(world):
+            b_r = eng.upload(build_workload(n_c2, first_seed=r * n_c2))
+            eng.predict(b_r, "efs")
+            e_r = eng.download(b_r, "efs")["e"]
+            b_r.free()
+            worst = max(worst, float(np.abs(table[r * n_c2:(r + 1) * n_c2] - e_r).max()))
+        check("C2_energy_table", worst <= 5e-6 and len(table) == world * n_c2, max_abs_err=worst, structures_per_rank=n_c2, ms_per_step_all_ranks_one_gpu=round(c2_ms, 3))
+
+    # ---- C3: the LPT-sharded ragged sweep (run_configs' leg, smaller), every slot of the gathered table vs rank 0's own full sweep ----
+    n_total = min(args.sweep_structures, 300) * world
+    counts = [sweep_atom_count(i) for i in range(n_total)]
+    shards = shard_indices([float(c) for c in counts], world)
+    structs = [sweep_structure(i) for i in shards[rank]]
+    width = max(len(sh) for sh in shards)
+    preds = model.predict_structure(structs, task="efs", batch_size=min(args.sweep_chunk, 100))
+    e_local = np.zeros(width, np.float32)
+    e_local[:len(preds)] = [p["e"] for p in preds]
+    table = ranks.all_gather(e_local)
+    if rank == 0:
+        worst, pad_ok = 0.0, True
+        for r, sh in enumerate(shards):
+            ref = model.predict_structure([sweep_structure(i) for i in sh], task="e", batch_size=100)
+            got = table[r * width:r * width + len(sh)]
+            worst = max(worst, float(np.abs(got - np.array([p["e"] for p in ref], np.float32)).max()))
+            pad_ok &= not np.any(table[r * width + len(sh):(r + 1) * width])
+        check("C3_energy_table", worst <= 5e-6 and pad_ok, max_abs_err=worst, structures=n_total, shard_sizes=[len(sh) for sh in shards])
+
+    # ---- C5: data-parallel fine-tuning steps: all-reduced gradient == mean of the per-shard gradients; identical weights afterwards ----
+    import chgnet_amd.trainer as trainer_mod
+
+    bs = 32
+    per_rank_graphs = [[conv(s) for s in workload_structures(bs, 7000 + 100 * r)] for r in range(world)]
+    def synthetic_targets(gs, seed):
+        rng_ = np.random.default_rng(seed)
+        return {"e": rng_.normal(0, 0.05, len(gs)).astype(np.float32),
+                "f": [rng_.normal(0, 0.05, (len(g_.atomic_number), 3)).astype(np.float32) for g_ in gs],
+                "s": [rng_.normal(0, 0.2, (3, 3)).astype(np.float32) for _ in gs],
+                "m": [np.abs(rng_.normal(0.5, 0.2, len(g_.atomic_number))).astype(np.float32) for g_ in gs]}
+
+    per_rank_targets = [synthetic_targets(gs, seed=r) for r, gs in enumerate(per_rank_graphs)]
+    seen = {}
+    real_allreduce = trainer_mod.allreduce_gradients
+
+    def spying_allreduce(grads, *a, **kw):
+        out = real_allreduce(grads, *a, **kw)
+        seen.setdefault("local", {k: np.array(v, copy=True) for k, v in grads.items()})
+        seen.setdefault("reduced", {k: np.array(v, copy=True) for k, v in out.items()})
+        return out
+
+    trainer_mod.allreduce_gradients = spying_allreduce
+    try:
+        step = TrainStep(model, targets="efsm", learning_rate=1e-3)
+        infos = [step(per_rank_graphs[rank], per_rank_targets[rank]) for _ in range(2)]
+    finally:
+        trainer_mod.allreduce_gradients = real_allreduce
+    after = model.state_dict()
+    key = "atom_conv_layers.0.twoBody_atom.mlp_core.layers.0.weight"
+    same_weights = ranks.all_gather(after[key].reshape(-1)[:64].astype(np.float32)).reshape(world, -1)
+    if rank == 0:
+        ref_model = CHGNet(state_dict=weights, use_device=0)
+        ref_model._engine = None
+        want = None
+        for r in range(world):           # the first step's gradient of every shard, on rank 0's own (fresh) model
+            pred = ref_model.forward(per_rank_graphs[r], task="efsm")
+            _, g = step.loss.gradients(per_rank_targets[r], pred)
+            gr = ref_model.backward(g.get("e"), g.get("m"), g.get("f"), g.get("s"))
+            want = gr if want is None else {k: want[k] + gr[k] for k in want}
+        ref_model.release_forward_state()
+        worst = 0.0
+        for k, v in want.items():
+            scale = float(np.abs(v).max()) / world
+            if scale > 0:
+                worst = max(worst, float(np.abs(seen["reduced"][k] - v / world).max()) / scale)
+        check("C5_allreduced_gradient", worst <= 2e-4, max_rel_err=worst, tensors=len(want), loss_first_last=[round(infos[0]["loss"], 5), round(infos[-1]["loss"], 5)])
+        check("C5_weights_identical_on_all_ranks", bool(np.all(same_weights == same_weights[0])))
+        if ref_model._engine is not None:
+            ref_model._engine.close()
+    ok_all = ranks.max_over_ranks(0.0 if all(flags.values()) else 1.0) == 0.0
+    ranks.close()
+    if rank == 0:
+        emit({"metric": "shared-device plumbing run (NOT a scaling measurement)", "n_gpus": 1, "process_group_ranks": world, "shared_device": True,
+              "backend": "gloo (torch.distributed)", "cpu_affinity": ranks.cpu_affinity, "parity": flags, "legs": legs, "ok": bool(ok_all)})
+    if not ok_all:
+        raise SystemExit("bench.py --shared-device: a parity check failed")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -900,6 +1079,9 @@ def main() -> None:
                     help="exchange steps: 'rccl' = the engine library's own RCCL entry points, failing if the communicator cannot be "
                          "created or ncclCommCount differs from the world size; 'torch' = torch.distributed (backend nccl = RCCL); "
                          "'auto' (default) = rccl, falling back to torch with a comm_note in the line")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="N ranks with their own engines on GPU 0, gloo collectives: the real sharded legs at world size N on a one-GPU box "
+                         "(parity of the gathered tables / all-reduced gradients; no scaling number)")
     ap.add_argument("--total-structures", type=int, default=0,
                     help="strong-scaling mode: this many structures of the headline workload in TOTAL, split evenly over the ranks "
                          "(the default mode is weak: --structures per rank)")
@@ -911,6 +1093,8 @@ def main() -> None:
     ranks = Ranks(args)
     if args.dry_run:
         return dry_run(args, ranks)
+    if args.shared_device:
+        return shared_device_run(args, ranks)
     rank, world = ranks.rank, ranks.world
 
     from chgnet_amd.engine import Engine

@@ -122,7 +122,9 @@ struct chg_engine {
   double last_r_atom = 0.0, last_r_bond = 0.0;
   long n_spec_builds = 0, n_spec_overflows = 0, n_cell_builds = 0, n_cell_fallbacks = 0;
   int graph_search = 0;       // chg_engine_set_graph_search: 0 by size, 1 all pairs, 2 cell list
-  int cell_min_atoms = 512;   // structures at least this large are binned (by size)
+  int cell_min_atoms = 2048;  // structures at least this large are binned (by size).  Round 6, same box: all pairs beats the cell list at 512 (build 210 vs 273 us)
+                              // and 1,024 atoms (245 vs 311 us): one wave per centre walks the structure's atoms 64 at a time -- 8-16 iterations --
+                              // while the cell path pays a bin walk and an in-LDS sort per centre
   size_t memory_limit = 0;  // chg_engine_set_memory_limit: arenas larger than this are refused with CHG_ENOMEM (0 = no limit)
 };
 

@@ -794,8 +794,11 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
     r.has_composition = eng->desc.has_composition; r.n_hidden = eng->desc.n_mlp_hidden;
     r.site_energy = b->site_energy; r.site_raw = b->site_raw; r.crystal_fea = b->crystal_fea;
     r.Ga = want_grad ? b->Ga : nullptr;
+    // few atoms: fewer working waves per workgroup, more workgroups (ReadoutArgs::wpb)
+    const int tiles16 = (b->N + TILE_ROWS - 1) / TILE_ROWS;
+    r.wpb = std::max(1, std::min(WAVES, (tiles16 + eng->num_cus - 1) / eng->num_cus));
     LaunchScope ls(eng, "readout");
-    hipLaunchKernelGGL(k_readout<false>, dim3(grid_for(b->N, eng->num_cus)), dim3(BLOCK), readout_lds(), st, r);
+    hipLaunchKernelGGL(k_readout<false>, dim3(grid_for(b->N, eng->num_cus, r.wpb * TILE_ROWS)), dim3(BLOCK), readout_lds(), st, r);
     HIP_TRY(eng, hipGetLastError());
   }
 

@@ -1197,6 +1197,9 @@ struct ReadoutArgs {
   float* crystal_fea;      // [B,64] zeroed
   float* Ga;               // [N,64] out: dE/d atom (null -> forward only)
   // training (k_readout<true>) only: the reverse sweep starts from d(sum_b cot[b] E_b)/d(site energy)
+  int wpb;                 // waves of a workgroup that take a tile (0 = all 8).  Small batches: the six 64 x 64 contractions of a tile are
+                           // 12k cycles of fp32 matrix instructions, and two of the 16 tiles of a 256-atom cell per SIMD made the kernel
+                           // 20 us; one tile per workgroup spreads them over 16 CUs
   const float* cot;        // [B] cotangent of the per-structure energy sums
   float* dump;             // [9][N,64]: x0, silu(l1), silu(l2), cot*silu(l3), g1, g2, g3, gx0, gx0*xhat  (kernels_train.h contracts them)
 };
@@ -1227,11 +1230,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_readout(ReadoutArgs p) 
   float* T = tiles + wave * TILE_FLOATS;
   float* Trow = T + j * TS;
   const float b3 = p.b3[0];
-  const int ntiles = (p.n_atoms + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int wpb = p.wpb > 0 ? p.wpb : WAVES, block_rows = wpb * TILE_ROWS;
+  const int ntiles = (p.n_atoms + block_rows - 1) / block_rows;
   int tb, te;
   tile_range(ntiles, tb, te);
+  if (wave >= wpb) return;                 // (no workgroup barrier below)
   for (int tile = tb; tile < te; ++tile) {
-    const int row0 = tile * BLOCK_ROWS + wave * TILE_ROWS;
+    const int row0 = tile * block_rows + wave * TILE_ROWS;
     const int nvalid = min(TILE_ROWS, p.n_atoms - row0);
     if (nvalid <= 0) continue;
     const bool valid = j < nvalid;

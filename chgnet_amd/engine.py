@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -125,7 +126,7 @@ class Engine:
 
     def set_graph_search(self, search: str = "auto", cell_min_atoms: int = 0) -> None:
         """Neighbour search of ``build_batch``: "auto" (cell list for structures of at least ``cell_min_atoms`` atoms,
-        default 512), "all_pairs" or "cells".  The graph does not depend on the choice."""
+        default 2048), "all_pairs" or "cells".  The graph does not depend on the choice."""
         self._check(self.lib.chg_engine_set_graph_search(self.handle, {"auto": 0, "all_pairs": 1, "cells": 2}[search], int(cell_min_atoms)))
 
     def cell_stats(self) -> tuple[int, int]:
@@ -149,8 +150,7 @@ class Engine:
         return int(self.lib.chg_batch_bytes_required(self.weights.n_conv, n_struct, n_atoms, n_directed, n_angles, n_bnodes))
 
     def close(self) -> None:
-        for ptr in [p for p, _ in self.__dict__.pop("_pinned", {}).values()] + self.__dict__.pop("_pinned_retired", []):
-            self.lib.chg_host_free(ctypes.c_void_p(ptr))
+        self.__dict__.get("_pinned", {}).clear()      # page-locked packing blocks: freed by their finalizers once no PackedBatch array views them
         if self.handle:
             self.lib.chg_engine_destroy(self.handle)
             self.handle = ctypes.c_void_p()
@@ -164,10 +164,11 @@ class Engine:
     # ------------------------------------------------------------------
     def pinned_allocator(self, slot: int = 0):
         """``alloc`` argument for ``pack_batch``: the packed arrays of a batch carved out of ONE page-locked block per ``slot`` (grown when
-        a batch needs more, freed with the engine).  ``upload`` from such arrays is asynchronous DMA at the link rate (1024 x 40 atoms:
+        a batch needs more; a block is returned to the system when the pool and every array carved out of it are gone).  ``upload`` from such arrays is asynchronous DMA at the link rate (1024 x 40 atoms:
         ~250 MB in 5 ms instead of 22 ms from pageable memory).  A slot's block is REUSED by the next ``pack_batch`` with the same
         slot: alternate two slots when one batch is packed while the previous one is still in use (``TrainStep.run_epoch`` does)."""
         pools = self.__dict__.setdefault("_pinned", {})
+        host_free = self.lib.chg_host_free
 
         def alloc(spec: dict) -> dict:
             offs, pos = {}, 0
@@ -175,18 +176,21 @@ class Engine:
                 offs[name] = pos
                 pos += (int(np.prod(shape)) * np.dtype(dtype).itemsize + 255) & ~255
             need = max(pos, 256)
-            ptr, have = pools.get(slot, (None, 0))
+            raw, have = pools.get(slot, (None, 0))
             if have < need:
-                if ptr:     # a block that proved too small is RETIRED, not freed: earlier PackedBatch objects may still point into it
-                    self.__dict__.setdefault("_pinned_retired", []).append(ptr)     # (freed with the engine; blocks grow geometrically)
-                    pools.pop(slot, None)
+                # A block that proved too small is dropped from the pool, not freed here: earlier PackedBatch objects may still view it.
+                # Every block is ONE ctypes buffer object that its arrays keep alive (numpy holds the exporter); a finalizer returns the
+                # page-locked memory when the last of them -- and the pool -- has let go.  New blocks get 50 % headroom, so a slowly
+                # growing batch size retires a block every few growths instead of every step (round 5 kept all retired blocks until
+                # Engine.close(): up to ~8x the final size in unswappable memory).
+                pools.pop(slot, None)
                 out = ctypes.c_void_p()
-                want = need + need // 8
+                want = need + need // 2
                 if self.lib.chg_host_alloc(want, ctypes.byref(out)) != 0 or not out.value:
                     return {k: np.empty(shape, dtype) for k, (shape, dtype) in spec.items()}    # no page-locked memory: pageable arrays
-                ptr, have = out.value, want
-                pools[slot] = (ptr, have)
-            raw = (ctypes.c_char * have).from_address(ptr)
+                raw, have = (ctypes.c_char * want).from_address(out.value), want
+                weakref.finalize(raw, host_free, ctypes.c_void_p(out.value))
+                pools[slot] = (raw, have)
             arrays = {}
             for name, (shape, dtype) in spec.items():
                 n = int(np.prod(shape))

@@ -63,9 +63,10 @@ class BerendsenNVT:
         self.forces = np.asarray(self.calc.results["forces"], dtype=np.float64)
         self.energy = float(self.calc.results["energy"])
 
-    def step(self) -> None:
-        if self.forces is None:
-            self._evaluate()
+    def advance_positions(self) -> None:
+        """Thermostat, first half kick and drift of one step (needs ``self.forces``); the caller evaluates the new forces and applies
+        the second half kick.  ``step`` is exactly this + ``_evaluate`` + the second kick; an ensemble driver (bench.py C4) calls it
+        for R replicas around ONE batched prediction."""
         lam = np.sqrt(1.0 + self.dt / self.taut * (self.T0 / max(self.temperature(), 1e-12) - 1.0))
         vel = self.vel
         vel *= min(max(lam, 0.9), 1.1)
@@ -79,8 +80,13 @@ class BerendsenNVT:
         new.lattice, new.atomic_numbers = lattice, self.structure.atomic_numbers
         new.frac_coords = self.structure.frac_coords + vel @ self._dt_inv
         self.structure = new
+
+    def step(self) -> None:
+        if self.forces is None:
+            self._evaluate()
+        self.advance_positions()
         self._evaluate()
-        vel += self._half_dt_over_m * self.forces
+        self.vel += self._half_dt_over_m * self.forces
         self.timing["steps"] += 1
 
     def run(self, n_steps: int) -> dict:

@@ -148,7 +148,7 @@ typedef struct chg_structs_host {
 int chg_batch_build(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
                     chg_batch** out, int32_t* counts_out);
 /* Neighbour search of chg_batch_build, the device-side twin of chg_graph_build_with's `search` (chgnet_graph.h):
- * 0 = by size (structures with at least cell_min_atoms atoms -- default 512, 0 keeps the current value -- are binned on
+ * 0 = by size (structures with at least cell_min_atoms atoms -- default 2048, 0 keeps the current value -- are binned on
  * the host and searched through a cell list, one wave per centre, rows sorted in LDS), 1 = all pairs, 2 = cell list for
  * every structure.  The rows are the same bit for bit either way; a centre with more than 1024 rows makes the build
  * repeat with all pairs (counted by chg_engine_cell_stats). */

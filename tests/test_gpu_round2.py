@@ -405,7 +405,7 @@ def test_device_cell_list_search_is_bit_exact(hip_engine):
             assert times["all_pairs_edges"] == times["cells_edges"]
         assert times["cells"] < times["all_pairs"]
     finally:
-        hip_engine.set_graph_search("auto", 512)
+        hip_engine.set_graph_search("auto", 2048)       # the engine's default (all pairs wins up to ~1,000 atoms: engine_internal.h)
 
 
 def test_pipelined_chunks_give_the_single_chunk_results(hip_engine, golden_weights):

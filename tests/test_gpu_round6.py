@@ -1,0 +1,146 @@
+"""Round 6 (GPU): the MD-size path -- team-mode angle adjoints, merged prologue / embedding launches, chained row GEMMs, the
+one-launch scans of the device graph build -- against the launch sequence of the large batches, the goldens and the oracle; the
+ensemble step; two real engines at world size 2 on one GPU (bench.py --shared-device)."""
+
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, load_case
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import load_case
+from chgnet_amd import Structure
+from chgnet_amd.graph.structure import Lattice
+from chgnet_amd.engine import Engine
+from chgnet_amd.pack import pack_weights
+W = dict(np.load(sys.argv[1] + "/tests/golden/weights_trained_like.npz"))
+_, d = load_case("li9co7o16")
+base = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"])
+rng = np.random.default_rng(3)
+out = {}
+eng = Engine(pack_weights(W), 0)
+for tag, scale in (("a32", (1, 1, 1)), ("a256", (2, 2, 2)), ("a384", (3, 2, 2))):
+    s = base.make_supercell(scale)
+    s = Structure(s.lattice, s.atomic_numbers, s.frac_coords + rng.normal(0, 0.01, s.frac_coords.shape))
+    b = eng.build_batch([s], 6.0, 3.0)
+    for task in ("efsm", "e"):
+        eng.predict(b, task)
+        r = eng.download(b, task, site_energies=True, crystal_feas=True)
+        for k, v in r.items():
+            out[f"{tag}/{task}/{k}"] = v
+    out[f"{tag}/flag"] = eng.debug_fetch_i32(b, "win_flag", 4)
+    out[f"{tag}/counts"] = np.array([b.packed.n_directed, b.packed.n_angles, b.packed.n_bnodes])
+    # the same structure through the HOST builder and an upload (uploaded batches keep the row-order fallback launch behind the team kernel)
+    from chgnet_amd import CrystalGraphConverter
+    g = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)(s)
+    b2 = eng.upload([g])
+    eng.predict(b2, "efsm")
+    for k, v in eng.download(b2, "efsm").items():
+        out[f"{tag}/upload/{k}"] = v
+    b.free(); b2.free()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def _run_child(env_extra: dict, tmp: str, name: str) -> dict:
+    env = dict(os.environ)
+    for k in ("CHGNET_TINY_FUSE", "CHGNET_TINY_CHAIN", "CHGNET_TEAM_MIN_ANGLES"):
+        env.pop(k, None)
+    env.update(env_extra)
+    path = os.path.join(tmp, name + ".npz")
+    subprocess.run([sys.executable, "-c", _CHILD, REPO, path], check=True, env=env, timeout=600)
+    return dict(np.load(path))
+
+
+def test_md_size_path_equals_the_large_batch_launch_sequence():
+    """32 / 256 / 384 atoms of Li9Co7O16 (trained-like weights): the round-6 small-batch path (default) against the launch sequence
+    of the large batches (CHGNET_TINY_FUSE=0, team mode off) in a child process each -- E / F / S / M, site energies and crystal
+    features to fp32 reassociation; the team index is valid (flag 1) for device-built graphs; uploaded == device-built."""
+    with tempfile.TemporaryDirectory() as tmp:
+        new = _run_child({"CHGNET_TEAM_MIN_ANGLES": "0"}, tmp, "new")          # every batch with angles through the team kernels
+        default = _run_child({}, tmp, "default")
+        nochain = _run_child({"CHGNET_TINY_CHAIN": "0", "CHGNET_TEAM_MIN_ANGLES": "0"}, tmp, "nochain")
+        old = _run_child({"CHGNET_TINY_FUSE": "0", "CHGNET_TEAM_MIN_ANGLES": "-1"}, tmp, "old")
+    tol = {"e": 2e-6, "f": 4e-5, "s": 4e-4, "m": 2e-5, "site_energies": 3e-5, "crystal_fea": 5e-4}     # the trained-like tolerances of tests/test_v020.py
+    for tag in ("a32", "a256", "a384"):
+        assert list(new[f"{tag}/flag"][:1]) == [1], tag
+        assert np.array_equal(new[f"{tag}/counts"], old[f"{tag}/counts"])
+        for variant in (new, default, nochain):
+            for key, ref in old.items():
+                if not key.startswith(tag + "/") or key.endswith(("/flag", "/counts")):
+                    continue
+                k = key.rsplit("/", 1)[1]
+                err = float(np.abs(variant[key] - ref).max())
+                assert np.isfinite(variant[key]).all() and err <= tol[k], (key, err)
+
+
+def test_ensemble_prediction_equals_single_predictions(golden_weights):
+    """R replicas of one cell with their own displacements through ONE predict_structure call (the MD-ensemble step of bench.py C4)
+    == R single calls."""
+    from chgnet_amd import Structure
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.model import CHGNet
+
+    _, d = load_case("li9co7o16")
+    base = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell([2, 2, 1])
+    rng = np.random.default_rng(5)
+    reps = [Structure(base.lattice, base.atomic_numbers, base.frac_coords + rng.normal(0, 0.01, base.frac_coords.shape)) for _ in range(6)]
+    model = CHGNet(state_dict=golden_weights)
+    try:
+        together = model.predict_structure(reps, task="ef", batch_size=6, min_atoms_per_batch=0)
+        for s, p in zip(reps, together):
+            one = model.predict_structure(s, task="ef")
+            assert abs(float(p["e"]) - float(one["e"])) < 2e-6
+            assert np.abs(p["f"] - one["f"]).max() < 5e-6
+    finally:
+        if model._engine is not None:
+            model._engine.close()
+
+
+def test_two_engines_at_world_size_two_on_one_gpu():
+    """bench.py --gpus 2 --shared-device: two ranks, two engines, GPU 0, gloo collectives -- the REAL C2 step, C3 sweep and C5 steps
+    at world size 2: every slot of the gathered energy tables and the all-reduced gradient checked on rank 0 against its own
+    single-engine results (no scaling claim: one device)."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--shared-device", "--structures", "64", "--sweep-structures", "60"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["process_group_ranks"] == 2 and line["shared_device"] is True and line["ok"] is True
+    assert all(line["parity"].values()) and set(line["parity"]) == {"C2_energy_table", "C3_energy_table", "C5_allreduced_gradient", "C5_weights_identical_on_all_ranks"}
+
+
+def test_mid_size_scans_of_the_graph_build_are_exact(hip_engine):
+    """The one-launch chained scans (3-5 chunks for a 256-atom cell; longer arrays keep the three-launch scan): the device-built
+    arrays of a 1,024-atom cell (13-28 chunks) equal the host builder's, bit for bit."""
+    from chgnet_amd import CrystalGraphConverter, Structure
+    from chgnet_amd.graph.structure import Lattice
+    from chgnet_amd.pack import pack_batch
+
+    _, d = load_case("li9co7o16")
+    s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell([4, 4, 2])
+    rng = np.random.default_rng(1)
+    s = Structure(s.lattice, s.atomic_numbers, s.frac_coords + rng.normal(0, 0.004, s.frac_coords.shape))
+    want = pack_batch([CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)(s)])
+    for _ in range(2):          # the exact pass, then the single-pass (speculative) build
+        b = hip_engine.build_batch([s])
+        try:
+            assert (b.packed.n_directed, b.packed.n_angles, b.packed.n_bnodes) == (want.n_directed, want.n_angles, want.n_bnodes)
+            for name in ("e_center", "e_nbr", "e_d2u", "e_rev", "u_u2d", "u_bnode", "bn_und", "a_ctr", "a_b1c", "a_b2c", "a_d1", "a_d2"):
+                got = hip_engine.debug_fetch_i32(b, name, len(want.arrays[name]))
+                assert np.array_equal(got, want.arrays[name]), name
+        finally:
+            b.free()

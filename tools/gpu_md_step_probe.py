@@ -19,6 +19,8 @@ rng = np.random.default_rng(0)
 inv = np.linalg.inv(s0.lattice.matrix)
 structs = [Structure(s0.lattice, s0.atomic_numbers, s0.frac_coords + rng.normal(0, sigma, (len(s0), 3)) @ inv) for _ in range(8)]
 eng = Engine(pack_weights(W), 0)
+if os.environ.get("PROBE_GRAPH_SEARCH"):
+    eng.set_graph_search(os.environ["PROBE_GRAPH_SEARCH"])
 for profile in (False, True):
     eng.profile(profile)
     tb = tp = td = 0.0
