@@ -195,7 +195,8 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                const double* d_reach, const int* d_owner, const int* d_aoff, const CellLists* cells, double r_atom, double r_bond, double tol,
                bool speculative, int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
                int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
-               int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2) {
+               int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2, int*& short_cnt_out, int*& boff, int*& aoff, int*& q_a, int*& q_ctr, int*& q_ab1,
+               int*& q_ab2) {
   const int N = h->n_atoms;
   hipStream_t st = eng->stream;
   overflowed = false;
@@ -267,7 +268,11 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                      d_flags + 2, WIN_LIST, d_flags + 4);
   int A = 0, Eb = 0;
   if (capU > 0) {
-    hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2, d_flags + 4);
+    boff = N + 1 <= 8192 ? tmp.get<int>(N + 1) : nullptr;     // (the in-launch scan is one workgroup: batches of a few thousand atoms)
+    aoff = boff ? tmp.get<int>(N + 1) : nullptr;
+    if (boff && !aoff) boff = nullptr;
+    hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2, d_flags + 4,
+                       N, boff, aoff);
     TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1, scan_state + SCAN_STATE_INTS));   // entries past Eu are zero: the total sits at ang_off[capU]
   } else {
     HIP_TRY(eng, hipMemsetAsync(ang_off, 0, sizeof(int) * (capU + 1), st));
@@ -283,9 +288,17 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   }
   a_ctr = tmp.get<int>(capA); a_b1 = tmp.get<int>(capA); a_d1 = tmp.get<int>(capA); a_b2 = tmp.get<int>(capA); a_d2 = tmp.get<int>(capA);
   if (!a_ctr || !a_b1 || !a_d1 || !a_b2 || !a_d2) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
+  // the centre-major order of the per-atom / team angle adjoints, emitted with the angles (small batches: the index launches that used
+  // to follow the build were 5 of an MD step's ~60)
+  short_cnt_out = short_cnt;
+  q_a = q_ctr = q_ab1 = q_ab2 = nullptr;
+  if (boff && capA > 0) {
+    q_a = tmp.get<int>(capA); q_ctr = tmp.get<int>(capA); q_ab1 = tmp.get<int>(capA); q_ab2 = tmp.get<int>(capA);
+    if (!q_a || !q_ctr || !q_ab1 || !q_ab2) q_a = q_ctr = q_ab1 = q_ab2 = nullptr;
+  }
   if (capA > 0 && capU > 0) {
     hipLaunchKernelGGL(k_angle_fill, g1((int64_t)capU * 64), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
-                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2);
+                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2, short_cnt, boff, aoff, q_a, q_ctr, q_ab1, q_ab2);
     TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1, scan_state + 2 * SCAN_STATE_INTS));
   } else {
     HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (capU + 1), st));
@@ -355,6 +368,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
   int *e_center = nullptr, *e_nbr = nullptr, *e_owner = nullptr, *e_rev = nullptr, *e_d2u = nullptr, *p_center = nullptr, *p_nbr = nullptr,
       *u_u2d = nullptr, *u_bnode = nullptr, *bn_und = nullptr, *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr;
   float* e_image = nullptr;
+  int *w_na = nullptr, *w_boff = nullptr, *w_aoff = nullptr, *w_qa = nullptr, *w_qctr = nullptr, *w_qab1 = nullptr, *w_qab2 = nullptr;
   double *d_cart = nullptr, *d_frac = nullptr, *d_lat = nullptr;
   int *d_owner = nullptr, *d_aoff = nullptr;
   for (int attempt = speculate ? 0 : 1; attempt < 2; ++attempt) {
@@ -413,7 +427,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     gc = GraphCounts();
     TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, use_cells ? &cells : nullptr, r_atom, r_bond, tol, spec, capE,
                    capA, capEb, gc, overflowed, e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr,
-                   a_b1, a_d1, a_b2, a_d2));
+                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_qa, w_qctr, w_qab1, w_qab2));
     if (overflowed && gc.cell_overflow) {   // a centre with more rows than the in-LDS sort holds: same attempt again, all pairs
       use_cells = false;
       eng->n_cell_fallbacks++;
@@ -458,7 +472,16 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       add(b->e_rev, e_rev, Ed); add(b->p_center, p_center, Ed); add(b->p_nbr, p_nbr, Ed); add(b->e_image, e_image, 3 * (size_t)Ed);
       add(b->u_u2d, u_u2d, Eu); add(b->u_bnode, u_bnode, Eu); add(b->bn_und, bn_und, Eb);
       add(b->a_ctr, a_ctr, A); add(b->a_d1, a_d1, A); add(b->a_d2, a_d2, A);
-      static_assert(MULTI_COPY_MAX >= 17, "one slot per array");
+      // the index of the per-atom / team angle adjoints, when the builder emitted it and the batch will use it (decide_windows)
+      const bool index_ready = b->canonical && w_qa && A > 0 && decide_windows(eng, b);
+      if (index_ready) {
+        add(b->win.na, w_na, N); add(b->win.boff, w_boff, (size_t)N + 1); add(b->win.aoff, w_aoff, (size_t)N + 1);
+        add(b->win.q_a, w_qa, A); add(b->win.q_ctr, w_qctr, A); add(b->win.q_ab1, w_qab1, A); add(b->win.q_ab2, w_qab2, A);
+        mc.q_a_new = w_qa; mc.q_ab1_new = w_qab1; mc.q_b1c = b->win.q_b1c; mc.q_b2c = b->win.q_b2c; mc.abbond = b->win.abbond;
+        mc.win_flag = b->win.flag; mc.win_grid = b->win_grid;
+      }
+      b->win_index_ready = index_ready;
+      static_assert(MULTI_COPY_MAX >= 24, "one slot per array");
       // ... and the float32 copies of the coordinates / lattices and the angles' compact bond indices ride in the same launch
       mc.n_copy = nseg;
       mc.cvt_src[0] = d_frac; mc.cvt_dst[0] = b->frac; mc.cvt_n[0] = 3 * N;

@@ -166,6 +166,7 @@ struct chg_batch {
   bool win_built = false;   // the index exists (batches too small to give every wave a few atoms never build it)
   bool canonical = false;   // built by chg_batch_build and known to have the canonical angle structure (uploaded graphs: unknown -> false):
                             // the per-atom / team adjoints then need no row-order launch behind them
+  bool win_index_ready = false;   // chg_batch_build emitted the centre-major index with the graph (prepare_windows only schedules)
   int win_team = 0;         // > 0: small batch in TEAM mode (kernels_angle_w.h) -- the index without the schedule exists and the angle
                             // adjoints give every atom to a team of this many waves; win_grid is their workgroup count
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
@@ -300,6 +301,7 @@ AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b);
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
 void carve(chg_batch* b, char* base, size_t& total);
 int prepare_windows(chg_engine* eng, chg_batch* b);
+bool decide_windows(chg_engine* eng, chg_batch* b);   // sets win_built / win_team / win_grid; true when the batch uses the per-atom index
 int ensure_windows(chg_engine* eng, chg_batch* b);   // launches a pending prepare_windows (compute stream)
 void register_names(chg_batch* b);
 

@@ -925,28 +925,41 @@ int ensure_windows(chg_engine* eng, chg_batch* b) {
   return prepare_windows(eng, b);
 }
 
-int prepare_windows(chg_engine* eng, chg_batch* b) {
-  hipStream_t st = eng->stream;
-  WinIndex& w = b->win;
+// Which angle adjoints a batch runs: the per-atom kernels (large batches), the TEAM kernels (MD-size batches), or the row-order ones.
+bool decide_windows(chg_engine* eng, chg_batch* b) {
   b->win_built = false;
+  b->win_team = 0;
   // one workgroup per CU (their LDS admits no second one), in whole groups of 64 waves = 8 workgroups per XCD (k_win_schedule)
   b->win_grid = std::max(64, std::min(eng->num_cus / 64 * 64, WIN_MAX_GRID));
-  // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle -- plain adjoints, and nothing to build
+  // MD-size batches: fewer than a few atoms per wave would leave most of the chip idle with an atom per wave
   // (CHGNET_WIN_MIN_ATOMS_PER_WAVE=0 sends small batches through the per-atom kernels too: parity tests on the golden cases)
   const char* min_env = std::getenv("CHGNET_WIN_MIN_ATOMS_PER_WAVE");
   const long min_atoms = min_env ? std::atol(min_env) : WIN_MIN_ATOMS_PER_WAVE;
-  b->win_team = 0;
-  if (b->A == 0) return CHG_OK;
+  if (b->A == 0) return false;
   if ((long)b->N < min_atoms * b->win_grid * WAVES) {
-    // TEAM mode (round 6): below a few atoms per wave an atom goes to a team of waves.  Worth its five index launches from a few
-    // tiles per workgroup on (CHGNET_TEAM_MIN_ANGLES, default 24k angles; 0 in the parity tests sends every batch through it)
+    // TEAM mode (round 6): below a few atoms per wave an atom goes to a team of waves.  Worth its index from a few tiles per
+    // workgroup on (CHGNET_TEAM_MIN_ANGLES, default 24k angles; 0 in the parity tests sends every batch through it)
     static const long team_min = [] { const char* e = std::getenv("CHGNET_TEAM_MIN_ANGLES"); return e ? std::atol(e) : 24576L; }();
-    if (team_min < 0 || b->A < team_min || b->N + 1 > 8192) return CHG_OK;
+    if (team_min < 0 || b->A < team_min || b->N + 1 > 8192) return false;
     const int cus = std::max(1, std::min(eng->num_cus, WIN_MAX_GRID));
     int tw = WAVES;
     while (tw > 1 && (long)cus * (WAVES / tw) < b->N) tw >>= 1;           // the largest team that still gives every atom its own
     b->win_team = tw;
     b->win_grid = std::max(1, std::min(cus, (b->N + WAVES / tw - 1) / (WAVES / tw)));
+    return true;
+  }
+  if (scan_scratch_ints(b->N + 1) > (size_t)(1u << 17)) return false;      // beyond the two-level scan (65,536 chunks): plain adjoints
+  b->win_built = true;
+  return true;
+}
+
+int prepare_windows(chg_engine* eng, chg_batch* b) {
+  hipStream_t st = eng->stream;
+  WinIndex& w = b->win;
+  const bool ready = b->win_index_ready;        // chg_batch_build wrote the index with the graph (and has called decide_windows)
+  if (!ready && !decide_windows(eng, b)) return CHG_OK;
+  if (b->win_team > 0) {
+    if (ready) return CHG_OK;
     hipLaunchKernelGGL(k_win_clear, g1(std::max(b->Ed, b->N + 1)), dim3(256), 0, st, w, b->N, b->Ed, b->win_grid);
     hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
     hipLaunchKernelGGL(k_win_scan2, dim3(1), dim3(1024), 0, st, b->N, w);
@@ -955,19 +968,19 @@ int prepare_windows(chg_engine* eng, chg_batch* b) {
     HIP_TRY(eng, hipGetLastError());
     return CHG_OK;
   }
-  if (scan_scratch_ints(b->N + 1) > (size_t)(1u << 17)) return CHG_OK;      // beyond the two-level scan (65,536 chunks): plain adjoints
-  b->win_built = true;
-  HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
-  HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
-  HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
-  HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
-  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w, b->win_grid);
-  hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
-  TRY(exclusive_scan_with(eng, b->win_scan, w.na, w.boff, b->N + 1));
-  hipLaunchKernelGGL(k_win_counts, g1((int64_t)b->N + 1), dim3(256), 0, st, b->N, w, b->win_tmp);
-  TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
-  hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
-  hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+  if (!ready) {
+    HIP_TRY(eng, hipMemsetAsync(w.flag, 0, sizeof(int) * 4, st));
+    HIP_TRY(eng, hipMemsetAsync(w.na, 0, sizeof(int) * ((size_t)b->N + 1), st));
+    HIP_TRY(eng, hipMemsetAsync(w.head, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+    HIP_TRY(eng, hipMemsetAsync(w.rank, 0xFF, sizeof(int) * (size_t)b->Ed, st));
+    hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1), 0, st, w, b->win_grid);
+    hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
+    TRY(exclusive_scan_with(eng, b->win_scan, w.na, w.boff, b->N + 1));
+    hipLaunchKernelGGL(k_win_counts, g1((int64_t)b->N + 1), dim3(256), 0, st, b->N, w, b->win_tmp);
+    TRY(exclusive_scan_with(eng, b->win_scan, b->win_tmp, w.aoff, b->N + 1));
+    hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
+    hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+  }
   hipLaunchKernelGGL(k_win_groups, g1(b->win_grid / 8 + 1), dim3(256), 0, st, b->N, b->A, b->win_grid / 8, w);
   hipLaunchKernelGGL(k_win_schedule, dim3(b->win_grid / 8), dim3(64), 0, st, b->win_grid, w);
   HIP_TRY(eng, hipGetLastError());

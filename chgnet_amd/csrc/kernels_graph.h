@@ -304,7 +304,28 @@ static __global__ __launch_bounds__(256) void k_short_count(const double* __rest
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
 static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
-                              int* __restrict__ ang_cnt, const int* __restrict__ overflow, int* __restrict__ noncanon) {
+                              int* __restrict__ ang_cnt, const int* __restrict__ overflow, int* __restrict__ noncanon, int n_atoms,
+                              int* __restrict__ boff, int* __restrict__ aoff) {
+  // Workgroup 0 first writes the per-atom offsets of the centre-major angle order (the index of the per-atom / team angle adjoints,
+  // kernels_angle_w.h): boff = exclusive scan of the short-bond counts n, aoff = exclusive scan of n (n - 1), N + 1 entries each.
+  // Riding in this launch they cost nothing; as k_win_* launches after the build they were five more of an MD step's ~60.
+  if (blockIdx.x == 0 && boff) {
+    __shared__ int sb[256], sa[256];
+    const int tid = threadIdx.x, n = n_atoms + 1, per = (n + 255) / 256;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    int tb = 0, ta = 0;
+    // (an atom with ONE short bond has no angles and owns no (atom, bond) pair: like k_win_heads, which counts group heads)
+    for (int q = b; q < e; ++q) { const int v = q < n_atoms ? short_cnt[q] : 0; tb += v >= 2 ? v : 0; ta += v * (v - 1); }
+    sb[tid] = tb; sa[tid] = ta;
+    __syncthreads();
+    int rb = 0, ra = 0;
+    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; }
+    for (int q = b; q < e; ++q) {
+      const int v = q < n_atoms ? short_cnt[q] : 0;
+      boff[q] = rb; aoff[q] = ra;
+      rb += v >= 2 ? v : 0; ra += v * (v - 1);
+    }
+  }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_und.get() || *overflow) return;
   const int f = u_u2d[k], s = e_rev[f];
@@ -326,7 +347,9 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
                                                     const int* __restrict__ e_d2u, const double* __restrict__ e_dist, const int* __restrict__ center_off,
                                                     const int* __restrict__ ang_off, DevCount n_und, double r_bond, int* __restrict__ a_ctr,
                                                     int* __restrict__ a_b1, int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2,
-                                                    int* __restrict__ is_node, int cap_angles, int* __restrict__ overflow) {
+                                                    int* __restrict__ is_node, int cap_angles, int* __restrict__ overflow,
+                                                    const int* __restrict__ short_cnt, const int* __restrict__ boff, const int* __restrict__ aoff,
+                                                    int* __restrict__ q_a, int* __restrict__ q_ctr, int* __restrict__ q_ab1, int* __restrict__ q_ab2) {
   const int lane = threadIdx.x & 63;
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (k >= n_und.get() || *overflow) return;
@@ -338,17 +361,39 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
   for (int end = 0; end < 2; ++end) {
     const int de = des[end], ctr = e_center[de];
     const int b = center_off[ctr], e = center_off[ctr + 1];
+    // centre-major position of this group (kernels_angle_w.h: rows of atom c at aoff[c] + rank of the first bond x (n - 1) + position
+    // in the group; ranks count the centre's SHORT edges in edge order -- the order k_win_ranks / k_win_rows establish)
+    int rank1 = 0;
+    if (q_a) {
+      for (int base = b; base < e; base += 64) {
+        const int other = base + lane;
+        rank1 += __popcll(__ballot(other < e && other < de && e_dist[other] < r_bond));
+      }
+    }
+    const int n_c = q_a ? short_cnt[ctr] : 0;
+    const long row0 = q_a ? (long)aoff[ctr] + (long)rank1 * (n_c - 1) : 0;
+    const int ab0 = q_a ? boff[ctr] : 0;
+    const int w_group = w;
+    int shorts_before = 0;
     for (int base = b; base < e; base += 64) {
       const int other = base + lane;
-      const bool take = other < e && other != de && e_dist[other] < r_bond;
-      const unsigned long long m = __ballot(take);
+      const bool is_short = other < e && e_dist[other] < r_bond;
+      const bool take = is_short && other != de;
+      const unsigned long long m = __ballot(take), ms = __ballot(is_short), lower = (1ull << lane) - 1ull;
       if (take) {
-        const int at = w + __popcll(m & ((1ull << lane) - 1ull));
+        const int at = w + __popcll(m & lower);
         const int b2 = e_d2u[other];
         a_ctr[at] = ctr; a_b1[at] = k; a_d1[at] = de; a_b2[at] = b2; a_d2[at] = other;
         is_node[b2] = 1;
+        if (q_a) {
+          const long row = row0 + (at - w_group);
+          if (row >= 0 && row < cap_angles) {
+            q_a[row] = at; q_ctr[row] = ctr; q_ab1[row] = ab0 + rank1; q_ab2[row] = ab0 + shorts_before + __popcll(ms & lower);
+          }
+        }
       }
       w += __popcll(m);
+      shorts_before += __popcll(ms);
     }
   }
   if (lane == 0) is_node[k] = 1;
@@ -505,7 +550,7 @@ static __global__ __launch_bounds__(1024) void k_scan_apply(const int* __restric
 
 // Several device-to-device copies in one launch (the index arrays of a freshly built graph into the batch arena):
 // blockIdx.y picks the segment, the blocks of a row stride over its 4-byte words.
-constexpr int MULTI_COPY_MAX = 20;
+constexpr int MULTI_COPY_MAX = 28;
 struct MultiCopy {
   void* dst[MULTI_COPY_MAX];
   const void* src[MULTI_COPY_MAX];
@@ -518,6 +563,11 @@ struct MultiCopy {
   const int *a_b1, *a_b2, *u_bnode_new;   // row n_copy + 2: compact bond-node indices of the angles (reads the builder's u_bnode, not the copy)
   int *a_b1c, *a_b2c;
   int n_ang;
+  // ... and, when the builder emitted the centre-major order (k_angle_fill), the rest of the per-atom adjoints' index: the compact bond
+  // indices in that order, the bond behind every (atom, rank) pair, the flags
+  const int *q_a_new, *q_ab1_new;
+  int *q_b1c, *q_b2c, *abbond, *win_flag;
+  int win_grid;
 };
 static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
   const int seg = blockIdx.y;
@@ -530,7 +580,15 @@ static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
       for (int a = t0; a < m.n_ang; a += tstride) {
         m.a_b1c[a] = m.u_bnode_new[m.a_b1[a]];
         m.a_b2c[a] = m.u_bnode_new[m.a_b2[a]];
+        if (m.q_a_new) {
+          const int ar = m.q_a_new[a];               // the angle that is row a of the centre-major order
+          const int c1 = m.u_bnode_new[m.a_b1[ar]];
+          m.q_b1c[a] = c1;
+          m.q_b2c[a] = m.u_bnode_new[m.a_b2[ar]];
+          m.abbond[m.q_ab1_new[a]] = c1;             // (every row of a group writes the same value)
+        }
       }
+      if (m.q_a_new && t0 == 0) { m.win_flag[0] = 1; m.win_flag[1] = 0; m.win_flag[2] = 0; m.win_flag[3] = m.win_grid; }
     }
     return;
   }

@@ -15,7 +15,12 @@ W = dict(np.load(os.path.join(REPO, "tests/golden/weights_seed0.npz")))
 _, d = load_case("li9co7o16")
 s = Structure(Lattice(d["lattice_f64"]), d["atomic_number"], d["frac_coord_f64"]).make_supercell(scale)
 eng = Engine(pack_weights(W), 0)
-batch = eng.build_batch([s], 6.0, 3.0)
+R = int(os.environ.get("PROBE_REPLICAS", "1"))
+rng = np.random.default_rng(0)
+inv = np.linalg.inv(s.lattice.matrix)
+structs = [Structure(s.lattice, s.atomic_numbers, s.frac_coords + (rng.normal(0, 0.08, (len(s), 3)) @ inv if R > 1 else 0.0)) for _ in range(R)]
+t0 = time.perf_counter(); batch = eng.build_batch(structs, 6.0, 3.0); batch.free()
+t0 = time.perf_counter(); batch = eng.build_batch(structs, 6.0, 3.0); print(f"build_batch of {R} structure(s): {1e6 * (time.perf_counter() - t0):.1f} us", flush=True)
 pb = batch.packed
 print(f"{len(s)} atoms: Ed={pb.n_directed} Eu={pb.n_undirected} A={pb.n_angles} Eb={pb.n_bnodes}", flush=True)
 for _ in range(10):
