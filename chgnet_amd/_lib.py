@@ -13,7 +13,7 @@ TASK_BITS = {"e": 1, "f": 2, "s": 4, "m": 8}
 
 EXPORTED_SYMBOLS = (
     "chg_device_count", "chg_weights_required", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
-    "chg_batch_upload", "chg_batch_build", "chg_debug_fetch_i32", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
+    "chg_batch_upload", "chg_batch_build", "chg_batch_build_predict", "chg_debug_fetch_i32", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
     "chg_debug_fetch", "chg_test_rows_gemm", "chg_test_split_gemm",
@@ -114,6 +114,8 @@ def load() -> ctypes.CDLL:
     lib.chg_host_free.argtypes = [vp]
     lib.chg_batch_build.argtypes = [vp, ctypes.POINTER(StructsHost), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.POINTER(vp), c_int_p]
+    lib.chg_batch_build_predict.argtypes = [vp, ctypes.POINTER(StructsHost), ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint32,
+                                            ctypes.POINTER(vp), c_int_p]
     lib.chg_debug_fetch_i32.argtypes = [vp, vp, ctypes.c_char_p, c_int_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     lib.chg_batch_update_geometry.argtypes = [vp, vp, c_float_p, c_float_p]
     lib.chg_batch_free.argtypes = [vp, vp]

@@ -195,8 +195,8 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                const double* d_reach, const int* d_owner, const int* d_aoff, const CellLists* cells, double r_atom, double r_bond, double tol,
                bool speculative, int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
                int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
-               int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2, int*& short_cnt_out, int*& boff, int*& aoff, int*& q_a, int*& q_ctr, int*& q_ab1,
-               int*& q_ab2) {
+               int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2, int*& short_cnt_out, int*& boff, int*& aoff, int*& toff, int*& q_a, int*& q_ctr,
+               int*& q_ab1, int*& q_ab2) {
   const int N = h->n_atoms;
   hipStream_t st = eng->stream;
   overflowed = false;
@@ -268,11 +268,16 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                      d_flags + 2, WIN_LIST, d_flags + 4);
   int A = 0, Eb = 0;
   if (capU > 0) {
-    boff = N + 1 <= 8192 ? tmp.get<int>(N + 1) : nullptr;     // (the in-launch scan is one workgroup: batches of a few thousand atoms)
+    // (the in-launch scan is one workgroup: batches of a few thousand atoms; and only when the batch is likely to use the index -- a
+    // single-pass build knows the previous build's angle count, an exact one emits it in any case)
+    const long tmin = team_min_angles();
+    const bool index_likely = tmin >= 0 && (!speculative || ((double)capA - 4096.0) / 1.25 >= 0.8 * (double)tmin);   // capA = previous A x 1.25 + 4096
+    boff = (N + 1 <= 8192 && index_likely) ? tmp.get<int>(N + 1) : nullptr;   // (not emitted but needed after all: prepare_windows builds it, k_win_*)
     aoff = boff ? tmp.get<int>(N + 1) : nullptr;
-    if (boff && !aoff) boff = nullptr;
+    toff = boff ? tmp.get<int>(N + 1) : nullptr;
+    if (boff && (!aoff || !toff)) boff = nullptr;
     hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2, d_flags + 4,
-                       N, boff, aoff);
+                       N, boff, aoff, toff);
     TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1, scan_state + SCAN_STATE_INTS));   // entries past Eu are zero: the total sits at ang_off[capU]
   } else {
     HIP_TRY(eng, hipMemsetAsync(ang_off, 0, sizeof(int) * (capU + 1), st));
@@ -368,7 +373,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
   int *e_center = nullptr, *e_nbr = nullptr, *e_owner = nullptr, *e_rev = nullptr, *e_d2u = nullptr, *p_center = nullptr, *p_nbr = nullptr,
       *u_u2d = nullptr, *u_bnode = nullptr, *bn_und = nullptr, *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr;
   float* e_image = nullptr;
-  int *w_na = nullptr, *w_boff = nullptr, *w_aoff = nullptr, *w_qa = nullptr, *w_qctr = nullptr, *w_qab1 = nullptr, *w_qab2 = nullptr;
+  int *w_na = nullptr, *w_boff = nullptr, *w_aoff = nullptr, *w_toff = nullptr, *w_qa = nullptr, *w_qctr = nullptr, *w_qab1 = nullptr, *w_qab2 = nullptr;
   double *d_cart = nullptr, *d_frac = nullptr, *d_lat = nullptr;
   int *d_owner = nullptr, *d_aoff = nullptr;
   for (int attempt = speculate ? 0 : 1; attempt < 2; ++attempt) {
@@ -427,7 +432,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     gc = GraphCounts();
     TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, use_cells ? &cells : nullptr, r_atom, r_bond, tol, spec, capE,
                    capA, capEb, gc, overflowed, e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr,
-                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_qa, w_qctr, w_qab1, w_qab2));
+                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_toff, w_qa, w_qctr, w_qab1, w_qab2));
     if (overflowed && gc.cell_overflow) {   // a centre with more rows than the in-LDS sort holds: same attempt again, all pairs
       use_cells = false;
       eng->n_cell_fallbacks++;
@@ -475,13 +480,13 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       // the index of the per-atom / team angle adjoints, when the builder emitted it and the batch will use it (decide_windows)
       const bool index_ready = b->canonical && w_qa && A > 0 && decide_windows(eng, b);
       if (index_ready) {
-        add(b->win.na, w_na, N); add(b->win.boff, w_boff, (size_t)N + 1); add(b->win.aoff, w_aoff, (size_t)N + 1);
+        add(b->win.na, w_na, N); add(b->win.boff, w_boff, (size_t)N + 1); add(b->win.aoff, w_aoff, (size_t)N + 1); add(b->win.toff, w_toff, (size_t)N + 1);
         add(b->win.q_a, w_qa, A); add(b->win.q_ctr, w_qctr, A); add(b->win.q_ab1, w_qab1, A); add(b->win.q_ab2, w_qab2, A);
         mc.q_a_new = w_qa; mc.q_ab1_new = w_qab1; mc.q_b1c = b->win.q_b1c; mc.q_b2c = b->win.q_b2c; mc.abbond = b->win.abbond;
         mc.win_flag = b->win.flag; mc.win_grid = b->win_grid;
       }
       b->win_index_ready = index_ready;
-      static_assert(MULTI_COPY_MAX >= 24, "one slot per array");
+      static_assert(MULTI_COPY_MAX >= 25, "one slot per array");
       // ... and the float32 copies of the coordinates / lattices and the angles' compact bond indices ride in the same launch
       mc.n_copy = nseg;
       mc.cvt_src[0] = d_frac; mc.cvt_dst[0] = b->frac; mc.cvt_n[0] = 3 * N;
@@ -518,6 +523,15 @@ int chg_batch_build(chg_engine* eng, const chg_structs_host* h, double r_atom, d
     return CHG_EINVAL;
   HIP_TRY(eng, hipSetDevice(eng->device));
   return build_batch_on_device(eng, h, r_atom, r_bond, numerical_tol, out, counts_out);
+}
+
+int chg_batch_build_predict(chg_engine* eng, const chg_structs_host* h, double r_atom, double r_bond, double numerical_tol, uint32_t task_mask,
+                            chg_batch** out, int32_t* counts_out) {
+  int s = chg_batch_build(eng, h, r_atom, r_bond, numerical_tol, out, counts_out);
+  if (s != CHG_OK) return s;
+  s = chg_predict(eng, *out, task_mask);
+  if (s != CHG_OK) { chg_batch_free(eng, *out); *out = nullptr; }
+  return s;
 }
 
 }  // extern "C"

@@ -301,6 +301,10 @@ AngleEmbedTArgs angle_embed_args(chg_engine* eng, chg_batch* b);
 int run_predict(chg_engine* eng, chg_batch* b, uint32_t task);
 void carve(chg_batch* b, char* base, size_t& total);
 int prepare_windows(chg_engine* eng, chg_batch* b);
+inline long team_min_angles() {   // TEAM-mode threshold of the angle adjoints (engine_predict.hip decide_windows; engine_graph.hip: is the index worth emitting)
+  static const long v = [] { const char* e = std::getenv("CHGNET_TEAM_MIN_ANGLES"); return e ? std::atol(e) : 131072L; }();
+  return v;
+}
 bool decide_windows(chg_engine* eng, chg_batch* b);   // sets win_built / win_team / win_grid; true when the batch uses the per-atom index
 int ensure_windows(chg_engine* eng, chg_batch* b);   // launches a pending prepare_windows (compute stream)
 void register_names(chg_batch* b);

@@ -474,7 +474,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     // MD-size batch: an atom per team of waves (kernels_angle_w.h TEAM); the row-order kernel below returns at once unless the graph
     // turned out not to have the canonical angle structure
     AngleWArgs w{};
-    w.a = a; w.w = b->win; w.team_waves = b->win_team; w.n_atoms = b->N;
+    w.a = a; w.w = b->win; w.n_atoms = b->N;
     w.a.image = eng->img_angle[1][a.slot];
     hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN, true>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
@@ -905,7 +905,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->phase = c.take<float>(PHASE_FLOATS);
   {   // windowed angle adjoints (kernels_angle_w.h)
     WinIndex& w = b->win;
-    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1);
+    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1); w.toff = c.take<int>(N + 1);
     w.head = c.take<int>(Ed); w.rank = c.take<int>(Ed); w.list = c.take<int>(A ? N * WIN_LIST : 0);
     w.q_a = c.take<int>(A); w.q_ctr = c.take<int>(A); w.q_b1c = c.take<int>(A); w.q_b2c = c.take<int>(A); w.q_ab1 = c.take<int>(A); w.q_ab2 = c.take<int>(A);
     w.abbond = c.take<int>(2 * Eb);
@@ -937,15 +937,20 @@ bool decide_windows(chg_engine* eng, chg_batch* b) {
   const long min_atoms = min_env ? std::atol(min_env) : WIN_MIN_ATOMS_PER_WAVE;
   if (b->A == 0) return false;
   if ((long)b->N < min_atoms * b->win_grid * WAVES) {
-    // TEAM mode (round 6): below a few atoms per wave an atom goes to a team of waves.  Worth its index from a few tiles per
-    // workgroup on (CHGNET_TEAM_MIN_ANGLES, default 24k angles; 0 in the parity tests sends every batch through it)
-    static const long team_min = [] { const char* e = std::getenv("CHGNET_TEAM_MIN_ANGLES"); return e ? std::atol(e) : 24576L; }();
+    // TEAM mode (round 6): below a few atoms per wave the tiles of the atoms are dealt evenly to the workgroups and a workgroup's eight
+    // waves share an atom.  Same box, thermalised Li9Co7O16 cells (displacements of 0.15 A), BondConv adjoint per launch, TEAM /
+    // row-order: 256 atoms (56k angles) 60 / 57 us, 512 atoms 95 / 102, 1,024 atoms 168 / 196, 2,048 atoms 322 / 368 -- with ~1.7
+    // tiles per wave the row-order kernel's 2-deep walk beats the per-atom segments (3 deep) although it sends 16x the atomic rows;
+    // from ~600 atoms on the segments amortise.  Hence the default threshold of 131,072 angles (CHGNET_TEAM_MIN_ANGLES; 0 in the
+    // parity tests sends every batch through it, -1 none).
+    const long team_min = team_min_angles();
     if (team_min < 0 || b->A < team_min || b->N + 1 > 8192) return false;
+    // one workgroup per CU, each with an equal share of the tiles (kernels_angle_w.h TEAM); fewer when that share would be below a
+    // tile per wave (the tile count is a device quantity: A / 16 full tiles + at most one partial tile per atom)
     const int cus = std::max(1, std::min(eng->num_cus, WIN_MAX_GRID));
-    int tw = WAVES;
-    while (tw > 1 && (long)cus * (WAVES / tw) < b->N) tw >>= 1;           // the largest team that still gives every atom its own
-    b->win_team = tw;
-    b->win_grid = std::max(1, std::min(cus, (b->N + WAVES / tw - 1) / (WAVES / tw)));
+    const long tiles_max = (long)b->A / TILE_ROWS + b->N;
+    b->win_team = WAVES;
+    b->win_grid = (int)std::max<long>(1, std::min<long>(cus, (tiles_max + WAVES - 1) / WAVES));
     return true;
   }
   if (scan_scratch_ints(b->N + 1) > (size_t)(1u << 17)) return false;      // beyond the two-level scan (65,536 chunks): plain adjoints

@@ -44,6 +44,7 @@ struct WinIndex {             // built by k_win_*; all in the batch arena
   int *wave_head, *next_atom; // [win_grid * WAVES], [N]: the atoms of every wave as a linked list (k_win_schedule)
   int* xatom;                 // [win_grid / 8 + 1] atoms [xatom[i], xatom[i + 1]) are dealt to the 64 waves of group i (k_win_groups)
   int *na, *boff, *aoff;      // [N+1] short bonds per atom, exclusive scans of na and na (na - 1)
+  int* toff;                  // [N+1] exclusive scan of the atoms' 16-row tile counts ceil(na (na - 1) / 16) (TEAM kernels: tiles dealt evenly)
   int *head, *rank;           // [Ed] first row of the group whose first bond is this directed edge (-1: none); its rank at the centre
   int* list;                  // [N][WIN_LIST] directed edges of the groups of an atom (unordered)
   int *q_a, *q_ctr, *q_b1c, *q_b2c, *q_ab1, *q_ab2;   // [A]
@@ -119,29 +120,29 @@ static __global__ void k_win_clear(WinIndex w, int N, int Ed, int grid) {
   if (i == 0) { w.flag[0] = 1; w.flag[1] = 0; w.flag[2] = 0; w.flag[3] = grid; }
 }
 
-// boff = exclusive scan of na, aoff = exclusive scan of na (na - 1), both over the N + 1 entries, by ONE workgroup (N + 1 <= 8192:
+// boff = exclusive scan of na, aoff = exclusive scan of na (na - 1), toff = exclusive scan of the tile counts, all over the N + 1 entries, by ONE workgroup (N + 1 <= 8192:
 // a few thousand atoms is all team mode is for): each thread sums a contiguous run, the 1024 run sums are scanned through LDS
 static __global__ __launch_bounds__(1024) void k_win_scan2(int N, WinIndex w) {
-  __shared__ int tot_b[16], tot_a[16];
+  __shared__ int tot_b[16], tot_a[16], tot_t[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = N + 1, per = (n + 1023) / 1024;
   const int b = min(tid * per, n), e = min(b + per, n);
-  int sb = 0, sa = 0;
-  for (int k = b; k < e; ++k) { const int v = k < N ? w.na[k] : 0; sb += v; sa += v * (v - 1); }
-  int ib = sb, ia = sa;                     // inclusive scans over the wave
+  int sb = 0, sa = 0, st = 0;
+  for (int k = b; k < e; ++k) { const int v = k < N ? w.na[k] : 0; sb += v; sa += v * (v - 1); st += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS; }
+  int ib = sb, ia = sa, it = st;            // inclusive scans over the wave
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off);
-    if (lane >= off) { ib += ub; ia += ua; }
+    const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off), ut = __shfl_up(it, off);
+    if (lane >= off) { ib += ub; ia += ua; it += ut; }
   }
-  if (lane == 63) { tot_b[wave] = ib; tot_a[wave] = ia; }
+  if (lane == 63) { tot_b[wave] = ib; tot_a[wave] = ia; tot_t[wave] = it; }
   __syncthreads();
-  int rb = ib - sb, ra = ia - sa;
-  for (int q = 0; q < wave; ++q) { rb += tot_b[q]; ra += tot_a[q]; }
+  int rb = ib - sb, ra = ia - sa, rt = it - st;
+  for (int q = 0; q < wave; ++q) { rb += tot_b[q]; ra += tot_a[q]; rt += tot_t[q]; }
   for (int k = b; k < e; ++k) {
     const int v = k < N ? w.na[k] : 0;
-    w.boff[k] = rb; w.aoff[k] = ra;
-    rb += v; ra += v * (v - 1);
+    w.boff[k] = rb; w.aoff[k] = ra; w.toff[k] = rt;
+    rb += v; ra += v * (v - 1); rt += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS;
   }
 }
 
@@ -217,7 +218,7 @@ static __global__ __launch_bounds__(64) void k_win_schedule(int grid, WinIndex w
 struct AngleWArgs {
   AngleArgs a;                // tables, weights, gradient buffers as for k_angle
   WinIndex w;                 // incl. the per-wave atom lists (k_win_schedule); the grid is the one the schedule was built for
-  int team_waves, n_atoms;    // TEAM kernels: waves that share one atom (1, 2, 4, 8), atoms of the batch
+  int n_atoms;                // TEAM kernels: atoms of the batch
 };
 
 // Private second-bond rows per wave: dE/dR_j (128 wide).  AngleUpdate: the angle block as two split images (64 KiB), 14 rows.
@@ -315,14 +316,16 @@ __device__ __forceinline__ void private_add(const Cols64 (&c)[NB], int nvalid, i
   }
 }
 
-// TEAM (round 6; MD-size batches): an atom belongs to a TEAM of 1 / 2 / 4 / 8 waves of one workgroup instead of to one wave, so that
-// a 256-atom cell still occupies 2,048 waves.  The waves of a team deal the atom's tiles among themselves (tile t to wave t mod team),
-// each accumulates the second-bond sums of ITS tiles in its own private rows as before, and when the atom is done the team adds its
-// copies of every row together in LDS (two workgroup barriers per atom) and sends n rows out -- not n (n - 1) as the row-order
-// adjoints do, which at this size are bound by exactly those memory-side atomics (939 B per angle at ~1.2 TB/s: 53 of the 72 us of
-// a 67,536-angle launch).  Atoms are dealt to the teams round robin (team g: atoms g, g + teams, ...; every team of a workgroup
-// runs the same number of iterations, idle ones included, so the barriers match).  Run sums of a wave's non-adjacent tiles simply
-// end at the tile's last row.
+// TEAM (round 6; MD-size batches): the 16-row tiles of all atoms, in centre-major order, are cut into EQUAL ranges, one per workgroup
+// (toff: exclusive scan of the atoms' tile counts), and a workgroup walks the atoms its range touches: the eight waves deal that
+// atom's tiles among themselves (tile k to wave k mod 8), each accumulates the second-bond sums of ITS tiles in its own private rows as
+// before, and when the atom (or the workgroup's part of it) is done the workgroup adds its eight copies of every row together in LDS
+// (two workgroup barriers per atom) and sends n rows out -- not n (n - 1) as the row-order adjoints do, which at this size are bound
+// by exactly those memory-side atomics (939 B per angle at ~1.2 TB/s: 53 of the 72 us of a 67,536-angle launch).  A 256-atom cell
+// then occupies all 2,048 waves, and because the cut is by TILES an atom with 24 short bonds (35 tiles) is shared by two or three
+// workgroups instead of holding one for five rounds: the first version gave every atom to one team of waves and took 75 us per launch
+// on a thermalised MD cell against 50 us on the perfect crystal (same angle count) -- the launch lasted as long as its largest atom.
+// Run sums of a wave's non-adjacent tiles simply end at the tile's last row.
 template <bool HIDDEN, bool TEAM = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs pw) {
   const AngleArgs& p = pw.a;
@@ -366,21 +369,34 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
   float* Trow = T + j * TS64;
   float* pacc = paccs + wave * NS * PST;
   PH_DECL
-  // TEAM: the waves [team0, team0 + tw) of this workgroup share atoms gt, gt + GT, ...; tiles wt, wt + tw, ... of an atom are this wave's
-  const int tw = TEAM ? pw.team_waves : 1;
-  const int wt = TEAM ? (wave & (tw - 1)) : 0, team0 = wave - wt;
-  const int GT = TEAM ? (int)gridDim.x * (WAVES / tw) : 1, gt = TEAM ? (int)blockIdx.x * (WAVES / tw) + wave / tw : 0;
-  const int iters = TEAM ? (pw.n_atoms + GT - 1) / GT : 0;
-  const int tstep = tw * TILE_ROWS;
+  // TEAM: this workgroup's tiles [t_lo, t_hi) of the centre-major tile sequence; c_team: the atom that holds tile t_lo
+  int t_lo = 0, t_hi = 0, c_team = 0;
+  if (TEAM) {
+    const int total = __builtin_amdgcn_readfirstlane(w.toff[pw.n_atoms]);
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    t_lo = min(total, (int)blockIdx.x * per);
+    t_hi = min(total, t_lo + per);
+    int lo = 0, hi = pw.n_atoms;              // the first atom whose tiles end after t_lo
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__builtin_amdgcn_readfirstlane(w.toff[mid + 1]) > t_lo) hi = mid; else lo = mid + 1;
+    }
+    c_team = lo;
+  }
+  const int wt = TEAM ? wave : 0;
+  constexpr int tstep = TEAM ? WAVES * TILE_ROWS : TILE_ROWS;
   int c_next = TEAM ? 0 : w.wave_head[blockIdx.x * WAVES + wave];     // this wave's atoms (k_win_schedule): a list, one atom ahead
-  for (int it = 0;; ++it) {
-    int c, n = 0, ab0 = 0;
+  for (;;) {
+    int c, n = 0, ab0 = 0, k_lo = 0, k_hi = 0x7fffffff;
     bool active = true;
     if (TEAM) {
-      if (it >= iters) break;
-      c = __builtin_amdgcn_readfirstlane(gt + it * GT);
-      active = c < pw.n_atoms;
-      if (active) { n = __builtin_amdgcn_readfirstlane(w.na[c]); active = n >= 2; }
+      if (t_lo >= t_hi) break;
+      c = c_team++;
+      const int a0 = __builtin_amdgcn_readfirstlane(w.toff[c]), a1 = __builtin_amdgcn_readfirstlane(w.toff[c + 1]);
+      if (a1 <= t_lo) continue;               // an atom without angles
+      n = __builtin_amdgcn_readfirstlane(w.na[c]);
+      k_lo = t_lo - a0; k_hi = min(t_hi, a1) - a0;     // this workgroup's tiles of atom c
+      t_lo = min(t_hi, a1);
     } else {
       c = __builtin_amdgcn_readfirstlane(c_next);
       if (c < 0) break;
@@ -389,16 +405,18 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     }
     if (active) {
     const int r_begin = __builtin_amdgcn_readfirstlane(w.aoff[c]), r_end = r_begin + n * (n - 1);
+    const int seg_end = TEAM ? min(r_end, r_begin + k_hi * TILE_ROWS) : r_end;    // (TEAM: the workgroup's part of the atom)
+    const int row_first = r_begin + (TEAM ? (k_lo + wt) * TILE_ROWS : 0);
     ab0 = __builtin_amdgcn_readfirstlane(w.boff[c]);
     // run sums carried over the tiles of this atom (lane = column): first bond (core | gate halves), centre, bond weights
     float ri0 = 0.f, ri1 = 0.f, rs0 = 0.f, rs1 = 0.f, rg = 0.f;
     int cur0 = -1, cur1 = -1, curg = -1;
     int a_n, b1_n, b2_n, ab2_n;
     {
-      const int row = min(r_begin + wt * TILE_ROWS + j, r_end - 1);
+      const int row = min(row_first + j, r_end - 1);
       a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
     }
-    for (int row0 = r_begin + wt * TILE_ROWS; row0 < r_end; row0 += tstep) {
+    for (int row0 = row_first; row0 < seg_end; row0 += tstep) {
       // lane index made opaque once per tile: everything derived from it (64-bit row pointers base + 4 lane for every buffer, row
       // constants) is recomputed where it is used instead of living -- and being spilled -- across the whole kernel; a spilled
       // value reloaded between stores or atomics costs their full round trip (the reload's wait is in order behind them)
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       if (HIDDEN) asm volatile("" : "+v"(lane_t));
       const int nvalid = min(TILE_ROWS, r_end - row0);
       const int a = a_n, b1 = b1_n, b2 = b2_n, ab2 = ab2_n;
-      if (row0 + tstep < r_end) {
+      if (row0 + tstep < seg_end) {
         const int row = min(row0 + tstep + j, r_end - 1);
         a_n = w.q_a[row]; b1_n = w.q_b1c[row]; b2_n = w.q_b2c[row]; ab2_n = w.q_ab2[row];
       }
@@ -466,7 +484,13 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
           to_columns(g1, T, Trow, g, lane_t, c1);
           to_columns(g2, T, Trow, g, lane_t, c2[0]);
           run_sum64(c1, nvalid, b1, rg, curg, p.Gwbgc, D, lane_t);
+#if defined(CHG_EXPERIMENTS) && defined(CHG_EXP_NO_G2_ATOMICS)
+          // TIMING-ONLY (wrong results; profiles/r06_experiments.md): the second bond's weight gradient is dropped -- the upper bound of
+          // what ANY scheme that takes these per-angle atomic rows out of the kernel (private rows, a deferred reduction) can gain
+          asm volatile("" :: "v"(c2[0].v[0]));
+#else
           row_add64(c2[0], nvalid, p.Gwbgc, b2, D, lane_t);
+#endif
         }
         PH(6)   // bond-weight gradient scatter
       } else {
@@ -546,17 +570,17 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
     PH(4)   // per-atom flush
     }   // active
     if (TEAM) {
-      // the team's copies of the private rows, summed and sent out: row sl by wave sl mod team.  (Workgroup barriers: the teams of
-      // a workgroup run the same number of iterations.)
+      // the workgroup's eight copies of the private rows, summed and sent out: row sl by wave sl mod 8
       __syncthreads();
       if (active) {
         const int nrows = min(n, NS);
         const int bond_of = w.abbond[ab0 + min(lane, nrows - 1)];
-        for (int sl = wt; sl < nrows; sl += tw) {
+        for (int sl = wt; sl < nrows; sl += WAVES) {
           const int bond = __builtin_amdgcn_readlane(bond_of, sl);
           float v0 = 0.f, v1 = 0.f;
-          for (int k = 0; k < tw; ++k) {
-            float* src = paccs + ((team0 + k) * NS + sl) * PST;
+#pragma unroll
+          for (int k = 0; k < WAVES; ++k) {
+            float* src = paccs + (k * NS + sl) * PST;
             v0 += src[lane]; v1 += src[D + lane];
             src[lane] = 0.f; src[D + lane] = 0.f;
           }

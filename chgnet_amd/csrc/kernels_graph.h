@@ -305,25 +305,26 @@ static __global__ __launch_bounds__(256) void k_short_count(const double* __rest
 static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
                               int* __restrict__ ang_cnt, const int* __restrict__ overflow, int* __restrict__ noncanon, int n_atoms,
-                              int* __restrict__ boff, int* __restrict__ aoff) {
+                              int* __restrict__ boff, int* __restrict__ aoff, int* __restrict__ toff) {
   // Workgroup 0 first writes the per-atom offsets of the centre-major angle order (the index of the per-atom / team angle adjoints,
-  // kernels_angle_w.h): boff = exclusive scan of the short-bond counts n, aoff = exclusive scan of n (n - 1), N + 1 entries each.
+  // kernels_angle_w.h): boff = exclusive scan of the short-bond counts n, aoff = exclusive scan of n (n - 1), toff = exclusive scan of
+  // the 16-row tile counts ceil(n (n - 1) / 16), N + 1 entries each.
   // Riding in this launch they cost nothing; as k_win_* launches after the build they were five more of an MD step's ~60.
   if (blockIdx.x == 0 && boff) {
-    __shared__ int sb[256], sa[256];
+    __shared__ int sb[256], sa[256], st[256];
     const int tid = threadIdx.x, n = n_atoms + 1, per = (n + 255) / 256;
     const int b = min(tid * per, n), e = min(b + per, n);
-    int tb = 0, ta = 0;
+    int tb = 0, ta = 0, tt = 0;
     // (an atom with ONE short bond has no angles and owns no (atom, bond) pair: like k_win_heads, which counts group heads)
-    for (int q = b; q < e; ++q) { const int v = q < n_atoms ? short_cnt[q] : 0; tb += v >= 2 ? v : 0; ta += v * (v - 1); }
-    sb[tid] = tb; sa[tid] = ta;
+    for (int q = b; q < e; ++q) { const int v = q < n_atoms ? short_cnt[q] : 0; tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; }
+    sb[tid] = tb; sa[tid] = ta; st[tid] = tt;
     __syncthreads();
-    int rb = 0, ra = 0;
-    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; }
+    int rb = 0, ra = 0, rt = 0;
+    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; rt += st[q]; }
     for (int q = b; q < e; ++q) {
       const int v = q < n_atoms ? short_cnt[q] : 0;
-      boff[q] = rb; aoff[q] = ra;
-      rb += v >= 2 ? v : 0; ra += v * (v - 1);
+      boff[q] = rb; aoff[q] = ra; toff[q] = rt;
+      rb += v >= 2 ? v : 0; ra += v * (v - 1); rt += (v * (v - 1) + 15) >> 4;
     }
   }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;

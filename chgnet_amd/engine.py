@@ -216,14 +216,19 @@ class Engine:
         return PreparedStructures(len(structures), z, a_off, frac, lattice)
 
     def build_prepared(self, prep: "PreparedStructures", atom_graph_cutoff: float = 6.0, bond_graph_cutoff: float = 3.0,
-                       numerical_tol: float = 1e-8) -> DeviceBatch:
-        """Device side of ``build_batch`` (chg_batch_build)."""
+                       numerical_tol: float = 1e-8, predict_task: str | None = None) -> DeviceBatch:
+        """Device side of ``build_batch`` (chg_batch_build).  ``predict_task``: the prediction is enqueued by the same native call
+        (chg_batch_build_predict) -- a single-structure caller saves the trip back to Python between the two."""
         host = _lib.StructsHost(prep.n_struct, int(prep.atom_off[-1]), _ip(prep.z), prep.frac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                 prep.lattice.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ip(prep.atom_off))
         handle = ctypes.c_void_p()
         counts = np.zeros(6, dtype=np.int32)
-        self._check(self.lib.chg_batch_build(self.handle, ctypes.byref(host), float(atom_graph_cutoff), float(bond_graph_cutoff),
-                                             float(numerical_tol), ctypes.byref(handle), _ip(counts)))
+        if predict_task is not None:
+            self._check(self.lib.chg_batch_build_predict(self.handle, ctypes.byref(host), float(atom_graph_cutoff), float(bond_graph_cutoff),
+                                                         float(numerical_tol), _lib.task_mask(predict_task), ctypes.byref(handle), _ip(counts)))
+        else:
+            self._check(self.lib.chg_batch_build(self.handle, ctypes.byref(host), float(atom_graph_cutoff), float(bond_graph_cutoff),
+                                                 float(numerical_tol), ctypes.byref(handle), _ip(counts)))
         packed = PackedBatch(prep.n_struct, int(prep.atom_off[-1]), int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3]),
                              {"z": prep.z, "atom_off": prep.atom_off, "frac": prep.frac.astype(np.float32),
                               "lattice": prep.lattice.astype(np.float32)})

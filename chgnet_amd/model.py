@@ -303,8 +303,12 @@ class CHGNet:
             # one structure (every MD / relaxation step through the calculator): no chunk plan, no pipeline, and the batch arrays ARE the
             # structure's results -- handed out without the per-structure copies (~25 us of interpreter work per call, 3 % of an MD step)
             def run_one(chunk):
-                batch = launch(chunk, eng.prepare_structures(chunk))
+                # graph build and sweep enqueued by ONE native call (chg_batch_build_predict); an isolated atom is reported afterwards
+                batch = eng.build_prepared(eng.prepare_structures(chunk), conv.atom_graph_cutoff, conv.bond_graph_cutoff, predict_task=task)
                 try:
+                    if batch.packed.n_isolated and conv.on_isolated_atoms != "ignore":
+                        for struct in chunk:          # raises ValueError / prints the warning like converter.py:161-174
+                            conv(struct)
                     res = eng.download(batch, task, **flags)
                 finally:
                     batch.free()

@@ -147,6 +147,11 @@ typedef struct chg_structs_host {
  * chg_engine_build_stats reports how many builds went each way. */
 int chg_batch_build(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
                     chg_batch** out, int32_t* counts_out);
+/* chg_batch_build followed at once by chg_predict(task_mask) on the new batch, in ONE call: between the two the device of a
+ * single-structure caller (an MD / relaxation step through CHGNetCalculator.calculate, reference chgnet/model/dynamics.py:129-181) sat
+ * idle for the trip back into the host language (~15 us of a ~1 ms step).  Same results and errors as the two calls. */
+int chg_batch_build_predict(chg_engine* eng, const chg_structs_host* host, double r_atom, double r_bond, double numerical_tol,
+                            uint32_t task_mask, chg_batch** out, int32_t* counts_out);
 /* Neighbour search of chg_batch_build, the device-side twin of chg_graph_build_with's `search` (chgnet_graph.h):
  * 0 = by size (structures with at least cell_min_atoms atoms -- default 2048, 0 keeps the current value -- are binned on
  * the host and searched through a cell list, one wave per centre, rows sorted in LDS), 1 = all pairs, 2 = cell list for

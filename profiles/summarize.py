@@ -111,7 +111,7 @@ if os.path.exists(sq_path):
 
 
 # ---- one training step (tools/gpu_train_probe.py): kernel stats verbatim, HBM counters of the second-order sweep's kernels
-for name in ("train", "md"):
+for name in ("train", "md", "md512"):
     src = os.path.join(SRC, f"{name}_kernel_stats.csv")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(REPO, "profiles", f"{tag}_{name}_kernel_stats.csv"))
