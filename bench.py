@@ -81,8 +81,11 @@ KERNEL_MODEL = {
     # (128 -> 64) per direction; the dE/dQ table (256 B per direction) is no longer written, the bond's dE/d h_bond row is read and
     # written instead (2 x 128 B per direction)
     "atomconv_bwd": ("n_directed", 32768 + 16384, 900 - 256 + 256),
-    "bondconv_fwd": ("n_angles", 32768, 300),
-    "bondconv_bwd": ("n_angles", 65536, 800),
+    # round 6 (csrc AngleArgs::zsave, large batches): the forward leaves z = W_ang x + table rows behind (512 B per angle written), the
+    # adjoint reads it back (512 B) instead of the angle row (256 B) and contracting W_ang (64 -> 128: 16,384 flop) again;
+    # CHGNET_ZSAVE=0 restores the round-5 formulation (300 B | 65,536 flop, 800 B)
+    "bondconv_fwd": ("n_angles", 32768, 300 + (512 if os.environ.get("CHGNET_ZSAVE", "1") != "0" else 0)),
+    "bondconv_bwd": ("n_angles", 65536 - 16384, 800 - 256 + 512) if os.environ.get("CHGNET_ZSAVE", "1") != "0" else ("n_angles", 65536, 800),
     "angleupd_fwd": ("n_angles", 16384, 524),
     "angleupd_bwd": ("n_angles", 32768, 780),
 }

@@ -155,6 +155,8 @@ struct chg_batch {
   float* GP_l[MAX_CONV];        // AtomConv l adjoint: [N,256]
   float* GR_l[2 * MAX_CONV];    // BondConv / AngleUpdate adjoint (slots like Rl): [Eb,256]
   float* GS_l[2 * MAX_CONV];    // same slots: [N,128]
+  float* zsave_l[2 * MAX_CONV] = {};   // same slots: [A,128] first-layer pre-activations kept by the forward angle kernels for their adjoints
+                                       // (large batches only: AngleArgs::zsave), else null
   // outputs
   float *energy, *site_energy, *site_raw, *magmom, *crystal_fea, *force, *virial, *volume;
   // reverse sweep
@@ -170,6 +172,7 @@ struct chg_batch {
   int win_team = 0;         // > 0: small batch in TEAM mode (kernels_angle_w.h) -- the index without the schedule exists and the angle
                             // adjoints give every atom to a team of this many waves; win_grid is their workgroup count
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
+  bool zsave_now = false;   // this prediction has a reverse sweep: its forward angle kernels keep z (zsave_l)
   int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already
   float *zero1, *zero1_end, *zero2, *zero2_end;   // contiguous ranges cleared by one memset each
   float* zero2_keep_end = nullptr;                // group 2 holds [energy, magmom) up to here: results of the prediction a later chg_backward keeps

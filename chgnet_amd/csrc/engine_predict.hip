@@ -441,6 +441,8 @@ AngleArgs angle_args(chg_batch* b, int slot, const float* ang, const float* w_an
   a.Gagg = b->Gagg; a.Gang = b->Gang; a.GR = b->GR_l[slot]; a.GS = b->GS_l[slot]; a.Gwbgc = b->Gwbgc; a.phase = b->phase;
   a.first_gang = slot == b->L - 2;   // slot l < L is BondConv l; the sweep's first angle kernel is BondConv L-2
   a.skip_flag = b->win.flag;
+  // the forward keeps z for the adjoint only when an adjoint that reads it follows (per-atom / TEAM kernels, kernels_angle_w.h)
+  a.zsave = (b->zsave_now && (b->win_built || b->win_team > 0)) ? b->zsave_l[slot] : nullptr;
   return a;
 }
 
@@ -723,6 +725,7 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
 
   // ---- geometry, bases, embeddings (model.py:826-871, 432-439) ----
   const bool tiny = tiny_batch(b);
+  b->zsave_now = want_grad;
   const size_t zero_bytes = (size_t)((char*)(want_grad ? b->zero2_end : b->zero1_end) - (char*)b->zero1);
   b->p_table_done = -1;
   if (tiny) {   // coordinates, bond vectors, atom embedding, the first P table and the cleared scatter targets: one launch
@@ -873,6 +876,14 @@ void carve(chg_batch* b, char* base, size_t& total) {
   for (int l = 0; l < L - 1; ++l) b->ang[l] = c.take<float>(A * D);
   for (int l = 0; l < L; ++l) { b->Pl[l] = c.take<float>(N * 4 * D); b->Ql[l] = c.take<float>(Eu * 2 * D); }
   for (int t = 0; t < 2 * L; ++t) { b->Rl[t] = c.take<float>(Eb * 4 * D); b->Sl[t] = c.take<float>(N * 2 * D); }
+  // z rows of the BondConv layers for their adjoints (large batches: AngleArgs::zsave; + 16 spare rows for the unconditional stores of
+  // the last tile).  Same box, headline batch, per launch: bondconv_bwd 2.40 -> 2.06 ms (no gathers of three table rows and the angle
+  // row, no W_ang contraction), bondconv_fwd 0.90 -> 1.16 ms (2.1 GB of stores next to its gathers), step 25.97 -> 25.75 ms; 6.3 GB of
+  // a 1024-structure batch's 21 GB.  CHGNET_ZSAVE=0: off.  (The AngleUpdate layers would need the store in the per-atom forward
+  // kernel, whose tiles are scheduled around ONE delayed store stream: not done.)
+  static const bool zsave_on = [] { const char* e = std::getenv("CHGNET_ZSAVE"); return !e || std::atoi(e) != 0; }();
+  for (int t = 0; t < 2 * L; ++t)
+    b->zsave_l[t] = (zsave_on && t < L - 1 && A > ((size_t)1 << 19)) ? c.take<float>((A + TILE_ROWS) * 2 * D) : nullptr;
   b->site_energy = c.take<float>(N); b->site_raw = c.take<float>(N); b->volume = c.take<float>(B);
   // zero group 1 (cleared with one memset before the readout)
   b->zero1 = c.take<float>(0);

@@ -434,6 +434,20 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       // ---- gathers: angle rows, then the two halves of the table sum.  (Requesting tile t+1's rows ahead -- before tile t's scatter
       // phase -- was tried: 112 loop-carried registers for the table rows cost 225 spills (2x slower), 16 for the angle rows alone 51
       // spills (+14 %): this kernel has no registers left to pipeline with.) ----
+      f32x4 z[2 * VT];
+      Rows64 gy_rows;
+      V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
+      if (p.zsave) {
+        // the forward kernel kept z (AngleArgs::zsave): one 512-byte row per angle instead of four gathered rows and the W_ang contraction
+        read_dl_g_nt<2 * VT>(p.zsave, (unsigned)a, 2 * D, g, z);
+        PH(0)
+        if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);
+        if (HIDDEN) {
+          read_dl_g<VT>(p.wbgc, (unsigned)b1, D, g, w1.t);
+          read_dl_g<VT>(p.wbgc, (unsigned)b2, D, g, w2.t);
+          read_dl_g<VT>(p.Gagg, (unsigned)b1, D, g, gu.t);
+        }
+      } else {
       Gather64 gc, gg;
       gather64_issue(gc, p.R, b1, 4 * D, p.R + 2 * D, b2, 4 * D, p.S, c, 2 * D, lane_t);
       gather64_issue(gg, p.R + D, b1, 4 * D, p.R + 3 * D, b2, 4 * D, p.S + D, c, 2 * D, lane_t);
@@ -442,7 +456,6 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       V64 x;
       read_dl<VT>(Trow, g, x.t);
       __builtin_amdgcn_wave_barrier();
-      f32x4 z[2 * VT];
       gather64_commit(gc, T, lane_t);
       __builtin_amdgcn_wave_barrier();
       read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[0]));
@@ -452,9 +465,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       read_dl<VT>(Trow, g, *reinterpret_cast<f32x4(*)[VT]>(&z[VT]));
       __builtin_amdgcn_wave_barrier();
       PH(0)   // indices + gathers
-      Rows64 gy_rows;
       if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);
-      V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
       if (HIDDEN) {
         read_dl_g<VT>(p.wbgc, (unsigned)b1, D, g, w1.t);
         read_dl_g<VT>(p.wbgc, (unsigned)b2, D, g, w2.t);
@@ -462,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       }
       if (HIDDEN) gemm_rm<VT, 2 * VT, false, false>(z, reinterpret_cast<const _Float16*>(Wang), 2 * D, D, x.t, j, g, lane_t);
       else gemm_split<VT, 2 * VT, false>(z, reinterpret_cast<const h16x8*>(Wang), 2 * D, x.t, j, g);
+      }
       V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
       GatedState s;
       V64 y;

@@ -919,6 +919,9 @@ struct AngleArgs {
   int first_gang;      // BondConv adjoint of the last layer: first writer of Gang in the sweep (store, do not read: not zeroed)
   float* phase;        // CHG_PHASE_TIMING builds only: per-phase shader-clock totals (40 floats)
   const int* skip_flag; // row-order kernels (not TRAIN): return at once when *skip_flag == 1 (a per-atom kernel of kernels_angle_w.h / _fa.h runs)
+  float* zsave;        // [A + 16,128] or null (large batches, round 6): the forward kernel leaves the first layer's pre-activations z = W_ang x +
+                       // R_i + R_j + S behind, the adjoint reads them back instead of gathering four rows per angle and contracting W_ang
+                       // again -- these kernels are bound by vector issue at 0.17-0.4 of the HBM rate: bytes are what they have to spare
   // training (k_angle<.., true, .., true>) only
   float* dumpG;        // [A,128] adjoint of the second-layer pre-activations; for AngleUpdate (no hidden layer) this IS dE/dz
   float* dumpH;        // [A,128] hidden activations (BondConv)
@@ -1087,6 +1090,10 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
     }
+    // (unconditional stores -- the rows past the end of the last tile go to 16 spare rows behind the array -- so that the compiler's count
+    // of outstanding memory operations stays exact: behind a divergent store every later wait becomes a full drain, and this kernel
+    // lives on the gathers of tile t + 1 being in flight: 0.90 -> 1.16 ms with `if (valid)`)
+    if (!BWD && p.zsave) write_dl_g_nt<2 * VT>(p.zsave, (unsigned)(valid ? a : p.n_angles + j), 2 * D, g, z);
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     PH(2)   // W_ang contraction
     GatedState s;

@@ -149,6 +149,18 @@ __device__ __forceinline__ void write_dl_g(float* __restrict__ base, unsigned r,
   for (int ft = 0; ft < NT; ++ft) *grow<f32x4>(base, r, ld, 16 * ft + 4 * g) = x[ft];
 }
 
+// streaming forms (non-temporal: the lines are not kept in L2, which the table gathers of the same kernel live on)
+template <int NT>
+__device__ __forceinline__ void read_dl_g_nt(const float* __restrict__ base, unsigned r, int ld, int g, f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft) x[ft] = __builtin_nontemporal_load(grow<f32x4>(base, r, ld, 16 * ft + 4 * g));
+}
+template <int NT>
+__device__ __forceinline__ void write_dl_g_nt(float* __restrict__ base, unsigned r, int ld, int g, const f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft) __builtin_nontemporal_store(x[ft], grow<f32x4>(base, r, ld, 16 * ft + 4 * g));
+}
+
 // ---- MFMA GEMMs in swapped form ---------------------------------------------------------------
 // acc[fo] (fo < NFT) += W[16*fo + i][k] * x[k]   for k over 16*KT inputs held in D layout.
 // W: LDS, row-major [out][ws] (ws = K + PAD): the A operand of lane (i,g) is read as float4.
