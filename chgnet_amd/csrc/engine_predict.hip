@@ -478,6 +478,8 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     AngleWArgs w{};
     w.a = a; w.w = b->win; w.n_atoms = b->N;
     w.a.image = eng->img_angle[1][a.slot];
+    if (HIDDEN && w.a.zsave) hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN, true, HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
+    else
     hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN, true>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
     if (b->canonical) return CHG_OK;    // built on the device: the index is valid by construction (a launch less per layer: ~4.5 us each)
@@ -487,6 +489,8 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     AngleWArgs w{};
     w.a = a; w.w = b->win;
     w.a.image = eng->img_angle[1][a.slot];
+    if (HIDDEN && w.a.zsave) hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN, false, HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
+    else
     hipLaunchKernelGGL((k_angle_bwd_w<HIDDEN>), dim3(b->win_grid), dim3(BLOCK), angle_w_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
     if (b->canonical) return CHG_OK;
@@ -1055,6 +1059,8 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, (k_angle_bwd_w<true, true>), angle_w_lds<true>()))) return s;
+  if ((s = set_lds(eng, (k_angle_bwd_w<true, false, true>), angle_w_lds<true>()))) return s;
+  if ((s = set_lds(eng, (k_angle_bwd_w<true, true, true>), angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, (k_angle_bwd_w<false, true>), angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle<true, false>, angle_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle<true, true>, (angle_lds<true, WAVES, true>())))) return s;

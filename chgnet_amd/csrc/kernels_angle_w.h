@@ -326,7 +326,9 @@ __device__ __forceinline__ void private_add(const Cols64 (&c)[NB], int nvalid, i
 // workgroups instead of holding one for five rounds: the first version gave every atom to one team of waves and took 75 us per launch
 // on a thermalised MD cell against 50 us on the perfect crystal (same angle count) -- the launch lasted as long as its largest atom.
 // Run sums of a wave's non-adjacent tiles simply end at the tile's last row.
-template <bool HIDDEN, bool TEAM = false>
+// ZS (BondConv, large batches): the forward kernel kept z (AngleArgs::zsave) -- the tile starts from ONE 512-byte row per angle instead of
+// four gathered rows and the W_ang contraction.
+template <bool HIDDEN, bool TEAM = false, bool ZS = false>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs pw) {
   const AngleArgs& p = pw.a;
   const WinIndex& w = pw.w;
@@ -437,8 +439,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_w(AngleWArgs 
       f32x4 z[2 * VT];
       Rows64 gy_rows;
       V64 w1, w2, gu;        // BondConv: bond weights and the aggregate's adjoint, requested ahead of the forward recomputation
-      if (p.zsave) {
-        // the forward kernel kept z (AngleArgs::zsave): one 512-byte row per angle instead of four gathered rows and the W_ang contraction
+      if (ZS) {
+        // (requesting the NEXT tile's rows a tile ahead -- 32 loop-carried registers -- spilled 11-13 and cost 2.06 -> 2.24 ms, like every
+        // other attempt to pipeline this kernel)
         read_dl_g_nt<2 * VT>(p.zsave, (unsigned)a, 2 * D, g, z);
         PH(0)
         if (!HIDDEN) rows64_issue(gy_rows, p.Gang, a, lane_t);

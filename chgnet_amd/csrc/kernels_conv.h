@@ -1091,8 +1091,8 @@ __global__ __launch_bounds__(64 * NW) CHG_TWO_WAVES void k_angle(AngleArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
     }
     // (unconditional stores -- the rows past the end of the last tile go to 16 spare rows behind the array -- so that the compiler's count
-    // of outstanding memory operations stays exact: behind a divergent store every later wait becomes a full drain, and this kernel
-    // lives on the gathers of tile t + 1 being in flight: 0.90 -> 1.16 ms with `if (valid)`)
+    // of outstanding memory operations stays exact.  The stores cost this kernel 0.26 ms per headline launch (0.90 -> 1.16 ms) whichever
+    // way they are issued: conditional or not, non-temporal or not; as whole 512-byte rows through the wave's LDS tile 1.28 ms.)
     if (!BWD && p.zsave) write_dl_g_nt<2 * VT>(p.zsave, (unsigned)(valid ? a : p.n_angles + j), 2 * D, g, z);
     V64 zc{{z[0], z[1], z[2], z[3]}}, zg{{z[4], z[5], z[6], z[7]}};
     PH(2)   // W_ang contraction
