@@ -755,12 +755,18 @@ int run_predict(chg_engine* eng, chg_batch* b, uint32_t task) {
       LaunchScope ls(eng, "embed_fwd");
       hipLaunchKernelGGL(k_embed_all<false>, dim3(ea.g_bond1 + ea.g_bond2 + ea.g_angle), dim3(BLOCK), bond_embed_lds(), st, ea);
     } else { LaunchScope ls(eng, "bond_embed_fwd");   // atom-graph expansion for every bond, bond-graph expansion for the bond-graph nodes only
+      static const int o4 = [] { const char* e = std::getenv("CHGNET_EMBED_O4"); return e ? std::atoi(e) : 1; }();
+      if (o4) hipLaunchKernelGGL((k_bond_embed_fwd_o4<1>), dim3(grid_for(b->Eu, o4 * 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
+      else
       hipLaunchKernelGGL((k_bond_embed_t<false, false, 1>), dim3(grid_for(b->Eu, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b));
       if (b->Eb > 0)
         hipLaunchKernelGGL((k_bond_embed_t<false, false, 2>), dim3(grid_for(b->Eb, 2 * eng->num_cus)), dim3(BLOCK), bond_embed_lds(), st, bond_embed_args(eng, b)); }
   }
   if (b->A > 0 && !(tiny && b->Ed > 0)) {
     LaunchScope ls(eng, "angle_embed_fwd");
+    static const int o4 = [] { const char* e = std::getenv("CHGNET_EMBED_O4"); return e ? std::atoi(e) : 1; }();
+    if (o4) hipLaunchKernelGGL((k_angle_embed_fwd_o4<0>), dim3(grid_for(b->A, o4 * embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
+    else
     hipLaunchKernelGGL((k_angle_embed_t<false>), dim3(grid_for(b->A, embed_grid_mult() * eng->num_cus)), dim3(BLOCK), angle_embed_lds(), st, angle_embed_args(eng, b));
   }
   if (!tiny) { LaunchScope ls(eng, "atom_embed");
@@ -1077,6 +1083,8 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, (k_bond_embed_t<true, false, 1>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, (k_bond_embed_t<true, false, 2>), bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<false>, angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_embed_fwd_o4<0>, angle_embed_lds()))) return s;
+  if ((s = set_lds(eng, k_bond_embed_fwd_o4<1>, bond_embed_lds()))) return s;
   if ((s = set_lds(eng, k_angle_embed_t<true>, angle_embed_lds()))) return s;
   if ((s = set_lds(eng, k_rows_chain, chain_lds()))) return s;
   if ((s = set_lds(eng, k_embed_all<false>, bond_embed_lds()))) return s;

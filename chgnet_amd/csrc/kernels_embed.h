@@ -313,6 +313,15 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_bond_embed_t(BondEmbedT
   bond_embed_body<BWD, TRAIN, PART>(p, gridDim.x, blockIdx.x);
 }
 
+// The forward expansions at FOUR waves per SIMD (100 / 82 registers: two workgroups of 62 / 44 KB LDS per CU): they wait on the
+// acknowledgements of their own stores (gfx950: loads and stores share ONE in-order counter; SQ_WAIT_ANY 70 %), and twice the waves
+// per CU is twice the stores in flight.
+#define CHG_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int PART>
+__global__ __launch_bounds__(BLOCK) CHG_FOUR_WAVES void k_bond_embed_fwd_o4(BondEmbedTArgs p) {
+  bond_embed_body<false, false, PART>(p, gridDim.x, blockIdx.x);
+}
+
 struct AngleEmbedTArgs {
   const f32x4* eu;            // [Ed] unit vectors
   const int *a_d1, *a_d2;     // [A] directed edges of the two bonds
@@ -468,6 +477,11 @@ __device__ __forceinline__ void angle_embed_body(const AngleEmbedTArgs& p, int v
 template <bool BWD, bool TRAIN = false>
 __global__ __launch_bounds__(BLOCK) CHG_EMBED_WAVES void k_angle_embed_t(AngleEmbedTArgs p) {
   angle_embed_body<BWD, TRAIN>(p, gridDim.x, blockIdx.x);
+}
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(BLOCK) CHG_FOUR_WAVES void k_angle_embed_fwd_o4(AngleEmbedTArgs p) {
+  angle_embed_body<false, false>(p, gridDim.x, blockIdx.x);
 }
 
 // Small batches: the three basis-expansion launches of a direction as ONE (blocks [0, g_bond1) are part 1 of the bond expansion,

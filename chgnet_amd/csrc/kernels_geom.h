@@ -247,9 +247,17 @@ struct ForceArgs {
 // Each wave takes EF_IT consecutive 64-edge chunks with all their loads in flight together (one edge per thread left the wave
 // slots waiting 95 % of their cycles: two dependent memory round trips and nothing to overlap them with), and the nine virial
 // sums are formed once per wave over the chunks when they belong to one structure.
-constexpr int EF_IT = 4;    // measured: 2 -> 0.157 ms, 4 -> 0.145, 8 -> 0.190 (one edge per thread: 0.180)
+#ifndef CHG_EF_IT
+#define CHG_EF_IT 4
+#endif
+#ifdef CHG_EF_WAVES
+#define CHG_EF_ATTR __attribute__((amdgpu_waves_per_eu(CHG_EF_WAVES, CHG_EF_WAVES)))
+#else
+#define CHG_EF_ATTR
+#endif
+constexpr int EF_IT = CHG_EF_IT;    // measured: 2 -> 0.157 ms, 4 -> 0.145, 8 -> 0.190 (one edge per thread: 0.180)
 constexpr int EF_EDGES_PER_BLOCK = 4 * 64 * EF_IT;
-static __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
+static __global__ __launch_bounds__(256) CHG_EF_ATTR void k_edge_force(ForceArgs p) {
   __shared__ float vir[4][9];
   __shared__ int vown[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,14 +287,8 @@ static __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
   float tv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // this lane's virial products summed over the chunks
   const int first = __builtin_amdgcn_readfirstlane(owner[0]);
   bool uniform = first >= 0;            // all chunks of the wave in one structure: one set of wave sums
-  bool uni_it[EF_IT];                   // else chunk by chunk; only a chunk that straddles two structures pays per-edge atomics
-  int first_it[EF_IT];
 #pragma unroll
-  for (int it = 0; it < EF_IT; ++it) {
-    first_it[it] = __builtin_amdgcn_readfirstlane(owner[it]);
-    uni_it[it] = __all(owner[it] == first_it[it] || owner[it] < 0) != 0;
-    uniform = uniform && uni_it[it] && (first_it[it] == first || first_it[it] < 0);
-  }
+  for (int it = 0; it < EF_IT; ++it) uniform = uniform && __all(owner[it] == first || owner[it] < 0) != 0;   // else chunk by chunk
 #pragma unroll
   for (int it = 0; it < EF_IT; ++it) {
     const int e = base + 64 * it + lane;
@@ -307,39 +309,60 @@ static __global__ __launch_bounds__(256) void k_edge_force(ForceArgs p) {
       }
     }
     // segmented inclusive scan over runs of equal key: `start` = first lane of this lane's run
+    // (DPP moves -- row_shr inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the row totals -- instead of 20
+    // ds_bpermute per chunk: the kernel waited on instruction ISSUE 43 % of its wave cycles, the LDS crossbar queue.)
     const int kcur = key[it];
-    const int kprev = __shfl_up(kcur, 1);
+    const int kprev = __builtin_amdgcn_update_dpp(-2, kcur, 0x138, 0xF, 0xF, false);    // wave_shr:1 (lane 0 keeps -2: a head anyway)
     const unsigned long long heads = __ballot(lane == 0 || kprev != kcur);
     const int start = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float t0 = __shfl_up(d[0], off), t1 = __shfl_up(d[1], off), t2 = __shfl_up(d[2], off);
-      if (lane - off >= start) {
-        d[0] += t0;
-        d[1] += t1;
-        d[2] += t2;
-      }
+#define CHG_SEG_STEP(ctrl, rmask, cond)                                                                                  \
+    {                                                                                                                      \
+      const float t0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[0]), (ctrl), (rmask), 0xF, true)); \
+      const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[1]), (ctrl), (rmask), 0xF, true)); \
+      const float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[2]), (ctrl), (rmask), 0xF, true)); \
+      if (cond) {                                                                                                          \
+        d[0] += t0;                                                                                                        \
+        d[1] += t1;                                                                                                        \
+        d[2] += t2;                                                                                                        \
+      }                                                                                                                    \
     }
-    const int knext = __shfl_down(kcur, 1);
+    const int row_lane = lane & 15, row_base = lane & ~15;
+    CHG_SEG_STEP(0x111, 0xF, row_lane >= 1 && lane - 1 >= start)     // row_shr:1
+    CHG_SEG_STEP(0x112, 0xF, row_lane >= 2 && lane - 2 >= start)     // row_shr:2
+    CHG_SEG_STEP(0x114, 0xF, row_lane >= 4 && lane - 4 >= start)     // row_shr:4
+    CHG_SEG_STEP(0x118, 0xF, row_lane >= 8 && lane - 8 >= start)     // row_shr:8
+    CHG_SEG_STEP(0x142, 0xA, (row_base & 16) && start < row_base)    // row_bcast:15 -> rows 1 and 3: the run reaches into the row before
+    CHG_SEG_STEP(0x143, 0xC, row_base >= 32 && start < 32)           // row_bcast:31 -> rows 2 and 3
+#undef CHG_SEG_STEP
+    const int knext = __builtin_amdgcn_update_dpp(-2, kcur, 0x130, 0xF, 0xF, false);    // wave_shl:1
     if (valid[it] && (lane == 63 || knext != kcur)) {
 #pragma unroll
       for (int k3 = 0; k3 < 3; ++k3) atomicAdd(p.force + 3 * (size_t)kcur + k3, d[k3]);
     }
     // virial: dE/d eps[a][b] = sum_e v_e[a] * gv_e[b]
+    float t9[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const float t = v[a] * gv[b];
-        if (uniform) {
-          tv[3 * a + b] += t;
-        } else if (uni_it[it]) {
-          const float sck = wave_sum(t);
-          if (lane == 0 && first_it[it] >= 0) atomicAdd(p.virial + 9 * (size_t)first_it[it] + 3 * a + b, sck);
-        } else if (valid[it]) {
-          atomicAdd(p.virial + 9 * (size_t)owner[it] + 3 * a + b, t);
+      for (int b = 0; b < 3; ++b) t9[3 * a + b] = v[a] * gv[b];
+    if (uniform) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) tv[c] += t9[c];
+    } else {
+      // the wave spans structures: one set of wave sums per structure present in the chunk (one or two).  Per-edge atomics on the
+      // chunks that straddle a boundary -- 576 same-address atomics each -- were 60 % of this kernel at 1,024 structures a batch.
+      unsigned long long rem = __ballot(valid[it]);
+      while (rem) {
+        const int o = __builtin_amdgcn_readlane(owner[it], __builtin_ctzll(rem));
+        const bool mine = valid[it] && owner[it] == o;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          const float sck = wave_sum(mine ? t9[c] : 0.f);
+          if (lane == 0) atomicAdd(p.virial + 9 * (size_t)o + c, sck);
         }
+        rem &= ~__ballot(mine);
       }
+    }
   }
   // wave sums when the wave's edges sit in one structure, combined per workgroup
   if (lane == 0) vown[wave] = uniform ? first : -2;
