@@ -196,7 +196,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                bool speculative, int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
                int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
                int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2, int*& short_cnt_out, int*& boff, int*& aoff, int*& toff, int*& q_a, int*& q_ctr,
-               int*& q_ab1, int*& q_ab2) {
+               int*& q_ab1, int*& q_ab2, int*& toff4, int*& blk_a, int& blk_cap) {
   const int N = h->n_atoms;
   hipStream_t st = eng->stream;
   overflowed = false;
@@ -206,7 +206,13 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   const size_t z_ccnt = 0, z_flags = z_ccnt + (size_t)N + 1, z_scan = z_flags + 8, z_head = z_scan + 3 * (size_t)SCAN_STATE_INTS;
   const int capU0 = capE / 2;
   auto tail_ints = [&](int cE, int cU) { return 2 * ((size_t)cU + 1) + ((size_t)cE + 1) + (size_t)std::max(N, 1); };
-  const size_t z_total = z_head + (speculative ? tail_ints(capE, capU0) : 0);
+  // 4 x 4 blocked tiles of the MD-size angle adjoints (kernels_angle_blk.h): slot -> angle + 1, written by k_angle_fill; a single-pass
+  // build knows the capacities up front and clears the slots with everything else, an exact one after it has learnt A
+  const long blk_max = blk_max_angles();
+  const bool blk_wanted = blk_max > 0 && N + 1 <= 8192;
+  toff4 = nullptr; blk_a = nullptr; blk_cap = 0;
+  if (speculative && blk_wanted && capA > 0 && ((double)capA - 4096.0) / 1.25 <= 1.1 * (double)blk_max) blk_cap = (int)blk_tile_bound(capA, capEb, N);
+  const size_t z_total = z_head + (speculative ? tail_ints(capE, capU0) + (size_t)blk_cap * 16 : 0);
   int* zblock = tmp.get<int>(z_total);
   int* d_coff = tmp.get<int>(N + 1);
   int* d_counts = tmp.get<int>(8);
@@ -276,8 +282,9 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     aoff = boff ? tmp.get<int>(N + 1) : nullptr;
     toff = boff ? tmp.get<int>(N + 1) : nullptr;
     if (boff && (!aoff || !toff)) boff = nullptr;
+    if (blk_wanted && (blk_cap > 0 || !speculative)) toff4 = tmp.get<int>(N + 1);
     hipLaunchKernelGGL(k_angle_count, g1(capU), dim3(256), 0, st, u_u2d, e_rev, e_center, e_dist, short_cnt, nU, r_bond, ang_cnt, d_flags + 2, d_flags + 4,
-                       N, boff, aoff, toff);
+                       N, boff, aoff, toff, toff4);
     TRY(exclusive_scan(eng, tmp, ang_cnt, ang_off, capU + 1, scan_state + SCAN_STATE_INTS));   // entries past Eu are zero: the total sits at ang_off[capU]
   } else {
     HIP_TRY(eng, hipMemsetAsync(ang_off, 0, sizeof(int) * (capU + 1), st));
@@ -301,9 +308,20 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
     q_a = tmp.get<int>(capA); q_ctr = tmp.get<int>(capA); q_ab1 = tmp.get<int>(capA); q_ab2 = tmp.get<int>(capA);
     if (!q_a || !q_ctr || !q_ab1 || !q_ab2) q_a = q_ctr = q_ab1 = q_ab2 = nullptr;
   }
+  if (toff4 && capA > 0) {
+    if (speculative) {
+      blk_a = zblock + z_head + tail_ints(capE, capU0);
+    } else if (capA <= blk_max) {
+      blk_cap = (int)blk_tile_bound(capA, capU, N);     // (Eb is not known yet: every bond could be a node)
+      blk_a = tmp.get<int>((size_t)blk_cap * 16);
+      if (!blk_a) blk_cap = 0;
+      else HIP_TRY(eng, hipMemsetAsync(blk_a, 0, sizeof(int) * (size_t)blk_cap * 16, st));
+    }
+  }
+  if (!blk_a) { toff4 = nullptr; blk_cap = 0; }
   if (capA > 0 && capU > 0) {
     hipLaunchKernelGGL(k_angle_fill, g1((int64_t)capU * 64), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
-                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2, short_cnt, boff, aoff, q_a, q_ctr, q_ab1, q_ab2);
+                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2, short_cnt, boff, aoff, q_a, q_ctr, q_ab1, q_ab2, toff4, blk_a, blk_cap);
     TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1, scan_state + 2 * SCAN_STATE_INTS));
   } else {
     HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (capU + 1), st));
@@ -374,6 +392,8 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       *u_u2d = nullptr, *u_bnode = nullptr, *bn_und = nullptr, *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr;
   float* e_image = nullptr;
   int *w_na = nullptr, *w_boff = nullptr, *w_aoff = nullptr, *w_toff = nullptr, *w_qa = nullptr, *w_qctr = nullptr, *w_qab1 = nullptr, *w_qab2 = nullptr;
+  int *w_toff4 = nullptr, *w_blk_a = nullptr;
+  int w_blk_cap = 0;
   double *d_cart = nullptr, *d_frac = nullptr, *d_lat = nullptr;
   int *d_owner = nullptr, *d_aoff = nullptr;
   for (int attempt = speculate ? 0 : 1; attempt < 2; ++attempt) {
@@ -432,7 +452,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     gc = GraphCounts();
     TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, use_cells ? &cells : nullptr, r_atom, r_bond, tol, spec, capE,
                    capA, capEb, gc, overflowed, e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr,
-                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_toff, w_qa, w_qctr, w_qab1, w_qab2));
+                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_toff, w_qa, w_qctr, w_qab1, w_qab2, w_toff4, w_blk_a, w_blk_cap));
     if (overflowed && gc.cell_overflow) {   // a centre with more rows than the in-LDS sort holds: same attempt again, all pairs
       use_cells = false;
       eng->n_cell_fallbacks++;
@@ -450,6 +470,10 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     if (!b) return CHG_ENOMEM;
     b->B = B; b->N = N; b->Ed = Ed; b->Eu = Eu; b->A = A; b->Eb = Eb; b->L = eng->desc.n_conv;
     b->canonical = !gc.noncanonical;   // built here: the angle sets are complete n (n - 1) blocks unless the builder saw one of the two exceptions
+    // the blocked tiles of the MD-size adjoints were emitted with the angles: the batch uses them (capacity from the exact counts:
+    // never more than the builder's own)
+    const bool use_blk = w_blk_a && b->canonical && A > 0 && (long)A <= blk_max_angles();
+    b->blk_cap = use_blk ? (int)std::min<size_t>(blk_tile_bound(A, Eb, N), (size_t)w_blk_cap) : 0;
     size_t total = 0;
     carve(b, nullptr, total);
     int s = acquire_arena(eng, b, total);
@@ -478,7 +502,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       add(b->u_u2d, u_u2d, Eu); add(b->u_bnode, u_bnode, Eu); add(b->bn_und, bn_und, Eb);
       add(b->a_ctr, a_ctr, A); add(b->a_d1, a_d1, A); add(b->a_d2, a_d2, A);
       // the index of the per-atom / team angle adjoints, when the builder emitted it and the batch will use it (decide_windows)
-      const bool index_ready = b->canonical && w_qa && A > 0 && decide_windows(eng, b);
+      const bool index_ready = !use_blk && b->canonical && w_qa && A > 0 && decide_windows(eng, b);
       if (index_ready) {
         add(b->win.na, w_na, N); add(b->win.boff, w_boff, (size_t)N + 1); add(b->win.aoff, w_aoff, (size_t)N + 1); add(b->win.toff, w_toff, (size_t)N + 1);
         add(b->win.q_a, w_qa, A); add(b->win.q_ctr, w_qctr, A); add(b->win.q_ab1, w_qab1, A); add(b->win.q_ab2, w_qab2, A);
@@ -492,9 +516,14 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       mc.cvt_src[0] = d_frac; mc.cvt_dst[0] = b->frac; mc.cvt_n[0] = 3 * N;
       mc.cvt_src[1] = d_lat; mc.cvt_dst[1] = b->lattice; mc.cvt_n[1] = 9 * B;
       mc.a_b1 = a_b1; mc.a_b2 = a_b2; mc.u_bnode_new = u_bnode; mc.a_b1c = b->a_b1c; mc.a_b2c = b->a_b2c; mc.n_ang = A;
+      if (use_blk) {
+        mc.blk_a_new = w_blk_a; mc.toff4_new = w_toff4; mc.a_ctr_new = a_ctr; mc.n_atoms = N; mc.cap_tiles4 = b->blk_cap;
+        mc.blk_a = b->blk_a; mc.blk_b1c = b->blk_b1c; mc.blk_b2c = b->blk_b2c; mc.blk_ctr = b->blk_ctr; mc.blk_tiles = b->blk_tiles;
+        most = std::max<unsigned long long>(most, (unsigned long long)b->blk_cap * 64);
+      }
       most = std::max<unsigned long long>(most, std::max<unsigned long long>((unsigned long long)A * 4, (unsigned long long)12 * N));
       const unsigned gx = (unsigned)std::min<unsigned long long>((most / 4 + 255) / 256 + 1, (unsigned long long)4 * eng->num_cus);
-      hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)nseg + 3), dim3(256), 0, st, mc);
+      hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)nseg + 4), dim3(256), 0, st, mc);
     }
     if (s == CHG_OK) s = prepare_windows(eng, b);
     // the scratch (TmpPool) is reused by the next build on this same stream, so stream order protects it; overflow

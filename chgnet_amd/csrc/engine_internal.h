@@ -27,6 +27,7 @@
 #include "mfma_split.h"
 #include "kernels_conv.h"     // argument structs (GatedW, AtomConvArgs, AngleArgs, RowsGemm) and the tile constants
 #include "kernels_angle_w.h"  // WinIndex
+#include "kernels_angle_blk.h"
 #include "kernels_embed.h"    // BondEmbedTArgs / AngleEmbedTArgs
 
 using namespace chg;
@@ -171,6 +172,10 @@ struct chg_batch {
   bool win_index_ready = false;   // chg_batch_build emitted the centre-major index with the graph (prepare_windows only schedules)
   int win_team = 0;         // > 0: small batch in TEAM mode (kernels_angle_w.h) -- the index without the schedule exists and the angle
                             // adjoints give every atom to a team of this many waves; win_grid is their workgroup count
+  // MD-size batches built on the device: the angle adjoints over 4 x 4 blocked tiles (kernels_angle_blk.h); blk_cap = capacity of the
+  // index in tiles (0: none), the tile count itself is a device quantity (blk_tiles)
+  int blk_cap = 0;
+  int *blk_a = nullptr, *blk_b1c = nullptr, *blk_b2c = nullptr, *blk_ctr = nullptr, *blk_tiles = nullptr;
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
   bool zsave_now = false;   // this prediction has a reverse sweep: its forward angle kernels keep z (zsave_l)
   int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already
@@ -308,6 +313,15 @@ inline long team_min_angles() {   // TEAM-mode threshold of the angle adjoints (
   static const long v = [] { const char* e = std::getenv("CHGNET_TEAM_MIN_ANGLES"); return e ? std::atol(e) : 131072L; }();
   return v;
 }
+// ... and device-built batches of up to 8,191 atoms (below ~6,000 the per-atom adjoints leave waves idle) and this many angles use the
+// 4 x 4 blocked tiles (kernels_angle_blk.h) instead of either; 0: never.  Same box, thermalised Li9Co7O16 cells, BondConv / AngleUpdate
+// adjoint per launch, blocked / TEAM / row order: 256 atoms 57 / -- / 58 and 35 / -- / 43 us, 512 atoms 92 / -- / 103 and 55 / -- / 74,
+// 1,024 atoms 166 / 175 / 200 and 94 / 115 / 140, 2,048 atoms 320 / 332 / 372 and 172 / 212 / 258.
+inline long blk_max_angles() {
+  static const long v = [] { const char* e = std::getenv("CHGNET_BLK_MAX_ANGLES"); return e ? std::atol(e) : (1L << 22); }();
+  return v;
+}
+inline size_t blk_tile_bound(size_t A, size_t Eb, size_t N) { return (A + 14 * Eb + 9 * N) / 16 + 1; }   // 16 ceil(n/4)^2 <= n (n - 1) + 7 n + 9, sum of n <= 2 Eb
 bool decide_windows(chg_engine* eng, chg_batch* b);   // sets win_built / win_team / win_grid; true when the batch uses the per-atom index
 int ensure_windows(chg_engine* eng, chg_batch* b);   // launches a pending prepare_windows (compute stream)
 void register_names(chg_batch* b);

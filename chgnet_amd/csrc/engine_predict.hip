@@ -472,6 +472,15 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     hipLaunchKernelGGL(k_angleupd_fwd_a, dim3(b->win_grid), dim3(BLOCK), angle_fa_lds(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
     if (b->canonical) return CHG_OK;
+  } else if (BWD && b->blk_cap > 0) {
+    // MD-size batch built on the device: self-contained 4 x 4 blocked tiles (kernels_angle_blk.h; the index is valid by construction)
+    AngleBlkArgs w{};
+    w.a = a; w.a.image = eng->img_angle[1][a.slot];
+    w.x.tiles = b->blk_tiles; w.x.a = b->blk_a; w.x.b1c = b->blk_b1c; w.x.b2c = b->blk_b2c; w.x.ctr = b->blk_ctr;
+    const int grid = std::max(1, std::min(eng->num_cus, (b->blk_cap + WAVES - 1) / WAVES));
+    hipLaunchKernelGGL((k_angle_bwd_blk<HIDDEN>), dim3(grid), dim3(BLOCK), angle_blk_lds<HIDDEN>(), eng->stream, w);
+    HIP_TRY(eng, hipGetLastError());
+    return CHG_OK;
   } else if (BWD && b->win_team > 0) {
     // MD-size batch: an atom per team of waves (kernels_angle_w.h TEAM); the row-order kernel below returns at once unless the graph
     // turned out not to have the canonical angle structure
@@ -934,6 +943,11 @@ void carve(chg_batch* b, char* base, size_t& total) {
     b->win_tmp = c.take<int>(N + 1);
     b->win_scan = c.take<int>(scan_scratch_ints((int)N + 1));
   }
+  {   // 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h)
+    const size_t slots = (size_t)b->blk_cap * TILE_ROWS;
+    b->blk_a = c.take<int>(slots); b->blk_b1c = c.take<int>(slots); b->blk_b2c = c.take<int>(slots); b->blk_ctr = c.take<int>(slots);
+    b->blk_tiles = c.take<int>(b->blk_cap ? 4 : 0);
+  }
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
   total = (c.pos + 255) & ~size_t(255);
 }
@@ -982,6 +996,7 @@ bool decide_windows(chg_engine* eng, chg_batch* b) {
 int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;
+  if (b->blk_cap > 0) { b->win_built = false; b->win_team = 0; return CHG_OK; }   // blocked tiles (kernels_angle_blk.h): the builder wrote their index
   const bool ready = b->win_index_ready;        // chg_batch_build wrote the index with the graph (and has called decide_windows)
   if (!ready && !decide_windows(eng, b)) return CHG_OK;
   if (b->win_team > 0) {
@@ -1041,6 +1056,9 @@ void register_names(chg_batch* b) {
   mi["win_flag"] = {b->win.flag, 4}; mi["win_q_a"] = {b->win.q_a, A}; mi["win_q_ctr"] = {b->win.q_ctr, A}; mi["win_na"] = {b->win.na, N + 1};
   mi["win_aoff"] = {b->win.aoff, N + 1}; mi["win_q_ab1"] = {b->win.q_ab1, A}; mi["win_q_ab2"] = {b->win.q_ab2, A};
   mi["win_next_atom"] = {b->win.next_atom, A ? N : 0};
+  mi["blk_tiles"] = {b->blk_tiles, b->blk_cap ? (size_t)1 : 0}; mi["blk_a"] = {b->blk_a, (size_t)b->blk_cap * TILE_ROWS};
+  mi["blk_b1c"] = {b->blk_b1c, (size_t)b->blk_cap * TILE_ROWS}; mi["blk_b2c"] = {b->blk_b2c, (size_t)b->blk_cap * TILE_ROWS};
+  mi["blk_ctr"] = {b->blk_ctr, (size_t)b->blk_cap * TILE_ROWS};
   mi["win_wave_head"] = {b->win.wave_head, A ? (size_t)WIN_MAX_GRID * WAVES : 0}; mi["win_xatom"] = {b->win.xatom, (size_t)WIN_MAX_GRID / 8 + 1};   // win_flag[3] = workgroups
 }
 
@@ -1062,6 +1080,8 @@ int predict_set_lds(chg_engine* eng) {
   if ((s = set_lds(eng, k_atomconv_bwd<false>, (atomconv_lds<WAVES, true>())))) return s;
   if ((s = set_lds(eng, (k_atomconv_bwd<false, true>), acb_fused_lds()))) return s;
   if ((s = set_lds(eng, k_angleupd_fwd_a, angle_fa_lds()))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_blk<true>, angle_blk_lds<true>()))) return s;
+  if ((s = set_lds(eng, k_angle_bwd_blk<false>, angle_blk_lds<false>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<true>, angle_w_lds<true>()))) return s;
   if ((s = set_lds(eng, k_angle_bwd_w<false>, angle_w_lds<false>()))) return s;
   if ((s = set_lds(eng, (k_angle_bwd_w<true, true>), angle_w_lds<true>()))) return s;

@@ -305,26 +305,31 @@ static __global__ __launch_bounds__(256) void k_short_count(const double* __rest
 static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
                               int* __restrict__ ang_cnt, const int* __restrict__ overflow, int* __restrict__ noncanon, int n_atoms,
-                              int* __restrict__ boff, int* __restrict__ aoff, int* __restrict__ toff) {
+                              int* __restrict__ boff, int* __restrict__ aoff, int* __restrict__ toff, int* __restrict__ toff4) {
   // Workgroup 0 first writes the per-atom offsets of the centre-major angle order (the index of the per-atom / team angle adjoints,
   // kernels_angle_w.h): boff = exclusive scan of the short-bond counts n, aoff = exclusive scan of n (n - 1), toff = exclusive scan of
-  // the 16-row tile counts ceil(n (n - 1) / 16), N + 1 entries each.
+  // the 16-row tile counts ceil(n (n - 1) / 16), N + 1 entries each -- and / or toff4 = exclusive scan of ceil(n / 4)^2, the 4 x 4
+  // blocked tiles of the MD-size adjoints (kernels_angle_blk.h).
   // Riding in this launch they cost nothing; as k_win_* launches after the build they were five more of an MD step's ~60.
-  if (blockIdx.x == 0 && boff) {
-    __shared__ int sb[256], sa[256], st[256];
+  if (blockIdx.x == 0 && (boff || toff4)) {
+    __shared__ int sb[256], sa[256], st[256], s4[256];
     const int tid = threadIdx.x, n = n_atoms + 1, per = (n + 255) / 256;
     const int b = min(tid * per, n), e = min(b + per, n);
-    int tb = 0, ta = 0, tt = 0;
+    int tb = 0, ta = 0, tt = 0, t4 = 0;
     // (an atom with ONE short bond has no angles and owns no (atom, bond) pair: like k_win_heads, which counts group heads)
-    for (int q = b; q < e; ++q) { const int v = q < n_atoms ? short_cnt[q] : 0; tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; }
-    sb[tid] = tb; sa[tid] = ta; st[tid] = tt;
-    __syncthreads();
-    int rb = 0, ra = 0, rt = 0;
-    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; rt += st[q]; }
     for (int q = b; q < e; ++q) {
       const int v = q < n_atoms ? short_cnt[q] : 0;
-      boff[q] = rb; aoff[q] = ra; toff[q] = rt;
-      rb += v >= 2 ? v : 0; ra += v * (v - 1); rt += (v * (v - 1) + 15) >> 4;
+      tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; t4 += v >= 2 ? ((v + 3) >> 2) * ((v + 3) >> 2) : 0;
+    }
+    sb[tid] = tb; sa[tid] = ta; st[tid] = tt; s4[tid] = t4;
+    __syncthreads();
+    int rb = 0, ra = 0, rt = 0, r4 = 0;
+    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; rt += st[q]; r4 += s4[q]; }
+    for (int q = b; q < e; ++q) {
+      const int v = q < n_atoms ? short_cnt[q] : 0;
+      if (boff) { boff[q] = rb; aoff[q] = ra; toff[q] = rt; }
+      if (toff4) toff4[q] = r4;
+      rb += v >= 2 ? v : 0; ra += v * (v - 1); rt += (v * (v - 1) + 15) >> 4; r4 += v >= 2 ? ((v + 3) >> 2) * ((v + 3) >> 2) : 0;
     }
   }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,7 +355,8 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
                                                     int* __restrict__ a_b1, int* __restrict__ a_d1, int* __restrict__ a_b2, int* __restrict__ a_d2,
                                                     int* __restrict__ is_node, int cap_angles, int* __restrict__ overflow,
                                                     const int* __restrict__ short_cnt, const int* __restrict__ boff, const int* __restrict__ aoff,
-                                                    int* __restrict__ q_a, int* __restrict__ q_ctr, int* __restrict__ q_ab1, int* __restrict__ q_ab2) {
+                                                    int* __restrict__ q_a, int* __restrict__ q_ctr, int* __restrict__ q_ab1, int* __restrict__ q_ab2,
+                                                    const int* __restrict__ toff4, int* __restrict__ blk_a, int cap_tiles4) {
   const int lane = threadIdx.x & 63;
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (k >= n_und.get() || *overflow) return;
@@ -365,13 +371,16 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
     // centre-major position of this group (kernels_angle_w.h: rows of atom c at aoff[c] + rank of the first bond x (n - 1) + position
     // in the group; ranks count the centre's SHORT edges in edge order -- the order k_win_ranks / k_win_rows establish)
     int rank1 = 0;
-    if (q_a) {
+    if (q_a || blk_a) {
       for (int base = b; base < e; base += 64) {
         const int other = base + lane;
         rank1 += __popcll(__ballot(other < e && other < de && e_dist[other] < r_bond));
       }
     }
-    const int n_c = q_a ? short_cnt[ctr] : 0;
+    const int n_c = (q_a || blk_a) ? short_cnt[ctr] : 0;
+    // 4 x 4 blocked tiles (kernels_angle_blk.h): the angle (first bond of rank i, second bond of rank j) of this atom is slot
+    // 4 (i & 3) + (j & 3) of tile toff4[ctr] + (i >> 2) nb + (j >> 2), nb = ceil(n / 4); blk_a holds angle + 1 (0: empty slot)
+    const int nb4 = (n_c + 3) >> 2, t4_0 = blk_a ? toff4[ctr] : 0;
     const long row0 = q_a ? (long)aoff[ctr] + (long)rank1 * (n_c - 1) : 0;
     const int ab0 = q_a ? boff[ctr] : 0;
     const int w_group = w;
@@ -391,6 +400,11 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
           if (row >= 0 && row < cap_angles) {
             q_a[row] = at; q_ctr[row] = ctr; q_ab1[row] = ab0 + rank1; q_ab2[row] = ab0 + shorts_before + __popcll(ms & lower);
           }
+        }
+        if (blk_a) {
+          const int rank2 = shorts_before + __popcll(ms & lower);
+          const long tile = (long)t4_0 + (long)(rank1 >> 2) * nb4 + (rank2 >> 2);
+          if (rank1 < n_c && rank2 < n_c && tile < cap_tiles4) blk_a[tile * 16 + 4 * (rank1 & 3) + (rank2 & 3)] = at + 1;   // (else: not a canonical graph, the index is not used)
         }
       }
       w += __popcll(m);
@@ -569,6 +583,11 @@ struct MultiCopy {
   const int *q_a_new, *q_ab1_new;
   int *q_b1c, *q_b2c, *abbond, *win_flag;
   int win_grid;
+  // ... or the 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h; row n_copy + 3): slot -> angle (-1: empty), compact
+  // bond indices, centre; [0 .. 16 toff4[N]) of the arena arrays (capacity cap_tiles4 tiles), and the tile count itself
+  const int *blk_a_new, *toff4_new, *a_ctr_new;
+  int *blk_a, *blk_b1c, *blk_b2c, *blk_ctr, *blk_tiles;
+  int n_atoms, cap_tiles4;
 };
 static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
   const int seg = blockIdx.y;
@@ -577,6 +596,17 @@ static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
     const int q = seg - m.n_copy;
     if (q < 2) {
       for (int t = t0; t < m.cvt_n[q]; t += tstride) m.cvt_dst[q][t] = (float)m.cvt_src[q][t];
+    } else if (q == 3) {
+      if (!m.blk_a_new) return;
+      const int tiles = min(m.toff4_new[m.n_atoms], m.cap_tiles4);
+      if (t0 == 0) *m.blk_tiles = tiles;
+      for (int sl = t0; sl < 16 * tiles; sl += tstride) {
+        const int a = m.blk_a_new[sl] - 1;
+        m.blk_a[sl] = a;
+        m.blk_b1c[sl] = a >= 0 ? m.u_bnode_new[m.a_b1[a]] : 0;      // (an empty slot reads row 0 of the tables and contributes zeros)
+        m.blk_b2c[sl] = a >= 0 ? m.u_bnode_new[m.a_b2[a]] : 0;
+        m.blk_ctr[sl] = a >= 0 ? m.a_ctr_new[a] : 0;
+      }
     } else {
       for (int a = t0; a < m.n_ang; a += tstride) {
         m.a_b1c[a] = m.u_bnode_new[m.a_b1[a]];

@@ -41,6 +41,11 @@ for tag, scale in (("a32", (1, 1, 1)), ("a256", (2, 2, 2)), ("a384", (3, 2, 2)))
         for k, v in r.items():
             out[f"{tag}/{task}/{k}"] = v
     out[f"{tag}/flag"] = eng.debug_fetch_i32(b, "win_flag", 4)
+    try:
+        out[f"{tag}/blk_tiles"] = eng.debug_fetch_i32(b, "blk_tiles", 1)
+        out[f"{tag}/blk_a"] = eng.debug_fetch_i32(b, "blk_a", 16 * int(out[f"{tag}/blk_tiles"][0]))
+    except Exception:
+        out[f"{tag}/blk_tiles"] = np.array([0])
     out[f"{tag}/counts"] = np.array([b.packed.n_directed, b.packed.n_angles, b.packed.n_bnodes])
     # the same structure through the HOST builder and an upload (uploaded batches keep the row-order fallback launch behind the team kernel)
     from chgnet_amd import CrystalGraphConverter
@@ -56,7 +61,7 @@ np.savez(sys.argv[2], **out)
 
 def _run_child(env_extra: dict, tmp: str, name: str) -> dict:
     env = dict(os.environ)
-    for k in ("CHGNET_TINY_FUSE", "CHGNET_TINY_CHAIN", "CHGNET_TEAM_MIN_ANGLES"):
+    for k in ("CHGNET_TINY_FUSE", "CHGNET_TINY_CHAIN", "CHGNET_TEAM_MIN_ANGLES", "CHGNET_BLK_MAX_ANGLES"):
         env.pop(k, None)
     env.update(env_extra)
     path = os.path.join(tmp, name + ".npz")
@@ -65,21 +70,26 @@ def _run_child(env_extra: dict, tmp: str, name: str) -> dict:
 
 
 def test_md_size_path_equals_the_large_batch_launch_sequence():
-    """32 / 256 / 384 atoms of Li9Co7O16 (trained-like weights): the round-6 small-batch path (default) against the launch sequence
-    of the large batches (CHGNET_TINY_FUSE=0, team mode off) in a child process each -- E / F / S / M, site energies and crystal
-    features to fp32 reassociation; the team index is valid (flag 1) for device-built graphs; uploaded == device-built."""
+    """32 / 256 / 384 atoms of Li9Co7O16 (trained-like weights): the round-6 small-batch path (default: merged launches, chained row
+    GEMMs, angle adjoints over 4 x 4 blocked tiles) against the launch sequence of the large batches (CHGNET_TINY_FUSE=0, blocked
+    tiles and team mode off) in a child process each -- E / F / S / M, site energies and crystal features to fp32 reassociation; the
+    team index is valid (flag 1) for device-built graphs; every angle sits in exactly one slot of the blocked tiles; uploaded == device-built."""
     with tempfile.TemporaryDirectory() as tmp:
-        new = _run_child({"CHGNET_TEAM_MIN_ANGLES": "0"}, tmp, "new")          # every batch with angles through the team kernels
-        default = _run_child({}, tmp, "default")
-        nochain = _run_child({"CHGNET_TINY_CHAIN": "0", "CHGNET_TEAM_MIN_ANGLES": "0"}, tmp, "nochain")
-        old = _run_child({"CHGNET_TINY_FUSE": "0", "CHGNET_TEAM_MIN_ANGLES": "-1"}, tmp, "old")
+        team = _run_child({"CHGNET_TEAM_MIN_ANGLES": "0", "CHGNET_BLK_MAX_ANGLES": "0"}, tmp, "team")   # every batch with angles through the team kernels
+        default = _run_child({}, tmp, "default")                                                          # ... through the blocked tiles
+        nochain = _run_child({"CHGNET_TINY_CHAIN": "0", "CHGNET_BLK_MAX_ANGLES": "0"}, tmp, "nochain")     # ... the row-order adjoints
+        old = _run_child({"CHGNET_TINY_FUSE": "0", "CHGNET_TEAM_MIN_ANGLES": "-1", "CHGNET_BLK_MAX_ANGLES": "0"}, tmp, "old")
     tol = {"e": 2e-6, "f": 4e-5, "s": 4e-4, "m": 2e-5, "site_energies": 3e-5, "crystal_fea": 5e-4}     # the trained-like tolerances of tests/test_v020.py
     for tag in ("a32", "a256", "a384"):
-        assert list(new[f"{tag}/flag"][:1]) == [1], tag
-        assert np.array_equal(new[f"{tag}/counts"], old[f"{tag}/counts"])
-        for variant in (new, default, nochain):
+        assert list(team[f"{tag}/flag"][:1]) == [1], tag
+        assert np.array_equal(team[f"{tag}/counts"], old[f"{tag}/counts"])
+        n_ang = int(old[f"{tag}/counts"][1])
+        assert int(default[f"{tag}/blk_tiles"][0]) > 0 and int(old[f"{tag}/blk_tiles"][0]) == 0
+        slots = default[f"{tag}/blk_a"]
+        assert np.array_equal(np.sort(slots[slots >= 0]), np.arange(n_ang)), tag      # a permutation of the angles, the rest empty
+        for variant in (team, default, nochain):
             for key, ref in old.items():
-                if not key.startswith(tag + "/") or key.endswith(("/flag", "/counts")):
+                if not key.startswith(tag + "/") or key.endswith(("/flag", "/counts", "/blk_tiles", "/blk_a")):
                     continue
                 k = key.rsplit("/", 1)[1]
                 err = float(np.abs(variant[key] - ref).max())
