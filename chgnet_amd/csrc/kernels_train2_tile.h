@@ -451,7 +451,15 @@ constexpr size_t t2_angle_lds() {
 // of the accumulator-layout form do not fit 256 registers (225-270 spilled registers: 40 ms instead of 29 per step), and a form that
 // parks the row state in the dump rows and streams it back slice by slice waits for its own loads behind the scatter's atomics (57 ms);
 // profiles/r05_experiments.md section 13.  CHG_T2_ROWS=1: every instantiation (A/B builds).
-constexpr bool t2_rows(bool hidden, bool reverse) { return CHG_T2_ROWS != 0 || (hidden && reverse); }
+// CHG_T2_BOND_ACC=1 (A/B builds): the BondConv reverse kernel in the accumulator layout as well -- three passes over the slices, the
+// first of which forms bar(y), G(y) from the six bond rows and keeps them in 32 registers, so that the other two read nothing.  Round 6,
+// same box: 84 spilled registers (56 scratch stores, 77 loads per tile against 25 / 25), t2_bond_b 31.2 ms against 29.7 in the
+// one-row-at-a-time form.  The passes themselves are the spill source: the same kernel cut off behind the BCG / GCG dump (the
+// "recompute + adjoint of the tail" half of a two-kernel split) spills 169.
+#ifndef CHG_T2_BOND_ACC
+#define CHG_T2_BOND_ACC 0
+#endif
+constexpr bool t2_rows(bool hidden, bool reverse) { return CHG_T2_ROWS != 0 || (hidden && reverse && !CHG_T2_BOND_ACC); }
 
 template <bool HIDDEN, bool REVERSE>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
@@ -641,9 +649,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     }
     } else {
     // ---- row-local part in the accumulator layout: sixteen rows at once (the helpers above) ----
-    static_assert(!(HIDDEN && REVERSE), "the BondConv reverse kernel keeps the one-row-at-a-time form (t2_rows)");
     const bool valid = j < nvalid;
     const int kb1 = valid ? b1 : -1;
+    [[maybe_unused]] const int kb2 = valid ? b2 : -1;
     float r1, r2, mt1, mt2;
     ln2_forward(cc, cdc, r1, mt1);            // cc = xhat1, cdc = P(cd): what the way back needs of the first LayerNorm
     ln2_forward(cg, cdg, r2, mt2);
@@ -652,11 +660,18 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     int sb1 = b1, sb2 = b2, srow = row, sg = g;   // the slices' row indices and column group (made opaque between the two reverse passes)
     // what a slice reads from memory, requested one slice ahead
     struct SliceIn { f32x4 w1, w1d, w2, w2d, a, b; };
-    auto slice_in = [&](int ft) {
+    // BondConv reverse: bar(y), G(y) of the tile, formed once (pass 3, which reads the six bond rows anyway) and kept for passes 1 and 2,
+    // which then read nothing from memory: 32 registers instead of 2 x 24 of slice inputs in flight and 2 x 24 loads per pass
+    [[maybe_unused]] V64 by, gy;
+    auto slice_in = [&](int ft, auto pass_c) {
+      constexpr int PASS = decltype(pass_c)::value;
       SliceIn in;
       in.w1 = in.w1d = in.w2 = in.w2d = in.a = in.b = zero4();
-      if (HIDDEN) {                          // BondConv (tangent forward): u = y wbg[b1] wbg[b2] summed over the angles of bond b1
-        in.w1 = rd4(p.w, sb1, ft, sg); in.w1d = rd4(p.wd, sb1, ft, sg); in.w2 = rd4(p.w, sb2, ft, sg); in.w2d = rd4(p.wd, sb2, ft, sg);
+      if (HIDDEN) {                          // BondConv: u = y wbg[b1] wbg[b2] summed over the angles of bond b1
+        if (PASS == 0 || PASS == 3) {
+          in.w1 = rd4(p.w, sb1, ft, sg); in.w1d = rd4(p.wd, sb1, ft, sg); in.w2 = rd4(p.w, sb2, ft, sg); in.w2d = rd4(p.wd, sb2, ft, sg);
+        }
+        if (PASS == 3) { in.a = rd4(p.bar_agg, sb1, ft, sg); in.b = rd4(p.g_agg, sb1, ft, sg); }     // the two adjoints of the owning bond's aggregate
       } else if (!REVERSE) {                 // AngleUpdate: ang' = ang + y
         in.a = rd4(p.angd, srow, ft, sg);
       } else {
@@ -680,9 +695,19 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
         if (PASS == 0) {
           if (HIDDEN) o0[r] = e.yd * in.w1[r] * in.w2[r] + e.y * (in.w1d[r] * in.w2[r] + in.w1[r] * in.w2d[r]);
           else o0[r] += e.yd;
+        } else if (PASS == 3) {
+          // BondConv reverse: bar adjoints of the two bond weights (first bond: a run sum over the tile's rows, second bond: a row each)
+          o0[r] = e.y * in.w2[r] * in.a[r] + (e.yd * in.w2[r] + e.y * in.w2d[r]) * in.b[r];
+          o1[r] = e.y * in.w1[r] * in.a[r] + (e.yd * in.w1[r] + e.y * in.w1d[r]) * in.b[r];
+          // y enters u = y w1 w2: bar(y) = w1 w2 bar(u) + (w1 w2)_d G(u), G(y) = w1 w2 G(u)
+          const float w12 = in.w1[r] * in.w2[r], w12d = in.w1d[r] * in.w2[r] + in.w1[r] * in.w2d[r];
+          by.t[ft][r] = w12 * in.a[r] + w12d * in.b[r];
+          gy.t[ft][r] = w12 * in.b[r];
         } else {
+          float bar_y = in.a[r], g_y = in.b[r];
+          if (HIDDEN) { bar_y = by.t[ft][r]; g_y = gy.t[ft][r]; }
           float bn1, gn1, bn2, gn2;
-          gate1_bwd(e, in.a[r], in.b[r], bn1, gn1, bn2, gn2);
+          gate1_bwd(e, bar_y, g_y, bn1, gn1, bn2, gn2);
           const float h1 = gn1 * ga1[r], p1 = bn1 * ga1[r], h2 = gn2 * ga2[r], p2 = bn2 * ga2[r];
           if (PASS == 1) {
             sum[0] += h1; sum[1] += h1 * xh1; sum[2] += h1 * pt1; sum[3] += p1; sum[4] += p1 * xh1;
@@ -707,9 +732,9 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
     };
     auto sweep = [&](auto pass_c) {
       __builtin_amdgcn_wave_barrier();
-      SliceIn cur = slice_in(0);
+      SliceIn cur = slice_in(0, pass_c);
       CHG_EV(ft) {
-        const SliceIn nxt = slice_in(ft + 1 < VT ? ft + 1 : ft);
+        const SliceIn nxt = slice_in(ft + 1 < VT ? ft + 1 : ft, pass_c);
         slice(ft, cur, pass_c);
         cur = nxt;
       }
@@ -732,6 +757,12 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k2_angle(Angle2Args p) {
       if (HIDDEN) seg_colsum_atomic<D>(T, TS, kb1, nvalid, p.aggd, D, lane_t);
       __builtin_amdgcn_wave_barrier();
       continue;
+    }
+    if (HIDDEN) {                               // (before pass 2 overwrites xhat / P(cd))
+      sweep(std::integral_constant<int, 3>{});
+      seg_colsum_atomic<D>(T, TS, kb1, nvalid, p.bar_w, D, lane_t);
+      row_atomic_add<D>(T + D, TS, kb2, nvalid, p.bar_w, D, lane_t);
+      __builtin_amdgcn_wave_barrier();
     }
     sweep(std::integral_constant<int, 1>{});
     tile_colsums(lnacc[2], lnacc[3]);
