@@ -135,17 +135,31 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_xty(XtyArgs p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // the workgroup's waves meet in LDS (ds_add_f32), then one global atomic per element and workgroup
+  // the workgroup's waves meet in LDS, then one global atomic per element and workgroup.  Plain stores and read-modify-writes into four
+  // partial copies (`red` and three in the idle tile area; waves w and w + 4 share a copy, one after the other) -- the eight waves' 128
+  // ds_add_f32 each were ~100 of the ~120 us EVERY call of this kernel took whatever its row count (LDS float atomics are serialised
+  // per lane, kernels_angle_w.h; 60 such calls per fine-tuning step).
+  static_assert(3 * M * N <= WAVES * TILE_ROWS * (SA + SB), "three more partial copies fit in the tile area");
+  __syncthreads();                                   // every wave is done with its tile
+  float* part = (wave & 3) == 0 ? red : tiles + ((wave & 3) - 1) * M * N;
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    if ((wave >> 2) == round) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mt + 4 * kk + r) * N + 16 * nt + i], acc[mt][nt][r]);
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) {
+            float* d = &part[(16 * mt + 4 * kk + r) * N + 16 * nt + i];
+            *d = round == 0 && (wave & 3) != 0 ? acc[mt][nt][r] : *d + acc[mt][nt][r];     // (`red` starts at zero; the other copies hold tile leftovers)
+          }
+    }
+    __syncthreads();
+  }
   for (int idx = tid; idx < M * N; idx += BLOCK) {
     const int m = idx / N, n = idx - m * N;
-    if (n < p.n_cols) atomicAdd(p.out + (size_t)m * p.ldo + n, p.alpha * red[idx]);
+    if (n < p.n_cols) atomicAdd(p.out + (size_t)m * p.ldo + n, p.alpha * ((red[idx] + tiles[idx]) + (tiles[M * N + idx] + tiles[2 * M * N + idx])));
   }
   if (p.a_colsum) {
 #pragma unroll
