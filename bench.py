@@ -255,7 +255,8 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.cpu_affinity = pin_rank_cpus(self.local_rank, self.world)
+        # (ranks of THIS node only: on a multi-node job the global world size would put every rank on NUMA node 0)
+        self.cpu_affinity = pin_rank_cpus(self.local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", self.world)))
         self.dist = None
         self.torch = None
         self.shared_device = bool(getattr(args, "shared_device", False))

@@ -12,7 +12,7 @@ c_float_p = ctypes.POINTER(ctypes.c_float)
 TASK_BITS = {"e": 1, "f": 2, "s": 4, "m": 8}
 
 EXPORTED_SYMBOLS = (
-    "chg_device_count", "chg_weights_required", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
+    "chg_abi_version", "chg_device_count", "chg_weights_required", "chg_engine_create", "chg_engine_destroy", "chg_last_error",
     "chg_batch_upload", "chg_batch_build", "chg_batch_build_predict", "chg_debug_fetch_i32", "chg_batch_update_geometry", "chg_batch_free", "chg_batch_device_bytes",
     "chg_predict", "chg_synchronize", "chg_batch_download", "chg_timer_start", "chg_timer_stop_ms",
     "chg_profile_enable", "chg_profile_reset", "chg_profile_count", "chg_profile_read",
@@ -67,6 +67,9 @@ def hip_lib_path() -> str:
     return os.environ.get("CHGNET_HIP_LIB", HIP_LIB)   # override: kernel timing experiments only
 
 
+ABI_VERSION = 3   # include/chgnet_hip.h CHG_ABI_VERSION
+
+
 def load() -> ctypes.CDLL:
     """Load the HIP engine library; raise loudly if it is not built or cannot be loaded."""
     global _LIB  # noqa: PLW0603
@@ -81,6 +84,15 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(path)
     except OSError as exc:
         raise RuntimeError(f"chgnet_amd: cannot load HIP extension {path}: {exc}") from exc
+    # the struct layouts below are those of include/chgnet_hip.h at this interface version: a library built from another one is refused
+    try:
+        lib.chg_abi_version.restype = ctypes.c_int
+        found = int(lib.chg_abi_version())
+    except AttributeError:
+        found = -1
+    if found != ABI_VERSION:
+        raise RuntimeError(f"chgnet_amd: HIP extension {path} has interface version {found}, this binding was written for {ABI_VERSION}: "
+                           "rebuild it with `python -m chgnet_amd.build --force`")
     vp = ctypes.c_void_p
     lib.chg_device_count.restype = ctypes.c_int
     lib.chg_weights_required.argtypes = [ctypes.c_int32]

@@ -97,6 +97,8 @@ void launch_test_split(hipStream_t st, const float* x, const float* W, float* y,
 // =====================================================================================================
 extern "C" {
 
+int chg_abi_version(void) { return CHG_ABI_VERSION; }
+
 int chg_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -117,6 +119,7 @@ int chg_engine_create(const chg_model_desc* desc, const float* weights_blob, int
   chg_engine* eng = new (std::nothrow) chg_engine();
   if (!eng) return CHG_ENOMEM;
   *out = eng;  // returned even on failure so that chg_last_error is readable; destroy it either way
+  eng->err = "";   // (a recycled address: this thread's slot may hold an earlier engine's text, engine_internal.h ErrText)
   eng->device = device;
   eng->desc = *desc;
   if (eng->desc.n_mlp_hidden == 0) eng->desc.n_mlp_hidden = 3;

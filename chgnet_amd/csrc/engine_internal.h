@@ -61,15 +61,19 @@ struct Weights {
 // computes (INTEGRATION.md "Threads"), and both may fail.  Every thread reads -- chg_last_error -- the text of the status IT
 // received; no std::string is shared between threads.
 struct ErrText {
-  std::string& slot() const {
-    thread_local std::unordered_map<const ErrText*, std::string> texts;
-    return texts[this];
+  static std::unordered_map<const ErrText*, std::string>& texts() {
+    thread_local std::unordered_map<const ErrText*, std::string> t;
+    return t;
   }
+  std::string& slot() const { return texts()[this]; }
   ErrText& operator=(const std::string& v) { slot() = v; return *this; }
   ErrText& operator=(const char* v) { slot() = v; return *this; }
   operator std::string() const { return slot(); }
   const char* c_str() const { return slot().c_str(); }
-  ~ErrText() { slot().clear(); }
+  // The destroying thread's entry is erased.  Entries OTHER threads made for this address stay in their maps: chg_engine_create
+  // clears the creating thread's slot, and any other thread reads its slot only after a call of its own on the engine has failed and
+  // written it -- so a recycled address never shows an earlier engine's text.
+  ~ErrText() { texts().erase(this); }
 };
 inline std::string operator+(const char* a, const ErrText& b) { return std::string(a) + std::string(b); }
 inline std::string operator+(const std::string& a, const ErrText& b) { return a + std::string(b); }

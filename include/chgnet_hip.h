@@ -106,6 +106,11 @@ typedef struct chg_out_host {
   float* crystal_fea;   /* [B,64]                                                 */
 } chg_out_host;
 
+/* Version of this interface: bumped whenever a struct of this header grows or an entry point changes meaning (chg_model_desc gained
+ * n_mlp_hidden / mlp_out_bias at 2; chg_batch_build_predict arrived at 3).  A binding compiled against another value must refuse the
+ * library: chg_engine_create COPIES *desc, so an older, shorter chg_model_desc would be read past its end. */
+#define CHG_ABI_VERSION 3
+int chg_abi_version(void);
 int chg_device_count(void);
 /* Length in floats of the weight blob for an n_conv-block model (same table as pack.py:weight_layout). */
 int64_t chg_weights_required(int32_t n_conv);

@@ -29,6 +29,17 @@ def test_graph_library_exports_header_symbols():
         assert hasattr(lib, n), n
 
 
+def test_interface_version_of_header_binding_and_library_agree():
+    """include/chgnet_hip.h CHG_ABI_VERSION == chgnet_amd._lib.ABI_VERSION == chg_abi_version() of the built library (load() refuses
+    any other): chg_engine_create copies *desc, a binding with an older, shorter chg_model_desc would be read past its end."""
+    from chgnet_amd import _lib
+
+    with open(os.path.join(REPO, "include", "chgnet_hip.h")) as fh:
+        declared = int(re.search(r"#define\s+CHG_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+    assert declared == _lib.ABI_VERSION
+    assert int(_lib.load().chg_abi_version()) == declared
+
+
 def test_hip_library_exports_header_symbols():
     from chgnet_amd import _lib
 

@@ -17,6 +17,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o m
 # the MD loop without the profiler, new path and the launch sequence of the large batches, alternating (same box)
 for i in 1 2 3; do
   timeout 300 python $R/tools/gpu_md_anatomy.py 500 2>&1 | grep "steps/s" | sed "s/^/new path: /"
-  CHGNET_TINY_FUSE=0 CHGNET_TEAM_MIN_ANGLES=-1 timeout 300 python $R/tools/gpu_md_anatomy.py 500 2>&1 | grep "steps/s" | sed "s/^/r05 launch sequence: /"
+  CHGNET_TINY_FUSE=0 CHGNET_TEAM_MIN_ANGLES=-1 CHGNET_BLK_MAX_ANGLES=0 timeout 300 python $R/tools/gpu_md_anatomy.py 500 2>&1 | grep "steps/s" | sed "s/^/r05 launch sequence: /"
 done > $O/md_ab.txt 2>&1; cat $O/md_ab.txt
 ls $O/prof | head -30
