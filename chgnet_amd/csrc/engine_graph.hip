@@ -196,7 +196,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
                bool speculative, int capE, int capA, int capEb, GraphCounts& gc, bool& overflowed, int*& e_center, int*& e_nbr, float*& e_image,
                int*& e_owner, int*& e_rev, int*& e_d2u, int*& p_center, int*& p_nbr, int*& u_u2d, int*& u_bnode, int*& bn_und, int*& a_ctr,
                int*& a_b1, int*& a_d1, int*& a_b2, int*& a_d2, int*& short_cnt_out, int*& boff, int*& aoff, int*& toff, int*& q_a, int*& q_ctr,
-               int*& q_ab1, int*& q_ab2, int*& toff4, int*& blk_a, int& blk_cap) {
+               int*& q_ab1, int*& q_ab2, int*& toff4, int*& blk_a, int*& blk_desc, int& blk_cap) {
   const int N = h->n_atoms;
   hipStream_t st = eng->stream;
   overflowed = false;
@@ -210,7 +210,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   // build knows the capacities up front and clears the slots with everything else, an exact one after it has learnt A
   const long blk_max = blk_max_angles();
   const bool blk_wanted = blk_max > 0 && N + 1 <= 8192;
-  toff4 = nullptr; blk_a = nullptr; blk_cap = 0;
+  toff4 = nullptr; blk_a = nullptr; blk_desc = nullptr; blk_cap = 0;
   if (speculative && blk_wanted && capA > 0 && ((double)capA - 4096.0) / 1.25 <= 1.1 * (double)blk_max) blk_cap = (int)blk_tile_bound(capA, capEb, N);
   const size_t z_total = z_head + (speculative ? tail_ints(capE, capU0) + (size_t)blk_cap * 16 : 0);
   int* zblock = tmp.get<int>(z_total);
@@ -318,10 +318,11 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
       else HIP_TRY(eng, hipMemsetAsync(blk_a, 0, sizeof(int) * (size_t)blk_cap * 16, st));
     }
   }
-  if (!blk_a) { toff4 = nullptr; blk_cap = 0; }
+  if (blk_a) blk_desc = tmp.get<int>(blk_cap);
+  if (!blk_a || !blk_desc) { toff4 = nullptr; blk_a = nullptr; blk_cap = 0; }
   if (capA > 0 && capU > 0) {
     hipLaunchKernelGGL(k_angle_fill, g1((int64_t)capU * 64), dim3(256), 0, st, u_u2d, e_rev, e_center, e_d2u, e_dist, d_coff, ang_off, nU, r_bond, a_ctr, a_b1,
-                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2, short_cnt, boff, aoff, q_a, q_ctr, q_ab1, q_ab2, toff4, blk_a, blk_cap);
+                       a_d1, a_b2, a_d2, is_node, capA, d_flags + 2, short_cnt, boff, aoff, q_a, q_ctr, q_ab1, q_ab2, toff4, blk_a, blk_desc, blk_cap);
     TRY(exclusive_scan(eng, tmp, is_node, node_scan, capU + 1, scan_state + 2 * SCAN_STATE_INTS));
   } else {
     HIP_TRY(eng, hipMemsetAsync(node_scan, 0, sizeof(int) * (capU + 1), st));
@@ -392,7 +393,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       *u_u2d = nullptr, *u_bnode = nullptr, *bn_und = nullptr, *a_ctr = nullptr, *a_b1 = nullptr, *a_d1 = nullptr, *a_b2 = nullptr, *a_d2 = nullptr;
   float* e_image = nullptr;
   int *w_na = nullptr, *w_boff = nullptr, *w_aoff = nullptr, *w_toff = nullptr, *w_qa = nullptr, *w_qctr = nullptr, *w_qab1 = nullptr, *w_qab2 = nullptr;
-  int *w_toff4 = nullptr, *w_blk_a = nullptr;
+  int *w_toff4 = nullptr, *w_blk_a = nullptr, *w_blk_desc = nullptr;
   int w_blk_cap = 0;
   double *d_cart = nullptr, *d_frac = nullptr, *d_lat = nullptr;
   int *d_owner = nullptr, *d_aoff = nullptr;
@@ -452,7 +453,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     gc = GraphCounts();
     TRY(graph_pass(eng, tmp, h, d_cart, d_frac, d_lat, d_reach, d_owner, d_aoff, use_cells ? &cells : nullptr, r_atom, r_bond, tol, spec, capE,
                    capA, capEb, gc, overflowed, e_center, e_nbr, e_image, e_owner, e_rev, e_d2u, p_center, p_nbr, u_u2d, u_bnode, bn_und, a_ctr,
-                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_toff, w_qa, w_qctr, w_qab1, w_qab2, w_toff4, w_blk_a, w_blk_cap));
+                   a_b1, a_d1, a_b2, a_d2, w_na, w_boff, w_aoff, w_toff, w_qa, w_qctr, w_qab1, w_qab2, w_toff4, w_blk_a, w_blk_desc, w_blk_cap));
     if (overflowed && gc.cell_overflow) {   // a centre with more rows than the in-LDS sort holds: same attempt again, all pairs
       use_cells = false;
       eng->n_cell_fallbacks++;
@@ -517,7 +518,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
       mc.cvt_src[1] = d_lat; mc.cvt_dst[1] = b->lattice; mc.cvt_n[1] = 9 * B;
       mc.a_b1 = a_b1; mc.a_b2 = a_b2; mc.u_bnode_new = u_bnode; mc.a_b1c = b->a_b1c; mc.a_b2c = b->a_b2c; mc.n_ang = A;
       if (use_blk) {
-        mc.blk_a_new = w_blk_a; mc.toff4_new = w_toff4; mc.a_ctr_new = a_ctr; mc.n_atoms = N; mc.cap_tiles4 = b->blk_cap;
+        mc.blk_a_new = w_blk_a; mc.blk_desc_new = w_blk_desc; mc.blk_desc = b->blk_desc; mc.toff4_new = w_toff4; mc.a_ctr_new = a_ctr; mc.n_atoms = N; mc.cap_tiles4 = b->blk_cap;
         mc.blk_a = b->blk_a; mc.blk_b1c = b->blk_b1c; mc.blk_b2c = b->blk_b2c; mc.blk_ctr = b->blk_ctr; mc.blk_tiles = b->blk_tiles;
         most = std::max<unsigned long long>(most, (unsigned long long)b->blk_cap * 64);
       }

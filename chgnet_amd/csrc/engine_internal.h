@@ -179,7 +179,7 @@ struct chg_batch {
   // MD-size batches built on the device: the angle adjoints over 4 x 4 blocked tiles (kernels_angle_blk.h); blk_cap = capacity of the
   // index in tiles (0: none), the tile count itself is a device quantity (blk_tiles)
   int blk_cap = 0;
-  int *blk_a = nullptr, *blk_b1c = nullptr, *blk_b2c = nullptr, *blk_ctr = nullptr, *blk_tiles = nullptr;
+  int *blk_a = nullptr, *blk_b1c = nullptr, *blk_b2c = nullptr, *blk_ctr = nullptr, *blk_desc = nullptr, *blk_tiles = nullptr;
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
   bool zsave_now = false;   // this prediction has a reverse sweep: its forward angle kernels keep z (zsave_l)
   int p_table_done = -1;    // forward sweep, small batches: the AtomConv layer whose P table an angle layer's launch has contracted already

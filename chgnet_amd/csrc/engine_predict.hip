@@ -476,7 +476,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     // MD-size batch built on the device: self-contained 4 x 4 blocked tiles (kernels_angle_blk.h; the index is valid by construction)
     AngleBlkArgs w{};
     w.a = a; w.a.image = eng->img_angle[1][a.slot];
-    w.x.tiles = b->blk_tiles; w.x.a = b->blk_a; w.x.b1c = b->blk_b1c; w.x.b2c = b->blk_b2c; w.x.ctr = b->blk_ctr;
+    w.x.tiles = b->blk_tiles; w.x.a = b->blk_a; w.x.b1c = b->blk_b1c; w.x.b2c = b->blk_b2c; w.x.ctr = b->blk_ctr; w.x.desc = b->blk_desc;
     const int grid = std::max(1, std::min(eng->num_cus, (b->blk_cap + WAVES - 1) / WAVES));
     hipLaunchKernelGGL((k_angle_bwd_blk<HIDDEN>), dim3(grid), dim3(BLOCK), angle_blk_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
@@ -946,6 +946,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   {   // 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h)
     const size_t slots = (size_t)b->blk_cap * TILE_ROWS;
     b->blk_a = c.take<int>(slots); b->blk_b1c = c.take<int>(slots); b->blk_b2c = c.take<int>(slots); b->blk_ctr = c.take<int>(slots);
+    b->blk_desc = c.take<int>(b->blk_cap);
     b->blk_tiles = c.take<int>(b->blk_cap ? 4 : 0);
   }
   if (A == 0) for (int l = 1; l < L; ++l) b->hbc[l] = b->hbc[0];   // no BondConv: bond features never change
@@ -1058,7 +1059,7 @@ void register_names(chg_batch* b) {
   mi["win_next_atom"] = {b->win.next_atom, A ? N : 0};
   mi["blk_tiles"] = {b->blk_tiles, b->blk_cap ? (size_t)1 : 0}; mi["blk_a"] = {b->blk_a, (size_t)b->blk_cap * TILE_ROWS};
   mi["blk_b1c"] = {b->blk_b1c, (size_t)b->blk_cap * TILE_ROWS}; mi["blk_b2c"] = {b->blk_b2c, (size_t)b->blk_cap * TILE_ROWS};
-  mi["blk_ctr"] = {b->blk_ctr, (size_t)b->blk_cap * TILE_ROWS};
+  mi["blk_ctr"] = {b->blk_ctr, (size_t)b->blk_cap * TILE_ROWS}; mi["blk_desc"] = {b->blk_desc, (size_t)b->blk_cap};
   mi["win_wave_head"] = {b->win.wave_head, A ? (size_t)WIN_MAX_GRID * WAVES : 0}; mi["win_xatom"] = {b->win.xatom, (size_t)WIN_MAX_GRID / 8 + 1};   // win_flag[3] = workgroups
 }
 

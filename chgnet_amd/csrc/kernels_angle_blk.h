@@ -8,12 +8,14 @@
 // coarse unit of work when the whole batch is a few thousand tiles: the launch lasts as long as its largest atom / pays two
 // workgroup barriers per atom segment.
 //
-// Here a tile is a 4 x 4 BLOCK of the atom's (first bond, second bond) matrix: rows 4 i + j hold first bond 4 I + i and second bond
-// 4 J + j.  The four rows of a first bond and the four rows of a second bond are summed in registers, so a tile sends 4 + 4 rows per
-// scatter target instead of 1-2 + 16 -- 505 B of atomics per angle for BondConv -- and every tile is self-contained: any wave takes any
-// tile, no barrier, no private rows, no schedule.  The price is the empty slots (the diagonal, and the ragged edge when n is not a
-// multiple of 4: 210 angles of an atom with 15 short bonds occupy 16 tiles instead of 14); they read row 0 of the tables and their
-// upstream gradient is set to zero, so they add zeros.
+// Here a tile is a P x Q BLOCK of the atom's n x (n - 1) matrix (first bond, position of the second bond among the other n - 1 bonds):
+// slot il Q + jl holds first bond i0 + il and position j'0 + jl.  P x Q = 4 x 4, 2 x 8 or 8 x 2 per atom, whichever takes the fewest tiles
+// (blk_shape_of, kernels_graph.h: 90 % of the slots hold an angle on a thermalised cell; 4 x 4 blocks over the n x n matrix with its
+// diagonal: 78 %).  The Q rows of a first bond are summed in registers; so are the rows of a second bond -- position j' is bond j' below the
+// diagonal and bond j' + 1 on / above it, so a column leaves as a "below" sum and an "on / above" sum and neighbouring columns share a
+// bond: Q + 1 second-bond rows per tile.  A tile sends P + Q + 1 <= 11 rows per scatter target instead of 1-2 + 16 -- ~550 B of atomics
+// per angle for BondConv -- and every tile is self-contained: any wave takes any tile, no barrier, no private rows, no schedule.  Empty
+// slots (the ragged edges) read row 0 of the tables and their upstream gradient is set to zero, so they add zeros.
 //
 // Index: the device graph builder writes slot -> angle while it emits the angles (k_angle_fill, from the ranks it counts anyway) and
 // k_multi_copy adds the compact bond indices: nothing is launched for it.  Hand-made / uploaded graphs keep the row-order adjoints.
@@ -26,6 +28,7 @@ namespace chg {
 struct BlkIndex {
   const int* tiles;                       // [1] number of 16-slot tiles (device quantity: sum of ceil(n / 4)^2 over the atoms)
   const int *a, *b1c, *b2c, *ctr;         // [16 tiles] angle (-1: empty slot), compact bond indices, centre atom
+  const int* desc;                        // [tiles] log2 P | log2 Q << 4 | i0 << 8 | j'0 << 16
 };
 struct AngleBlkArgs {
   AngleArgs a;
@@ -37,26 +40,76 @@ constexpr size_t angle_blk_lds() {
   return sizeof(float) * ((size_t)AngleLds<HIDDEN, true>::tiles + WAVES * TILE64_FLOATS);
 }
 
-// dst rows `key1` (first bond: rows 4 i .. 4 i + 3) and `key2` (second bond: rows j, j + 4, j + 8, j + 12) += the column sums of a
-// 64-wide tile held column-wise; vmask: bit r = slot r holds an angle (empty slots hold zeros).  Keys are per-lane values of lanes 0-15.
-__device__ __forceinline__ void block_scatter64(const Cols64& c, unsigned vmask, int key1, int key2, float* __restrict__ dst1, float* __restrict__ dst2,
-                                                int ld, int lane) {
+// The tile's scatter for one 64-wide array held column-wise (lane = column, c.v[slot]; empty slots hold zeros): rows of dst1 keyed by the
+// first bond (ROWS: slots il Q .. il Q + Q - 1 share it) and rows of dst2 keyed by the second bond (COLS: position jl is bond j'0 + jl for
+// the slots below the diagonal, j'0 + jl + 1 on / above it -- `ge`, bit per slot -- so output k of 0 .. Q sums column k's "below" part and
+// column k - 1's "on / above" part).  vmask: bit per slot that holds an angle; keys: per-lane values of lanes 0-15.
+template <int PS, int QS, bool ROWS, bool COLS>
+__device__ __forceinline__ void blk_scatter(const Cols64& c, unsigned vmask, unsigned ge, int key1, int key2, float* __restrict__ dst1,
+                                            float* __restrict__ dst2, int ld, int lane) {
+  constexpr int P = 1 << PS, Q = 1 << QS;
+  if (ROWS) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned gm = (vmask >> (4 * i)) & 0xFu;
-    if (gm) {
-      const int k = __builtin_amdgcn_readlane(key1, 4 * i + __builtin_ctz(gm));
-      atomicAdd(grow<float>(dst1, (unsigned)k, ld, lane), (c.v[4 * i] + c.v[4 * i + 1]) + (c.v[4 * i + 2] + c.v[4 * i + 3]));
+    for (int il = 0; il < P; ++il) {
+      const unsigned gm = (vmask >> (il * Q)) & ((1u << Q) - 1u);
+      if (gm) {
+        float s = 0.f;
+#pragma unroll
+        for (int jl = 0; jl < Q; ++jl) s += c.v[il * Q + jl];
+        atomicAdd(grow<float>(dst1, (unsigned)__builtin_amdgcn_readlane(key1, il * Q + __builtin_ctz(gm)), ld, lane), s);
+      }
     }
   }
+  if (COLS) {
+    float lo[Q], hi[Q];
+    unsigned col = 0;                        // slots of column 0
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned cm = vmask & (0x1111u << j);
-    if (cm) {
-      const int k = __builtin_amdgcn_readlane(key2, __builtin_ctz(cm));
-      atomicAdd(grow<float>(dst2, (unsigned)k, ld, lane), (c.v[j] + c.v[j + 4]) + (c.v[j + 8] + c.v[j + 12]));
+    for (int il = 0; il < P; ++il) col |= 1u << (il * Q);
+    if ((ge & vmask) == 0u || ((~ge) & vmask) == 0u) {          // the tile does not cross the diagonal: plain column sums
+      const int up = (ge & vmask) ? 1 : 0;
+#pragma unroll
+      for (int jl = 0; jl < Q; ++jl) {
+        const unsigned cm = vmask & (col << jl);
+        if (cm) {
+          float s = 0.f;
+#pragma unroll
+          for (int il = 0; il < P; ++il) s += c.v[il * Q + jl];
+          atomicAdd(grow<float>(dst2, (unsigned)__builtin_amdgcn_readlane(key2, __builtin_ctz(cm)), ld, lane), s);
+        }
+      }
+      (void)up;
+      return;
+    }
+#pragma unroll
+    for (int jl = 0; jl < Q; ++jl) {
+      lo[jl] = 0.f; hi[jl] = 0.f;
+#pragma unroll
+      for (int il = 0; il < P; ++il) {
+        const int sl = il * Q + jl;
+        const float v = c.v[sl];
+        const bool up = (ge >> sl) & 1u;       // uniform
+        lo[jl] += up ? 0.f : v;
+        hi[jl] += up ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k <= Q; ++k) {
+      const unsigned ml = k < Q ? (vmask & ~ge & (col << (k < Q ? k : 0))) : 0u;
+      const unsigned mh = k > 0 ? (vmask & ge & (col << (k > 0 ? k - 1 : 0))) : 0u;
+      if (ml | mh) {
+        const float s = (k < Q ? lo[k < Q ? k : 0] : 0.f) + (k > 0 ? hi[k > 0 ? k - 1 : 0] : 0.f);
+        atomicAdd(grow<float>(dst2, (unsigned)__builtin_amdgcn_readlane(key2, __builtin_ctz(ml | mh)), ld, lane), s);
+      }
     }
   }
+}
+// ... dispatched on the tile's shape (uniform)
+template <bool ROWS, bool COLS>
+__device__ __forceinline__ void blk_scatter_any(int ps, const Cols64& c, unsigned vmask, unsigned ge, int key1, int key2, float* __restrict__ dst1,
+                                                float* __restrict__ dst2, int ld, int lane) {
+  if (ps == 2) blk_scatter<2, 2, ROWS, COLS>(c, vmask, ge, key1, key2, dst1, dst2, ld, lane);
+  else if (ps == 1) blk_scatter<1, 3, ROWS, COLS>(c, vmask, ge, key1, key2, dst1, dst2, ld, lane);
+  else blk_scatter<3, 1, ROWS, COLS>(c, vmask, ge, key1, key2, dst1, dst2, ld, lane);
 }
 
 // rows idx (< 0: none) of dst = old + tile: the read-modify-write of rows this tile owns
@@ -95,10 +148,10 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_blk(AngleBlkA
   // this wave's tiles: t0, t0 + nw, ... (neighbouring waves on neighbouring tiles: one atom's rows of the tables stay in one L2)
   const int nw = (int)gridDim.x * WAVES, t0 = (int)blockIdx.x * WAVES + wave;
   const int ntiles = __builtin_amdgcn_readfirstlane(*x.tiles);
-  int a_n = -1, b1_n = 0, b2_n = 0, c_n = 0;
+  int a_n = -1, b1_n = 0, b2_n = 0, c_n = 0, d_n = 0x22;
   if (t0 < ntiles) {
     const size_t sl = (size_t)t0 * TILE_ROWS + j;
-    a_n = x.a[sl]; b1_n = x.b1c[sl]; b2_n = x.b2c[sl]; c_n = x.ctr[sl];
+    a_n = x.a[sl]; b1_n = x.b1c[sl]; b2_n = x.b2c[sl]; c_n = x.ctr[sl]; d_n = x.desc[t0];
   }
   stage_image<AngleLds<HIDDEN, true>::tiles / 4, BLOCK>(smem, p.image, tid);
   __syncthreads();
@@ -108,13 +161,18 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_blk(AngleBlkA
     int lane_t = lane;
     if (HIDDEN) asm volatile("" : "+v"(lane_t));     // as in k_angle_bwd_w: row pointers formed where they are used
     const int a_raw = a_n, b1 = b1_n, b2 = b2_n, c = c_n;
+    const int desc = __builtin_amdgcn_readfirstlane(d_n);
     if (t + nw < ntiles) {
       const size_t sl = (size_t)(t + nw) * TILE_ROWS + j;
-      a_n = x.a[sl]; b1_n = x.b1c[sl]; b2_n = x.b2c[sl]; c_n = x.ctr[sl];
+      a_n = x.a[sl]; b1_n = x.b1c[sl]; b2_n = x.b2c[sl]; c_n = x.ctr[sl]; d_n = x.desc[t + nw];
     }
     const bool valid = a_raw >= 0;
     const int a = valid ? a_raw : 0;
     const unsigned vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(valid) & 0xFFFFull));
+    // the tile's shape and origin; ge: bit per slot whose position j' lies on / above the diagonal (its second bond is j' + 1)
+    const int ps = desc & 15, qs = (desc >> 4) & 15, i0 = (desc >> 8) & 255, j0 = (desc >> 16) & 255;
+    const unsigned ge = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(__builtin_amdgcn_ballot_w64(j0 + (j & ((1 << qs) - 1)) >= i0 + (j >> qs)) & 0xFFFFull));
     // ---- gathers: angle rows, the two halves of the table sum ----
     f32x4 z[2 * VT];
     Rows64 gy_rows;
@@ -164,23 +222,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_blk(AngleBlkA
       Cols64 c1, c2;
       to_columns(g1, T, Trow, g, lane_t, c1);
       to_columns(g2, T, Trow, g, lane_t, c2);
-      // (two calls: first-bond sums of g1, second-bond sums of g2 -- the other four sums of each call are skipped through an empty mask)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned gm = (vmask >> (4 * i)) & 0xFu;
-        if (gm) {
-          const int k = __builtin_amdgcn_readlane(b1, 4 * i + __builtin_ctz(gm));
-          atomicAdd(grow<float>(p.Gwbgc, (unsigned)k, D, lane_t), (c1.v[4 * i] + c1.v[4 * i + 1]) + (c1.v[4 * i + 2] + c1.v[4 * i + 3]));
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const unsigned cm = vmask & (0x1111u << jj);
-        if (cm) {
-          const int k = __builtin_amdgcn_readlane(b2, __builtin_ctz(cm));
-          atomicAdd(grow<float>(p.Gwbgc, (unsigned)k, D, lane_t), (c2.v[jj] + c2.v[jj + 4]) + (c2.v[jj + 8] + c2.v[jj + 12]));
-        }
-      }
+      blk_scatter_any<true, false>(ps, c1, vmask, ge, b1, b2, p.Gwbgc, p.Gwbgc, D, lane_t);      // first-bond sums of g1
+      blk_scatter_any<false, true>(ps, c2, vmask, ge, b1, b2, p.Gwbgc, p.Gwbgc, D, lane_t);      // second-bond sums of g2
     } else {
       rows64_commit(gy_rows, T, TS64, lane_t);
       __builtin_amdgcn_wave_barrier();
@@ -214,8 +257,8 @@ __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_blk(AngleBlkA
       Cols64 cc[2];
       to_columns(gzc, T, Trow, g, lane_t, cc[0]);
       to_columns(gzg, T, Trow, g, lane_t, cc[1]);
-      block_scatter64(cc[0], vmask, b1, b2, p.GR, p.GR + 2 * D, 4 * D, lane_t);
-      block_scatter64(cc[1], vmask, b1, b2, p.GR + D, p.GR + 3 * D, 4 * D, lane_t);
+      blk_scatter_any<true, true>(ps, cc[0], vmask, ge, b1, b2, p.GR, p.GR + 2 * D, 4 * D, lane_t);
+      blk_scatter_any<true, true>(ps, cc[1], vmask, ge, b1, b2, p.GR + D, p.GR + 3 * D, 4 * D, lane_t);
       if (vmask) {
         const int ck = __builtin_amdgcn_readlane(c, __builtin_ctz(vmask));
         float s0 = 0.f, s1 = 0.f;

@@ -301,6 +301,17 @@ static __global__ __launch_bounds__(256) void k_short_count(const double* __rest
   }
 }
 
+// Blocked tiles of the MD-size angle adjoints (kernels_angle_blk.h): the n x (n - 1) matrix (first bond rank, position of the second
+// bond among the OTHER n - 1 bonds) of an atom is cut into 16-slot tiles of P x Q = 4 x 4, 2 x 8 or 8 x 2, whichever takes fewest
+// (4 x 4 on a tie: it sends the fewest atomic rows).  qs = log2 Q; returns the tile count.
+__host__ __device__ inline int blk_shape_of(int n, int& ps, int& qs) {
+  if (n < 2) { ps = 2; qs = 2; return 0; }
+  const int t44 = ((n + 3) >> 2) * ((n + 2) >> 2), t28 = ((n + 1) >> 1) * ((n + 6) >> 3), t82 = ((n + 7) >> 3) * (n >> 1);   // ceil(n / P) ceil((n - 1) / Q)
+  if (t44 <= t28 && t44 <= t82) { ps = 2; qs = 2; return t44; }
+  if (t28 <= t82) { ps = 1; qs = 3; return t28; }
+  ps = 3; qs = 1; return t82;
+}
+
 // angles owned by undirected bond k (graph.py:283-327): both ends, the end's other short edges
 static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* __restrict__ e_rev, const int* __restrict__ e_center,
                               const double* __restrict__ e_dist, const int* __restrict__ short_cnt, DevCount n_und, double r_bond,
@@ -308,8 +319,8 @@ static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* _
                               int* __restrict__ boff, int* __restrict__ aoff, int* __restrict__ toff, int* __restrict__ toff4) {
   // Workgroup 0 first writes the per-atom offsets of the centre-major angle order (the index of the per-atom / team angle adjoints,
   // kernels_angle_w.h): boff = exclusive scan of the short-bond counts n, aoff = exclusive scan of n (n - 1), toff = exclusive scan of
-  // the 16-row tile counts ceil(n (n - 1) / 16), N + 1 entries each -- and / or toff4 = exclusive scan of ceil(n / 4)^2, the 4 x 4
-  // blocked tiles of the MD-size adjoints (kernels_angle_blk.h).
+  // the 16-row tile counts ceil(n (n - 1) / 16), N + 1 entries each -- and / or toff4 = exclusive scan of the blocked-tile counts of
+  // the MD-size adjoints (blk_shape_of above, kernels_angle_blk.h).
   // Riding in this launch they cost nothing; as k_win_* launches after the build they were five more of an MD step's ~60.
   if (blockIdx.x == 0 && (boff || toff4)) {
     __shared__ int sb[256], sa[256], st[256], s4[256];
@@ -319,7 +330,8 @@ static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* _
     // (an atom with ONE short bond has no angles and owns no (atom, bond) pair: like k_win_heads, which counts group heads)
     for (int q = b; q < e; ++q) {
       const int v = q < n_atoms ? short_cnt[q] : 0;
-      tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; t4 += v >= 2 ? ((v + 3) >> 2) * ((v + 3) >> 2) : 0;
+      int ps, qs;
+      tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; t4 += blk_shape_of(v, ps, qs);
     }
     sb[tid] = tb; sa[tid] = ta; st[tid] = tt; s4[tid] = t4;
     __syncthreads();
@@ -329,7 +341,8 @@ static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* _
       const int v = q < n_atoms ? short_cnt[q] : 0;
       if (boff) { boff[q] = rb; aoff[q] = ra; toff[q] = rt; }
       if (toff4) toff4[q] = r4;
-      rb += v >= 2 ? v : 0; ra += v * (v - 1); rt += (v * (v - 1) + 15) >> 4; r4 += v >= 2 ? ((v + 3) >> 2) * ((v + 3) >> 2) : 0;
+      int ps, qs;
+      rb += v >= 2 ? v : 0; ra += v * (v - 1); rt += (v * (v - 1) + 15) >> 4; r4 += blk_shape_of(v, ps, qs);
     }
   }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,7 +369,7 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
                                                     int* __restrict__ is_node, int cap_angles, int* __restrict__ overflow,
                                                     const int* __restrict__ short_cnt, const int* __restrict__ boff, const int* __restrict__ aoff,
                                                     int* __restrict__ q_a, int* __restrict__ q_ctr, int* __restrict__ q_ab1, int* __restrict__ q_ab2,
-                                                    const int* __restrict__ toff4, int* __restrict__ blk_a, int cap_tiles4) {
+                                                    const int* __restrict__ toff4, int* __restrict__ blk_a, int* __restrict__ blk_desc, int cap_tiles4) {
   const int lane = threadIdx.x & 63;
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (k >= n_und.get() || *overflow) return;
@@ -378,9 +391,12 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
       }
     }
     const int n_c = (q_a || blk_a) ? short_cnt[ctr] : 0;
-    // 4 x 4 blocked tiles (kernels_angle_blk.h): the angle (first bond of rank i, second bond of rank j) of this atom is slot
-    // 4 (i & 3) + (j & 3) of tile toff4[ctr] + (i >> 2) nb + (j >> 2), nb = ceil(n / 4); blk_a holds angle + 1 (0: empty slot)
-    const int nb4 = (n_c + 3) >> 2, t4_0 = blk_a ? toff4[ctr] : 0;
+    // blocked tiles (kernels_angle_blk.h): the angle (first bond of rank i, second bond at position j' among the other n - 1) of this
+    // atom is slot (i mod P) Q + (j' mod Q) of tile toff4[ctr] + (i / P) ceil((n - 1) / Q) + (j' / Q); blk_a holds angle + 1 (0: empty
+    // slot), blk_desc the tile's shape and origin: log2 P | log2 Q << 4 | i0 << 8 | j'0 << 16
+    int ps4 = 2, qs4 = 2;
+    if (blk_a) blk_shape_of(n_c, ps4, qs4);
+    const int nq4 = (n_c - 1 + (1 << qs4) - 1) >> qs4, t4_0 = blk_a ? toff4[ctr] : 0;
     const long row0 = q_a ? (long)aoff[ctr] + (long)rank1 * (n_c - 1) : 0;
     const int ab0 = q_a ? boff[ctr] : 0;
     const int w_group = w;
@@ -402,9 +418,12 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
           }
         }
         if (blk_a) {
-          const int rank2 = shorts_before + __popcll(ms & lower);
-          const long tile = (long)t4_0 + (long)(rank1 >> 2) * nb4 + (rank2 >> 2);
-          if (rank1 < n_c && rank2 < n_c && tile < cap_tiles4) blk_a[tile * 16 + 4 * (rank1 & 3) + (rank2 & 3)] = at + 1;   // (else: not a canonical graph, the index is not used)
+          const int jp = at - w_group;            // position in the group = rank of the second bond among the others
+          const long tile = (long)t4_0 + (long)(rank1 >> ps4) * nq4 + (jp >> qs4);
+          if (rank1 < n_c && jp < n_c - 1 && tile < cap_tiles4) {   // (else: not a canonical graph, the index is not used)
+            blk_a[tile * 16 + ((rank1 & ((1 << ps4) - 1)) << qs4) + (jp & ((1 << qs4) - 1))] = at + 1;
+            blk_desc[tile] = ps4 | (qs4 << 4) | ((rank1 >> ps4 << ps4) << 8) | ((jp >> qs4 << qs4) << 16);   // (every angle of the tile writes the same value)
+          }
         }
       }
       w += __popcll(m);
@@ -585,8 +604,8 @@ struct MultiCopy {
   int win_grid;
   // ... or the 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h; row n_copy + 3): slot -> angle (-1: empty), compact
   // bond indices, centre; [0 .. 16 toff4[N]) of the arena arrays (capacity cap_tiles4 tiles), and the tile count itself
-  const int *blk_a_new, *toff4_new, *a_ctr_new;
-  int *blk_a, *blk_b1c, *blk_b2c, *blk_ctr, *blk_tiles;
+  const int *blk_a_new, *blk_desc_new, *toff4_new, *a_ctr_new;
+  int *blk_a, *blk_b1c, *blk_b2c, *blk_ctr, *blk_desc, *blk_tiles;
   int n_atoms, cap_tiles4;
 };
 static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
@@ -600,6 +619,7 @@ static __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m) {
       if (!m.blk_a_new) return;
       const int tiles = min(m.toff4_new[m.n_atoms], m.cap_tiles4);
       if (t0 == 0) *m.blk_tiles = tiles;
+      for (int t = t0; t < tiles; t += tstride) m.blk_desc[t] = m.blk_desc_new[t];
       for (int sl = t0; sl < 16 * tiles; sl += tstride) {
         const int a = m.blk_a_new[sl] - 1;
         m.blk_a[sl] = a;
