@@ -55,6 +55,20 @@ for tag, scale in (("a32", (1, 1, 1)), ("a256", (2, 2, 2)), ("a384", (3, 2, 2)))
     for k, v in eng.download(b2, "efsm").items():
         out[f"{tag}/upload/{k}"] = v
     b.free(); b2.free()
+# a ragged batch: 40 random cells of 10-100 atoms (the C3 sweep's generator): atoms with 2 ... 30 short bonds, every block shape
+import bench
+rag = [bench.sweep_structure(i) for i in range(40)]
+b = eng.build_batch(rag, 6.0, 3.0)
+eng.predict(b, "efsm")
+for k, v in eng.download(b, "efsm").items():
+    out[f"ragged/efsm/{k}"] = v
+out["ragged/counts"] = np.array([b.packed.n_directed, b.packed.n_angles, b.packed.n_bnodes])
+try:
+    nt = int(eng.debug_fetch_i32(b, "blk_tiles", 1)[0])
+    out["ragged/blk_tiles"] = np.array([nt]); out["ragged/blk_a"] = eng.debug_fetch_i32(b, "blk_a", 16 * nt); out["ragged/blk_desc"] = eng.debug_fetch_i32(b, "blk_desc", nt)
+except Exception:
+    out["ragged/blk_tiles"] = np.array([0])
+b.free()
 np.savez(sys.argv[2], **out)
 '''
 
@@ -80,6 +94,18 @@ def test_md_size_path_equals_the_large_batch_launch_sequence():
         nochain = _run_child({"CHGNET_TINY_CHAIN": "0", "CHGNET_BLK_MAX_ANGLES": "0"}, tmp, "nochain")     # ... the row-order adjoints
         old = _run_child({"CHGNET_TINY_FUSE": "0", "CHGNET_TEAM_MIN_ANGLES": "-1", "CHGNET_BLK_MAX_ANGLES": "0"}, tmp, "old")
     tol = {"e": 2e-6, "f": 4e-5, "s": 4e-4, "m": 2e-5, "site_energies": 3e-5, "crystal_fea": 5e-4}     # the trained-like tolerances of tests/test_v020.py
+    # the ragged batch: every angle in exactly one slot, all three block shapes in use, results as without the blocked tiles
+    n_ang = int(old["ragged/counts"][1])
+    slots = default["ragged/blk_a"]
+    assert np.array_equal(np.sort(slots[slots >= 0]), np.arange(n_ang))
+    assert {int(d) & 0xFF for d in default["ragged/blk_desc"]} == {0x22, 0x31, 0x13}      # log2 P | log2 Q << 4: 4 x 4, 2 x 8, 8 x 2
+    assert slots.size <= 1.35 * n_ang                                                       # at least ~75 % of the slots hold an angle
+    for variant in (team, default, nochain):
+        for key, ref in old.items():
+            if key.startswith("ragged/efsm/"):
+                k = key.rsplit("/", 1)[1]
+                err = float(np.abs(variant[key] - ref).max())
+                assert np.isfinite(variant[key]).all() and err <= tol[k], (key, err)
     for tag in ("a32", "a256", "a384"):
         assert list(team[f"{tag}/flag"][:1]) == [1], tag
         assert np.array_equal(team[f"{tag}/counts"], old[f"{tag}/counts"])
