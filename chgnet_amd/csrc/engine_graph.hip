@@ -206,7 +206,7 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   const size_t z_ccnt = 0, z_flags = z_ccnt + (size_t)N + 1, z_scan = z_flags + 8, z_head = z_scan + 3 * (size_t)SCAN_STATE_INTS;
   const int capU0 = capE / 2;
   auto tail_ints = [&](int cE, int cU) { return 2 * ((size_t)cU + 1) + ((size_t)cE + 1) + (size_t)std::max(N, 1); };
-  // 4 x 4 blocked tiles of the MD-size angle adjoints (kernels_angle_blk.h): slot -> angle + 1, written by k_angle_fill; a single-pass
+  // blocked tiles of the MD-size angle adjoints (kernels_angle_blk.h): slot -> angle + 1, written by k_angle_fill; a single-pass
   // build knows the capacities up front and clears the slots with everything else, an exact one after it has learnt A
   const long blk_max = blk_max_angles();
   const bool blk_wanted = blk_max > 0 && N + 1 <= 8192;

@@ -176,7 +176,7 @@ struct chg_batch {
   bool win_index_ready = false;   // chg_batch_build emitted the centre-major index with the graph (prepare_windows only schedules)
   int win_team = 0;         // > 0: small batch in TEAM mode (kernels_angle_w.h) -- the index without the schedule exists and the angle
                             // adjoints give every atom to a team of this many waves; win_grid is their workgroup count
-  // MD-size batches built on the device: the angle adjoints over 4 x 4 blocked tiles (kernels_angle_blk.h); blk_cap = capacity of the
+  // MD-size batches built on the device: the angle adjoints over blocked tiles (kernels_angle_blk.h); blk_cap = capacity of the
   // index in tiles (0: none), the tile count itself is a device quantity (blk_tiles)
   int blk_cap = 0;
   int *blk_a = nullptr, *blk_b1c = nullptr, *blk_b2c = nullptr, *blk_ctr = nullptr, *blk_desc = nullptr, *blk_tiles = nullptr;
@@ -318,9 +318,9 @@ inline long team_min_angles() {   // TEAM-mode threshold of the angle adjoints (
   return v;
 }
 // ... and device-built batches of up to 8,191 atoms (below ~6,000 the per-atom adjoints leave waves idle) and this many angles use the
-// 4 x 4 blocked tiles (kernels_angle_blk.h) instead of either; 0: never.  Same box, thermalised Li9Co7O16 cells, BondConv / AngleUpdate
-// adjoint per launch, blocked / TEAM / row order: 256 atoms 57 / -- / 58 and 35 / -- / 43 us, 512 atoms 92 / -- / 103 and 55 / -- / 74,
-// 1,024 atoms 166 / 175 / 200 and 94 / 115 / 140, 2,048 atoms 320 / 332 / 372 and 172 / 212 / 258.
+// blocked tiles (kernels_angle_blk.h) instead of either; 0: never.  Same box, thermalised Li9Co7O16 cells, BondConv / AngleUpdate
+// adjoint per launch, blocked / TEAM / row order: 256 atoms 46 / -- / 58 and 27 / -- / 43 us, 512 atoms 82 / -- / 103 and 50 / -- / 74,
+// 1,024 atoms 153 / 175 / 200 and ~90 / 115 / 140 (profiles/r06_experiments.md section 14).
 inline long blk_max_angles() {
   static const long v = [] { const char* e = std::getenv("CHGNET_BLK_MAX_ANGLES"); return e ? std::atol(e) : (1L << 22); }();
   return v;

@@ -473,7 +473,7 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     HIP_TRY(eng, hipGetLastError());
     if (b->canonical) return CHG_OK;
   } else if (BWD && b->blk_cap > 0) {
-    // MD-size batch built on the device: self-contained 4 x 4 blocked tiles (kernels_angle_blk.h; the index is valid by construction)
+    // MD-size batch built on the device: self-contained blocked tiles (kernels_angle_blk.h; the index is valid by construction)
     AngleBlkArgs w{};
     w.a = a; w.a.image = eng->img_angle[1][a.slot];
     w.x.tiles = b->blk_tiles; w.x.a = b->blk_a; w.x.b1c = b->blk_b1c; w.x.b2c = b->blk_b2c; w.x.ctr = b->blk_ctr; w.x.desc = b->blk_desc;
@@ -943,7 +943,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
     b->win_tmp = c.take<int>(N + 1);
     b->win_scan = c.take<int>(scan_scratch_ints((int)N + 1));
   }
-  {   // 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h)
+  {   // blocked tiles of the MD-size adjoints (kernels_angle_blk.h)
     const size_t slots = (size_t)b->blk_cap * TILE_ROWS;
     b->blk_a = c.take<int>(slots); b->blk_b1c = c.take<int>(slots); b->blk_b2c = c.take<int>(slots); b->blk_ctr = c.take<int>(slots);
     b->blk_desc = c.take<int>(b->blk_cap);

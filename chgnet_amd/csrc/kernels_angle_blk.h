@@ -1,6 +1,6 @@
-// kernels_angle_blk.h -- adjoints of BondConv / AngleUpdate for MD-size batches over 4 x 4 BLOCKED angle tiles.
+// kernels_angle_blk.h -- adjoints of BondConv / AngleUpdate for MD-size batches over BLOCKED angle tiles.
 //
-// Why (profiles/r06_experiments.md section 12): at a few hundred atoms the row-order adjoints (k_angle<.., true>) are bound by the
+// Why (profiles/r06_experiments.md section 14): at a few hundred atoms the row-order adjoints (k_angle<.., true>) are bound by the
 // fp32 atomics of their scatter -- the L2 executes them at one lane per clock and channel, ~1.3 TB/s chip-wide whatever the scope or
 // the sharing (tools/lab/atomic_scope_lab.hip) -- and nearly all of those are the SECOND bond's rows: a 16-row tile of the reference's
 // order is 16 angles with one first bond and 16 different second bonds (939 B of atomics per angle for BondConv).  The per-atom and
@@ -26,7 +26,7 @@
 namespace chg {
 
 struct BlkIndex {
-  const int* tiles;                       // [1] number of 16-slot tiles (device quantity: sum of ceil(n / 4)^2 over the atoms)
+  const int* tiles;                       // [1] number of 16-slot tiles (device quantity: sum of blk_shape_of(n) over the atoms)
   const int *a, *b1c, *b2c, *ctr;         // [16 tiles] angle (-1: empty slot), compact bond indices, centre atom
   const int* desc;                        // [tiles] log2 P | log2 Q << 4 | i0 << 8 | j'0 << 16
 };

@@ -1,8 +1,9 @@
 // kernels_angle_w.h -- adjoints of BondConv / AngleUpdate with the second-bond scatter aggregated per ATOM in LDS.
 //
 // Why (profiles/r03_experiments.md): the per-row fp32 atomics of the angle adjoints (the second bond of every angle:
-// 939 B per angle for BondConv) are executed at the memory side of the fabric -- the per-XCD L2s cannot own a
-// line -- at ~1.2 TB/s chip-wide, and that, not the matrix pipe or the gathers, is what bounded both kernels
+// 939 B per angle for BondConv) run at ~1.2-1.3 TB/s chip-wide -- one lane per clock and L2 channel, whatever their scope
+// and however the target rows are shared between the XCDs (round 6: tools/lab/atomic_scope_lab.hip; round 3 read it as
+// "executed at the memory side") -- and that, not the matrix pipe or the gathers, is what bounded both kernels
 // (no atomics: -28 % / -13 %; no atomics AND a 4x faster matrix pipe: -50 % / -55 %).
 //
 // Order.  The reference emits angles sorted by their first bond (graph.py:283-327).  All n (n - 1) angles around one atom

@@ -602,7 +602,7 @@ struct MultiCopy {
   const int *q_a_new, *q_ab1_new;
   int *q_b1c, *q_b2c, *abbond, *win_flag;
   int win_grid;
-  // ... or the 4 x 4 blocked tiles of the MD-size adjoints (kernels_angle_blk.h; row n_copy + 3): slot -> angle (-1: empty), compact
+  // ... or the blocked tiles of the MD-size adjoints (kernels_angle_blk.h; row n_copy + 3): slot -> angle (-1: empty), compact
   // bond indices, centre; [0 .. 16 toff4[N]) of the arena arrays (capacity cap_tiles4 tiles), and the tile count itself
   const int *blk_a_new, *blk_desc_new, *toff4_new, *a_ctr_new;
   int *blk_a, *blk_b1c, *blk_b2c, *blk_ctr, *blk_desc, *blk_tiles;
