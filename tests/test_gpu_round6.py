@@ -180,3 +180,35 @@ def test_mid_size_scans_of_the_graph_build_are_exact(hip_engine):
                 assert np.array_equal(got, want.arrays[name]), name
         finally:
             b.free()
+
+
+def test_fine_tuning_gradient_of_a_device_built_batch_equals_the_uploaded_one(trained_like_weights):
+    """chg_backward (tangent + two-adjoint sweeps) starts from the first-order adjoints the force sweep leaves in the batch: on a batch built on
+    the device those come from the blocked-tile angle adjoints, on an uploaded one from the row-order kernels -- same gradient."""
+    import bench
+    from chgnet_amd import CrystalGraphConverter
+
+    from chgnet_amd.engine import Engine
+    from chgnet_amd.pack import pack_weights
+
+    eng = Engine(pack_weights(trained_like_weights), 0)
+    structs = [bench.sweep_structure(i) for i in range(12)]
+    conv = CrystalGraphConverter(atom_graph_cutoff=6, bond_graph_cutoff=3)
+    b_dev = eng.build_batch(structs, 6.0, 3.0)
+    b_up = eng.upload([conv(s) for s in structs])
+    try:
+        n, n_atoms = len(structs), b_dev.packed.n_atoms
+        assert int(eng.debug_fetch_i32(b_dev, "blk_tiles", 1)[0]) > 0
+        rng = np.random.default_rng(0)
+        cot = rng.normal(1, 0.1, n).astype(np.float32)
+        gf = rng.normal(0, 0.01, (n_atoms, 3)).astype(np.float32)
+        gs = rng.normal(0, 0.01, (n, 3, 3)).astype(np.float32)
+        grads = []
+        for b in (b_dev, b_up):
+            eng.predict(b, "efs")
+            grads.append(eng.backward(b, cot, f_grad=gf, s_grad=gs))
+        assert np.isfinite(grads[0]).all()
+        assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * np.abs(grads[1]).max()
+    finally:
+        b_dev.free(); b_up.free()
+        eng.close()
