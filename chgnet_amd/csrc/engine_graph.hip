@@ -336,12 +336,15 @@ int graph_pass(chg_engine* eng, TmpPool& tmp, const chg_structs_host* h, const d
   }
   bn_und = tmp.get<int>(capEb);
   if (!bn_und) { eng->err = "graph build: scratch allocation failed"; return CHG_ENOMEM; }
-  if (capU > 0) hipLaunchKernelGGL(k_bond_nodes, g1(capU), dim3(256), 0, st, is_node, node_scan, nU, u_bnode, bn_und, capEb, d_flags + 2);
+  // (single-pass builds: the kernel's last workgroup also gathers the counts for the one device-to-host copy below; d_flags[6] is its ticket)
+  const CollectCounts collect{d_coff + N, ang_off + capU, node_scan + capU, d_flags, (speculative && capU > 0) ? d_counts : nullptr, d_flags + 6};
+  if (capU > 0) hipLaunchKernelGGL(k_bond_nodes, g1(capU), dim3(256), 0, st, is_node, node_scan, nU, u_bnode, bn_und, capEb, d_flags + 2, collect);
   HIP_TRY(eng, hipGetLastError());
   if (speculative) {   // the one round trip of this path
     int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, (const int*)(d_coff + N), (const int*)(ang_off + capU),
-                       (const int*)(node_scan + capU), (const int*)d_flags, d_counts);
+    if (capU <= 0)     // (no bond at all: k_bond_nodes was not launched)
+      hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, (const int*)(d_coff + N), (const int*)(ang_off + capU),
+                         (const int*)(node_scan + capU), (const int*)d_flags, d_counts);
     HIP_TRY(eng, hipMemcpyAsync(hc, d_counts, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(eng, hipStreamSynchronize(st));
     Ed = hc[0]; A = hc[1]; Eb = hc[2]; flags[0] = hc[3]; flags[1] = hc[4]; flags[2] = hc[5]; flags[4] = hc[7];

@@ -323,7 +323,7 @@ static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* _
   // the MD-size adjoints (blk_shape_of above, kernels_angle_blk.h).
   // Riding in this launch they cost nothing; as k_win_* launches after the build they were five more of an MD step's ~60.
   if (blockIdx.x == 0 && (boff || toff4)) {
-    __shared__ int sb[256], sa[256], st[256], s4[256];
+    __shared__ int wtot[4][4];
     const int tid = threadIdx.x, n = n_atoms + 1, per = (n + 255) / 256;
     const int b = min(tid * per, n), e = min(b + per, n);
     int tb = 0, ta = 0, tt = 0, t4 = 0;
@@ -333,10 +333,19 @@ static __global__ void k_angle_count(const int* __restrict__ u_u2d, const int* _
       int ps, qs;
       tb += v >= 2 ? v : 0; ta += v * (v - 1); tt += (v * (v - 1) + 15) >> 4; t4 += blk_shape_of(v, ps, qs);
     }
-    sb[tid] = tb; sa[tid] = ta; st[tid] = tt; s4[tid] = t4;
+    // exclusive prefixes over the 256 threads: inclusive scans inside the four waves, their totals through LDS (a serial walk over the
+    // earlier threads' sums -- up to 255 x 4 LDS reads -- made workgroup 0 the longest of the launch)
+    const int lane = tid & 63, wave = tid >> 6;
+    int ib = tb, ia = ta, it = tt, i4 = t4;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off), ut = __shfl_up(it, off), u4 = __shfl_up(i4, off);
+      if (lane >= off) { ib += ub; ia += ua; it += ut; i4 += u4; }
+    }
+    if (lane == 63) { wtot[wave][0] = ib; wtot[wave][1] = ia; wtot[wave][2] = it; wtot[wave][3] = i4; }
     __syncthreads();
-    int rb = 0, ra = 0, rt = 0, r4 = 0;
-    for (int q = 0; q < tid; ++q) { rb += sb[q]; ra += sa[q]; rt += st[q]; r4 += s4[q]; }
+    int rb = ib - tb, ra = ia - ta, rt = it - tt, r4 = i4 - t4;
+    for (int q = 0; q < wave; ++q) { rb += wtot[q][0]; ra += wtot[q][1]; rt += wtot[q][2]; r4 += wtot[q][3]; }
     for (int q = b; q < e; ++q) {
       const int v = q < n_atoms ? short_cnt[q] : 0;
       if (boff) { boff[q] = rb; aoff[q] = ra; toff[q] = rt; }
@@ -433,16 +442,34 @@ static __global__ __launch_bounds__(256) void k_angle_fill(const int* __restrict
   if (lane == 0) is_node[k] = 1;
 }
 
-static __global__ void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und, int* __restrict__ u_bnode,
-                             int* __restrict__ bn_und, int cap_nodes, int* __restrict__ overflow) {
+// (single-pass builds: the LAST workgroup to finish also gathers the counts of the build for its one device-to-host copy -- `collect`
+// non-null; ticket = a zeroed counter -- instead of a launch of its own, 5.6 us of an MD step, behind this one.)
+struct CollectCounts { const int *ed, *a, *eb, *flags; int* out; int* ticket; };
+static __global__ __launch_bounds__(256) void k_bond_nodes(const int* __restrict__ is_node, const int* __restrict__ node_scan, DevCount n_und,
+                                                    int* __restrict__ u_bnode, int* __restrict__ bn_und, int cap_nodes, int* __restrict__ overflow,
+                                                    CollectCounts collect) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_und.get() || *overflow) return;
-  if (is_node[k]) {
-    u_bnode[k] = node_scan[k];
-    if (node_scan[k] >= cap_nodes) { *overflow = 1; return; }
-    bn_und[node_scan[k]] = k;
-  } else {
-    u_bnode[k] = -1;
+  if (k < n_und.get() && !*overflow) {
+    if (is_node[k]) {
+      u_bnode[k] = node_scan[k];
+      if (node_scan[k] >= cap_nodes) *overflow = 1;
+      else bn_und[node_scan[k]] = k;
+    } else {
+      u_bnode[k] = -1;
+    }
+  }
+  if (!collect.out) return;
+  __threadfence();                     // this thread's flag write is visible before the workgroup takes its ticket
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0) last = atomicAdd(collect.ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    const volatile int* f = collect.flags;
+    // {Ed, A, Eb, unpaired-edge flag, isolated atoms, overflow, cell-sort overflow, non-canonical angle sets}
+    collect.out[0] = *collect.ed; collect.out[1] = *collect.a; collect.out[2] = *collect.eb;
+    collect.out[3] = f[0]; collect.out[4] = f[1]; collect.out[5] = f[2]; collect.out[6] = f[3]; collect.out[7] = f[4];
   }
 }
 
