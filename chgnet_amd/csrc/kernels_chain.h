@@ -52,9 +52,14 @@ struct ChainArgs {
   int n;
 };
 
-constexpr int CH_TS = 2 * D + PAD;   // row stride of the wave tiles (stage-1 inputs up to 128 wide)
+constexpr int CH_TS = D + PAD;       // row stride of the wave tiles (64 wide: a 128-wide stage-1 input goes through in two halves)
+constexpr int CH_W1 = D * (2 * D + PAD);   // floats of one term's weight image
+// All terms' weight images are resident at once (three buffers: 101 KB of the 154 KB; the 128-wide wave tiles they displaced were only
+// ever used as a transposition buffer): one workgroup barrier per launch instead of two per term.  (Simpler, not faster: the three-term
+// in-place chains of the reverse sweep stay at ~18 us -- timing-only builds: every further 128-wide term costs ~3 us of contraction, the
+// operand split of eight waves on four SIMDs, and ~1.7 us of weight load + image build; the barriers cost nothing measurable.)
 constexpr size_t chain_lds() {
-  return sizeof(float) * ((size_t)D * (2 * D + PAD) + (size_t)D * (D + PAD) + D + D + (size_t)WAVES * TILE_ROWS * CH_TS);
+  return sizeof(float) * ((size_t)CHAIN_TERMS * CH_W1 + (size_t)D * (D + PAD) + D + D + (size_t)WAVES * TILE_ROWS * CH_TS);
 }
 
 // Everything a workgroup reads is REQUESTED before anything is waited for: a launch of this size is one or two memory round trips
@@ -108,19 +113,28 @@ template <int K>
 __device__ __forceinline__ void chain_x_contract(f32x4 (&acc)[VT], const ChainX& r, const float* W1, float* T, int lane, int j, int g) {
   constexpr int LPR = K / 4, RPS = 64 / LPR, NV = TILE_ROWS / RPS, KT = K / 16;
   const int sub = lane / LPR, t = lane % LPR;
-#pragma unroll
-  for (int it = 0; it < NV; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + sub) * CH_TS + 4 * t) = r.v[it];
-  __builtin_amdgcn_wave_barrier();
   f32x4 x[KT];
-  read_dl<KT>(T + j * CH_TS, g, x);
-  __builtin_amdgcn_wave_barrier();
+  // the row tile through the wave's 64-wide LDS tile, one 64-column half at a time (registers: 16 lanes per row -> accumulator layout)
+#pragma unroll
+  for (int h = 0; h < K / D; ++h) {
+    if ((t >> 4) == h) {
+#pragma unroll
+      for (int it = 0; it < NV; ++it) *reinterpret_cast<f32x4*>(T + (RPS * it + sub) * CH_TS + 4 * (t & 15)) = r.v[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 xh[VT];
+    read_dl<VT>(T + j * CH_TS, g, xh);
+#pragma unroll
+    for (int f = 0; f < VT; ++f) x[VT * h + f] = xh[f];
+    __builtin_amdgcn_wave_barrier();
+  }
   gemm_split<KT, VT, true>(acc, reinterpret_cast<const h16x8*>(W1), D, x, j, g);
 }
 
 static __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_chain(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1 = smem;                              // [64][K + PAD], one term at a time
-  float* W2 = W1 + D * (2 * D + PAD);            // [16 or 64][64 + PAD]
+  float* W1 = smem;                              // [CHAIN_TERMS][64][K + PAD]: every term's image
+  float* W2 = W1 + CHAIN_TERMS * CH_W1;          // [16 or 64][64 + PAD]
   float* b1s = W2 + D * (D + PAD);               // [64]
   float* b2s = b1s + D;                          // [64]
   float* tiles = b2s + D;                        // [WAVES][16][CH_TS]
@@ -183,22 +197,20 @@ static __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_chain(Chain
   }
   if (tid < D) { b1s[tid] = bias1; b2s[tid] = bias2; }
   if (p.nouts) chain_ws_commit(w2r, reinterpret_cast<h16x8*>(W2), D, tid);
-  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < CHAIN_TERMS; ++t)
+    if (t < p.nterms) chain_ws_commit(wr[t], reinterpret_cast<h16x8*>(W1 + t * CH_W1), p.t[t].K, tid);
+  __syncthreads();                               // the only workgroup barrier
+  if (!active) return;
   f32x4 acc[VT];
   read_dl<VT>(b1s, g, acc);
   // ---- stage 1 ----
 #pragma unroll
   for (int t = 0; t < CHAIN_TERMS; ++t)
     if (t < p.nterms) {
-      if (t > 0) __syncthreads();                // the previous term's operand reads are done
-      chain_ws_commit(wr[t], reinterpret_cast<h16x8*>(W1), p.t[t].K, tid);
-      __syncthreads();
-      if (active) {
-        if (p.t[t].K == D) chain_x_contract<D>(acc, xr[t], W1, T, lane, j, g);
-        else chain_x_contract<2 * D>(acc, xr[t], W1, T, lane, j, g);
-      }
+      if (p.t[t].K == D) chain_x_contract<D>(acc, xr[t], W1 + t * CH_W1, T, lane, j, g);
+      else chain_x_contract<2 * D>(acc, xr[t], W1 + t * CH_W1, T, lane, j, g);
     }
-  if (!active) return;                           // (no workgroup barrier below)
   write_dl<VT>(T + j * CH_TS, g, acc);
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
