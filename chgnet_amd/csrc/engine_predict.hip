@@ -620,8 +620,13 @@ int launch_chain(chg_engine* eng, const char* label, ChainBuilder& cb) {
     blocks += p.col_blocks;
   }
   if (cb.max_rows <= 0 || blocks == 0) return CHG_OK;
+  int row_blocks = 1;                  // the grid covers the problem with the most row blocks (kernels_chain.h: 4 or 8 row tiles per workgroup)
+  for (int i = 0; i < cb.a.n; ++i) {
+    const int rows_per_wg = chain_tiles_per_wg(cb.a.p[i].nterms) * TILE_ROWS;
+    row_blocks = std::max(row_blocks, (cb.a.p[i].rows + rows_per_wg - 1) / rows_per_wg);
+  }
   LaunchScope ls(eng, label);
-  hipLaunchKernelGGL(k_rows_chain, dim3((cb.max_rows + BLOCK_ROWS - 1) / BLOCK_ROWS, blocks), dim3(BLOCK), chain_lds(), eng->stream, cb.a);
+  hipLaunchKernelGGL(k_rows_chain, dim3(row_blocks, blocks), dim3(BLOCK), chain_lds(), eng->stream, cb.a);
   HIP_TRY(eng, hipGetLastError());
   return CHG_OK;
 }

@@ -52,6 +52,7 @@ struct ChainArgs {
   int n;
 };
 
+__host__ __device__ constexpr int chain_tiles_per_wg(int nterms) { return nterms >= 2 ? 4 : WAVES; }
 constexpr int CH_TS = D + PAD;       // row stride of the wave tiles (64 wide: a 128-wide stage-1 input goes through in two halves)
 constexpr int CH_W1 = D * (2 * D + PAD);   // floats of one term's weight image
 // All terms' weight images are resident at once (three buffers: 101 KB of the 154 KB; the 128-wide wave tiles they displaced were only
@@ -146,10 +147,14 @@ static __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_rows_chain(Chain
   if (pi >= a.n) return;
   const ChainProb& p = a.p[pi];
   const int cb = y;
-  if ((int)blockIdx.x * BLOCK_ROWS >= p.rows) return;      // (uniform: the grid covers the longest problem)
+  // Row tiles per workgroup: eight, or FOUR for problems with several terms -- the waves 4-7 then only help to build the weight images
+  // and leave, so that each of the others has a SIMD to itself for its two or three 128-wide contractions (~3 us each with two waves
+  // per SIMD: these launches are a few dozen workgroups on 256 CUs) and twice as many CUs take part.
+  const int tpw = chain_tiles_per_wg(p.nterms);
+  if ((int)blockIdx.x * tpw * TILE_ROWS >= p.rows) return;      // (uniform: the grid covers the longest problem)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * BLOCK_ROWS + wave * TILE_ROWS;
-  const int nvalid = min(TILE_ROWS, p.rows - row0);
+  const int row0 = (blockIdx.x * tpw + wave) * TILE_ROWS;
+  const int nvalid = wave < tpw ? min(TILE_ROWS, p.rows - row0) : 0;
   const bool active = nvalid > 0;
   const int rr_ = active ? row0 + min(j, nvalid - 1) : 0;
   float* T = tiles + wave * TILE_ROWS * CH_TS;
