@@ -198,7 +198,8 @@ def test_fine_tuning_gradient_of_a_device_built_batch_equals_the_uploaded_one(tr
     b_up = eng.upload([conv(s) for s in structs])
     try:
         n, n_atoms = len(structs), b_dev.packed.n_atoms
-        assert int(eng.debug_fetch_i32(b_dev, "blk_tiles", 1)[0]) > 0
+        if os.environ.get("CHGNET_BLK_MAX_ANGLES") is None:      # (the suite is also run with the blocked tiles switched off)
+            assert int(eng.debug_fetch_i32(b_dev, "blk_tiles", 1)[0]) > 0
         rng = np.random.default_rng(0)
         cot = rng.normal(1, 0.1, n).astype(np.float32)
         gf = rng.normal(0, 0.01, (n_atoms, 3)).astype(np.float32)
