@@ -225,6 +225,7 @@ int64_t chg_batch_bytes_required(int32_t n_conv, int32_t n_struct, int32_t n_ato
   if (n_conv < 2 || n_conv > MAX_CONV || n_struct < 0 || n_atoms < 0 || n_directed < 0 || (n_directed & 1) || n_angles < 0 || n_bnodes < 0) return -1;
   chg_batch probe{};
   probe.B = n_struct; probe.N = n_atoms; probe.Ed = n_directed; probe.Eu = n_directed / 2; probe.A = n_angles; probe.Eb = n_bnodes; probe.L = n_conv;
+  probe.blk_cap = upload_blk_cap(probe.N, probe.A, probe.Eb);
   size_t total = 0;
   carve(&probe, nullptr, total);
   return (int64_t)total;
@@ -242,6 +243,7 @@ int chg_batch_upload(chg_engine* eng, const chg_batch_host* h, chg_batch** out) 
   if (!b) return CHG_ENOMEM;
   b->B = h->n_struct; b->N = h->n_atoms; b->Ed = h->n_directed; b->Eu = h->n_undirected; b->A = h->n_angles; b->Eb = h->n_bnodes;
   b->L = eng->desc.n_conv;
+  b->blk_cap = upload_blk_cap(b->N, b->A, b->Eb);      // small batches: the angle adjoints over blocked tiles (index: prepare_windows)
   size_t total = 0;
   carve(b, nullptr, total);
   {

@@ -478,6 +478,7 @@ int build_batch_on_device(chg_engine* eng, const chg_structs_host* h, double r_a
     // never more than the builder's own)
     const bool use_blk = w_blk_a && b->canonical && A > 0 && (long)A <= blk_max_angles();
     b->blk_cap = use_blk ? (int)std::min<size_t>(blk_tile_bound(A, Eb, N), (size_t)w_blk_cap) : 0;
+    b->blk_ready = use_blk;
     size_t total = 0;
     carve(b, nullptr, total);
     int s = acquire_arena(eng, b, total);

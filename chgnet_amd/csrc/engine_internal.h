@@ -179,6 +179,7 @@ struct chg_batch {
   // MD-size batches built on the device: the angle adjoints over blocked tiles (kernels_angle_blk.h); blk_cap = capacity of the
   // index in tiles (0: none), the tile count itself is a device quantity (blk_tiles)
   int blk_cap = 0;
+  bool blk_ready = false;   // the index is in place (device-built: written by the graph builder; uploaded: prepare_windows launches it)
   int *blk_a = nullptr, *blk_b1c = nullptr, *blk_b2c = nullptr, *blk_ctr = nullptr, *blk_desc = nullptr, *blk_tiles = nullptr;
   bool win_pending = false; // uploaded, prepare_windows not launched yet (ensure_windows: first predict / debug fetch)
   bool zsave_now = false;   // this prediction has a reverse sweep: its forward angle kernels keep z (zsave_l)
@@ -325,7 +326,10 @@ inline long blk_max_angles() {
   static const long v = [] { const char* e = std::getenv("CHGNET_BLK_MAX_ANGLES"); return e ? std::atol(e) : (1L << 22); }();
   return v;
 }
-inline size_t blk_tile_bound(size_t A, size_t Eb, size_t N) { return (A + 14 * Eb + 9 * N) / 16 + 1; }   // 16 ceil(n/4)^2 <= n (n - 1) + 7 n + 9, sum of n <= 2 Eb
+inline size_t blk_tile_bound(size_t A, size_t Eb, size_t N) { return (A + 14 * Eb + 9 * N) / 16 + 1; }
+inline int upload_blk_cap(size_t N, size_t A, size_t Eb) {    // capacity of the blocked-tile index of an uploaded batch (0: none)
+  return (A > 0 && N + 1 <= 8192 && (long)A <= blk_max_angles()) ? (int)blk_tile_bound(A, Eb, N) : 0;
+}   // 16 ceil(n/4)^2 <= n (n - 1) + 7 n + 9, sum of n <= 2 Eb
 bool decide_windows(chg_engine* eng, chg_batch* b);   // sets win_built / win_team / win_grid; true when the batch uses the per-atom index
 int ensure_windows(chg_engine* eng, chg_batch* b);   // launches a pending prepare_windows (compute stream)
 void register_names(chg_batch* b);

@@ -473,14 +473,15 @@ int launch_angle(chg_engine* eng, const char* label, chg_batch* b, const AngleAr
     HIP_TRY(eng, hipGetLastError());
     if (b->canonical) return CHG_OK;
   } else if (BWD && b->blk_cap > 0) {
-    // MD-size batch built on the device: self-contained blocked tiles (kernels_angle_blk.h; the index is valid by construction)
+    // small batch: self-contained blocked tiles (kernels_angle_blk.h; built on the device: the index is valid by construction)
     AngleBlkArgs w{};
     w.a = a; w.a.image = eng->img_angle[1][a.slot];
     w.x.tiles = b->blk_tiles; w.x.a = b->blk_a; w.x.b1c = b->blk_b1c; w.x.b2c = b->blk_b2c; w.x.ctr = b->blk_ctr; w.x.desc = b->blk_desc;
+    w.x.flag = b->canonical ? nullptr : b->win.flag;      // uploaded: valid only if the graph has the canonical angle structure
     const int grid = std::max(1, std::min(eng->num_cus, (b->blk_cap + WAVES - 1) / WAVES));
     hipLaunchKernelGGL((k_angle_bwd_blk<HIDDEN>), dim3(grid), dim3(BLOCK), angle_blk_lds<HIDDEN>(), eng->stream, w);
     HIP_TRY(eng, hipGetLastError());
-    return CHG_OK;
+    if (b->canonical) return CHG_OK;                      // else the row-order kernel below: it returns at once when the flag says 1
   } else if (BWD && b->win_team > 0) {
     // MD-size batch: an atom per team of waves (kernels_angle_w.h TEAM); the row-order kernel below returns at once unless the graph
     // turned out not to have the canonical angle structure
@@ -940,7 +941,7 @@ void carve(chg_batch* b, char* base, size_t& total) {
   b->phase = c.take<float>(PHASE_FLOATS);
   {   // windowed angle adjoints (kernels_angle_w.h)
     WinIndex& w = b->win;
-    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1); w.toff = c.take<int>(N + 1);
+    w.flag = c.take<int>(4); w.na = c.take<int>(N + 1); w.boff = c.take<int>(N + 1); w.aoff = c.take<int>(N + 1); w.toff = c.take<int>(N + 1); w.toff4 = c.take<int>(N + 1);
     w.head = c.take<int>(Ed); w.rank = c.take<int>(Ed); w.list = c.take<int>(A ? N * WIN_LIST : 0);
     w.q_a = c.take<int>(A); w.q_ctr = c.take<int>(A); w.q_b1c = c.take<int>(A); w.q_b2c = c.take<int>(A); w.q_ab1 = c.take<int>(A); w.q_ab2 = c.take<int>(A);
     w.abbond = c.take<int>(2 * Eb);
@@ -1002,7 +1003,25 @@ bool decide_windows(chg_engine* eng, chg_batch* b) {
 int prepare_windows(chg_engine* eng, chg_batch* b) {
   hipStream_t st = eng->stream;
   WinIndex& w = b->win;
-  if (b->blk_cap > 0) { b->win_built = false; b->win_team = 0; return CHG_OK; }   // blocked tiles (kernels_angle_blk.h): the builder wrote their index
+  if (b->blk_cap > 0) {   // blocked tiles (kernels_angle_blk.h)
+    b->win_built = false; b->win_team = 0;
+    if (b->blk_ready) return CHG_OK;             // the graph builder wrote their index
+    // an uploaded graph: the centre-major order first (ranks of the bonds at their atom; flag[0] = 0 unless the graph has the canonical
+    // angle structure), then row -> slot
+    b->win_grid = std::max(1, std::min(eng->num_cus, WIN_MAX_GRID));
+    hipLaunchKernelGGL(k_win_clear, g1(std::max(b->Ed, b->N + 1)), dim3(256), 0, st, w, b->N, b->Ed, b->win_grid);
+    hipLaunchKernelGGL(k_win_heads, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->A, b->Ed, b->N, w);
+    hipLaunchKernelGGL(k_win_scan2, dim3(1), dim3(1024), 0, st, b->N, w);
+    hipLaunchKernelGGL(k_win_ranks, g1(b->A), dim3(256), 0, st, b->a_d1, b->a_ctr, b->a_b1c, b->A, b->N, w);
+    hipLaunchKernelGGL(k_win_rows, g1(b->A), dim3(256), 0, st, b->a_ctr, b->a_b1c, b->a_b2c, b->a_d1, b->a_d2, b->A, b->N, b->Ed, w);
+    const size_t slots = (size_t)b->blk_cap * TILE_ROWS;
+    HIP_TRY(eng, hipMemsetAsync(b->blk_a, 0xFF, sizeof(int) * slots, st));
+    HIP_TRY(eng, hipMemsetAsync(b->blk_b1c, 0, (size_t)((char*)(b->blk_ctr + slots) - (char*)b->blk_b1c), st));     // blk_b1c | blk_b2c | blk_ctr are neighbours (carve)
+    hipLaunchKernelGGL(k_blk_from_q, g1(b->A), dim3(256), 0, st, b->A, b->N, w, b->blk_a, b->blk_b1c, b->blk_b2c, b->blk_ctr, b->blk_desc, b->blk_tiles, b->blk_cap);
+    HIP_TRY(eng, hipGetLastError());
+    b->blk_ready = true;
+    return CHG_OK;
+  }
   const bool ready = b->win_index_ready;        // chg_batch_build wrote the index with the graph (and has called decide_windows)
   if (!ready && !decide_windows(eng, b)) return CHG_OK;
   if (b->win_team > 0) {

@@ -18,7 +18,9 @@
 // slots (the ragged edges) read row 0 of the tables and their upstream gradient is set to zero, so they add zeros.
 //
 // Index: the device graph builder writes slot -> angle while it emits the angles (k_angle_fill, from the ranks it counts anyway) and
-// k_multi_copy adds the compact bond indices: nothing is launched for it.  Hand-made / uploaded graphs keep the row-order adjoints.
+// k_multi_copy adds the compact bond indices: nothing is launched for it.  Uploaded graphs get the same index from the centre-major
+// order of kernels_angle_w.h (k_win_*: ranks of the bonds at their atom) and k_blk_from_q below, once per upload; a graph without the
+// canonical angle structure leaves WinIndex::flag at 0 and the row-order adjoint, launched behind this one, does the work.
 #pragma once
 
 #include "kernels_angle_w.h"
@@ -29,6 +31,7 @@ struct BlkIndex {
   const int* tiles;                       // [1] number of 16-slot tiles (device quantity: sum of blk_shape_of(n) over the atoms)
   const int *a, *b1c, *b2c, *ctr;         // [16 tiles] angle (-1: empty slot), compact bond indices, centre atom
   const int* desc;                        // [tiles] log2 P | log2 Q << 4 | i0 << 8 | j'0 << 16
+  const int* flag;                        // uploaded graphs: WinIndex::flag (1: the graph has the canonical angle structure, the index is valid); else null
 };
 struct AngleBlkArgs {
   AngleArgs a;
@@ -130,10 +133,32 @@ __device__ __forceinline__ void scatter_rows64_add_masked(const float* tile, int
     if (r[it] >= 0) *grow<f32x4>(dst, (unsigned)r[it], D, 4 * t) = v[it];
 }
 
+// The index of an UPLOADED graph from its centre-major order (WinIndex: q_a .. q_ab2 after k_win_rows, toff4 after k_win_scan2): row -> slot.
+// blk_a was set to -1, the other slot arrays to 0 (memsets).
+static __global__ void k_blk_from_q(int A, int N, WinIndex w, int* __restrict__ blk_a, int* __restrict__ blk_b1c, int* __restrict__ blk_b2c,
+                                    int* __restrict__ blk_ctr, int* __restrict__ blk_desc, int* __restrict__ blk_tiles, int cap_tiles) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row == 0) *blk_tiles = min(w.toff4[N], cap_tiles);
+  if (row >= A || w.flag[0] != 1) return;
+  const int c = w.q_ctr[row], n = w.na[c], ab0 = w.boff[c];
+  const int i = w.q_ab1[row] - ab0, r2 = w.q_ab2[row] < 0 ? -1 : w.q_ab2[row] - ab0;
+  if (i < 0 || i >= n || r2 < 0 || r2 >= n || r2 == i) { w.flag[0] = 0; return; }    // the second bond is not one of the atom's first bonds
+  const int jp = r2 - (r2 > i ? 1 : 0);
+  int ps, qs;
+  blk_shape_of(n, ps, qs);
+  const int nq = (n - 1 + (1 << qs) - 1) >> qs;
+  const long tile = (long)w.toff4[c] + (long)(i >> ps) * nq + (jp >> qs);
+  if (tile >= cap_tiles) { w.flag[0] = 0; return; }
+  const size_t sl = (size_t)tile * 16 + ((i & ((1 << ps) - 1)) << qs) + (jp & ((1 << qs) - 1));
+  blk_a[sl] = w.q_a[row]; blk_b1c[sl] = w.q_b1c[row]; blk_b2c[sl] = w.q_b2c[row]; blk_ctr[sl] = c;
+  blk_desc[tile] = ps | (qs << 4) | ((i >> ps << ps) << 8) | ((jp >> qs << qs) << 16);
+}
+
 template <bool HIDDEN>
 __global__ __launch_bounds__(BLOCK) CHG_TWO_WAVES void k_angle_bwd_blk(AngleBlkArgs pb) {
   const AngleArgs& p = pb.a;
   const BlkIndex& x = pb.x;
+  if (x.flag && *x.flag != 1) return;           // not a canonical graph: the row-order adjoint launched behind this one runs
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // the weight block of k_angle<HIDDEN, true> / k_angle_bwd_w (prebuilt image: AngleLds<HIDDEN, true>)
   constexpr int MODE = HIDDEN ? 2 : 1;

@@ -29,6 +29,7 @@
 // second bond is not a first bond at the same atom fall back to direct row atomics.
 #pragma once
 
+#include "blk_shape.h"
 #include "kernels_conv.h"
 
 namespace chg {
@@ -46,6 +47,7 @@ struct WinIndex {             // built by k_win_*; all in the batch arena
   int* xatom;                 // [win_grid / 8 + 1] atoms [xatom[i], xatom[i + 1]) are dealt to the 64 waves of group i (k_win_groups)
   int *na, *boff, *aoff;      // [N+1] short bonds per atom, exclusive scans of na and na (na - 1)
   int* toff;                  // [N+1] exclusive scan of the atoms' 16-row tile counts ceil(na (na - 1) / 16) (TEAM kernels: tiles dealt evenly)
+  int* toff4;                 // [N+1] exclusive scan of the atoms' blocked-tile counts (blk_shape_of; kernels_angle_blk.h, uploaded graphs)
   int *head, *rank;           // [Ed] first row of the group whose first bond is this directed edge (-1: none); its rank at the centre
   int* list;                  // [N][WIN_LIST] directed edges of the groups of an atom (unordered)
   int *q_a, *q_ctr, *q_b1c, *q_b2c, *q_ab1, *q_ab2;   // [A]
@@ -124,26 +126,31 @@ static __global__ void k_win_clear(WinIndex w, int N, int Ed, int grid) {
 // boff = exclusive scan of na, aoff = exclusive scan of na (na - 1), toff = exclusive scan of the tile counts, all over the N + 1 entries, by ONE workgroup (N + 1 <= 8192:
 // a few thousand atoms is all team mode is for): each thread sums a contiguous run, the 1024 run sums are scanned through LDS
 static __global__ __launch_bounds__(1024) void k_win_scan2(int N, WinIndex w) {
-  __shared__ int tot_b[16], tot_a[16], tot_t[16];
+  __shared__ int tot_b[16], tot_a[16], tot_t[16], tot_4[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = N + 1, per = (n + 1023) / 1024;
   const int b = min(tid * per, n), e = min(b + per, n);
-  int sb = 0, sa = 0, st = 0;
-  for (int k = b; k < e; ++k) { const int v = k < N ? w.na[k] : 0; sb += v; sa += v * (v - 1); st += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS; }
-  int ib = sb, ia = sa, it = st;            // inclusive scans over the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off), ut = __shfl_up(it, off);
-    if (lane >= off) { ib += ub; ia += ua; it += ut; }
-  }
-  if (lane == 63) { tot_b[wave] = ib; tot_a[wave] = ia; tot_t[wave] = it; }
-  __syncthreads();
-  int rb = ib - sb, ra = ia - sa, rt = it - st;
-  for (int q = 0; q < wave; ++q) { rb += tot_b[q]; ra += tot_a[q]; rt += tot_t[q]; }
+  int sb = 0, sa = 0, st = 0, s4 = 0;
   for (int k = b; k < e; ++k) {
     const int v = k < N ? w.na[k] : 0;
-    w.boff[k] = rb; w.aoff[k] = ra; w.toff[k] = rt;
-    rb += v; ra += v * (v - 1); rt += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS;
+    int ps, qs;
+    sb += v; sa += v * (v - 1); st += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS; s4 += blk_shape_of(v, ps, qs);
+  }
+  int ib = sb, ia = sa, it = st, i4 = s4;            // inclusive scans over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int ub = __shfl_up(ib, off), ua = __shfl_up(ia, off), ut = __shfl_up(it, off), u4 = __shfl_up(i4, off);
+    if (lane >= off) { ib += ub; ia += ua; it += ut; i4 += u4; }
+  }
+  if (lane == 63) { tot_b[wave] = ib; tot_a[wave] = ia; tot_t[wave] = it; tot_4[wave] = i4; }
+  __syncthreads();
+  int rb = ib - sb, ra = ia - sa, rt = it - st, r4 = i4 - s4;
+  for (int q = 0; q < wave; ++q) { rb += tot_b[q]; ra += tot_a[q]; rt += tot_t[q]; r4 += tot_4[q]; }
+  for (int k = b; k < e; ++k) {
+    const int v = k < N ? w.na[k] : 0;
+    int ps, qs;
+    w.boff[k] = rb; w.aoff[k] = ra; w.toff[k] = rt; w.toff4[k] = r4;
+    rb += v; ra += v * (v - 1); rt += (v * (v - 1) + TILE_ROWS - 1) / TILE_ROWS; r4 += blk_shape_of(v, ps, qs);
   }
 }
 

@@ -54,6 +54,10 @@ for tag, scale in (("a32", (1, 1, 1)), ("a256", (2, 2, 2)), ("a384", (3, 2, 2)))
     eng.predict(b2, "efsm")
     for k, v in eng.download(b2, "efsm").items():
         out[f"{tag}/upload/{k}"] = v
+    try:
+        out[f"{tag}/upload_blk"] = np.array([int(eng.debug_fetch_i32(b2, "blk_tiles", 1)[0]), int(eng.debug_fetch_i32(b2, "win_flag", 4)[0])])
+    except Exception:
+        out[f"{tag}/upload_blk"] = np.array([0, 0])
     b.free(); b2.free()
 # a ragged batch: 40 random cells of 10-100 atoms (the C3 sweep's generator): atoms with 2 ... 30 short bonds, every block shape
 import bench
@@ -111,11 +115,13 @@ def test_md_size_path_equals_the_large_batch_launch_sequence():
         assert np.array_equal(team[f"{tag}/counts"], old[f"{tag}/counts"])
         n_ang = int(old[f"{tag}/counts"][1])
         assert int(default[f"{tag}/blk_tiles"][0]) > 0 and int(old[f"{tag}/blk_tiles"][0]) == 0
+        # the uploaded copy of the graph gets the same number of tiles from its centre-major order (k_blk_from_q), flag 1 = canonical
+        assert list(default[f"{tag}/upload_blk"]) == [int(default[f"{tag}/blk_tiles"][0]), 1] and int(old[f"{tag}/upload_blk"][0]) == 0
         slots = default[f"{tag}/blk_a"]
         assert np.array_equal(np.sort(slots[slots >= 0]), np.arange(n_ang)), tag      # a permutation of the angles, the rest empty
         for variant in (team, default, nochain):
             for key, ref in old.items():
-                if not key.startswith(tag + "/") or key.endswith(("/flag", "/counts", "/blk_tiles", "/blk_a")):
+                if not key.startswith(tag + "/") or key.endswith(("/flag", "/counts", "/blk_tiles", "/blk_a", "/upload_blk")):
                     continue
                 k = key.rsplit("/", 1)[1]
                 err = float(np.abs(variant[key] - ref).max())
@@ -213,3 +219,32 @@ def test_fine_tuning_gradient_of_a_device_built_batch_equals_the_uploaded_one(tr
     finally:
         b_dev.free(); b_up.free()
         eng.close()
+
+
+def test_uploaded_graph_without_the_canonical_angle_order_falls_back_behind_the_blocked_tiles(hip_engine):
+    """A small uploaded batch runs its angle adjoints over blocked tiles (index from the centre-major order, k_blk_from_q) when its angle
+    rows have the reference's group structure (flag 1); with the rows shuffled inside every structure the device clears the flag, the
+    blocked-tile kernels return at once and the row-order adjoints launched behind them do the work -- same forces and stresses."""
+    import bench
+    from chgnet_amd.pack import pack_batch
+    from test_gpu_round3 import _reordered
+
+    pb = pack_batch(bench.build_workload(24, 300))          # 960 atoms
+    rng = np.random.default_rng(4)
+    off = pb.ang_off
+    perm = np.concatenate([off[b] + rng.permutation(off[b + 1] - off[b]) for b in range(pb.n_struct)])
+    out = []
+    for p_, want_flag in ((pb, 1), (_reordered(pb, perm), 0)):
+        batch = hip_engine.upload(p_)
+        try:
+            hip_engine.predict(batch, "efs")
+            out.append(hip_engine.download(batch, "efs"))
+            if os.environ.get("CHGNET_BLK_MAX_ANGLES") is None:
+                assert int(hip_engine.debug_fetch_i32(batch, "blk_tiles", 1)[0]) > 0
+                assert hip_engine.debug_fetch_i32(batch, "win_flag", 4)[0] == want_flag
+        finally:
+            batch.free()
+    a, b = out
+    assert np.isfinite(a["f"]).all() and np.abs(a["f"]).max() > 1e-3
+    for k, t in {"e": 2e-6, "f": 2e-6, "s": 2e-5}.items():
+        assert np.abs(a[k] - b[k]).max() < t, (k, float(np.abs(a[k] - b[k]).max()))
